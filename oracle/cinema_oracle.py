@@ -1,0 +1,529 @@
+"""CPU oracle for the CineMA MAE hot path -- TEST INFRASTRUCTURE ONLY.
+
+A functional, fp32, CPU restatement of the algorithm of ``mathpluscode/CineMA``'s MAE
+pre-training forward (``cinema/mae/mae.py:504-612``) written against a flat ``state_dict``
+(the reference's own key names) instead of ``nn.Module`` objects.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file;
+the product package ``cinema_amd`` never does (it fails loudly without its HIP library).
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function below against
+golden vectors captured from the imported upstream reference (``oracle/make_golden.py``,
+fixtures under ``tests/golden/``), including loss, predictions, metrics, gradients and a 3-step
+AdamW trajectory.
+
+The arithmetic itself lives in PyTorch ATen (``torch==2.11.0`` pinned upstream, 2.10.0 here) and
+timm 1.0.15's ``Mlp`` (fc1 -> GELU -> fc2); both are restated with plain ``torch`` ops.
+
+Every function cites the reference lines it follows.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn.functional as F  # noqa: N812
+
+Tensor = torch.Tensor
+Params = dict  # flat {reference state_dict key: tensor}
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class MAEConfig:
+    """Constructor arguments of the reference ``CineMA`` (``cinema/mae/mae.py:288-313``)."""
+
+    image_size_dict: dict
+    in_chans_dict: dict
+    enc_patch_size_dict: dict
+    enc_scale_factor_dict: dict
+    enc_conv_chans: list
+    enc_conv_n_blocks: int
+    enc_embed_dim: int
+    enc_depth: int
+    enc_n_heads: int
+    dec_embed_dim: int
+    dec_depth: int
+    dec_n_heads: int
+    mlp_ratio: int = 4
+    norm_target: bool = False
+    cross_attn: bool = True
+    norm_eps: float = 1e-5
+    views: list = field(default_factory=list)
+
+    def __post_init__(self) -> None:
+        self.views = list(self.image_size_dict.keys())
+        for d in (self.image_size_dict, self.enc_patch_size_dict, self.enc_scale_factor_dict):
+            for k in d:
+                d[k] = tuple(int(v) for v in d[k])
+
+    # derived geometry ------------------------------------------------------------------------
+    def patch_sizes(self, view: str) -> list:
+        """``DownsampleEncoder.patch_sizes`` (``cinema/convvit.py:85``)."""
+        return [self.enc_patch_size_dict[view]] + [self.enc_scale_factor_dict[view]] * len(self.enc_conv_chans)
+
+    def grid_size(self, view: str) -> tuple:
+        size = self.image_size_dict[view]
+        for p in self.patch_sizes(view):
+            size = tuple(s // q for s, q in zip(size, p))
+        return size
+
+    def dec_patch_size(self, view: str) -> tuple:
+        """``get_decoder_patch_size`` (``cinema/mae/mae.py:207-228``)."""
+        out = (1,) * len(self.image_size_dict[view])
+        for p in self.patch_sizes(view):
+            out = tuple(a * b for a, b in zip(out, p))
+        return out
+
+
+VIT_SIZES = {  # ``get_vit_config`` (``cinema/vit.py:784-831``)
+    "tiny": dict(enc_embed_dim=16, enc_depth=1, enc_n_heads=2, dec_embed_dim=16, dec_depth=1, dec_n_heads=2),
+    "base": dict(enc_embed_dim=768, enc_depth=12, enc_n_heads=12, dec_embed_dim=512, dec_depth=8, dec_n_heads=16),
+    "large": dict(enc_embed_dim=1024, enc_depth=24, enc_n_heads=16, dec_embed_dim=512, dec_depth=8, dec_n_heads=16),
+    "huge": dict(enc_embed_dim=1280, enc_depth=32, enc_n_heads=16, dec_embed_dim=512, dec_depth=8, dec_n_heads=16),
+}
+
+
+def mae_config(size: str, sax_size=None, lax_size=None, views=("sax", "lax_2c", "lax_3c", "lax_4c"),  # noqa: ANN001
+               patch_size=(4, 4, 1), scale_factor=(2, 2, 1), conv_chans=(64, 128), conv_n_blocks=2, in_chans=1) -> MAEConfig:
+    """Same mapping as the reference ``get_model`` (``cinema/mae/mae.py:231-282``)."""
+    img, pch, scl, chn = {}, {}, {}, {}
+    for v in views:
+        nd = 3 if v == "sax" else 2
+        img[v] = tuple(sax_size) if v == "sax" else tuple(lax_size)
+        pch[v], scl[v], chn[v] = tuple(patch_size[:nd]), tuple(scale_factor[:nd]), in_chans
+    return MAEConfig(image_size_dict=img, in_chans_dict=chn, enc_patch_size_dict=pch, enc_scale_factor_dict=scl,
+                     enc_conv_chans=list(conv_chans), enc_conv_n_blocks=conv_n_blocks, **VIT_SIZES[size])
+
+
+# ----------------------------------------------------------------------------------------------
+# patches and positional tables
+# ----------------------------------------------------------------------------------------------
+def patchify(image: Tensor, patch_size: tuple) -> Tensor:
+    """(b, C, *S) -> (b, prod(S/p), prod(p)*C), token raster order, feature order (p..., C).
+
+    ``patchify_2d/3d/4d`` (``cinema/vit.py:67-161``); raises ``ValueError`` like the reference.
+    """
+    n = len(patch_size)
+    if n not in (2, 3, 4):
+        raise ValueError(f"Patchify only supports 2D, 3D, and 4D images, got {n}D.")
+    b, c, *size = image.shape
+    for s, p in zip(size, patch_size):
+        if s % p != 0:
+            raise ValueError(f"Input size ({s}) cannot be divided by patch size ({p}).")
+    grid = [s // p for s, p in zip(size, patch_size)]
+    x = image.reshape(b, c, *[v for gp in zip(grid, patch_size) for v in gp])
+    grid_axes = [2 + 2 * i for i in range(n)]
+    patch_axes = [3 + 2 * i for i in range(n)]
+    x = x.permute(0, *grid_axes, *patch_axes, 1).contiguous()
+    return x.reshape(b, math.prod(grid), math.prod(patch_size) * c)
+
+
+def unpatchify(x: Tensor, patch_size: tuple, grid_size: tuple) -> Tensor:
+    """Inverse of :func:`patchify` (``cinema/vit.py:164-256``)."""
+    b, n_patches, chans = x.shape
+    if n_patches != math.prod(grid_size):
+        raise ValueError(f"Number of patches {n_patches} != product of grid size {grid_size}.")
+    if chans % math.prod(patch_size) != 0:
+        raise ValueError(f"Number of channels {chans} is not divisible by product of patch size {patch_size}.")
+    if len(patch_size) != len(grid_size):
+        raise ValueError(f"Patch size {patch_size} and grid size {grid_size} do not match.")
+    n = len(patch_size)
+    if n not in (2, 3, 4):
+        raise ValueError(f"Unpatchify only supports 2D, 3D, and 4D images, got {n}D.")
+    x = x.reshape(b, *grid_size, *patch_size, -1)
+    order = [0, 1 + 2 * n]
+    for i in range(n):
+        order += [1 + i, 1 + n + i]
+    x = x.permute(*order).contiguous()
+    return x.reshape(b, -1, *[g * p for g, p in zip(grid_size, patch_size)])
+
+
+def sincos_1d(dim: int, pos: np.ndarray, max_period: int = 10000) -> np.ndarray:
+    """``get_1d_sincos_pos_embed_from_grid`` (``cinema/vit.py:347-383``): [sin | cos] halves."""
+    if dim % 2 != 0:
+        raise ValueError(f"Embedding dimension must be divisible by 2, got {dim}.")
+    half = dim // 2
+    omega = np.exp(-np.log(max_period) * np.arange(half, dtype=np.float32) / half)
+    ang = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(ang), np.cos(ang)], axis=1)
+
+
+def sincos_pos_embed(dim: int, grid_size: tuple) -> Tensor:
+    """(1, prod(grid), dim) table, ``get_pos_embed`` (``cinema/vit.py:386-443``).
+
+    Faithful quirks: ``np.meshgrid`` default ``indexing='xy'`` (``vit.py:421``), per-axis width
+    ``dim // n`` rounded down to even with zero padding (``vit.py:398-405``).
+    """
+    grid = np.stack(np.meshgrid(*[np.arange(s, dtype=np.float32) for s in grid_size]), axis=0)
+    n = grid.shape[0]
+    d = dim // n
+    d -= d % 2
+    emb = np.concatenate([sincos_1d(d, grid[i]) for i in range(n)], axis=1)
+    if dim - d * n > 0:
+        emb = np.concatenate([emb, np.zeros((emb.shape[0], dim - d * n))], axis=1)
+    return torch.from_numpy(emb).float().unsqueeze(0)
+
+
+def upsample_mask(mask: Tensor, scale_factor: tuple) -> Tensor:
+    """Nearest-neighbour upsampling of a (b, *grid) bool mask (``cinema/convvit.py:24-51``)."""
+    if mask.ndim != len(scale_factor) + 1:
+        raise ValueError("mask must have the same number of dimensions as scale_factor except batch")
+    for axis, f in enumerate(scale_factor):
+        mask = mask.repeat_interleave(int(f), dim=axis + 1)
+    return mask
+
+
+def random_patch_mask(batch: int, n_patches: int, ratio: float, generator: torch.Generator | None = None) -> Tensor:
+    """``get_batch_random_patch_mask`` (``cinema/mae/mae.py:30-65``): True = removed."""
+    if ratio < 0:
+        raise ValueError(f"mask_ratio must be positive, got {ratio}.")
+    if ratio == 0:
+        return torch.zeros(batch, n_patches, dtype=torch.bool)
+    noise = torch.rand(batch, n_patches, generator=generator)
+    rank = torch.argsort(torch.argsort(noise, dim=1), dim=1)
+    return rank >= int(n_patches * (1 - ratio))
+
+
+# ----------------------------------------------------------------------------------------------
+# layers (functional, on a flat parameter dict)
+# ----------------------------------------------------------------------------------------------
+def _ln(x: Tensor, p: Params, key: str, eps: float) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), p[f"{key}.weight"], p[f"{key}.bias"], eps)
+
+
+def _lin(x: Tensor, p: Params, key: str) -> Tensor:
+    return F.linear(x, p[f"{key}.weight"], p.get(f"{key}.bias"))
+
+
+def _conv(x: Tensor, p: Params, key: str, stride=1, padding=0, groups: int = 1) -> Tensor:  # noqa: ANN001
+    fn = F.conv3d if x.ndim == 5 else F.conv2d
+    return fn(x, p[f"{key}.weight"], p.get(f"{key}.bias"), stride=stride, padding=padding, groups=groups)
+
+
+def _conv_ln(x: Tensor, p: Params, key: str, eps: float = 1e-6) -> Tensor:
+    """``ConvLayerNorm`` (``cinema/conv.py:169-187``): LN over the channel axis of (b, C, *S); eps 1e-6 (``conv.py:190``)."""
+    return _ln(x.movedim(1, -1), p, key, eps).movedim(-1, 1).contiguous()
+
+
+def attention(q_in: Tensor, k_in: Tensor, p: Params, key: str, n_heads: int) -> Tensor:
+    """``Attention.forward`` (``cinema/vit.py:482-522``), explicit softmax branch (``:513-517``).
+
+    ``kv`` out-features are laid out (2, heads, head_dim) (``vit.py:499``).
+    """
+    b, tq, c = q_in.shape
+    tk = k_in.shape[1]
+    hd = c // n_heads
+    q = _lin(q_in, p, f"{key}.q").reshape(b, tq, n_heads, hd).permute(0, 2, 1, 3)
+    kv = _lin(k_in, p, f"{key}.kv").reshape(b, tk, 2, n_heads, hd).permute(2, 0, 3, 1, 4)
+    k, v = kv[0], kv[1]
+    w = torch.softmax((q * hd**-0.5) @ k.transpose(-2, -1), dim=-1)
+    o = (w @ v).transpose(1, 2).reshape(b, tq, c)
+    return _lin(o, p, f"{key}.proj")
+
+
+def block(q: Tensor, k: Tensor | None, p: Params, key: str, n_heads: int, eps: float) -> Tensor:
+    """Pre-LN ``Block`` (``cinema/vit.py:587-609``); cross-attention keys are *not* normed (``:589``)."""
+    qn = _ln(q, p, f"{key}.norm1", eps)
+    q = q + attention(qn, qn if k is None else k, p, f"{key}.attn", n_heads)
+    h = F.gelu(_lin(_ln(q, p, f"{key}.norm2", eps), p, f"{key}.mlp.fc1"))
+    return q + _lin(h, p, f"{key}.mlp.fc2")
+
+
+def masked_conv_block(x: Tensor, vis: Tensor | None, p: Params, key: str) -> Tensor:
+    """``MaskedConvBlock.forward`` (``cinema/conv.py:400-415``); ``vis`` is (b, *S), 1 = visible."""
+    h = _conv(_conv_ln(x, p, f"{key}.norm1"), p, f"{key}.conv1")
+    if vis is not None:
+        h = vis.unsqueeze(1).to(h.dtype) * h
+    h = _conv(h, p, f"{key}.dw_conv", padding=2, groups=h.shape[1])  # kernel 5 in every axis (conv.py:385)
+    x = x + _conv(h, p, f"{key}.conv2")
+    h = F.gelu(_conv(_conv_ln(x, p, f"{key}.norm2"), p, f"{key}.mlp.fc1"))
+    return x + _conv(h, p, f"{key}.mlp.fc2")
+
+
+def downsample_encoder(image: Tensor, mask: Tensor | None, p: Params, key: str, cfg: MAEConfig, view: str):  # noqa: ANN201
+    """``DownsampleEncoder.forward`` (``cinema/convvit.py:165-207``) -> (skips, tokens (b, n, E))."""
+    sizes = cfg.patch_sizes(view)
+    b = image.shape[0]
+    eff = [math.prod(s[i] for s in sizes) for i in range(len(sizes[0]))]
+    grid = tuple(s // e for s, e in zip(image.shape[2:], eff))
+    vis_masks: list = [None] * len(cfg.enc_conv_chans)
+    if mask is not None:
+        m = mask.reshape(b, *grid)
+        for lvl in range(len(sizes) - 1, 0, -1):  # coarse -> fine (convvit.py:186-192)
+            m = upsample_mask(m, sizes[lvl])
+            vis_masks[lvl - 1] = ~m
+    skips, x = [], image
+    for lvl in range(len(cfg.enc_conv_chans)):
+        kb = f"{key}.conv_blocks.{lvl}"
+        x = F.gelu(_conv_ln(_conv(x, p, f"{kb}.patch_embed.conv", stride=sizes[lvl]), p, f"{kb}.patch_embed.norm"))
+        for j in range(cfg.enc_conv_n_blocks):
+            x = masked_conv_block(x, vis_masks[lvl], p, f"{kb}.conv.{j}")
+        skips.append(x)
+    tok = _lin(_lin(patchify(x, sizes[-1]), p, f"{key}.patch_embed.proj"), p, f"{key}.linear")
+    pe = p[f"{key}.pos_embed"]
+    if grid != cfg.grid_size(view):  # ``interpolate_pos_encoding`` (convvit.py:140-163)
+        e = pe.shape[-1]
+        mode = {2: "bicubic", 3: "trilinear"}[len(grid)]
+        pe = F.interpolate(pe.reshape(1, *cfg.grid_size(view), e).movedim(-1, 1), size=grid, mode=mode)
+        pe = pe.movedim(1, -1).reshape(1, -1, e)
+    return skips, tok + pe
+
+
+def multi_scale_fusion(skips: list, x: Tensor, mask: Tensor | None, p: Params, key: str, eps: float) -> Tensor:
+    """``MultiScaleFusion.forward`` (``cinema/convvit.py:265-291``): LN(x + sum_i down_i(skip_i)[kept])."""
+    for i, skip in enumerate(skips):
+        w = p[f"{key}.down_convs.{i}.weight"]
+        down = _conv(skip, p, f"{key}.down_convs.{i}", stride=tuple(w.shape[2:])).flatten(2).transpose(1, 2)
+        if mask is not None:
+            down = down[~mask].reshape(x.shape[0], -1, x.shape[-1])
+        x = x + down
+    return _ln(x, p, f"{key}.norm", eps)
+
+
+def mse_loss(target: Tensor, pred: Tensor, mask: Tensor, norm_target: bool, epsilon: float = 1e-6):  # noqa: ANN201
+    """``mse_loss`` (``cinema/mae/mae.py:107-152``): masked-patch MSE + metrics (unbiased variance)."""
+    mean = target.mean(dim=-1, keepdim=True)
+    std = target.var(dim=-1, keepdim=True) ** 0.5
+    metrics = {"target_mean": mean.mean(), "target_std": std.mean()}
+    if norm_target:
+        target = (target - mean) / (std + epsilon)
+    target = target[mask].reshape(pred.shape)
+    loss = ((pred - target.detach()) ** 2).mean()
+    metrics["mse_loss"] = loss
+    if norm_target and target.shape[1] > 0:
+        metrics["normed_target_max"] = target.max()
+        metrics["pred_max"] = pred.max()
+    return loss, metrics
+
+
+# ----------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------
+def encode(p: Params, cfg: MAEConfig, image_dict: dict, mask_dict: dict | None):  # noqa: ANN201
+    """Stem + token selection + ViT encoder + fusion (``cinema/mae/mae.py:541-563`` / ``:478-499``)."""
+    views = list(image_dict)
+    if any(v not in cfg.views for v in views):
+        raise ValueError(f"views {views} must be in self.input_keys {cfg.views}.")
+    b = image_dict[views[0]].shape[0]
+    toks, skips_all, n_keep = [], [], []
+    for v in views:
+        m = None if mask_dict is None else mask_dict[v]
+        skips, x = downsample_encoder(image_dict[v], m, p, f"enc_down_dict.{v}", cfg, v)
+        if m is not None:
+            x = x[~m].reshape(b, -1, x.shape[-1])  # raster order of kept tokens (mae.py:550)
+        toks.append(x)
+        skips_all.append(skips)
+        n_keep.append(x.shape[1])
+    x = torch.cat([p["encoder.cls_token"].expand(b, -1, -1), *toks], dim=1)  # vit.py:672-674
+    for i in range(cfg.enc_depth):
+        x = block(x, None, p, f"encoder.blocks.{i}", cfg.enc_n_heads, cfg.norm_eps)
+    x = _ln(x, p, "encoder.norm", cfg.norm_eps)
+    parts = list(torch.split(x, [1, *n_keep], dim=1))
+    for i, v in enumerate(views):
+        m = None if mask_dict is None else mask_dict[v]
+        parts[i + 1] = multi_scale_fusion(skips_all[i], parts[i + 1], m, p, f"enc_fusion_dict.{v}", cfg.norm_eps)
+    return parts, n_keep
+
+
+def feature_forward(p: Params, cfg: MAEConfig, image_dict: dict) -> dict:
+    """``CineMA.feature_forward`` (``cinema/mae/mae.py:457-502``)."""
+    parts, _ = encode(p, cfg, image_dict, None)
+    return dict(zip(["cls", *image_dict], parts))
+
+
+def mae_forward(p: Params, cfg: MAEConfig, image_dict: dict, mask_dict: dict):  # noqa: ANN201
+    """``CineMA.forward`` (``cinema/mae/mae.py:504-612``) with the random masks injected.
+
+    Returns (loss, pred_dict, metrics).
+    """
+    views = list(image_dict)
+    parts, n_keep = encode(p, cfg, image_dict, mask_dict)
+    b = parts[0].shape[0]
+    x = _lin(torch.cat(parts, dim=1), p, "dec_linear")  # mae.py:567
+    parts = torch.split(x, [1, *n_keep], dim=1)
+    vis, msk, n_masked = [], [], []
+    for i, v in enumerate(views):  # ``DecoderEmbedding`` (mae.py:92-104,179-204)
+        pe = p[f"dec_embed_dict.{v}.pos_embed"].expand(b, -1, -1)
+        m = mask_dict[v]
+        e = pe.shape[-1]
+        vis.append(parts[i + 1] + pe[~m].reshape(b, -1, e))
+        msk.append(p[f"dec_embed_dict.{v}.mask_token"] + pe[m].reshape(b, -1, e))
+        n_masked.append(msk[-1].shape[1])
+    if cfg.cross_attn:  # mae.py:579-582
+        x_q, x_k = torch.cat([parts[0], *msk], dim=1), torch.cat(vis, dim=1)
+    else:  # mae.py:584-585
+        x_q, x_k = torch.cat([parts[0], *vis, *msk], dim=1), None
+    for i in range(cfg.dec_depth):
+        x_q = block(x_q, x_k, p, f"decoder.blocks.{i}", cfg.dec_n_heads, cfg.norm_eps)
+    x = _ln(x_q[:, x_q.shape[1] - sum(n_masked):], p, "decoder.norm", 1e-5)  # vit.py:738 default eps
+    outs = torch.split(x, n_masked, dim=1)
+    preds, losses, metrics = {}, [], {}
+    for i, v in enumerate(views):
+        preds[v] = _lin(outs[i], p, f"pred_head_dict.{v}")
+        lv, mv = mse_loss(patchify(image_dict[v], cfg.dec_patch_size(v)), preds[v], mask_dict[v], cfg.norm_target)
+        metrics.update({f"{v}_{k}": val for k, val in mv.items()})
+        if torch.isfinite(lv):
+            losses.append(lv)
+    loss = sum(losses) / len(losses) if losses else torch.tensor(float("nan"))
+    metrics["loss"] = loss
+    return loss, preds, metrics
+
+
+# ----------------------------------------------------------------------------------------------
+# parameters and the optimisation step (harness semantics of cinema/mae/pretrain.py + cinema/optim.py)
+# ----------------------------------------------------------------------------------------------
+def param_shapes(cfg: MAEConfig) -> dict:
+    """{key: (shape, kind)} for every ``state_dict`` entry of the reference ``CineMA``."""
+    out: dict = {}
+
+    def lin(key: str, i: int, o: int) -> None:
+        out[f"{key}.weight"], out[f"{key}.bias"] = ((o, i), "xavier"), ((o,), "zero")
+
+    def ln(key: str, c: int) -> None:
+        out[f"{key}.weight"], out[f"{key}.bias"] = ((c,), "one"), ((c,), "zero")
+
+    def conv(key: str, i: int, o: int, k: tuple, groups: int = 1) -> None:
+        out[f"{key}.weight"], out[f"{key}.bias"] = ((o, i // groups, *k), "conv"), ((o,), "conv_bias")
+
+    def vit_block(key: str, c: int) -> None:
+        ln(f"{key}.norm1", c)
+        lin(f"{key}.attn.q", c, c)
+        lin(f"{key}.attn.kv", c, 2 * c)
+        lin(f"{key}.attn.proj", c, c)
+        ln(f"{key}.norm2", c)
+        lin(f"{key}.mlp.fc1", c, c * cfg.mlp_ratio)
+        lin(f"{key}.mlp.fc2", c * cfg.mlp_ratio, c)
+
+    e, d = cfg.enc_embed_dim, cfg.dec_embed_dim
+    for v in cfg.views:
+        nd = len(cfg.image_size_dict[v])
+        sizes, grid = cfg.patch_sizes(v), cfg.grid_size(v)
+        kd = f"enc_down_dict.{v}"
+        out[f"{kd}.pos_embed"] = ((1, math.prod(grid), e), "sincos")
+        cin = cfg.in_chans_dict[v]
+        for lvl, ch in enumerate(cfg.enc_conv_chans):
+            kb = f"{kd}.conv_blocks.{lvl}"
+            conv(f"{kb}.patch_embed.conv", cin, ch, sizes[lvl])
+            ln(f"{kb}.patch_embed.norm", ch)
+            for j in range(cfg.enc_conv_n_blocks):
+                kc = f"{kb}.conv.{j}"
+                ln(f"{kc}.norm1", ch)
+                ln(f"{kc}.norm2", ch)
+                conv(f"{kc}.conv1", ch, ch, (1,) * nd)
+                conv(f"{kc}.conv2", ch, ch, (1,) * nd)
+                conv(f"{kc}.dw_conv", ch, ch, (5,) * nd, groups=ch)
+                conv(f"{kc}.mlp.fc1", ch, 4 * ch, (1,) * nd)
+                conv(f"{kc}.mlp.fc2", 4 * ch, ch, (1,) * nd)
+            cin = ch
+        lin(f"{kd}.patch_embed.proj", cin * math.prod(sizes[-1]), e)
+        lin(f"{kd}.linear", e, e)
+    for v in cfg.views:
+        sizes, grid = cfg.patch_sizes(v), cfg.grid_size(v)
+        size = cfg.image_size_dict[v]
+        for lvl, ch in enumerate(cfg.enc_conv_chans):
+            size = tuple(s // q for s, q in zip(size, sizes[lvl]))
+            conv(f"enc_fusion_dict.{v}.down_convs.{lvl}", ch, e, tuple(s // g for s, g in zip(size, grid)))
+        ln(f"enc_fusion_dict.{v}.norm", e)
+    out["encoder.cls_token"] = ((1, 1, e), "token")
+    for i in range(cfg.enc_depth):
+        vit_block(f"encoder.blocks.{i}", e)
+    ln("encoder.norm", e)
+    lin("dec_linear", e, d)
+    for v in cfg.views:
+        out[f"dec_embed_dict.{v}.pos_embed"] = ((1, math.prod(cfg.grid_size(v)), d), "sincos")
+        out[f"dec_embed_dict.{v}.mask_token"] = ((1, 1, d), "token")
+    for i in range(cfg.dec_depth):
+        vit_block(f"decoder.blocks.{i}", d)
+    ln("decoder.norm", d)
+    for v in cfg.views:
+        lin(f"pred_head_dict.{v}", d, math.prod(cfg.dec_patch_size(v)) * cfg.in_chans_dict[v])
+    return out
+
+
+def init_params(cfg: MAEConfig, seed: int = 0) -> Params:
+    """Random parameters with the reference's *distributions* (``cinema/vit.py:32-64``): xavier-uniform
+    Linear, zero bias, N(0, .02) tokens, torch-default conv init, frozen sin-cos tables.  (The draw
+    order differs from the reference's module construction order; tests that need bit-identical
+    weights load a ``state_dict``.)"""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    shapes = param_shapes(cfg)
+    for key, (shape, kind) in shapes.items():
+        if kind == "xavier":
+            bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind == "zero":
+            t = torch.zeros(shape)
+        elif kind == "one":
+            t = torch.ones(shape)
+        elif kind == "token":
+            t = torch.randn(shape, generator=g) * 0.02
+        elif kind in ("conv", "conv_bias"):
+            wshape = shape if kind == "conv" else shapes[key.replace(".bias", ".weight")][0]
+            bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind == "sincos":
+            view = key.split(".")[1]
+            t = sincos_pos_embed(shape[-1], cfg.grid_size(view))
+        else:
+            raise AssertionError(kind)
+        p[key] = t
+    return p
+
+
+def trainable_keys(p: Params) -> list:
+    """Everything except the frozen sin-cos tables (``requires_grad=False``, ``cinema/vit.py:441``)."""
+    return [k for k in p if not k.endswith("pos_embed")]
+
+
+def weight_decay_groups(p: Params, weight_decay: float) -> list:
+    """timm ``param_groups_weight_decay`` as called at ``cinema/mae/pretrain.py:365``:
+    ``ndim <= 1`` or ``*.bias`` -> no decay; tokens (ndim 3) ARE decayed."""
+    no_decay = [k for k in trainable_keys(p) if p[k].ndim <= 1 or k.endswith(".bias")]
+    decay = [k for k in trainable_keys(p) if k not in set(no_decay)]
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+def lr_at(step: float, warmup_steps: float, max_n_steps: float, lr: float, min_lr: float) -> float:
+    """``adjust_learning_rate`` (``cinema/optim.py:21-52``): linear warm-up then half cosine."""
+    if step < warmup_steps:
+        return lr * step / warmup_steps
+    return min_lr + (lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * (step - warmup_steps) / (max_n_steps - warmup_steps)))
+
+
+class Trainer:
+    """fp32 CPU restatement of one optimisation step of ``pretrain_one_epoch``
+    (``cinema/mae/pretrain.py:242-269``) + ``GradScaler.__call__`` (``cinema/optim.py:204-215``):
+    forward, backward, global-L2 clip at ``clip_grad`` (pre-clip norm returned), AdamW."""
+
+    def __init__(self, params: Params, cfg: MAEConfig, lr: float = 1e-3, betas=(0.9, 0.95), weight_decay: float = 0.05,  # noqa: ANN001
+                 clip_grad: float | None = 5.0) -> None:
+        self.cfg = cfg
+        self.p = {k: v.detach().clone().float() for k, v in params.items()}
+        for k in trainable_keys(self.p):
+            self.p[k].requires_grad_(True)
+        groups = [{"params": [self.p[k] for k in g["params"]], "weight_decay": g["weight_decay"]}
+                  for g in weight_decay_groups(self.p, weight_decay)]
+        self.opt = torch.optim.AdamW(groups, lr=lr, betas=tuple(betas))
+        self.clip_grad = clip_grad
+
+    def set_lr(self, lr: float) -> None:
+        for g in self.opt.param_groups:
+            g["lr"] = lr * g.get("lr_scale", 1.0)
+
+    def step(self, image_dict: dict, mask_dict: dict):  # noqa: ANN201
+        loss, preds, metrics = mae_forward(self.p, self.cfg, image_dict, mask_dict)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        tensors = [self.p[k] for k in trainable_keys(self.p)]
+        if self.clip_grad is not None:
+            norm = torch.nn.utils.clip_grad_norm_(tensors, self.clip_grad)
+        else:
+            norm = torch.linalg.vector_norm(torch.stack([t.grad.norm() for t in tensors if t.grad is not None]))
+        self.opt.step()
+        return loss.detach(), norm.detach(), preds, metrics

@@ -1,0 +1,188 @@
+"""The CPU oracle (oracle/cinema_oracle.py) against golden vectors captured from the upstream reference.
+
+Pins the oracle.  CPU only.
+"""
+
+from __future__ import annotations
+
+import json
+
+import pytest
+import torch
+
+import cinema_oracle as O
+from conftest import GOLDEN, load_golden
+
+torch.set_num_threads(8)
+
+
+def split(t: dict, prefix: str) -> dict:
+    return {k[len(prefix):]: v for k, v in t.items() if k.startswith(prefix)}
+
+
+def tiny_cfg() -> O.MAEConfig:
+    return O.mae_config("tiny", sax_size=(128, 128, 8), views=("sax",))
+
+
+def mini_cfg(**kw) -> O.MAEConfig:  # noqa: ANN003
+    views = ["sax", "lax_2c", "lax_3c", "lax_4c"]
+    return O.MAEConfig(
+        image_size_dict={v: (32, 32, 4) if v == "sax" else (32, 32) for v in views},
+        in_chans_dict=dict.fromkeys(views, 1),
+        enc_patch_size_dict={v: (4, 4, 1) if v == "sax" else (4, 4) for v in views},
+        enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views},
+        enc_conv_chans=[16, 32], enc_conv_n_blocks=1, enc_embed_dim=64, enc_depth=2, enc_n_heads=4,
+        dec_embed_dim=32, dec_depth=2, dec_n_heads=4, **kw)
+
+
+def run_model(cfg: O.MAEConfig, g: dict, params: dict, tol: float = 2e-5) -> None:
+    p = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in params.items()}
+    images = split(g, "image/")
+    masks = {k: v.bool() for k, v in split(g, "mask/").items()}
+    loss, preds, metrics = O.mae_forward(p, cfg, images, masks)
+    assert torch.allclose(loss, g["loss"][0], rtol=tol, atol=tol)
+    for v, t in split(g, "pred/").items():
+        assert preds[v].shape == t.shape
+        assert torch.allclose(preds[v], t, rtol=1e-4, atol=tol), v
+    for k, t in split(g, "metric/").items():
+        assert torch.allclose(metrics[k], t[0], rtol=1e-4, atol=tol), k
+    loss.backward()
+    for k, t in split(g, "grad/").items():
+        assert p[k].grad is not None, k
+        assert torch.allclose(p[k].grad, t, rtol=2e-3, atol=2e-6), (k, (p[k].grad - t).abs().max())
+    sq = sum((v.grad.double() ** 2).sum() for v in p.values() if v.grad is not None)
+    assert abs(float(sq) - float(g["grad_sq_norm"][0])) <= 1e-3 * float(g["grad_sq_norm"][0])
+
+
+def test_tiny_cfg1_forward_backward() -> None:
+    g = load_golden("tiny_sax.safetensors")
+    run_model(tiny_cfg(), g, split(g, "param/"))
+
+
+def test_mini_4view_forward_backward_and_features() -> None:
+    g = load_golden("mini_4view.safetensors")
+    params = split(g, "param/")
+    run_model(mini_cfg(), g, params)
+    feats = O.feature_forward(params, mini_cfg(), split(g, "image/"))
+    for k, t in split(g, "feature/").items():
+        assert torch.allclose(feats[k], t, rtol=1e-4, atol=2e-5), k
+
+
+@pytest.mark.parametrize(("name", "kw"), [("mini_4view_selfattn", {"cross_attn": False}), ("mini_4view_normtarget", {"norm_target": True})])
+def test_mini_variants(name: str, kw: dict) -> None:
+    params = split(load_golden("mini_4view.safetensors"), "param/")
+    run_model(mini_cfg(**kw), load_golden(f"{name}.safetensors"), params)
+
+
+def test_param_shapes_match_reference_manifests() -> None:
+    man = json.loads((GOLDEN / "state_dict_manifests.json").read_text())
+    for name, size, sax, lax in [("base_4view_192", "base", (192, 192, 16), (192, 192)), ("large_4view_256", "large", (256, 256, 24), (256, 256)),
+                                 ("base_4view_refdefault", "base", (192, 192, 16), (256, 256))]:
+        cfg = O.mae_config(size, sax_size=sax, lax_size=lax)
+        shapes = {k: list(s) for k, (s, _) in O.param_shapes(cfg).items()}
+        assert shapes == man[name]["keys"], name
+        assert list(shapes) == list(man[name]["keys"])  # same ordering as the reference state_dict
+
+
+def test_weight_decay_groups_match_timm_split() -> None:
+    man = json.loads((GOLDEN / "state_dict_manifests.json").read_text())["base_4view_192"]
+    cfg = O.mae_config("base", sax_size=(192, 192, 16), lax_size=(192, 192))
+    p = {k: torch.empty(s, device="meta") for k, (s, _) in O.param_shapes(cfg).items()}
+    groups = O.weight_decay_groups(p, 0.05)
+    assert sorted(groups[0]["params"]) == sorted(man["no_decay"])
+    assert "encoder.cls_token" in groups[1]["params"]
+    assert sum(p[k].numel() for g in groups for k in g["params"]) == man["n_trainable"]
+
+
+def test_three_step_trajectory() -> None:
+    g = load_golden("tiny_sax_trajectory.safetensors")
+    params = split(load_golden("tiny_sax.safetensors"), "param/")
+    tr = O.Trainer(params, tiny_cfg(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0)
+    gen = torch.Generator().manual_seed(7)
+    for i in range(3):
+        lr = O.lr_at(i / 4, 1, 5, 1e-3, 1e-6)
+        assert lr == pytest.approx(float(g[f"step{i}/lr"][0]), rel=1e-12, abs=1e-15)
+        tr.set_lr(lr)
+        image = torch.rand(2, 1, 128, 128, 8, generator=gen)
+        assert torch.equal(image.flatten()[:64], g[f"step{i}/image_head"])
+        loss, norm, _, _ = tr.step({"sax": image}, {"sax": g[f"step{i}/mask"].bool()})
+        assert torch.allclose(loss, g[f"step{i}/loss"][0], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(norm, g[f"step{i}/grad_norm"][0], rtol=1e-3, atol=1e-5)
+        for k, t in split(g, f"step{i}/param/").items():
+            assert torch.allclose(tr.p[k].detach(), t, rtol=1e-3, atol=2e-6), (i, k)
+
+
+def test_lr_schedule_table() -> None:
+    for row in json.loads((GOLDEN / "lr_schedule.json").read_text()):
+        assert O.lr_at(*row["args"]) == pytest.approx(row["lr"], rel=1e-12, abs=1e-18)
+
+
+def test_layer_kats() -> None:
+    g = load_golden("layers.safetensors")
+    for hd, heads in [(8, 2), (32, 2), (64, 1)]:
+        p = {f"a.{k}": v for k, v in split(g, f"attn{hd}/param/").items()}
+        q, k = g[f"attn{hd}/q"], g[f"attn{hd}/k"]
+        assert torch.allclose(O.attention(q, q, p, "a", heads), g[f"attn{hd}/self"], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(O.attention(q, k, p, "a", heads), g[f"attn{hd}/cross"], rtol=1e-4, atol=1e-5)
+    # reference quirk: rotary indexed by head cancels in q.k^T -> identical to no rotary
+    p = {f"a.{k}": v for k, v in split(g, "rotary/param/").items()}
+    assert torch.allclose(g["rotary/out"], g["rotary/out_plain"], atol=1e-6)
+    assert torch.allclose(O.attention(g["rotary/x"], g["rotary/x"], p, "a", 4), g["rotary/out"], rtol=1e-4, atol=1e-5)
+    assert g["rotary/cos"].shape == (4, 4)  # rows = n_heads, cols = head_dim / 2
+    for nd in (2, 3):
+        p = {f"b.{k}": v for k, v in split(g, f"mcb{nd}d/param/").items()}
+        x, vis = g[f"mcb{nd}d/x"], g[f"mcb{nd}d/vis"].bool()
+        assert torch.allclose(O.masked_conv_block(x, vis, p, "b"), g[f"mcb{nd}d/out_masked"], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(O.masked_conv_block(x, None, p, "b"), g[f"mcb{nd}d/out"], rtol=1e-4, atol=1e-5)
+    for nd, size in [(2, (32, 32)), (3, (32, 32, 4))]:
+        cfg = O.MAEConfig(image_size_dict={"v": size}, in_chans_dict={"v": 1}, enc_patch_size_dict={"v": (4, 4, 1)[:nd]},
+                          enc_scale_factor_dict={"v": (2, 2, 1)[:nd]}, enc_conv_chans=[8, 16], enc_conv_n_blocks=1, enc_embed_dim=24,
+                          enc_depth=0, enc_n_heads=1, dec_embed_dim=8, dec_depth=0, dec_n_heads=1)
+        p = {f"d.{k}": v for k, v in split(g, f"down{nd}d/param/").items()}
+        p.update({f"f.{k}": v for k, v in split(g, f"fuse{nd}d/param/").items()})
+        m = g[f"down{nd}d/mask"].bool()
+        skips, tok = O.downsample_encoder(g[f"down{nd}d/image"], m, p, "d", cfg, "v")
+        assert torch.allclose(tok, g[f"down{nd}d/tokens"], rtol=1e-4, atol=1e-5)
+        for i, s in enumerate(skips):
+            assert torch.allclose(s, g[f"down{nd}d/skip{i}"], rtol=1e-4, atol=1e-5)
+        _, tok2 = O.downsample_encoder(g[f"down{nd}d/image_other"], None, p, "d", cfg, "v")
+        assert torch.allclose(tok2, g[f"down{nd}d/tokens_other"], rtol=1e-4, atol=1e-5)  # pos-embed interpolation
+        kept = tok[~m].reshape(2, -1, 24)
+        assert torch.allclose(O.multi_scale_fusion(skips, kept, m, p, "f", 1e-5), g[f"fuse{nd}d/out_masked"], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(O.multi_scale_fusion(skips, tok, None, p, "f", 1e-5), g[f"fuse{nd}d/out_full"], rtol=1e-4, atol=1e-5)
+    for name, dim, grid in [("sax768", 768, (12, 12, 16)), ("sax512", 512, (12, 12, 16)), ("lax768", 768, (12, 12)), ("odd", 20, (2, 3, 4)),
+                            ("odd2d", 10, (3, 2))]:
+        pe = O.sincos_pos_embed(dim, grid)
+        pe = pe[:, ::37] if pe.shape[1] > 64 else pe
+        assert torch.allclose(pe, g[f"pos_embed/{name}"], atol=1e-6), name
+    for i in range(4):
+        out = O.upsample_mask(g[f"upsample_mask/{i}/in"].bool(), tuple(g[f"upsample_mask/{i}/scale"].tolist()))
+        assert torch.equal(out, g[f"upsample_mask/{i}/out"].bool())
+    for nt in (0, 1):
+        loss, metrics = O.mse_loss(g["mse/target"], g["mse/pred"], g["mse/mask"].bool(), bool(nt))
+        assert torch.allclose(loss, g[f"mse/{nt}/loss"][0], rtol=1e-5)
+        for k, v in metrics.items():
+            assert torch.allclose(v, g[f"mse/{nt}/{k}"][0], rtol=1e-5), k
+    assert torch.equal(O.patchify(g["patchify/image3d"], (2, 3, 1)), g["patchify/out3d"])
+    assert torch.equal(O.patchify(g["patchify/image2d"], (2, 2)), g["patchify/out2d"])
+    assert torch.equal(O.unpatchify(g["patchify/out3d"], (2, 3, 1), (2, 2, 2)), g["patchify/image3d"])
+    assert torch.equal(O.unpatchify(g["patchify/out2d"], (2, 2), (2, 3)), g["patchify/image2d"])
+
+
+def test_reference_value_tables() -> None:
+    """Value tests restated from the reference's own suite (convvit_test.py:21-50, mae_test.py:15-32, vit errors)."""
+    m = torch.tensor([[[True, False], [False, True]]])
+    out = O.upsample_mask(m, (2, 2))
+    expect = torch.tensor([[[1, 1, 0, 0], [1, 1, 0, 0], [0, 0, 1, 1], [0, 0, 1, 1]]]).bool()
+    assert torch.equal(out, expect)
+    for n, r in [(16, 0.75), (10, 0.5), (7, 0.3), (512, 0.75)]:
+        mask = O.random_patch_mask(3, n, r)
+        assert mask.shape == (3, n)
+        assert int((~mask).sum()) == int(n * (1 - r)) * 3
+    assert not O.random_patch_mask(2, 5, 0.0).any()
+    with pytest.raises(ValueError):
+        O.random_patch_mask(2, 5, -0.1)
+    with pytest.raises(ValueError):
+        O.patchify(torch.zeros(1, 1, 5, 4), (2, 2))
+    with pytest.raises(ValueError):
+        O.unpatchify(torch.zeros(1, 4, 8), (2, 2), (2, 3))
