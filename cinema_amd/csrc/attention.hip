@@ -1,0 +1,570 @@
+// Flash attention forward / backward for gfx950 (no mask, no dropout), head_dim 32 / 64 on MFMA 32x32x16 bf16.
+//
+// Layout trick used by all three MFMA kernels: scores are produced TRANSPOSED so that the softmax row statistics are
+// lane-local, and the probability accumulator registers are re-used *as is* as the k-slot operand of the second
+// MFMA (the MFMA only needs both operands to agree on which reduction index sits in which k-slot):
+//   acc reg r of lane l  <->  row (r&3)+8*(r>>2)+4*(l>>5), col l&31;   regs 8s..8s+7 = the 8 k-slots of MFMA step s.
+// The operand that is strided along the reduction index (V^T, K^T, dO^T, Q^T) is read from its row-major LDS tile
+// with ds_read_b64_tr_b16.  Tiles are staged through registers into XOR-swizzled LDS, double buffered.
+#include "common.cuh"
+#include <initializer_list>
+#include <type_traits>
+#include "../../include/cinema_hip.h"
+
+namespace {
+
+struct AttnP {
+  const bf16_t* q; int ldq; const bf16_t* k; int ldk; const bf16_t* v; int ldv;
+  bf16_t* o; int ldo; float* lse;
+  const bf16_t* d_o; int lddo; float* delta;
+  bf16_t* dq; int lddq; bf16_t* dk; int lddk; bf16_t* dv; int lddv;
+  int b, h, tq, tk, hd;
+  float scale;   // softmax scale (head_dim^-0.5)
+  float c2;      // scale * log2(e)
+};
+
+constexpr float NEG_INF = -1e30f;
+
+// ---- stage a [ROWS][HD] bf16 tile (rows = tokens row0.., this head's HD columns) global -> regs -> swizzled LDS
+template <int HD, int ROWS>
+struct TileStage {
+  static constexpr int CPR = HD / 8;                 // 16-byte chunks per row
+  static constexpr int NCH = ROWS * CPR;
+  static constexpr int PASSES = (NCH + 255) / 256;
+  static constexpr int BYTES = ROWS * HD * 2;
+  uint4 r[PASSES];
+  __device__ __forceinline__ void load(const bf16_t* base, int ld, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int pss = 0; pss < PASSES; pss++) {
+      const int cid = pss * 256 + tid;
+      const int row = cid / CPR, c = cid % CPR;
+      if (cid < NCH && row0 + row < nrows) r[pss] = *reinterpret_cast<const uint4*>(base + (size_t)(row0 + row) * ld + c * 8);
+      else r[pss] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+    for (int pss = 0; pss < PASSES; pss++) {
+      const int cid = pss * 256 + tid;
+      const int row = cid / CPR, c = cid % CPR;
+      if (cid < NCH) *reinterpret_cast<uint4*>(lds + swz_off<HD * 2>(row, c)) = r[pss];
+    }
+  }
+};
+
+// K-major fragment: lane l -> tile row base+(l&31), reduction (head-dim) elements 16*ks + 8*(l>>5) .. +7
+template <int HD>
+__device__ __forceinline__ short8v frag_km(const char* lds, int base, int ks, int lane) {
+  return *reinterpret_cast<const short8v*>(lds + swz_off<HD * 2>(base + (lane & 31), ks * 2 + (lane >> 5)));
+}
+// Transposed fragment: lane l -> tile COLUMN dcol0 + (l&31) (a head-dim index), reduction = tile rows
+// rbase + 4*(l>>5) + {0..3} and + 8 + {0..3}  (matching acc-register k-slots, see header comment).
+template <int HD>
+__device__ __forceinline__ short8v frag_tr(const char* lds, int rbase, int dcol0, int lane) {
+  const int q4 = lane >> 4, t = lane & 15;
+  const int col = dcol0 + 16 * (q4 & 1) + 4 * (t & 3);
+  const int row = rbase + 4 * (q4 >> 1) + (t >> 2);
+  const short4v lo = lds_tr16_b64(lds + swz_off<HD * 2>(row, col >> 3) + (col & 7) * 2);
+  const short4v hi = lds_tr16_b64(lds + swz_off<HD * 2>(row + 8, col >> 3) + (col & 7) * 2);
+  short8v out;
+  out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+  out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+  return out;
+}
+// pack accumulator regs 8s..8s+7 to the bf16 k-slot operand
+__device__ __forceinline__ short8v pack_slots(const float16v& a, int s) {
+  union { uint32_t u[4]; short8v v; } x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) x.u[i] = pack_bf2(a[8 * s + 2 * i], a[8 * s + 2 * i + 1]);
+  return x.v;
+}
+template <int HD>
+__device__ __forceinline__ void load_row_frags(short8v (&f)[HD / 16], const bf16_t* rowptr, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ks++) f[ks] = *reinterpret_cast<const short8v*>(rowptr + ks * 16 + 8 * (lane >> 5));
+}
+__device__ __forceinline__ void zero16(float16v& a) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) a[r] = 0.f;
+}
+
+// ================================================================================================
+// forward: block = 4 waves x 32 queries; K/V tiles of 64 keys
+// ================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(AttnP p) {
+  using Stage = TileStage<HD, 64>;
+  constexpr int TB = Stage::BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TB];  // [2 stages][K | V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int qc = qrow < p.tq ? qrow : p.tq - 1;
+  const bf16_t* kbase = p.k + (size_t)b * p.tk * p.ldk + h * HD;
+  const bf16_t* vbase = p.v + (size_t)b * p.tk * p.ldv + h * HD;
+
+  short8v qf[HD / 16];
+  load_row_frags<HD>(qf, p.q + ((size_t)b * p.tq + qc) * p.ldq + h * HD, lane);
+
+  float16v o[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++) zero16(o[i]);
+  float m_run = NEG_INF, l_run = 0.f;
+
+  const int nkt = (p.tk + 63) / 64;
+  Stage sk, sv;
+  sk.load(kbase, p.ldk, 0, p.tk, tid);
+  sv.load(vbase, p.ldv, 0, p.tk, tid);
+  sk.store(smem, tid);
+  sv.store(smem + TB, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; kt++) {
+    const char* ks_ = smem + (kt & 1) * 2 * TB;
+    const char* vs_ = ks_ + TB;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      sk.load(kbase, p.ldk, (kt + 1) * 64, p.tk, tid);
+      sv.load(vbase, p.ldv, (kt + 1) * 64, p.tk, tid);
+    }
+    float16v s[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      zero16(s[u]);
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(ks_, 32 * u, ks, lane), qf[ks], s[u], 0, 0, 0);
+    }
+    // online softmax (base-2 domain); this lane owns query column lane&31, keys spread over regs (+ partner lane^32)
+    float mx = NEG_INF;
+    const int key0 = kt * 64 + 4 * g;
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = key0 + 32 * u + (r & 3) + 8 * (r >> 2);
+        const float v = key < p.tk ? s[u][r] * p.c2 : NEG_INF;
+        s[u][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float e = exp2f(s[u][r] - m_new);
+        s[u][r] = e;
+        ps += e;
+      }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+    // O^T[d][q] += V^T[d][key] * P^T[key][q]
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int st = 0; st < 2; st++) {
+        const short8v pf = pack_slots(s[u], st);
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; dt++)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(vs_, 32 * u + 16 * st, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+      }
+    if (more) {
+      char* nk = smem + ((kt + 1) & 1) * 2 * TB;
+      sk.store(nk, tid);
+      sv.store(nk + TB, tid);
+    }
+    __syncthreads();
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (qrow < p.tq) {
+    const float inv = 1.f / l_tot;
+    bf16_t* op = p.o + ((size_t)b * p.tq + qrow) * p.ldo + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; dt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint2 pk;
+        pk.x = pack_bf2(o[dt][4 * j] * inv, o[dt][4 * j + 1] * inv);
+        pk.y = pack_bf2(o[dt][4 * j + 2] * inv, o[dt][4 * j + 3] * inv);
+        *reinterpret_cast<uint2*>(op + dt * 32 + 8 * j + 4 * g) = pk;
+      }
+    if (g == 0 && p.lse) p.lse[((size_t)b * p.h + h) * p.tq + qrow] = m_run + log2f(l_tot);
+  }
+}
+
+// ================================================================================================
+// backward, dQ: block = 4 waves x 32 queries; loop over K/V tiles of 64 keys
+// ================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnP p) {
+  using Stage = TileStage<HD, 64>;
+  constexpr int TB = Stage::BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int qc = qrow < p.tq ? qrow : p.tq - 1;
+  const bf16_t* kbase = p.k + (size_t)b * p.tk * p.ldk + h * HD;
+  const bf16_t* vbase = p.v + (size_t)b * p.tk * p.ldv + h * HD;
+  short8v qf[HD / 16], dof[HD / 16];
+  load_row_frags<HD>(qf, p.q + ((size_t)b * p.tq + qc) * p.ldq + h * HD, lane);
+  load_row_frags<HD>(dof, p.d_o + ((size_t)b * p.tq + qc) * p.lddo + h * HD, lane);
+  const size_t sidx = ((size_t)b * p.h + h) * p.tq + qc;
+  const float lse = p.lse[sidx], dl = p.delta[sidx];
+
+  float16v dq[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++) zero16(dq[i]);
+
+  const int nkt = (p.tk + 63) / 64;
+  Stage sk, sv;
+  sk.load(kbase, p.ldk, 0, p.tk, tid);
+  sv.load(vbase, p.ldv, 0, p.tk, tid);
+  sk.store(smem, tid);
+  sv.store(smem + TB, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt++) {
+    const char* ks_ = smem + (kt & 1) * 2 * TB;
+    const char* vs_ = ks_ + TB;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      sk.load(kbase, p.ldk, (kt + 1) * 64, p.tk, tid);
+      sv.load(vbase, p.ldv, (kt + 1) * 64, p.tk, tid);
+    }
+    const int key0 = kt * 64 + 4 * g;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      float16v s, dp;
+      zero16(s); zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(ks_, 32 * u, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(vs_, 32 * u, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = key0 + 32 * u + (r & 3) + 8 * (r >> 2);
+        const float pr = key < p.tk ? exp2f(s[r] * p.c2 - lse) : 0.f;
+        s[r] = pr * (dp[r] - dl);  // dS^T
+      }
+#pragma unroll
+      for (int st = 0; st < 2; st++) {
+        const short8v dsf = pack_slots(s, st);
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; dt++)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ks_, 32 * u + 16 * st, 32 * dt, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      char* nk = smem + ((kt + 1) & 1) * 2 * TB;
+      sk.store(nk, tid);
+      sv.store(nk + TB, tid);
+    }
+    __syncthreads();
+  }
+  if (qrow < p.tq) {
+    bf16_t* op = p.dq + ((size_t)b * p.tq + qrow) * p.lddq + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; dt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint2 pk;
+        pk.x = pack_bf2(dq[dt][4 * j] * p.scale, dq[dt][4 * j + 1] * p.scale);
+        pk.y = pack_bf2(dq[dt][4 * j + 2] * p.scale, dq[dt][4 * j + 3] * p.scale);
+        *reinterpret_cast<uint2*>(op + dt * 32 + 8 * j + 4 * g) = pk;
+      }
+  }
+}
+
+// ================================================================================================
+// backward, dK/dV: block = 4 waves x 32 keys; loop over Q/dO tiles of 64 queries
+// ================================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
+  using Stage = TileStage<HD, 64>;
+  constexpr int TB = Stage::BYTES;
+  constexpr int ST = 2 * TB + 512;  // Q | dO | lse[64] | delta[64]
+  __shared__ __attribute__((aligned(16))) char smem[2 * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int krow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int kc = krow < p.tk ? krow : p.tk - 1;
+  const bf16_t* qbase = p.q + (size_t)b * p.tq * p.ldq + h * HD;
+  const bf16_t* dobase = p.d_o + (size_t)b * p.tq * p.lddo + h * HD;
+  const float* lsebase = p.lse + ((size_t)b * p.h + h) * p.tq;
+  const float* dlbase = p.delta + ((size_t)b * p.h + h) * p.tq;
+  short8v kf[HD / 16], vf[HD / 16];
+  load_row_frags<HD>(kf, p.k + ((size_t)b * p.tk + kc) * p.ldk + h * HD, lane);
+  load_row_frags<HD>(vf, p.v + ((size_t)b * p.tk + kc) * p.ldv + h * HD, lane);
+
+  float16v dk[HD / 32], dv[HD / 32];
+#pragma unroll
+  for (int i = 0; i < HD / 32; i++) { zero16(dk[i]); zero16(dv[i]); }
+
+  const int nqt = (p.tq + 63) / 64;
+  Stage sq, sdo;
+  float st_l = 0.f;  // threads 0..63: lse, 64..127: delta
+  auto load_stats = [&](int q0) {
+    if (tid < 128) {
+      const int qi = q0 + (tid & 63);
+      st_l = qi < p.tq ? (tid < 64 ? lsebase[qi] : dlbase[qi]) : (tid < 64 ? 1e30f : 0.f);  // lse=+big -> p=0 for padded queries
+    }
+  };
+  auto store_stats = [&](char* base) {
+    if (tid < 128) reinterpret_cast<float*>(base + 2 * TB)[tid] = st_l;
+  };
+  sq.load(qbase, p.ldq, 0, p.tq, tid);
+  sdo.load(dobase, p.lddo, 0, p.tq, tid);
+  load_stats(0);
+  sq.store(smem, tid);
+  sdo.store(smem + TB, tid);
+  store_stats(smem);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; qt++) {
+    const char* qs_ = smem + (qt & 1) * ST;
+    const char* dos_ = qs_ + TB;
+    const float* stats = reinterpret_cast<const float*>(qs_ + 2 * TB);
+    const bool more = qt + 1 < nqt;
+    if (more) {
+      sq.load(qbase, p.ldq, (qt + 1) * 64, p.tq, tid);
+      sdo.load(dobase, p.lddo, (qt + 1) * 64, p.tq, tid);
+      load_stats((qt + 1) * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      float16v s, dp;
+      zero16(s); zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(qs_, 32 * u, ks, lane), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(dos_, 32 * u, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      // acc reg r <-> query 32u + (r&3) + 8*(r>>2) + 4g of this tile; column = this lane's key
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float4 l4 = *reinterpret_cast<const float4*>(stats + 32 * u + 8 * j + 4 * g);
+        const float4 d4 = *reinterpret_cast<const float4*>(stats + 64 + 32 * u + 8 * j + 4 * g);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float pr = exp2f(s[4 * j + i] * p.c2 - lv[i]);
+          s[4 * j + i] = pr;                             // P
+          dp[4 * j + i] = pr * (dp[4 * j + i] - dv4[i]);  // dS
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < 2; st++) {
+        const short8v pf = pack_slots(s, st);
+        const short8v dsf = pack_slots(dp, st);
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; dt++) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(dos_, 32 * u + 16 * st, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(qs_, 32 * u + 16 * st, 32 * dt, lane), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      char* nb = smem + ((qt + 1) & 1) * ST;
+      sq.store(nb, tid);
+      sdo.store(nb + TB, tid);
+      store_stats(nb);
+    }
+    __syncthreads();
+  }
+  if (krow < p.tk) {
+    bf16_t* kp = p.dk + ((size_t)b * p.tk + krow) * p.lddk + h * HD;
+    bf16_t* vp = p.dv + ((size_t)b * p.tk + krow) * p.lddv + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; dt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint2 pk;
+        pk.x = pack_bf2(dk[dt][4 * j] * p.scale, dk[dt][4 * j + 1] * p.scale);
+        pk.y = pack_bf2(dk[dt][4 * j + 2] * p.scale, dk[dt][4 * j + 3] * p.scale);
+        *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * j + 4 * g) = pk;
+        pk.x = pack_bf2(dv[dt][4 * j], dv[dt][4 * j + 1]);
+        pk.y = pack_bf2(dv[dt][4 * j + 2], dv[dt][4 * j + 3]);
+        *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * j + 4 * g) = pk;
+      }
+  }
+}
+
+// delta[b,h,q] = sum_d dO*O
+__global__ void attn_delta_kernel(AttnP p) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)p.b * p.h * p.tq;
+  if (idx >= total) return;
+  const int q = (int)(idx % p.tq);
+  const int h = (int)((idx / p.tq) % p.h);
+  const int b = (int)(idx / ((long long)p.tq * p.h));
+  const bf16_t* op = p.o + ((size_t)b * p.tq + q) * p.ldo + h * p.hd;
+  const bf16_t* dop = p.d_o + ((size_t)b * p.tq + q) * p.lddo + h * p.hd;
+  float s = 0.f;
+  for (int d = 0; d < p.hd; d++) s += bf2f(op[d]) * bf2f(dop[d]);
+  p.delta[idx] = s;
+}
+
+// ================================================================================================
+// generic kernels (any head_dim <= 128): one wave per output row, scores staged in LDS
+// ================================================================================================
+__global__ __launch_bounds__(256) void attn_fwd_generic(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sc = reinterpret_cast<float*>(dyn_smem) + (size_t)wave * p.tk;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= (long long)p.b * p.h * p.tq) return;
+  const int q = (int)(row % p.tq), h = (int)((row / p.tq) % p.h), b = (int)(row / ((long long)p.tq * p.h));
+  const bf16_t* qp = p.q + ((size_t)b * p.tq + q) * p.ldq + h * p.hd;
+  float mx = NEG_INF;
+  for (int j = lane; j < p.tk; j += 64) {
+    const bf16_t* kp = p.k + ((size_t)b * p.tk + j) * p.ldk + h * p.hd;
+    float s = 0.f;
+    for (int d = 0; d < p.hd; d++) s += bf2f(qp[d]) * bf2f(kp[d]);
+    s *= p.c2;
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float l = 0.f;
+  for (int j = lane; j < p.tk; j += 64) {
+    const float e = exp2f(sc[j] - mx);
+    sc[j] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < p.hd; d += 64) {
+    float acc = 0.f;
+    // P is rounded to bf16 before the PV product, like the MFMA kernel and like a bf16 SDPA
+    for (int j = 0; j < p.tk; j++) acc += bf2f(f2bf(sc[j])) * bf2f(p.v[((size_t)b * p.tk + j) * p.ldv + h * p.hd + d]);
+    p.o[((size_t)b * p.tq + q) * p.ldo + h * p.hd + d] = f2bf(acc / l);
+  }
+  if (lane == 0 && p.lse) p.lse[row] = mx + log2f(l);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_q_generic(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ds = reinterpret_cast<float*>(dyn_smem) + (size_t)wave * p.tk;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= (long long)p.b * p.h * p.tq) return;
+  const int q = (int)(row % p.tq), h = (int)((row / p.tq) % p.h), b = (int)(row / ((long long)p.tq * p.h));
+  const bf16_t* qp = p.q + ((size_t)b * p.tq + q) * p.ldq + h * p.hd;
+  const bf16_t* dop = p.d_o + ((size_t)b * p.tq + q) * p.lddo + h * p.hd;
+  const float lse = p.lse[row], dl = p.delta[row];
+  for (int j = lane; j < p.tk; j += 64) {
+    const bf16_t* kp = p.k + ((size_t)b * p.tk + j) * p.ldk + h * p.hd;
+    const bf16_t* vp = p.v + ((size_t)b * p.tk + j) * p.ldv + h * p.hd;
+    float s = 0.f, dp = 0.f;
+    for (int d = 0; d < p.hd; d++) { s += bf2f(qp[d]) * bf2f(kp[d]); dp += bf2f(dop[d]) * bf2f(vp[d]); }
+    ds[j] = bf2f(f2bf(exp2f(s * p.c2 - lse) * (dp - dl)));
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < p.hd; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < p.tk; j++) acc += ds[j] * bf2f(p.k[((size_t)b * p.tk + j) * p.ldk + h * p.hd + d]);
+    p.dq[((size_t)b * p.tq + q) * p.lddq + h * p.hd + d] = f2bf(acc * p.scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_generic(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* pb = reinterpret_cast<float*>(dyn_smem) + (size_t)wave * 2 * p.tq;
+  float* dsb = pb + p.tq;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= (long long)p.b * p.h * p.tk) return;
+  const int j = (int)(row % p.tk), h = (int)((row / p.tk) % p.h), b = (int)(row / ((long long)p.tk * p.h));
+  const bf16_t* kp = p.k + ((size_t)b * p.tk + j) * p.ldk + h * p.hd;
+  const bf16_t* vp = p.v + ((size_t)b * p.tk + j) * p.ldv + h * p.hd;
+  for (int i = lane; i < p.tq; i += 64) {
+    const bf16_t* qp = p.q + ((size_t)b * p.tq + i) * p.ldq + h * p.hd;
+    const bf16_t* dop = p.d_o + ((size_t)b * p.tq + i) * p.lddo + h * p.hd;
+    const size_t si = ((size_t)b * p.h + h) * p.tq + i;
+    float s = 0.f, dp = 0.f;
+    for (int d = 0; d < p.hd; d++) { s += bf2f(qp[d]) * bf2f(kp[d]); dp += bf2f(dop[d]) * bf2f(vp[d]); }
+    const float pr = exp2f(s * p.c2 - p.lse[si]);
+    pb[i] = bf2f(f2bf(pr));
+    dsb[i] = bf2f(f2bf(pr * (dp - p.delta[si])));
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < p.hd; d += 64) {
+    float ak = 0.f, av = 0.f;
+    for (int i = 0; i < p.tq; i++) {
+      av += pb[i] * bf2f(p.d_o[((size_t)b * p.tq + i) * p.lddo + h * p.hd + d]);
+      ak += dsb[i] * bf2f(p.q[((size_t)b * p.tq + i) * p.ldq + h * p.hd + d]);
+    }
+    p.dk[((size_t)b * p.tk + j) * p.lddk + h * p.hd + d] = f2bf(ak * p.scale);
+    p.dv[((size_t)b * p.tk + j) * p.lddv + h * p.hd + d] = f2bf(av);
+  }
+}
+
+bool mfma_ok(int hd, int force_generic, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  if (force_generic || (hd != 32 && hd != 64)) return false;
+  for (int v : lds) if (v & 7) return false;
+  for (const void* q : ptrs) if (((uintptr_t)q) & 15) return false;
+  return true;
+}
+
+}  // namespace
+
+CINEMA_API int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
+                                    float* lse, int b, int h, int tq, int tk, int hd, float scale, int force_generic, void* stream) {
+  if (!q || !k || !v || !o || b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || hd <= 0 || hd > 128) return CINEMA_ERR_BAD_ARG;
+  AttnP p{};
+  p.q = q; p.ldq = ldq; p.k = k; p.ldk = ldk; p.v = v; p.ldv = ldv; p.o = o; p.ldo = ldo; p.lse = lse;
+  p.b = b; p.h = h; p.tq = tq; p.tk = tk; p.hd = hd; p.scale = scale; p.c2 = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo}, {q, k, v, o})) {
+    dim3 grid((tq + 127) / 128, h, b);
+    if (hd == 64) hipLaunchKernelGGL(attn_fwd_mfma<64>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_mfma<32>, grid, dim3(256), 0, st, p);
+    return launch_status();
+  }
+  const size_t smem = (size_t)4 * tk * sizeof(float);
+  if (smem > 150 * 1024) return CINEMA_ERR_UNSUPPORTED;
+  const long long rows = (long long)b * h * tq;
+  hipLaunchKernelGGL(attn_fwd_generic, dim3((unsigned)((rows + 3) / 4)), dim3(256), smem, st, p);
+  return launch_status();
+}
+
+CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+                                    int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
+                                    uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
+                                    int force_generic, void* stream) {
+  if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || hd <= 0 || hd > 128)
+    return CINEMA_ERR_BAD_ARG;
+  AttnP p{};
+  p.q = q; p.ldq = ldq; p.k = k; p.ldk = ldk; p.v = v; p.ldv = ldv; p.o = const_cast<uint16_t*>(o); p.ldo = ldo;
+  p.lse = const_cast<float*>(lse); p.d_o = d_o; p.lddo = lddo; p.delta = delta;
+  p.dq = dq; p.lddq = lddq; p.dk = dk; p.lddk = lddk; p.dv = dv; p.lddv = lddv;
+  p.b = b; p.h = h; p.tq = tq; p.tk = tk; p.hd = hd; p.scale = scale; p.c2 = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  const long long nq = (long long)b * h * tq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, p);
+  if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv})) {
+    dim3 gq((tq + 127) / 128, h, b), gk((tk + 127) / 128, h, b);
+    if (hd == 64) {
+      hipLaunchKernelGGL(attn_bwd_dq_mfma<64>, gq, dim3(256), 0, st, p);
+      hipLaunchKernelGGL(attn_bwd_dkv_mfma<64>, gk, dim3(256), 0, st, p);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dq_mfma<32>, gq, dim3(256), 0, st, p);
+      hipLaunchKernelGGL(attn_bwd_dkv_mfma<32>, gk, dim3(256), 0, st, p);
+    }
+    return launch_status();
+  }
+  if ((size_t)4 * tk * sizeof(float) > 150 * 1024 || (size_t)8 * tq * sizeof(float) > 150 * 1024) return CINEMA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_bwd_q_generic, dim3((unsigned)((nq + 3) / 4)), dim3(256), (size_t)4 * tk * sizeof(float), st, p);
+  const long long nk = (long long)b * h * tk;
+  hipLaunchKernelGGL(attn_bwd_kv_generic, dim3((unsigned)((nk + 3) / 4)), dim3(256), (size_t)8 * tq * sizeof(float), st, p);
+  return launch_status();
+}

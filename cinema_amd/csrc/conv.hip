@@ -1,0 +1,343 @@
+// Channels-last depthwise convolution (MaskedConvBlock.dw_conv) and non-overlapping patch gather/scatter
+// (patchify / k==s convolutions) for gfx950.  HBM/L2-bound integer-indexed data movement + VALU FMAs: 16-byte
+// accesses along the channel axis, weights staged once per block in LDS, sliding z-window register reuse in the
+// weight-gradient kernel.
+#include "common.cuh"
+#include "../../include/cinema_hip.h"
+
+namespace {
+
+struct DwP {
+  const bf16_t* x; const bf16_t* dy; const float* w; const float* bias; bf16_t* y;
+  float* dw; float* dbias;
+  int b, X, Y, Z, c, kx, ky, kz;
+  int flip;  // 1: correlate with the flipped kernel (data gradient)
+};
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(u.x & 0xffff)); f[1] = bf2f((bf16_t)(u.x >> 16));
+  f[2] = bf2f((bf16_t)(u.y & 0xffff)); f[3] = bf2f((bf16_t)(u.y >> 16));
+  f[4] = bf2f((bf16_t)(u.z & 0xffff)); f[5] = bf2f((bf16_t)(u.z >> 16));
+  f[6] = bf2f((bf16_t)(u.w & 0xffff)); f[7] = bf2f((bf16_t)(u.w >> 16));
+}
+
+// y[v, c] = bias[c] + sum_t w[c][t] * x[v + t - r, c]; block = 64 voxels x 4 groups of 8 channels (one 32-channel slab)
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwP p) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* wl = reinterpret_cast<float*>(dyn_smem);  // [taps][32]
+  const int taps = p.kx * p.ky * p.kz;
+  const int c0 = blockIdx.y * 32;
+  for (int i = threadIdx.x; i < taps * 32; i += 256) {
+    const int t = i >> 5, cc = i & 31;
+    const int ts = p.flip ? taps - 1 - t : t;
+    wl[i] = (c0 + cc < p.c) ? p.w[(size_t)(c0 + cc) * taps + ts] : 0.f;
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 3;
+  const int ch = c0 + cg * 8;
+  const long long nvox = (long long)p.b * p.X * p.Y * p.Z;
+  const long long vox = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (vox >= nvox || ch >= p.c) return;
+  const int z = (int)(vox % p.Z), y = (int)((vox / p.Z) % p.Y), x = (int)((vox / ((long long)p.Z * p.Y)) % p.X);
+  const long long bb = vox / ((long long)p.Z * p.Y * p.X);
+  const int rx = p.kx >> 1, ry = p.ky >> 1, rz = p.kz >> 1;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = p.bias ? p.bias[ch + i] : 0.f;
+  for (int i = 0; i < p.kx; i++) {
+    const int xx = x + i - rx;
+    if (xx < 0 || xx >= p.X) continue;
+    for (int j = 0; j < p.ky; j++) {
+      const int yy = y + j - ry;
+      if (yy < 0 || yy >= p.Y) continue;
+      for (int k = 0; k < p.kz; k++) {
+        const int zz = z + k - rz;
+        if (zz < 0 || zz >= p.Z) continue;
+        const size_t src = ((((size_t)bb * p.X + xx) * p.Y + yy) * p.Z + zz) * p.c + ch;
+        const uint4 u = *reinterpret_cast<const uint4*>(p.x + src);
+        float f[8];
+        unpack8(u, f);
+        const float* wt = wl + ((i * p.ky + j) * p.kz + k) * 32 + cg * 8;
+        const float4 w0 = *reinterpret_cast<const float4*>(wt), w1 = *reinterpret_cast<const float4*>(wt + 4);
+        acc[0] = fmaf(w0.x, f[0], acc[0]); acc[1] = fmaf(w0.y, f[1], acc[1]); acc[2] = fmaf(w0.z, f[2], acc[2]); acc[3] = fmaf(w0.w, f[3], acc[3]);
+        acc[4] = fmaf(w1.x, f[4], acc[4]); acc[5] = fmaf(w1.y, f[5], acc[5]); acc[6] = fmaf(w1.z, f[6], acc[6]); acc[7] = fmaf(w1.w, f[7], acc[7]);
+      }
+    }
+  }
+  uint4 o;
+  o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]); o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
+  *reinterpret_cast<uint4*>(p.y + (size_t)vox * p.c + ch) = o;
+}
+
+// Weight gradient with a sliding window along z (kz == KZ): thread = (tap_xy, channel group of 8); it walks whole z
+// columns of its block's (b, x, y) set, re-using the KZ-wide x window in registers: 2 loads per KZ*8 FMAs.
+template <int KZ>
+__global__ void dwconv_wgrad_walk_kernel(DwP p, int cols_per_block) {
+  const int ncg = min(8, (p.c - blockIdx.y * 64) / 8);
+  const int nxy = p.kx * p.ky;
+  const int role = threadIdx.x;
+  if (role >= nxy * ncg) return;
+  const int cg = role % ncg, txy = role / ncg;
+  const int ti = txy / p.ky, tj = txy % p.ky;
+  const int ch = blockIdx.y * 64 + cg * 8;
+  const int rx = p.kx >> 1, ry = p.ky >> 1;
+  constexpr int RZ = KZ / 2;
+  float acc[KZ][8];
+  float accb[8];
+#pragma unroll
+  for (int k = 0; k < KZ; k++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[k][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) accb[i] = 0.f;
+  const bool center = (ti == rx && tj == ry);
+  const long long ncols = (long long)p.b * p.X * p.Y;
+  const long long col_begin = (long long)blockIdx.x * cols_per_block;
+  const long long col_end = min(ncols, col_begin + cols_per_block);
+  for (long long col = col_begin; col < col_end; col++) {
+    const int y = (int)(col % p.Y), x = (int)((col / p.Y) % p.X);
+    const long long bb = col / ((long long)p.Y * p.X);
+    const int xx = x + ti - rx, yy = y + tj - ry;
+    if (xx < 0 || xx >= p.X || yy < 0 || yy >= p.Y) continue;
+    const bf16_t* xcol = p.x + ((((size_t)bb * p.X + xx) * p.Y + yy) * p.Z) * p.c + ch;
+    const bf16_t* dcol = p.dy + ((size_t)col * p.Z) * p.c + ch;
+    // window win[k] = x[z + k - RZ]
+    float win[KZ][8];
+#pragma unroll
+    for (int k = 0; k < KZ; k++) {
+      const int zz = k - RZ;
+      if (zz >= 0 && zz < p.Z) { const uint4 u = *reinterpret_cast<const uint4*>(xcol + (size_t)zz * p.c); unpack8(u, win[k]); }
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) win[k][i] = 0.f;
+      }
+    }
+    for (int z = 0; z < p.Z; z++) {
+      float d[8];
+      { const uint4 u = *reinterpret_cast<const uint4*>(dcol + (size_t)z * p.c); unpack8(u, d); }
+#pragma unroll
+      for (int k = 0; k < KZ; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[k][i] = fmaf(d[i], win[k][i], acc[k][i]);
+      if (center) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) accb[i] += d[i];
+      }
+      // slide
+#pragma unroll
+      for (int k = 0; k + 1 < KZ; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) win[k][i] = win[k + 1][i];
+      const int zn = z + 1 + RZ;
+      if (zn < p.Z) { const uint4 u = *reinterpret_cast<const uint4*>(xcol + (size_t)zn * p.c); unpack8(u, win[KZ - 1]); }
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) win[KZ - 1][i] = 0.f;
+      }
+    }
+  }
+  const int taps = nxy * KZ;
+#pragma unroll
+  for (int k = 0; k < KZ; k++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) unsafeAtomicAdd(p.dw + (size_t)(ch + i) * taps + txy * KZ + k, acc[k][i]);
+  if (center && p.dbias) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) unsafeAtomicAdd(p.dbias + ch + i, accb[i]);
+  }
+}
+
+// naive weight gradient for other kernel extents: thread = (tap, channel); each block reduces a voxel chunk
+__global__ __launch_bounds__(256) void dwconv_wgrad_naive_kernel(DwP p, long long vox_per_block) {
+  const int taps = p.kx * p.ky * p.kz;
+  const long long nvox = (long long)p.b * p.X * p.Y * p.Z;
+  const long long v0 = (long long)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+  const int rx = p.kx >> 1, ry = p.ky >> 1, rz = p.kz >> 1;
+  for (int role = threadIdx.x; role < taps * p.c; role += blockDim.x) {
+    const int ch = role % p.c, t = role / p.c;
+    const int k = t % p.kz, j = (t / p.kz) % p.ky, i = t / (p.kz * p.ky);
+    float acc = 0.f, accb = 0.f;
+    for (long long vox = v0; vox < v1; vox++) {
+      const int z = (int)(vox % p.Z), y = (int)((vox / p.Z) % p.Y), x = (int)((vox / ((long long)p.Z * p.Y)) % p.X);
+      const long long bb = vox / ((long long)p.Z * p.Y * p.X);
+      const float d = bf2f(p.dy[(size_t)vox * p.c + ch]);
+      accb += d;
+      const int xx = x + i - rx, yy = y + j - ry, zz = z + k - rz;
+      if (xx < 0 || xx >= p.X || yy < 0 || yy >= p.Y || zz < 0 || zz >= p.Z) continue;
+      acc = fmaf(d, bf2f(p.x[((((size_t)bb * p.X + xx) * p.Y + yy) * p.Z + zz) * p.c + ch]), acc);
+    }
+    unsafeAtomicAdd(p.dw + (size_t)ch * taps + t, acc);
+    if (p.dbias && t == (rx * p.ky + ry) * p.kz + rz) unsafeAtomicAdd(p.dbias + ch, accb);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct PatchP {
+  int b, c, gx, gy, gz, px, py, pz;
+  long long sb, sc, sx, sy, sz;
+  int n_rows;
+  const int* token_idx;
+};
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+__device__ __forceinline__ long long patch_src_offset(const PatchP& g, int row, int f, int& cc) {
+  const int tok = g.token_idx ? g.token_idx[row] : row;
+  const int G = g.gx * g.gy * g.gz;
+  const int bb = tok / G, gi = tok % G;
+  const int iz = gi % g.gz, iy = (gi / g.gz) % g.gy, ix = gi / (g.gz * g.gy);
+  cc = f % g.c;
+  const int pf = f / g.c;
+  const int kz = pf % g.pz, ky = (pf / g.pz) % g.py, kx = pf / (g.pz * g.py);
+  return (long long)bb * g.sb + (long long)(ix * g.px + kx) * g.sx + (long long)(iy * g.py + ky) * g.sy +
+         (long long)(iz * g.pz + kz) * g.sz + (long long)cc * g.sc;
+}
+
+// VEC=4: c % 4 == 0 and sc == 1 (channels-last source), 4 consecutive features share one patch voxel
+template <typename TS, typename TO, int VEC>
+__global__ void patch_gather_kernel(const TS* src, TO* out, int ld_out, PatchP g) {
+  const int F = g.px * g.py * g.pz * g.c;
+  const long long total = (long long)g.n_rows * (F / VEC);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / (F / VEC)), f = (int)(i % (F / VEC)) * VEC;
+    int cc;
+    const long long off = patch_src_offset(g, row, f, cc);
+#pragma unroll
+    for (int v = 0; v < VEC; v++) stf<TO>(out + (size_t)row * ld_out + f + v, ldf<TS>(src + off + v));
+  }
+}
+
+template <typename TR, typename TD, int VEC>
+__global__ void patch_scatter_kernel(const TR* rows, int ld_rows, TD* dst, int accumulate, PatchP g) {
+  const int F = g.px * g.py * g.pz * g.c;
+  const long long total = (long long)g.n_rows * (F / VEC);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / (F / VEC)), f = (int)(i % (F / VEC)) * VEC;
+    int cc;
+    const long long off = patch_src_offset(g, row, f, cc);
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+      float val = ldf<TR>(rows + (size_t)row * ld_rows + f + v);
+      if (accumulate) val += ldf<TD>(dst + off + v);
+      stf<TD>(dst + off + v, val);
+    }
+  }
+}
+
+PatchP to_dev(const cinema_patch_geom* g) {
+  PatchP p;
+  p.b = g->b; p.c = g->c; p.gx = g->gx; p.gy = g->gy; p.gz = g->gz; p.px = g->px; p.py = g->py; p.pz = g->pz;
+  p.sb = g->sb; p.sc = g->sc; p.sx = g->sx; p.sy = g->sy; p.sz = g->sz; p.n_rows = g->n_rows; p.token_idx = g->token_idx;
+  return p;
+}
+bool geom_ok(const cinema_patch_geom* g) {
+  return g && g->b > 0 && g->c > 0 && g->gx > 0 && g->gy > 0 && g->gz > 0 && g->px > 0 && g->py > 0 && g->pz > 0 && g->n_rows > 0;
+}
+int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+static int dw_check(int b, int X, int Y, int Z, int c, int kx, int ky, int kz) {
+  if (b <= 0 || X <= 0 || Y <= 0 || Z <= 0 || c <= 0 || kx <= 0 || ky <= 0 || kz <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((c & 7) || !(kx & 1) || !(ky & 1) || !(kz & 1)) return CINEMA_ERR_UNSUPPORTED;
+  return 0;
+}
+
+static int dw_launch_fwd(const DwP& p, hipStream_t st) {
+  const long long nvox = (long long)p.b * p.X * p.Y * p.Z;
+  dim3 grid((unsigned)((nvox + 63) / 64), (p.c + 31) / 32);
+  const size_t smem = (size_t)p.kx * p.ky * p.kz * 32 * sizeof(float);
+  hipLaunchKernelGGL(dwconv_fwd_kernel, grid, dim3(256), smem, st, p);
+  return launch_status();
+}
+
+CINEMA_API int cinema_dwconv_fwd(const uint16_t* x, const float* w, const float* bias, uint16_t* y, int b, int X, int Y, int Z, int c, int kx,
+                                 int ky, int kz, void* stream) {
+  if (!x || !w || !y) return CINEMA_ERR_BAD_ARG;
+  if (int e = dw_check(b, X, Y, Z, c, kx, ky, kz)) return e;
+  DwP p{}; p.x = x; p.w = w; p.bias = bias; p.y = y; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.flip = 0;
+  return dw_launch_fwd(p, (hipStream_t)stream);
+}
+
+CINEMA_API int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, int b, int X, int Y, int Z, int c, int kx, int ky, int kz,
+                                      void* stream) {
+  if (!dy || !w || !dx) return CINEMA_ERR_BAD_ARG;
+  if (int e = dw_check(b, X, Y, Z, c, kx, ky, kz)) return e;
+  DwP p{}; p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.flip = 1;
+  return dw_launch_fwd(p, (hipStream_t)stream);
+}
+
+CINEMA_API int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, int b, int X, int Y, int Z, int c, int kx,
+                                        int ky, int kz, void* stream) {
+  if (!x || !dy || !dw) return CINEMA_ERR_BAD_ARG;
+  if (int e = dw_check(b, X, Y, Z, c, kx, ky, kz)) return e;
+  DwP p{}; p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz;
+  hipStream_t st = (hipStream_t)stream;
+  if (kz == 5 && kx * ky * 8 <= 1024) {
+    const long long ncols = (long long)b * X * Y;
+    int cpb = (int)((ncols + 1023) / 1024);
+    if (cpb < 4) cpb = 4;
+    dim3 grid((unsigned)((ncols + cpb - 1) / cpb), (c + 63) / 64);
+    int threads = kx * ky * 8;
+    threads = ((threads + 63) / 64) * 64;
+    hipLaunchKernelGGL(dwconv_wgrad_walk_kernel<5>, grid, dim3(threads), 0, st, p, cpb);
+    return launch_status();
+  }
+  const long long nvox = (long long)b * X * Y * Z;
+  long long vpb = (nvox + 511) / 512;
+  if (vpb < 64) vpb = 64;
+  hipLaunchKernelGGL(dwconv_wgrad_naive_kernel, dim3((unsigned)((nvox + vpb - 1) / vpb)), dim3(256), 0, st, p, vpb);
+  return launch_status();
+}
+
+CINEMA_API int cinema_patch_gather(const void* src, int src_dtype, void* out, int out_dtype, int ld_out, const cinema_patch_geom* geom,
+                                   void* stream) {
+  if (!src || !out || !geom_ok(geom)) return CINEMA_ERR_BAD_ARG;
+  const PatchP g = to_dev(geom);
+  const long long F = (long long)g.px * g.py * g.pz * g.c;
+  const bool vec = (g.c % 4 == 0) && g.sc == 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long long)g.n_rows * F / (vec ? 4 : 1), 256);
+#define CINEMA_PG(TS, TO)                                                                                                  \
+  do {                                                                                                                     \
+    if (vec) hipLaunchKernelGGL((patch_gather_kernel<TS, TO, 4>), dim3(grid), dim3(256), 0, st, (const TS*)src, (TO*)out, ld_out, g); \
+    else hipLaunchKernelGGL((patch_gather_kernel<TS, TO, 1>), dim3(grid), dim3(256), 0, st, (const TS*)src, (TO*)out, ld_out, g);     \
+  } while (0)
+  if (src_dtype == 1 && out_dtype == 0) CINEMA_PG(float, bf16_t);
+  else if (src_dtype == 1 && out_dtype == 1) CINEMA_PG(float, float);
+  else if (src_dtype == 0 && out_dtype == 0) CINEMA_PG(bf16_t, bf16_t);
+  else if (src_dtype == 0 && out_dtype == 1) CINEMA_PG(bf16_t, float);
+  else return CINEMA_ERR_BAD_ARG;
+#undef CINEMA_PG
+  return launch_status();
+}
+
+CINEMA_API int cinema_patch_scatter(const void* rows, int rows_dtype, int ld_rows, void* dst, int dst_dtype, int accumulate,
+                                    const cinema_patch_geom* geom, void* stream) {
+  if (!rows || !dst || !geom_ok(geom)) return CINEMA_ERR_BAD_ARG;
+  const PatchP g = to_dev(geom);
+  const long long F = (long long)g.px * g.py * g.pz * g.c;
+  const bool vec = (g.c % 4 == 0) && g.sc == 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long long)g.n_rows * F / (vec ? 4 : 1), 256);
+#define CINEMA_PS(TR, TD)                                                                                                                 \
+  do {                                                                                                                                    \
+    if (vec) hipLaunchKernelGGL((patch_scatter_kernel<TR, TD, 4>), dim3(grid), dim3(256), 0, st, (const TR*)rows, ld_rows, (TD*)dst, accumulate, g); \
+    else hipLaunchKernelGGL((patch_scatter_kernel<TR, TD, 1>), dim3(grid), dim3(256), 0, st, (const TR*)rows, ld_rows, (TD*)dst, accumulate, g);     \
+  } while (0)
+  if (rows_dtype == 0 && dst_dtype == 0) CINEMA_PS(bf16_t, bf16_t);
+  else if (rows_dtype == 0 && dst_dtype == 1) CINEMA_PS(bf16_t, float);
+  else if (rows_dtype == 1 && dst_dtype == 1) CINEMA_PS(float, float);
+  else if (rows_dtype == 1 && dst_dtype == 0) CINEMA_PS(float, bf16_t);
+  else return CINEMA_ERR_BAD_ARG;
+#undef CINEMA_PS
+  return launch_status();
+}

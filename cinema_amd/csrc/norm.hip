@@ -1,0 +1,238 @@
+// LayerNorm forward / backward for gfx950: sub-wave row groups (4..64 lanes per row), 16-byte accesses,
+// xor-shuffle reductions, optional fused exact GELU (ConvNormActBlock), fused residual-gradient add and
+// bf16 copy in the backward, dgamma/dbeta block-reduced then fp32 atomics.
+#include "common.cuh"
+#include <initializer_list>
+#include <type_traits>
+#include "../../include/cinema_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float4 load4(const void* base, bool is_bf16, size_t off) {
+  if (is_bf16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + off);
+    return make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+}
+__device__ __forceinline__ void store4_bf16(bf16_t* p, float4 v) {
+  uint2 u; u.x = pack_bf2(v.x, v.y); u.y = pack_bf2(v.z, v.w);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct LnFwdP {
+  const void* x; int x_bf16; int ldx;
+  const float* gamma; const float* beta;
+  int rows, c; float eps; int act;
+  bf16_t* y_bf16; float* y_f32; int ldy;
+  float* mean; float* rstd;
+  int lpr;  // lanes per row (power of two, <= 64)
+};
+
+template <int CPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (p.lpr - 1);
+  const int rows_per_wave = 64 / p.lpr;
+  const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * (blockDim.x >> 6);
+  const int nch = p.c >> 2;
+  const float inv_c = 1.f / (float)p.c;
+  for (int row0 = wave_global * rows_per_wave; row0 < p.rows; row0 += n_waves * rows_per_wave) {
+    const int row = row0 + lane / p.lpr;
+    const bool rv = row < p.rows;
+    float4 v[CPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const int ch = sub + i * p.lpr;
+      v[i] = (rv && ch < nch) ? load4(p.x, p.x_bf16, (size_t)row * p.ldx + ch * 4) : make_float4(0, 0, 0, 0);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mu = group_sum(s, p.lpr) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const int ch = sub + i * p.lpr;
+      if (ch < nch) {
+        const float a = v[i].x - mu, b = v[i].y - mu, c2 = v[i].z - mu, d = v[i].w - mu;
+        q += a * a + b * b + c2 * c2 + d * d;
+      }
+    }
+    const float rs = rsqrtf(group_sum(q, p.lpr) * inv_c + p.eps);
+    if (!rv) continue;
+    if (sub == 0) {
+      if (p.mean) p.mean[row] = mu;
+      if (p.rstd) p.rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const int ch = sub + i * p.lpr;
+      if (ch >= nch) continue;
+      const float4 g = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
+      const float4 b = *reinterpret_cast<const float4*>(p.beta + ch * 4);
+      float4 y;
+      y.x = (v[i].x - mu) * rs * g.x + b.x; y.y = (v[i].y - mu) * rs * g.y + b.y;
+      y.z = (v[i].z - mu) * rs * g.z + b.z; y.w = (v[i].w - mu) * rs * g.w + b.w;
+      if (p.act == 1) { y.x = gelu_f(y.x); y.y = gelu_f(y.y); y.z = gelu_f(y.z); y.w = gelu_f(y.w); }
+      if (p.y_bf16) store4_bf16(p.y_bf16 + (size_t)row * p.ldy + ch * 4, y);
+      if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + (size_t)row * p.ldy + ch * 4) = y;
+    }
+  }
+}
+
+struct LnBwdP {
+  const void* dy; int dy_bf16; int lddy;
+  const void* x; int x_bf16; int ldx;
+  const float* gamma; const float* beta; const float* mean; const float* rstd;
+  int rows, c, act;
+  const float* dx_res; float* dx_f32; bf16_t* dx_bf16; int lddx;
+  float* dgamma; float* dbeta;
+  int lpr;
+};
+
+template <int CPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* red = reinterpret_cast<float*>(dyn_smem);  // [n_waves_in_block][2][c]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int sub = lane & (p.lpr - 1);
+  const int rows_per_wave = 64 / p.lpr;
+  const int wave_global = blockIdx.x * nw + wave;
+  const int n_waves = gridDim.x * nw;
+  const int nch = p.c >> 2;
+  const float inv_c = 1.f / (float)p.c;
+  float4 ag[CPL], ab[CPL];
+#pragma unroll
+  for (int i = 0; i < CPL; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+
+  for (int row0 = wave_global * rows_per_wave; row0 < p.rows; row0 += n_waves * rows_per_wave) {
+    const int row = row0 + lane / p.lpr;
+    const bool rv = row < p.rows;
+    const float mu = rv ? p.mean[row] : 0.f, rs = rv ? p.rstd[row] : 0.f;
+    float4 xh[CPL], dxh[CPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const int ch = sub + i * p.lpr;
+      xh[i] = make_float4(0, 0, 0, 0); dxh[i] = make_float4(0, 0, 0, 0);
+      if (rv && ch < nch) {
+        const float4 xv = load4(p.x, p.x_bf16, (size_t)row * p.ldx + ch * 4);
+        float4 d = load4(p.dy, p.dy_bf16, (size_t)row * p.lddy + ch * 4);
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        if (p.act == 1) {
+          const float4 b = *reinterpret_cast<const float4*>(p.beta + ch * 4);
+          d.x *= gelu_grad_f(xh[i].x * g.x + b.x); d.y *= gelu_grad_f(xh[i].y * g.y + b.y);
+          d.z *= gelu_grad_f(xh[i].z * g.z + b.z); d.w *= gelu_grad_f(xh[i].w * g.w + b.w);
+        }
+        ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        dxh[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        s1 += dxh[i].x + dxh[i].y + dxh[i].z + dxh[i].w;
+        s2 += dxh[i].x * xh[i].x + dxh[i].y * xh[i].y + dxh[i].z * xh[i].z + dxh[i].w * xh[i].w;
+      }
+    }
+    s1 = group_sum(s1, p.lpr) * inv_c;
+    s2 = group_sum(s2, p.lpr) * inv_c;
+    if (!rv) continue;
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const int ch = sub + i * p.lpr;
+      if (ch >= nch) continue;
+      float4 dx;
+      dx.x = rs * (dxh[i].x - s1 - xh[i].x * s2); dx.y = rs * (dxh[i].y - s1 - xh[i].y * s2);
+      dx.z = rs * (dxh[i].z - s1 - xh[i].z * s2); dx.w = rs * (dxh[i].w - s1 - xh[i].w * s2);
+      const size_t off = (size_t)row * p.lddx + ch * 4;
+      if (p.dx_res) {
+        const float4 r = *reinterpret_cast<const float4*>(p.dx_res + off);
+        dx.x += r.x; dx.y += r.y; dx.z += r.z; dx.w += r.w;
+      }
+      if (p.dx_f32) *reinterpret_cast<float4*>(p.dx_f32 + off) = dx;
+      if (p.dx_bf16) store4_bf16(p.dx_bf16 + off, dx);
+    }
+  }
+  if (!p.dgamma && !p.dbeta) return;
+  // reduce over the row sub-groups of the wave (lanes that own the same columns), then over the block's waves
+#pragma unroll
+  for (int i = 0; i < CPL; i++) {
+    for (int o = p.lpr; o < 64; o <<= 1) {
+      ag[i].x += __shfl_xor(ag[i].x, o, 64); ag[i].y += __shfl_xor(ag[i].y, o, 64);
+      ag[i].z += __shfl_xor(ag[i].z, o, 64); ag[i].w += __shfl_xor(ag[i].w, o, 64);
+      ab[i].x += __shfl_xor(ab[i].x, o, 64); ab[i].y += __shfl_xor(ab[i].y, o, 64);
+      ab[i].z += __shfl_xor(ab[i].z, o, 64); ab[i].w += __shfl_xor(ab[i].w, o, 64);
+    }
+    const int ch = sub + i * p.lpr;
+    if (lane < p.lpr && ch < nch) {
+      *reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 0) * p.c + ch * 4) = ag[i];
+      *reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 1) * p.c + ch * 4) = ab[i];
+    }
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < p.c; col += blockDim.x) {
+    float g = 0.f, b = 0.f;
+    for (int w = 0; w < nw; w++) { g += red[(size_t)(w * 2 + 0) * p.c + col]; b += red[(size_t)(w * 2 + 1) * p.c + col]; }
+    if (p.dgamma) unsafeAtomicAdd(p.dgamma + col, g);
+    if (p.dbeta) unsafeAtomicAdd(p.dbeta + col, b);
+  }
+}
+
+int pick_lpr(int c) {
+  int nch = c >> 2, l = 1;
+  while (l < nch && l < 64) l <<= 1;
+  return l;
+}
+
+template <typename P, typename F>
+int dispatch_cpl(int cpl, F&& f) {
+  if (cpl <= 1) return f(std::integral_constant<int, 1>{});
+  if (cpl <= 2) return f(std::integral_constant<int, 2>{});
+  if (cpl <= 3) return f(std::integral_constant<int, 3>{});
+  if (cpl <= 4) return f(std::integral_constant<int, 4>{});
+  if (cpl <= 5) return f(std::integral_constant<int, 5>{});
+  if (cpl <= 8) return f(std::integral_constant<int, 8>{});
+  if (cpl <= 12) return f(std::integral_constant<int, 12>{});
+  if (cpl <= 16) return f(std::integral_constant<int, 16>{});
+  return CINEMA_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
+                                    int act, uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, void* stream) {
+  if (!x || !gamma || !beta || rows <= 0 || c <= 0 || (!y_bf16 && !y_f32)) return CINEMA_ERR_BAD_ARG;
+  if ((c & 3) || (ldx & 3) || (ldy & 3)) return CINEMA_ERR_UNSUPPORTED;
+  LnFwdP p{x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, pick_lpr(c)};
+  const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
+  const int rows_per_block = 4 * (64 / p.lpr);
+  int grid = (rows + rows_per_block - 1) / rows_per_block;
+  if (grid > 8192) grid = 8192;
+  return dispatch_cpl<LnFwdP>(cpl, [&](auto tag) {
+    hipLaunchKernelGGL((ln_fwd_kernel<decltype(tag)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status();
+  });
+}
+
+CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
+                                    const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
+                                    const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
+                                    void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
+  if (act == 1 && !beta) return CINEMA_ERR_BAD_ARG;
+  if ((c & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CINEMA_ERR_UNSUPPORTED;
+  LnBwdP p{dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
+           pick_lpr(c)};
+  const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
+  const int rows_per_block = 4 * (64 / p.lpr);
+  int grid = (rows + rows_per_block - 1) / rows_per_block;
+  if (grid > 1024) grid = 1024;
+  const size_t smem = (size_t)4 * 2 * c * sizeof(float);
+  return dispatch_cpl<LnBwdP>(cpl, [&](auto tag) {
+    hipLaunchKernelGGL((ln_bwd_kernel<decltype(tag)::value>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    return launch_status();
+  });
+}

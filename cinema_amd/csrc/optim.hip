@@ -1,0 +1,102 @@
+// Optimiser kernels for gfx950 (flat fp32 buffers, HBM-bound): global grad-norm, clip coefficient, fused AdamW
+// with optional bf16 shadow-weight emission.  Reference semantics: torch.optim.AdamW + clip_grad_norm_ as driven by
+// cinema/optim.py:204-215 and cinema/mae/pretrain.py:365-366.
+#include "common.cuh"
+#include "../../include/cinema_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* out) {
+  __shared__ float part[4];
+  float s = 0.f;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
+__global__ void clip_coef_kernel(const float* sq, float max_norm, float* coef, float* norm_out) {
+  if (threadIdx.x || blockIdx.x) return;
+  const float nrm = sqrtf(sq[0]);
+  if (norm_out) norm_out[0] = nrm;
+  if (coef) coef[0] = max_norm > 0.f ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
+}
+
+struct AdamP {
+  float* p; const float* g; float* m; float* v; long long n;
+  float lr, b1, b2, eps, wd, bc1, bc2;
+  const float* clip; bf16_t* shadow;
+};
+
+__device__ __forceinline__ float adam1(float& p, float g, float& m, float& v, const AdamP& a, float cc) {
+  g *= cc;
+  p *= (1.f - a.lr * a.wd);
+  m = a.b1 * m + (1.f - a.b1) * g;
+  v = a.b2 * v + (1.f - a.b2) * g * g;
+  const float denom = sqrtf(v) / sqrtf(a.bc2) + a.eps;
+  p -= (a.lr / a.bc1) * (m / denom);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
+  const float cc = a.clip ? a.clip[0] : 1.f;
+  const long long n4 = a.n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 p = reinterpret_cast<float4*>(a.p)[i];
+    const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+    float4 m = reinterpret_cast<float4*>(a.m)[i];
+    float4 v = reinterpret_cast<float4*>(a.v)[i];
+    adam1(p.x, g.x, m.x, v.x, a, cc); adam1(p.y, g.y, m.y, v.y, a, cc);
+    adam1(p.z, g.z, m.z, v.z, a, cc); adam1(p.w, g.w, m.w, v.w, a, cc);
+    reinterpret_cast<float4*>(a.p)[i] = p;
+    reinterpret_cast<float4*>(a.m)[i] = m;
+    reinterpret_cast<float4*>(a.v)[i] = v;
+    if (a.shadow) {
+      uint2 u; u.x = pack_bf2(p.x, p.y); u.y = pack_bf2(p.z, p.w);
+      reinterpret_cast<uint2*>(a.shadow)[i] = u;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    const long long j = n4 * 4 + threadIdx.x;
+    const float r = adam1(a.p[j], a.g[j], a.m[j], a.v[j], a, cc);
+    if (a.shadow) a.shadow[j] = f2bf(r);
+  }
+}
+
+}  // namespace
+
+CINEMA_API int cinema_sqnorm_f32(const float* g, long long n, float* out, void* stream) {
+  if (!g || !out || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if (((uintptr_t)g) & 15) return CINEMA_ERR_UNSUPPORTED;
+  long long grid = (n / 4 + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  return launch_status();
+}
+
+CINEMA_API int cinema_clip_coef(const float* sqnorm, float max_norm, float* coef_out, float* norm_out, void* stream) {
+  if (!sqnorm) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sqnorm, max_norm, coef_out, norm_out);
+  return launch_status();
+}
+
+CINEMA_API int cinema_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float bias_corr1, float bias_corr2, const float* clip_coef, uint16_t* p_bf16, void* stream) {
+  if (!p || !g || !m || !v || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CINEMA_ERR_UNSUPPORTED;
+  if (p_bf16 && (((uintptr_t)p_bf16) & 7)) return CINEMA_ERR_UNSUPPORTED;
+  AdamP a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, clip_coef, p_bf16};
+  long long grid = (n / 4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}

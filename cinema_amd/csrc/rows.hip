@@ -1,0 +1,160 @@
+// Row gather/scatter/add, dtype casts, transposes and elementwise GELU for gfx950 (HBM-bound data movement).
+#include "common.cuh"
+#include "../../include/cinema_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const void* base, int dtype, size_t off) {
+  if (dtype == 0) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + off);
+    return make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+}
+__device__ __forceinline__ void st4(void* base, int dtype, size_t off, float4 v) {
+  if (dtype == 0) {
+    uint2 u; u.x = pack_bf2(v.x, v.y); u.y = pack_bf2(v.z, v.w);
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(base) + off) = u;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = v;
+  }
+}
+__device__ __forceinline__ float ld1(const void* base, int dtype, size_t off) {
+  return dtype == 0 ? bf2f(reinterpret_cast<const bf16_t*>(base)[off]) : reinterpret_cast<const float*>(base)[off];
+}
+__device__ __forceinline__ void st1(void* base, int dtype, size_t off, float v) {
+  if (dtype == 0) reinterpret_cast<bf16_t*>(base)[off] = f2bf(v); else reinterpret_cast<float*>(base)[off] = v;
+}
+
+struct RowP {
+  void* dst; int dst_dtype, ld_dst; const int* dst_idx;
+  const void* src; int src_dtype, ld_src; const int* src_idx;
+  const void* add; int add_dtype, ld_add; const int* add_idx;
+  int n_rows, c, accumulate;
+};
+
+template <int VEC>
+__global__ void row_copy_kernel(RowP p) {
+  const int per_row = p.c / VEC;
+  const long long total = (long long)p.n_rows * per_row;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / per_row), col = (int)(i % per_row) * VEC;
+    const int dr = p.dst_idx ? p.dst_idx[row] : row;
+    const int sr = p.src_idx ? p.src_idx[row] : row;
+    const int ar = p.add_idx ? p.add_idx[row] : row;
+    if (VEC == 4) {
+      float4 v = p.src ? ld4(p.src, p.src_dtype, (size_t)sr * p.ld_src + col) : make_float4(0, 0, 0, 0);
+      if (p.add) { const float4 a = ld4(p.add, p.add_dtype, (size_t)ar * p.ld_add + col); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+      if (p.accumulate) { const float4 a = ld4(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+      st4(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col, v);
+    } else {
+      float v = p.src ? ld1(p.src, p.src_dtype, (size_t)sr * p.ld_src + col) : 0.f;
+      if (p.add) v += ld1(p.add, p.add_dtype, (size_t)ar * p.ld_add + col);
+      if (p.accumulate) v += ld1(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col);
+      st1(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col, v);
+    }
+  }
+}
+
+__global__ void cast_kernel(const void* src, int sd, void* dst, int dd, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    st4(dst, dd, (size_t)i * 4, ld4(src, sd, (size_t)i * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1(dst, dd, (size_t)(n4 * 4 + threadIdx.x), ld1(src, sd, (size_t)(n4 * 4 + threadIdx.x)));
+}
+
+// dst[c][r] = src[r][c]; 64x64 tile through LDS (+1 pad)
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const void* src, int sd, int rows, int cols, bf16_t* dst) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? ld1(src, sd, (size_t)(r0 + r) * cols + c0 + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * rows + r0 + r] = f2bf(tile[r][c]);
+  }
+}
+
+__global__ void gelu_fwd_kernel(const bf16_t* x, bf16_t* y, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = ld4(x, 0, (size_t)i * 4);
+    v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+    st4(y, 0, (size_t)i * 4, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = f2bf(gelu_f(bf2f(x[n4 * 4 + threadIdx.x])));
+}
+__global__ void gelu_bwd_kernel(const bf16_t* x, const bf16_t* dy, bf16_t* dx, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = ld4(x, 0, (size_t)i * 4);
+    float4 d = ld4(dy, 0, (size_t)i * 4);
+    d.x *= gelu_grad_f(v.x); d.y *= gelu_grad_f(v.y); d.z *= gelu_grad_f(v.z); d.w *= gelu_grad_f(v.w);
+    st4(dx, 0, (size_t)i * 4, d);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t j = n4 * 4 + threadIdx.x;
+    dx[j] = f2bf(bf2f(dy[j]) * gelu_grad_f(bf2f(x[j])));
+  }
+}
+
+int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+bool a16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+CINEMA_API int cinema_hip_info(int* out) {
+  if (!out) return CINEMA_ERR_BAD_ARG;
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  out[0] = 1;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+    out[1] = prop.multiProcessorCount; out[2] = (int)prop.sharedMemPerBlock; out[3] = prop.warpSize;
+  }
+  (void)hipGetLastError();
+  return 0;
+}
+
+CINEMA_API int cinema_row_copy(void* dst, int dst_dtype, int ld_dst, const int* dst_idx, const void* src, int src_dtype, int ld_src,
+                               const int* src_idx, const void* add, int add_dtype, int ld_add, const int* add_idx, int n_rows, int c,
+                               int accumulate, void* stream) {
+  if (!dst || n_rows <= 0 || c <= 0 || (!src && !add)) return CINEMA_ERR_BAD_ARG;
+  RowP p{dst, dst_dtype, ld_dst, dst_idx, src, src_dtype, ld_src, src_idx, add, add_dtype, ld_add, add_idx, n_rows, c, accumulate};
+  const bool vec = !(c & 3) && !(ld_dst & 3) && (!src || !(ld_src & 3)) && (!add || !(ld_add & 3)) && a16(dst) && (!src || a16(src)) && (!add || a16(add));
+  if (vec) hipLaunchKernelGGL(row_copy_kernel<4>, dim3(grid_for((long long)n_rows * c / 4, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(row_copy_kernel<1>, dim3(grid_for((long long)n_rows * c, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+CINEMA_API int cinema_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream) {
+  if (!src || !dst || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!a16(src) || !a16(dst)) return CINEMA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, dst, dst_dtype, n);
+  return launch_status();
+}
+
+CINEMA_API int cinema_transpose_cast(const void* src, int src_dtype, int rows, int cols, uint16_t* dst, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, src_dtype, rows, cols, dst);
+  return launch_status();
+}
+
+CINEMA_API int cinema_gelu_fwd(const uint16_t* x, uint16_t* y, long long n, void* stream) {
+  if (!x || !y || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!a16(x) || !a16(y)) return CINEMA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return launch_status();
+}
+CINEMA_API int cinema_gelu_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, long long n, void* stream) {
+  if (!x || !dy || !dx || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!a16(x) || !a16(dy) || !a16(dx)) return CINEMA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+  return launch_status();
+}

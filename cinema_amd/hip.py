@@ -1,0 +1,422 @@
+"""ctypes binding of ``libcinema_hip.so`` (C-ABI in ``include/cinema_hip.h``).
+
+Thin, typed launchers: every function takes torch tensors that already live on the GPU, checks
+dtype / contiguity / device, and enqueues one or two HIP kernels on torch's *current* stream.
+There is deliberately no CPU or ATen fallback: without the library, or with a CPU tensor, the
+call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "libcinema_hip.so"
+_lib = None
+
+BF16, F32 = 0, 1
+_DT = {torch.bfloat16: BF16, torch.float32: F32}
+
+
+class HipLibraryError(RuntimeError):
+    """Raised when the HIP kernel library is missing or a kernel launch is rejected."""
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("b", C.c_void_p), ("d", C.c_void_p),
+        ("m", C.c_int), ("n", C.c_int), ("k", C.c_int),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldd", C.c_int),
+        ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
+        ("alpha", C.c_float),
+        ("bias", C.c_void_p), ("residual_f32", C.c_void_p), ("residual_bf16", C.c_void_p), ("ld_res", C.c_int),
+        ("gelu_in", C.c_void_p), ("ld_gelu", C.c_int),
+        ("row_mask", C.c_void_p),
+        ("aux_out", C.c_void_p), ("ld_aux", C.c_int),
+        ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
+    ]
+
+
+class PatchGeom(C.Structure):
+    _fields_ = [
+        ("b", C.c_int), ("c", C.c_int), ("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int),
+        ("px", C.c_int), ("py", C.c_int), ("pz", C.c_int),
+        ("sb", C.c_longlong), ("sc", C.c_longlong), ("sx", C.c_longlong), ("sy", C.c_longlong), ("sz", C.c_longlong),
+        ("n_rows", C.c_int), ("token_idx", C.c_void_p),
+    ]
+
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+_PROTOS = {
+    "cinema_hip_info": [C.POINTER(C.c_int)],
+    "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "cinema_colsum_bf16": [_vp, _i, _i, _i, _vp, _vp],
+    "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_dwconv_bwd_data": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_patch_gather": [_vp, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
+    "cinema_patch_scatter": [_vp, _i, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
+    "cinema_row_copy": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "cinema_cast": [_vp, _i, _vp, _i, _ll, _vp],
+    "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
+    "cinema_gelu_fwd": [_vp, _vp, _ll, _vp],
+    "cinema_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "cinema_mse_fwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _f, _vp, _vp],
+    "cinema_mse_bwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _vp, _f, _vp, _i, _vp],
+    "cinema_patch_stats": [_vp, C.POINTER(PatchGeom), _vp, _vp],
+    "cinema_mean_finite": [_vp, _i, _vp, _vp, _vp],
+    "cinema_sqnorm_f32": [_vp, _ll, _vp, _vp],
+    "cinema_clip_coef": [_vp, _f, _vp, _vp, _vp],
+    "cinema_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp],
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+FORCE_GENERIC = bool(int(os.environ.get("CINEMA_HIP_FORCE_GENERIC", "0")))
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load():  # noqa: ANN201
+    """Load the shared library (once). Raises :class:`HipLibraryError` if it was not built."""
+    global _lib  # noqa: PLW0603
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise HipLibraryError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). cinema_amd has no CPU/ATen fallback."
+        )
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported shape/alignment"}.get(rc, f"hipError {rc}")
+        raise HipLibraryError(f"{what} failed: {kind}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _dev(*ts: torch.Tensor | None) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError("cinema_amd kernels need GPU (HIP) tensors; got a CPU tensor. There is no CPU fallback.")
+
+
+def _rowmajor(t: torch.Tensor, name: str) -> int:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise HipLibraryError(f"{name} must be 2-D with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0)
+
+
+# --------------------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True, out: torch.Tensor | None = None,
+         out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None,
+         gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, aux_out: torch.Tensor | None = None,
+         act: int = 0, accumulate: bool = False, split_k: int = 1, alpha: float = 1.0, force_generic: bool = False) -> torch.Tensor:
+    """D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N]."""
+    lib = load()
+    _dev(a, b, out, bias, residual, gelu_in, row_mask, aux_out)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise HipLibraryError("gemm operands must be bf16")
+    lda, ldb = _rowmajor(a, "a"), _rowmajor(b, "b")
+    m, k = (a.shape[0], a.shape[1]) if a_kmajor else (a.shape[1], a.shape[0])
+    n, kb = (b.shape[0], b.shape[1]) if b_kmajor else (b.shape[1], b.shape[0])
+    if k != kb:
+        raise HipLibraryError(f"gemm reduction mismatch: {k} vs {kb}")
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    elif tuple(out.shape) != (m, n):
+        raise HipLibraryError(f"gemm out shape {tuple(out.shape)} != {(m, n)}")
+    g = GemmArgs()
+    g.a, g.b, g.d = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    g.m, g.n, g.k, g.lda, g.ldb, g.ldd = m, n, k, lda, ldb, _rowmajor(out, "out")
+    g.a_kmajor, g.b_kmajor, g.alpha = int(a_kmajor), int(b_kmajor), alpha
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != n:
+            raise HipLibraryError("gemm bias must be fp32 [n]")
+        g.bias = bias.data_ptr()
+    if residual is not None:
+        g.ld_res = _rowmajor(residual, "residual")
+        if residual.dtype == torch.float32:
+            g.residual_f32 = residual.data_ptr()
+        elif residual.dtype == torch.bfloat16:
+            g.residual_bf16 = residual.data_ptr()
+        else:
+            raise HipLibraryError("gemm residual must be fp32 or bf16")
+    if gelu_in is not None:
+        g.gelu_in, g.ld_gelu = gelu_in.data_ptr(), _rowmajor(gelu_in, "gelu_in")
+    if row_mask is not None:
+        if row_mask.dtype not in (torch.uint8, torch.bool) or row_mask.numel() != m:
+            raise HipLibraryError("gemm row_mask must be uint8/bool [m]")
+        g.row_mask = row_mask.data_ptr()
+    if aux_out is not None:
+        g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
+    g.act, g.out_f32, g.accumulate = act, int(out.dtype == torch.float32), int(accumulate)
+    g.split_k, g.force_generic = split_k, int(force_generic or FORCE_GENERIC)
+    _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[n] += sum_m x[m, n] (x bf16 2-D, out fp32)."""
+    _dev(x, out)
+    _check(load().cinema_colsum_bf16(x.data_ptr(), x.shape[0], x.shape[1], _rowmajor(x, "x"), out.data_ptr(), _stream()), "colsum")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, act: int = 0, want_bf16: bool = True,
+                  want_f32: bool = False):  # noqa: ANN201
+    """x: [rows, c] fp32/bf16 -> (y_bf16 | None, y_f32 | None, mean, rstd)."""
+    _dev(x, gamma, beta)
+    rows, c = x.shape
+    y16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    y32 = torch.empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(load().cinema_layernorm_fwd(x.data_ptr(), int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), beta.data_ptr(),
+                                       rows, c, eps, act, _p(y16), _p(y32), c, mean.data_ptr(), rstd.data_ptr(), _stream()), "layernorm_fwd")
+    return y16, y32, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor | None, mean: torch.Tensor, rstd: torch.Tensor, *,
+                  act: int = 0, dx_residual: torch.Tensor | None = None, want_f32: bool = True, want_bf16: bool = False,
+                  dgamma: torch.Tensor | None = None, dbeta: torch.Tensor | None = None, dx_f32_out: torch.Tensor | None = None):  # noqa: ANN201
+    """-> (dx_f32 | None, dx_bf16 | None); dgamma/dbeta (fp32 [c]) are accumulated in place when given."""
+    _dev(dy, x, gamma, mean, rstd, dx_residual, dgamma, dbeta)
+    rows, c = x.shape
+    dx32 = dx_f32_out if dx_f32_out is not None else (torch.empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
+    dx16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
+        raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
+    _check(load().cinema_layernorm_bwd(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
+                                       int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
+                                       rstd.data_ptr(), rows, c, act, _p(dx_residual), _p(dx32), _p(dx16), c, _p(dgamma), _p(dbeta),
+                                       _stream()), "layernorm_bwd")
+    return dx32, dx16
+
+
+def _attn_view(t: torch.Tensor, heads: int, hd: int, name: str):  # noqa: ANN202
+    """t: [b, tokens, >= heads*hd] view with unit inner stride and batch stride = tokens*row stride."""
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1) or t.shape[2] != heads * hd or t.dtype != torch.bfloat16:
+        raise HipLibraryError(f"{name}: expected bf16 [b, t, heads*hd] view with packed batch stride, got {tuple(t.shape)} {t.stride()}")
+    return t.data_ptr(), t.stride(1)
+
+
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, force_generic: bool = False):  # noqa: ANN201
+    """q: [b,tq,C], k/v: [b,tk,C] bf16 views (C = heads*hd) -> (o [b,tq,C] bf16, lse [b,heads,tq] fp32 log2-domain)."""
+    _dev(q, k, v)
+    b, tq, cdim = q.shape
+    tk, hd = k.shape[1], cdim // heads
+    (qp, ldq), (kp, ldk), (vp, ldv) = _attn_view(q, heads, hd, "q"), _attn_view(k, heads, hd, "k"), _attn_view(v, heads, hd, "v")
+    o = torch.empty((b, tq, cdim), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((b, heads, tq), dtype=torch.float32, device=q.device)
+    _check(load().cinema_attention_fwd(qp, ldq, kp, ldk, vp, ldv, o.data_ptr(), cdim, lse.data_ptr(), b, heads, tq, tk, hd, scale,
+                                       int(force_generic or FORCE_GENERIC), _stream()), "attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, d_o: torch.Tensor, lse: torch.Tensor, heads: int,
+                  scale: float, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, force_generic: bool = False) -> None:
+    """Writes dq/dk/dv (bf16 views with the same addressing rules as q/k/v)."""
+    _dev(q, k, v, o, d_o, lse, dq, dk, dv)
+    b, tq, cdim = q.shape
+    tk, hd = k.shape[1], cdim // heads
+    ptrs = [_attn_view(t, heads, hd, n) for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv"))]
+    delta = torch.empty((b, heads, tq), dtype=torch.float32, device=q.device)
+    _check(load().cinema_attention_bwd(ptrs[0][0], ptrs[0][1], ptrs[1][0], ptrs[1][1], ptrs[2][0], ptrs[2][1], ptrs[3][0], ptrs[3][1],
+                                       ptrs[4][0], ptrs[4][1], lse.data_ptr(), delta.data_ptr(), ptrs[5][0], ptrs[5][1], ptrs[6][0], ptrs[6][1],
+                                       ptrs[7][0], ptrs[7][1], b, heads, tq, tk, hd, scale, int(force_generic or FORCE_GENERIC), _stream()),
+           "attention_bwd")
+
+
+# --------------------------------------------------------------------------------------------------------
+def _dw_dims(x: torch.Tensor, ksize: tuple) -> tuple:
+    """x: channels-last [b, *spatial, c]; 2-D maps are walked as (1, H, W) so the sliding-window axis is W."""
+    b, *sp, c = x.shape
+    if len(sp) == 2:
+        return b, 1, sp[0], sp[1], c, 1, ksize[0], ksize[1]
+    return b, sp[0], sp[1], sp[2], c, ksize[0], ksize[1], ksize[2]
+
+
+def dwconv_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """x: bf16 channels-last [b, *spatial, c]; w: fp32 torch layout (c, 1, *k)."""
+    _dev(x, w, bias)
+    if not x.is_contiguous() or x.dtype != torch.bfloat16 or w.dtype != torch.float32 or not w.is_contiguous():
+        raise HipLibraryError("dwconv: x must be contiguous bf16 channels-last, w contiguous fp32")
+    y = torch.empty_like(x)
+    b, X, Y, Z, c, kx, ky, kz = _dw_dims(x, tuple(w.shape[2:]))  # noqa: N806
+    _check(load().cinema_dwconv_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), b, X, Y, Z, c, kx, ky, kz, _stream()), "dwconv_fwd")
+    return y
+
+
+def dwconv_bwd_data(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    _dev(dy, w)
+    dx = torch.empty_like(dy)
+    b, X, Y, Z, c, kx, ky, kz = _dw_dims(dy, tuple(w.shape[2:]))  # noqa: N806
+    _check(load().cinema_dwconv_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), b, X, Y, Z, c, kx, ky, kz, _stream()), "dwconv_bwd_data")
+    return dx
+
+
+def dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dbias: torch.Tensor | None) -> None:
+    """dw (fp32, torch layout (c,1,*k)) and dbias (fp32 [c]) are accumulated in place."""
+    _dev(x, dy, dw, dbias)
+    b, X, Y, Z, c, kx, ky, kz = _dw_dims(x, tuple(dw.shape[2:]))  # noqa: N806
+    _check(load().cinema_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), b, X, Y, Z, c, kx, ky, kz, _stream()),
+           "dwconv_bwd_weight")
+
+
+def patch_geom(batch: int, chans: int, grid: tuple, patch: tuple, strides: tuple, token_idx: torch.Tensor | None = None,
+               n_rows: int | None = None) -> PatchGeom:
+    """``strides`` = element strides (batch, channel, *spatial) of the volume; 2-D is padded with a unit z axis."""
+    g = PatchGeom()
+    grid3 = tuple(grid) + (1,) * (3 - len(grid))
+    patch3 = tuple(patch) + (1,) * (3 - len(patch))
+    sp = tuple(strides[2:]) + (0,) * (3 - len(grid))
+    g.b, g.c = batch, chans
+    g.gx, g.gy, g.gz = grid3
+    g.px, g.py, g.pz = patch3
+    g.sb, g.sc, g.sx, g.sy, g.sz = strides[0], strides[1], sp[0], sp[1], sp[2]
+    n_tok = batch * grid3[0] * grid3[1] * grid3[2]
+    if token_idx is not None:
+        if token_idx.dtype != torch.int32:
+            raise HipLibraryError("token_idx must be int32")
+        g.token_idx = token_idx.data_ptr()
+        g.n_rows = token_idx.numel() if n_rows is None else n_rows
+    else:
+        g.n_rows = n_tok
+    return g
+
+
+def patch_gather(src: torch.Tensor, geom: PatchGeom, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    _dev(src)
+    feat = geom.px * geom.py * geom.pz * geom.c
+    out = torch.empty((geom.n_rows, feat), dtype=out_dtype, device=src.device)
+    _check(load().cinema_patch_gather(src.data_ptr(), _DT[src.dtype], out.data_ptr(), _DT[out_dtype], feat, C.byref(geom), _stream()), "patch_gather")
+    return out
+
+
+def patch_scatter(rows: torch.Tensor, dst: torch.Tensor, geom: PatchGeom, accumulate: bool = False) -> torch.Tensor:
+    _dev(rows, dst)
+    _check(load().cinema_patch_scatter(rows.data_ptr(), _DT[rows.dtype], _rowmajor(rows, "rows"), dst.data_ptr(), _DT[dst.dtype], int(accumulate),
+                                       C.byref(geom), _stream()), "patch_scatter")
+    return dst
+
+
+def row_copy(dst: torch.Tensor, src: torch.Tensor | None = None, *, dst_idx: torch.Tensor | None = None, src_idx: torch.Tensor | None = None,
+             add: torch.Tensor | None = None, add_idx: torch.Tensor | None = None, n_rows: int | None = None, accumulate: bool = False) -> torch.Tensor:
+    """dst[di(i)] (+)= src[si(i)] + add[ai(i)] over 2-D row-major tensors (bf16/fp32), indices int32."""
+    _dev(dst, src, add, dst_idx, src_idx, add_idx)
+    for idx in (dst_idx, src_idx, add_idx):
+        if idx is not None and idx.dtype != torch.int32:
+            raise HipLibraryError("row_copy indices must be int32")
+    if n_rows is None:
+        n_rows = next((i.numel() for i in (dst_idx, src_idx, add_idx) if i is not None), dst.shape[0])
+    c = dst.shape[1]
+    _check(load().cinema_row_copy(dst.data_ptr(), _DT[dst.dtype], _rowmajor(dst, "dst"), _p(dst_idx), _p(src), _DT[src.dtype] if src is not None else 0,
+                                  _rowmajor(src, "src") if src is not None else 0, _p(src_idx), _p(add), _DT[add.dtype] if add is not None else 0,
+                                  _rowmajor(add, "add") if add is not None else 0, _p(add_idx), n_rows, c, int(accumulate), _stream()), "row_copy")
+    return dst
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
+    _dev(src, out)
+    if not src.is_contiguous():
+        raise HipLibraryError("cast needs a contiguous source")
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _check(load().cinema_cast(src.data_ptr(), _DT[src.dtype], out.data_ptr(), _DT[out.dtype], src.numel(), _stream()), "cast")
+    return out
+
+
+def transpose_cast(src: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """[r, c] fp32/bf16 contiguous -> [c, r] bf16."""
+    _dev(src, out)
+    r, c = src.shape
+    if out is None:
+        out = torch.empty((c, r), dtype=torch.bfloat16, device=src.device)
+    _check(load().cinema_transpose_cast(src.data_ptr(), _DT[src.dtype], r, c, out.data_ptr(), _stream()), "transpose_cast")
+    return out
+
+
+def gelu_fwd(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    y = torch.empty_like(x)
+    _check(load().cinema_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gelu_fwd")
+    return y
+
+
+def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _dev(x, dy)
+    dx = torch.empty_like(x)
+    _check(load().cinema_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "gelu_bwd")
+    return dx
+
+
+def mse_fwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_target: bool, eps: float, loss_out: torch.Tensor) -> None:
+    _dev(image, pred, loss_out)
+    feat = geom.px * geom.py * geom.pz * geom.c
+    _check(load().cinema_mse_fwd(image.data_ptr(), C.byref(geom), pred.data_ptr(), _DT[pred.dtype], _rowmajor(pred, "pred"), int(norm_target), eps,
+                                 1.0 / (geom.n_rows * feat), loss_out.data_ptr(), _stream()), "mse_fwd")
+
+
+def mse_bwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_target: bool, eps: float, upstream: torch.Tensor | None,
+            host_scale: float) -> torch.Tensor:
+    _dev(image, pred, upstream)
+    dpred = torch.empty(pred.shape, dtype=torch.bfloat16, device=pred.device)
+    _check(load().cinema_mse_bwd(image.data_ptr(), C.byref(geom), pred.data_ptr(), _DT[pred.dtype], _rowmajor(pred, "pred"), int(norm_target), eps,
+                                 _p(upstream), host_scale, dpred.data_ptr(), dpred.stride(0), _stream()), "mse_bwd")
+    return dpred
+
+
+def patch_stats(image: torch.Tensor, geom_all: PatchGeom, out2: torch.Tensor) -> None:
+    _dev(image, out2)
+    _check(load().cinema_patch_stats(image.data_ptr(), C.byref(geom_all), out2.data_ptr(), _stream()), "patch_stats")
+
+
+def mean_finite(vals: torch.Tensor, mean_out: torch.Tensor, coef_out: torch.Tensor | None) -> None:
+    _dev(vals, mean_out, coef_out)
+    _check(load().cinema_mean_finite(vals.data_ptr(), vals.numel(), mean_out.data_ptr(), _p(coef_out), _stream()), "mean_finite")
+
+
+def sqnorm(g: torch.Tensor, out: torch.Tensor) -> None:
+    _dev(g, out)
+    _check(load().cinema_sqnorm_f32(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "sqnorm")
+
+
+def clip_coef(sq: torch.Tensor, max_norm: float, coef_out: torch.Tensor | None, norm_out: torch.Tensor | None) -> None:
+    _dev(sq, coef_out, norm_out)
+    _check(load().cinema_clip_coef(sq.data_ptr(), max_norm, _p(coef_out), _p(norm_out), _stream()), "clip_coef")
+
+
+def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+          step: int, clip: torch.Tensor | None = None, shadow: torch.Tensor | None = None) -> None:
+    _dev(p, g, m, v, clip, shadow)
+    _check(load().cinema_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                               1.0 - beta1**step, 1.0 - beta2**step, _p(clip), _p(shadow), _stream()), "adamw")
+
+
+def info() -> dict:
+    out = (C.c_int * 8)()
+    _check(load().cinema_hip_info(out), "info")
+    return {"abi_version": out[0], "n_cus": out[1], "lds_bytes_per_block": out[2], "wave_size": out[3]}

@@ -1,0 +1,173 @@
+/* C-ABI of libcinema_hip.so -- the MI355X (gfx950) compute path behind cinema_amd's nn.Module layer.
+ *
+ * The upstream reference (mathpluscode/CineMA) has no FFI/plugin interface: every "kernel" is a PyTorch
+ * ATen call inside cinema/vit.py, cinema/conv.py, cinema/convvit.py and cinema/mae/mae.py.  Each entry
+ * point below therefore cites the ATen call site(s) of the reference it replaces (ids A1-A20).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is stream-ordered, no host sync;
+ *   - bf16 = raw bfloat16 bits (uint16_t); matrices are row-major with explicit leading dimensions (elements);
+ *   - return value: 0 on success, CINEMA_ERR_* (<0) for rejected arguments, hipError_t (>0) if the launch failed.
+ */
+#ifndef CINEMA_HIP_H
+#define CINEMA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CINEMA_ERR_BAD_ARG (-1)
+#define CINEMA_ERR_UNSUPPORTED (-2)
+
+/* library / device info: fills out[0..7] = {abi_version, n_CUs, lds_bytes_per_block, wave_size, 0...} */
+int cinema_hip_info(int* out_host);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GEMM  (reference: nn.Linear / F.linear at cinema/vit.py:472-477,498-499,520, timm Mlp fc1/fc2 vit.py:570-575,
+ * 1x1 ConvNd of MaskedConvBlock/ConvMlp cinema/conv.py:383-389, k==s patch convs cinema/convvit.py:94-102,252,
+ * PatchEmbed.proj vit.py:294-298, dec_linear / pred heads cinema/mae/mae.py:395,435-440 and their autograd
+ * backward.)   D[M,N] (+)= epilogue( alpha * sum_k A[m,k] * B[k,n] )
+ *   a_kmajor=1: A stored [M][lda], k contiguous.     a_kmajor=0: A stored [K][lda], m contiguous.
+ *   b_kmajor=1: B stored [N][ldb], k contiguous (the nn.Linear weight layout).  b_kmajor=0: B stored [K][ldb].
+ * Epilogue, in order:  v = alpha*acc + bias[n];  aux_out[m,n] = bf16(v);  v = gelu(v) if act==1;
+ *   v *= gelu'(gelu_in[m,n]);  v *= row_mask[m];  v += residual[m,n];  store (bf16 or fp32) or atomicAdd (fp32).
+ * split_k > 1 requires accumulate=1 (fp32 atomics).  force_generic=1 selects the plain FMA kernel (any shape).
+ */
+typedef struct {
+  const void* a; const void* b; void* d;
+  int m, n, k;
+  int lda, ldb, ldd;
+  int a_kmajor, b_kmajor;
+  float alpha;
+  const float* bias;          /* [n] fp32 or NULL */
+  const float* residual_f32;  /* [m][ld_res] or NULL */
+  const uint16_t* residual_bf16;
+  int ld_res;
+  const uint16_t* gelu_in;    /* [m][ld_gelu] bf16 pre-activations or NULL */
+  int ld_gelu;
+  const uint8_t* row_mask;    /* [m] 0/1 or NULL */
+  uint16_t* aux_out;          /* [m][ld_aux] bf16 pre-activation copy or NULL */
+  int ld_aux;
+  int act;                    /* 0 none, 1 exact GELU */
+  int out_f32;                /* 1: D is fp32, 0: D is bf16 */
+  int accumulate;             /* 1: D += result with fp32 atomics (out_f32 must be 1) */
+  int split_k;                /* >=1 */
+  int force_generic;
+} cinema_gemm_args;
+int cinema_gemm_bf16(const cinema_gemm_args* args_host, void* stream);
+
+/* column sums: out[n] += sum_m x[m,n]  (bias gradients).  x bf16 [m][ldx], out fp32 [n] (accumulated atomically) */
+int cinema_colsum_bf16(const uint16_t* x, int m, int n, int ldx, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LayerNorm (reference: nn.LayerNorm norm1/norm2/encoder.norm/fusion.norm/decoder.norm cinema/vit.py:549,564,650,738,
+ * cinema/convvit.py:254; ConvLayerNorm + nn.GELU cinema/conv.py:169-187,271-272).
+ * fwd: y = LN(x)*gamma+beta over the last dim (c), optional exact GELU; x fp32 or bf16, y bf16 and/or fp32;
+ *      mean/rstd (fp32 [rows]) saved for the backward.
+ * bwd: dx = LN'(dy) (+ dx_residual);  writes dx_f32 and/or dx_bf16; dgamma/dbeta accumulated atomically (fp32).
+ *      If act==1 the incoming dy is w.r.t. gelu(LN(x)) and is chained through gelu' (recomputed from x, stats).
+ */
+int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
+                         int act, uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, void* stream);
+int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
+                         const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
+                         const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Attention (reference: F.scaled_dot_product_attention / matmul-softmax-matmul cinema/vit.py:505-517, no mask, no
+ * dropout).  q:[b,tq,h,hd] k,v:[b,tk,h,hd] addressed as base + (b*t + t_i)*ld + h*hd + d (bf16) so that the fused
+ * qkv / kv GEMM outputs are consumed in place.  o:[b,tq,h*hd] bf16.  lse:[b,h,tq] fp32 = log2-domain
+ * log-sum-exp of scale*log2(e)*q.k.  hd in {32,64} -> MFMA flash kernel; any hd<=128 -> generic kernel.
+ */
+int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
+                         float* lse, int b, int h, int tq, int tk, int hd, float scale, int force_generic, void* stream);
+/* delta:[b,h,tq] fp32 scratch (rowsum(dO*O)) is written by the call. dq/dk/dv use the same addressing as q/k/v. */
+int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+                         int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
+                         uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
+                         int force_generic, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Depthwise 5^n convolution, channels-last (reference: MaskedConvBlock.dw_conv, kernel 5 in every axis, "same"
+ * zero padding, cinema/conv.py:385,410-413).  x,y: [b, X, Y, Z, c] bf16 (2-D views use Z=1,kz=1).
+ * w: fp32 [c][kx*ky*kz] (the torch (c,1,kx,ky,kz) layout flattened), bias fp32 [c].
+ */
+int cinema_dwconv_fwd(const uint16_t* x, const float* w, const float* bias, uint16_t* y, int b, int X, int Y, int Z, int c, int kx, int ky,
+                      int kz, void* stream);
+int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, int b, int X, int Y, int Z, int c, int kx, int ky, int kz,
+                           void* stream);
+/* dw[c][taps] += sum x*dy ; dbias[c] += sum dy (fp32 atomics) */
+int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, int b, int X, int Y, int Z, int c, int kx,
+                             int ky, int kz, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Non-overlapping patch gather / scatter (reference: patchify cinema/vit.py:67-161 and the im2col of the k==s
+ * ConvNd layers cinema/convvit.py:94-102,252).  Source is addressed by element strides (sb, sc, sx, sy, sz) so both
+ * channels-first images and channels-last feature maps work.  Output row = token (b, gx, gy, gz) raster order,
+ * feature order (px, py, pz, c).  token_idx (int32, [n_rows]) optionally selects flat token ids b*G + g (kept tokens).
+ * gather: out[row, f] = src[...]  (out bf16 or fp32).  scatter (backward): dst[...] (+)= rows[row, f].
+ */
+typedef struct {
+  int b, c, gx, gy, gz, px, py, pz;     /* grid and patch extents */
+  long long sb, sc, sx, sy, sz;         /* element strides of the volume */
+  int n_rows;                           /* rows produced/consumed (= b*gx*gy*gz when token_idx is NULL) */
+  const int* token_idx;
+} cinema_patch_geom;
+int cinema_patch_gather(const void* src, int src_dtype, void* out, int out_dtype, int ld_out, const cinema_patch_geom* geom_host,
+                        void* stream);
+int cinema_patch_scatter(const void* rows, int rows_dtype, int ld_rows, void* dst, int dst_dtype, int accumulate,
+                         const cinema_patch_geom* geom_host, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Row copy with optional gather/scatter indices and an optional added row (reference: bool-mask token selection,
+ * cat/split, pos-embed adds  cinema/mae/mae.py:98-104,550,580-582, cinema/vit.py:672-674, cinema/convvit.py:205,288).
+ *   dst[di(i), :] (+)= src[si(i), :] + add[ai(i), :]      for i in [0, n_rows)
+ * with xi(i) = idx ? idx[i] : i.  dtypes: 0 = bf16, 1 = fp32.  src may be NULL (treated as zeros).
+ */
+int cinema_row_copy(void* dst, int dst_dtype, int ld_dst, const int* dst_idx, const void* src, int src_dtype, int ld_src,
+                    const int* src_idx, const void* add, int add_dtype, int ld_add, const int* add_idx, int n_rows, int c,
+                    int accumulate, void* stream);
+
+/* elementwise: dtype codes as above */
+int cinema_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
+/* dst[c][r] = src[r][c] (bf16 out); src fp32 or bf16 */
+int cinema_transpose_cast(const void* src, int src_dtype, int rows, int cols, uint16_t* dst, void* stream);
+/* y = x * row_mask[row]  on [rows][c] bf16 */
+int cinema_gelu_fwd(const uint16_t* x, uint16_t* y, long long n, void* stream);
+int cinema_gelu_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, long long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Masked-patch MSE (reference: mse_loss cinema/mae/mae.py:107-152 with patchify(image, dec_patch) as target; the
+ * target patch is gathered on the fly from the fp32 image through `geom`, never materialised).
+ *   fwd : loss_out[0] += inv_count * sum_{rows, f} (pred - target)^2        (rows = masked tokens, token_idx = their ids)
+ *   bwd : dpred[row, f] = 2 * host_scale * upstream[0] * (pred - target)      (bf16)
+ *   patch_stats: out2[0] += mean over ALL patches of the patch mean, out2[1] += mean of the patch unbiased std
+ *                (the `target_mean` / `target_std` metrics, mae.py:129-137)
+ *   mean_finite: mean_out[0] = mean of the finite vals (NaN if none), coef_out[i] = d mean / d vals[i]
+ *                (the per-view `torch.isfinite` filter + mean over views, mae.py:604-608, without a host sync)
+ */
+int cinema_mse_fwd(const float* image, const cinema_patch_geom* geom_masked_host, const void* pred, int pred_dtype, int ld_pred,
+                   int norm_target, float eps, float inv_count, float* loss_out, void* stream);
+int cinema_mse_bwd(const float* image, const cinema_patch_geom* geom_masked_host, const void* pred, int pred_dtype, int ld_pred,
+                   int norm_target, float eps, const float* upstream, float host_scale, uint16_t* dpred, int ld_dpred, void* stream);
+int cinema_patch_stats(const float* image, const cinema_patch_geom* geom_all_host, float* out2, void* stream);
+int cinema_mean_finite(const float* vals, int n, float* mean_out, float* coef_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Optimiser (reference harness: torch.optim.AdamW + clip_grad_norm_ via GradScaler, cinema/optim.py:204-215,
+ * cinema/mae/pretrain.py:365-366).  Flat fp32 buffers.
+ *   sqnorm: out[0] += sum g^2.
+ *   adamw : p,m,v updated in place; grad is multiplied by *clip_coef (device scalar, may be NULL=1);
+ *           optional bf16 shadow copy of the updated parameter written to p_bf16.
+ */
+int cinema_sqnorm_f32(const float* g, long long n, float* out, void* stream);
+int cinema_clip_coef(const float* sqnorm, float max_norm, float* coef_out, float* norm_out, void* stream);
+int cinema_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, float bias_corr1, float bias_corr2, const float* clip_coef, uint16_t* p_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,337 @@
+"""Kernel-level parity: every C-ABI entry point (through cinema_amd.hip) against a plain PyTorch fp32 statement of
+the same op on the same (bf16-rounded) inputs.  Tolerances are written next to each check.  Needs an MI355X."""
+
+from __future__ import annotations
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F  # noqa: N812
+
+pytestmark = pytest.mark.gpu
+
+import cinema_oracle as O  # noqa: E402
+from cinema_amd import hip as K  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, dtype=torch.bfloat16, seed=None):  # noqa: ANN001, ANN002, ANN201
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) % 10007))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def close(a: torch.Tensor, b: torch.Tensor, rtol: float, atol: float, what: str = "") -> None:
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max abs err {float(err.max()):.4g}, max ref {float(b.abs().max()):.4g}"
+
+
+def test_library_info() -> None:
+    info = K.info()
+    assert info["abi_version"] == 1 and info["wave_size"] == 64 and info["n_cus"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(300, 256, 192), (1000, 768, 768), (129, 16, 16), (2053, 512, 2048), (70, 24, 40), (128, 128, 64), (4100, 64, 256)]
+
+
+@pytest.mark.parametrize(("m", "n", "k"), GEMM_SHAPES)
+@pytest.mark.parametrize("generic", [False, True])
+def test_gemm_forward_layout(m: int, n: int, k: int, generic: bool) -> None:
+    a, w = rnd(m, k, seed=1), rnd(n, k, seed=2)
+    bias = rnd(n, dtype=torch.float32, seed=3)
+    ref = a.float() @ w.float().t() + bias
+    out = K.gemm(a, w, bias=bias, out_dtype=torch.float32, force_generic=generic)
+    close(out, ref, 2e-4, 2e-3, "fwd f32")  # fp32 accumulation-order noise only
+    out16 = K.gemm(a, w, bias=bias, force_generic=generic)
+    close(out16, ref, 1e-2, 2e-2, "fwd bf16")  # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize(("m", "n", "k"), [(300, 256, 192), (1000, 768, 3072), (129, 16, 64), (685, 768, 768)])
+@pytest.mark.parametrize("generic", [False, True])
+def test_gemm_dgrad_and_wgrad_layouts(m: int, n: int, k: int, generic: bool) -> None:
+    """Y = X W^T with X[m,k], W[n,k]:  dX = dY W  (A k-major, B stored [red][out]);  dW = dY^T X (both reduction-strided)."""
+    x, w, dy = rnd(m, k, seed=4), rnd(n, k, seed=5), rnd(m, n, seed=6)
+    dx_ref = dy.float() @ w.float()
+    dx = K.gemm(dy, w, a_kmajor=True, b_kmajor=False, out_dtype=torch.float32, force_generic=generic)
+    close(dx, dx_ref, 2e-4, 5e-3, "dgrad")
+    dw_ref = dy.float().t() @ x.float()
+    dw = K.gemm(dy, x, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32, force_generic=generic)
+    close(dw, dw_ref, 2e-4, 1e-2, "wgrad")
+    acc = torch.ones(n, k, dtype=torch.float32, device=DEV)
+    K.gemm(dy, x, a_kmajor=False, b_kmajor=False, out=acc, accumulate=True, split_k=5, force_generic=generic)
+    close(acc, dw_ref + 1.0, 2e-4, 1e-2, "wgrad split-k accumulate")
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_gemm_epilogues(generic: bool) -> None:
+    m, n, k = 517, 256, 128
+    a, w = rnd(m, k, seed=7), rnd(n, k, seed=8, scale=0.2)
+    bias = rnd(n, dtype=torch.float32, seed=9)
+    pre = a.float() @ w.float().t() + bias
+    aux = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    out = K.gemm(a, w, bias=bias, act=1, aux_out=aux, force_generic=generic)
+    close(aux, pre, 1e-2, 2e-2, "aux pre-activation")
+    close(out, F.gelu(pre), 1e-2, 2e-2, "gelu epilogue")
+    res = rnd(m, n, dtype=torch.float32, seed=10)
+    out = K.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32, force_generic=generic)
+    close(out, pre + res, 2e-4, 2e-3, "fp32 residual")
+    out_inplace = res.clone()
+    K.gemm(a, w, bias=bias, residual=out_inplace, out=out_inplace, force_generic=generic)
+    close(out_inplace, pre + res, 2e-4, 2e-3, "in-place residual")
+    res16 = rnd(m, n, seed=11)
+    out = K.gemm(a, w, residual=res16, out_dtype=torch.float32, alpha=0.5, force_generic=generic)
+    close(out, 0.5 * (a.float() @ w.float().t()) + res16.float(), 2e-4, 2e-3, "bf16 residual + alpha")
+    mask = (torch.arange(m, device=DEV) % 3 != 0).to(torch.uint8)
+    out = K.gemm(a, w, bias=bias, row_mask=mask, out_dtype=torch.float32, force_generic=generic)
+    close(out, pre * mask[:, None].float(), 2e-4, 2e-3, "row mask")
+    h = rnd(m, n, seed=12)
+    hx = h.float().requires_grad_(True)
+    F.gelu(hx).backward(torch.ones_like(hx))
+    out = K.gemm(a, w, gelu_in=h, out_dtype=torch.float32, force_generic=generic)
+    close(out, (a.float() @ w.float().t()) * hx.grad, 5e-4, 5e-3, "gelu' epilogue")
+
+
+def test_gemm_strided_views_and_colsum() -> None:
+    big = rnd(300, 3 * 256, seed=13)
+    a = big[:, 256:512]  # column slice of a fused buffer
+    w = rnd(128, 256, seed=14)
+    close(K.gemm(a, w, out_dtype=torch.float32), a.float() @ w.float().t(), 2e-4, 2e-3, "lda > k")
+    out = torch.zeros(768, dtype=torch.float32, device=DEV)
+    K.colsum(big, out)
+    close(out, big.float().sum(0), 1e-4, 1e-3, "colsum")
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("c", [16, 24, 64, 128, 512, 768, 1024])
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("x_bf16", [False, True])
+def test_layernorm(c: int, act: int, x_bf16: bool) -> None:
+    rows = 333
+    x = rnd(rows, c, dtype=torch.bfloat16 if x_bf16 else torch.float32, seed=20, scale=2.0) + 0.5
+    gamma, beta = rnd(c, dtype=torch.float32, seed=21) + 1.0, rnd(c, dtype=torch.float32, seed=22)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (c,), gr, br, 1e-6)
+    if act:
+        y_ref = F.gelu(y_ref)
+    y16, y32, mean, rstd = K.layernorm_fwd(x, gamma, beta, 1e-6, act=act, want_bf16=True, want_f32=True)
+    close(y32, y_ref, 1e-4, 1e-4, "ln fwd f32")
+    close(y16, y_ref, 1e-2, 1e-2, "ln fwd bf16")
+    dy = rnd(rows, c, seed=23)
+    y_ref.backward(dy.float())
+    resid = rnd(rows, c, dtype=torch.float32, seed=24)
+    dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(beta)
+    dx32, dx16 = K.layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=act, dx_residual=resid, want_f32=True, want_bf16=True, dgamma=dgamma,
+                                 dbeta=dbeta)
+    close(dx32, xr.grad + resid, 1e-3, 1e-3, "ln dx")
+    close(dx16, xr.grad + resid, 1e-2, 2e-2, "ln dx bf16")
+    close(dgamma, gr.grad, 1e-3, 2e-3, "ln dgamma")
+    close(dbeta, br.grad, 1e-3, 2e-3, "ln dbeta")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, heads):  # noqa: ANN001, ANN201
+    b, tq, c = q.shape
+    hd = c // heads
+    qh = q.float().reshape(b, tq, heads, hd).transpose(1, 2)
+    kh = k.float().reshape(b, -1, heads, hd).transpose(1, 2)
+    vh = v.float().reshape(b, -1, heads, hd).transpose(1, 2)
+    w = torch.softmax(qh @ kh.transpose(-1, -2) * hd**-0.5, dim=-1)
+    return (w @ vh).transpose(1, 2).reshape(b, tq, c)
+
+
+@pytest.mark.parametrize(("hd", "heads", "tq", "tk", "generic"), [
+    (64, 3, 685, 685, False), (32, 4, 300, 77, False), (64, 2, 64, 64, False), (32, 2, 129, 200, False), (64, 2, 200, 130, True),
+    (8, 2, 129, 129, True), (8, 2, 385, 128, True), (16, 4, 50, 33, False), (32, 16, 2053, 684, False)])
+def test_attention_forward_backward(hd: int, heads: int, tq: int, tk: int, generic: bool) -> None:
+    b, c = 2, hd * heads
+    self_attn = tq == tk
+    if self_attn:  # consume a fused [q | k | v] projection buffer in place (strided views)
+        qkv = rnd(b, tq, 3 * c, seed=30)
+        q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+    else:
+        q, kv = rnd(b, tq, c, seed=31), rnd(b, tk, 2 * c, seed=32)
+        k, v = kv[..., :c], kv[..., c:]
+    scale = hd**-0.5
+    qr, kr, vr = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qr, kr, vr, heads)
+    o, lse = K.attention_fwd(q, k, v, heads, scale, force_generic=generic)
+    close(o, ref, 1e-2, 1e-2, "attention fwd")  # bf16 P and bf16 output
+    # lse check (log2 domain)
+    s = (qr.detach().reshape(b, tq, heads, hd).transpose(1, 2) @ kr.detach().reshape(b, tk, heads, hd).transpose(1, 2).transpose(-1, -2)) * scale
+    close(lse, torch.logsumexp(s, dim=-1) / math.log(2.0), 1e-4, 1e-3, "lse")
+    d_o = rnd(b, tq, c, seed=33)
+    ref.backward(d_o.float())
+    if self_attn:
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[..., :c], dqkv[..., c:2 * c], dqkv[..., 2 * c:]
+    else:
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        dk, dv = dkv[..., :c], dkv[..., c:]
+    K.attention_bwd(q, k, v, o, d_o, lse, heads, scale, dq, dk, dv, force_generic=generic)
+    # gradients pass through bf16 P/dS and bf16 outputs: 2% of the tensor scale
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        tol = 2e-2 * float(want.abs().max())
+        close(got, want, 2e-2, tol, f"attention {name}")
+
+
+def test_attention_rescale_branch() -> None:
+    """Force large running-max jumps between key tiles (guide rule 26): one spiked key per tile, increasing."""
+    b, heads, hd, t = 1, 1, 64, 256
+    q, k, v = rnd(b, t, hd, seed=34), rnd(b, t, hd, seed=35), rnd(b, t, hd, seed=36)
+    k = k.clone()
+    for tile in range(4):
+        k[0, tile * 64 + 7] = q[0, 3] * (2.0 + 2.0 * tile)
+    o, _ = K.attention_fwd(q, k, v, heads, hd**-0.5)
+    close(o, attn_ref(q, k, v, heads), 1e-2, 2e-2, "attention with max jumps")
+
+
+# ------------------------------------------------------------------------------------------------ depthwise conv
+@pytest.mark.parametrize(("shape", "c"), [((2, 12, 10, 6), 64), ((1, 7, 9, 16), 128), ((2, 13, 11), 64), ((2, 6, 4, 5), 8), ((3, 6, 8), 8)])
+def test_dwconv(shape: tuple, c: int) -> None:
+    b, *sp = shape
+    nd = len(sp)
+    x = rnd(b, *sp, c, seed=40)
+    w = rnd(c, 1, *([5] * nd), dtype=torch.float32, seed=41, scale=0.2)
+    bias = rnd(c, dtype=torch.float32, seed=42)
+    conv = F.conv3d if nd == 3 else F.conv2d
+    xr = x.float().movedim(-1, 1).contiguous().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = conv(xr, wr, br, padding=2, groups=c)
+    y = K.dwconv_fwd(x, w, bias)
+    close(y, ref.movedim(1, -1), 1e-2, 2e-2, "dwconv fwd")
+    dy = rnd(b, *sp, c, seed=43)
+    ref.backward(dy.float().movedim(-1, 1))
+    close(K.dwconv_bwd_data(dy, w), xr.grad.movedim(1, -1), 1e-2, 2e-2, "dwconv dgrad")
+    dw, db = torch.zeros_like(w), torch.zeros_like(bias)
+    K.dwconv_bwd_weight(x, dy, dw, db)
+    close(dw, wr.grad, 1e-3, 1e-3 * float(wr.grad.abs().max()) + 1e-3, "dwconv wgrad")
+    close(db, br.grad, 1e-3, 1e-3 * float(br.grad.abs().max()) + 1e-3, "dwconv bgrad")
+
+
+# ------------------------------------------------------------------------------------------------ patches / rows
+def test_patch_gather_scatter_channels_first_image() -> None:
+    img = rnd(2, 3, 8, 12, 4, dtype=torch.float32, seed=50)
+    patch, grid = (4, 4, 1), (2, 3, 4)
+    geom = K.patch_geom(2, 3, grid, patch, img.stride())
+    out = K.patch_gather(img, geom, torch.float32)
+    ref = O.patchify(img.cpu(), patch).reshape(-1, 48).to(DEV)
+    assert torch.equal(out, ref)
+    back = torch.zeros_like(img)
+    K.patch_scatter(out, back, geom)
+    assert torch.equal(back, img)
+    img2 = rnd(2, 1, 8, 6, dtype=torch.float32, seed=51)
+    geom2 = K.patch_geom(2, 1, (4, 3), (2, 2), img2.stride())
+    assert torch.equal(K.patch_gather(img2, geom2, torch.float32), O.patchify(img2.cpu(), (2, 2)).reshape(-1, 4).to(DEV))
+
+
+def test_patch_gather_channels_last_with_token_subset() -> None:
+    b, c, sp = 2, 16, (8, 6, 4)
+    x = rnd(b, *sp, c, dtype=torch.float32, seed=52)  # channels-last feature map
+    patch, grid = (2, 2, 1), (4, 3, 4)
+    strides = (x.stride(0), 1, x.stride(1), x.stride(2), x.stride(3))
+    ref_all = O.patchify(x.movedim(-1, 1).cpu(), patch).reshape(-1, 4 * c).to(DEV)
+    geom = K.patch_geom(b, c, grid, patch, strides)
+    close(K.patch_gather(x, geom), ref_all, 1e-2, 1e-2, "gather all (bf16 out)")
+    idx = torch.tensor([0, 5, 47, 48, 95, 17], dtype=torch.int32, device=DEV)
+    gsub = K.patch_geom(b, c, grid, patch, strides, token_idx=idx)
+    assert torch.equal(K.patch_gather(x, gsub, torch.float32), ref_all[idx.long()])
+    dst = torch.zeros_like(x)
+    K.patch_scatter(ref_all[idx.long()].contiguous(), dst, gsub)
+    ref_dst = torch.zeros_like(ref_all)
+    ref_dst[idx.long()] = ref_all[idx.long()]
+    assert torch.equal(dst, O.unpatchify(ref_dst.reshape(b, -1, 4 * c).cpu(), patch, grid).movedim(1, -1).to(DEV))
+
+
+def test_row_copy_cast_transpose_gelu() -> None:
+    src = rnd(10, 32, dtype=torch.float32, seed=60)
+    add = rnd(7, 32, dtype=torch.float32, seed=61)
+    dst = torch.zeros(12, 32, dtype=torch.float32, device=DEV)
+    di = torch.tensor([11, 0, 3], dtype=torch.int32, device=DEV)
+    si = torch.tensor([2, 9, 4], dtype=torch.int32, device=DEV)
+    ai = torch.tensor([6, 6, 1], dtype=torch.int32, device=DEV)
+    K.row_copy(dst, src, dst_idx=di, src_idx=si, add=add, add_idx=ai)
+    ref = torch.zeros_like(dst)
+    ref[di.long()] = src[si.long()] + add[ai.long()]
+    assert torch.equal(dst, ref)
+    K.row_copy(dst, src, dst_idx=di, src_idx=si, accumulate=True)
+    ref[di.long()] += src[si.long()]
+    assert torch.equal(dst, ref)
+    d16 = torch.zeros(3, 32, dtype=torch.bfloat16, device=DEV)
+    K.row_copy(d16, None, add=add, add_idx=ai)
+    assert torch.equal(d16, add[ai.long()].to(torch.bfloat16))
+    odd = rnd(5, 7, dtype=torch.float32, seed=62)
+    assert torch.equal(K.row_copy(torch.zeros(5, 7, dtype=torch.float32, device=DEV), odd), odd)
+    x = rnd(1003, dtype=torch.float32, seed=63)
+    assert torch.equal(K.cast(x, torch.bfloat16), x.to(torch.bfloat16))
+    assert torch.equal(K.cast(x.to(torch.bfloat16), torch.float32), x.to(torch.bfloat16).float())
+    w = rnd(70, 130, dtype=torch.float32, seed=64)
+    assert torch.equal(K.transpose_cast(w), w.t().contiguous().to(torch.bfloat16))
+    h = rnd(999, seed=65, scale=2.0)
+    close(K.gelu_fwd(h), F.gelu(h.float()), 1e-2, 1e-2, "gelu")
+    hx = h.float().requires_grad_(True)
+    dy = rnd(999, seed=66)
+    F.gelu(hx).backward(dy.float())
+    close(K.gelu_bwd(h, dy), hx.grad, 1e-2, 1e-2, "gelu bwd")
+
+
+# ------------------------------------------------------------------------------------------------ loss / optimiser
+@pytest.mark.parametrize("norm_target", [False, True])
+def test_masked_mse(norm_target: bool) -> None:
+    b = 2
+    img = torch.rand(b, 1, 32, 32, 4, generator=torch.Generator().manual_seed(70)).to(DEV)
+    patch, grid = (16, 16, 1), (2, 2, 4)
+    mask = O.random_patch_mask(b, 16, 0.75, torch.Generator().manual_seed(71))
+    ids = torch.nonzero(mask.flatten()).flatten().to(torch.int32).to(DEV)
+    pred = rnd(ids.numel(), 256, seed=72)
+    target = O.patchify(img.cpu(), patch)
+    pr = pred.float().cpu().reshape(b, -1, 256).requires_grad_(True)
+    ref_loss, ref_metrics = O.mse_loss(target, pr, mask, norm_target)
+    geom = K.patch_geom(b, 1, grid, patch, img.stride(), token_idx=ids)
+    loss = torch.zeros(1, dtype=torch.float32, device=DEV)
+    K.mse_fwd(img, geom, pred, norm_target, 1e-6, loss)
+    close(loss.cpu(), ref_loss.detach().reshape(1), 1e-4, 1e-6, "mse loss")
+    stats = torch.zeros(2, dtype=torch.float32, device=DEV)
+    K.patch_stats(img, K.patch_geom(b, 1, grid, patch, img.stride()), stats)
+    close(stats.cpu(), torch.stack([ref_metrics["target_mean"], ref_metrics["target_std"]]), 1e-4, 1e-6, "patch stats")
+    ref_loss.backward()
+    up = torch.full((1,), 0.5, dtype=torch.float32, device=DEV)
+    dpred = K.mse_bwd(img, geom, pred, norm_target, 1e-6, up, 1.0 / pred.numel())
+    close(dpred.cpu(), 0.5 * pr.grad.reshape(-1, 256), 1e-2, 1e-7, "mse dpred")
+
+
+def test_mean_finite() -> None:
+    vals = torch.tensor([1.0, float("nan"), 3.0, float("inf")], device=DEV)
+    mean, coef = torch.zeros(1, device=DEV), torch.zeros(4, device=DEV)
+    K.mean_finite(vals, mean, coef)
+    assert float(mean) == 2.0 and coef.tolist() == [0.5, 0.0, 0.5, 0.0]
+    K.mean_finite(torch.tensor([float("nan")], device=DEV), mean, None)
+    assert math.isnan(float(mean))
+
+
+def test_adamw_and_clip() -> None:
+    n = 10007
+    p0, g = rnd(n, dtype=torch.float32, seed=80), rnd(n, dtype=torch.float32, seed=81)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    sq = torch.zeros(1, device=DEV)
+    K.sqnorm(g, sq)
+    close(sq, (g.double() ** 2).sum().float().reshape(1), 1e-5, 0, "sqnorm")
+    coef, norm = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    K.clip_coef(sq, 5.0, coef, norm)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in (1, 2, 3):
+        pr.grad = g.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        K.adamw(p, g, m, v, 1e-3, 0.9, 0.95, 1e-8, 0.05, step, clip=coef, shadow=shadow)
+    close(norm, ref_norm.reshape(1), 1e-5, 0, "grad norm")
+    close(p, pr.detach(), 1e-5, 1e-6, "adamw params")
+    assert torch.equal(shadow, p.to(torch.bfloat16))
