@@ -1,0 +1,185 @@
+"""MAE-pretrain throughput benchmark on MI355X (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one optimisation step of the reference harness (``cinema/mae/pretrain.py:242-269``) on one synthetic
+minibatch that is already resident in HBM: forward (random 75 % masks) + backward + [gradient all-reduce] + global-norm
+clip + AdamW + zero_grad.  Workload = BASELINE.json configs[1]: CineMA ViT-Base, 4 views (SAX 192x192x16 + 3 LAX 192x192),
+per-GPU batch 16, bf16 MFMA compute with fp32 accumulation / residual stream / master weights.  Weak scaling: the per-GPU
+batch is fixed, ``value`` is the whole-job samples/s.
+
+Rank 0 prints ONE JSON line with the extra ``roofline`` (dominant kernel, live HIP-event timing of every GEMM launch on
+the launch stream during extra instrumented steps) and ``cpu_baseline`` (the CPU oracle timed on the host cores) objects.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+STEP_GFLOP_PER_SAMPLE = 835.0  # 3 x 278.4 GF forward, reference graph, no recompute credit
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def base_kwargs(size: str = "base", sax=(192, 192, 16), lax=(192, 192)) -> dict:  # noqa: ANN001
+    from cinema_amd.vit import get_vit_config
+
+    views = ["sax", "lax_2c", "lax_3c", "lax_4c"]
+    return dict(image_size_dict={v: tuple(sax) if v == "sax" else tuple(lax) for v in views}, in_chans_dict=dict.fromkeys(views, 1),
+                enc_patch_size_dict={v: (4, 4, 1) if v == "sax" else (4, 4) for v in views},
+                enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2,
+                **get_vit_config(size))
+
+
+def synthetic_batch(kw: dict, batch: int, seed: int, device: str) -> dict:
+    gen = torch.Generator().manual_seed(seed)
+    return {v: torch.rand(batch, 1, *s, generator=gen).to(device) for v, s in kw["image_size_dict"].items()}
+
+
+def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float) -> dict:
+    """The CPU oracle (fp32, torch CPU ops on all host cores) on a bounded sample of the same workload."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import cinema_oracle as O  # noqa: N812
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.MAEConfig(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
+    trainer = O.Trainer({k: v.detach().float().cpu() for k, v in state_dict.items()}, cfg, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0)
+    gen = torch.Generator().manual_seed(99)
+    images = {v: torch.rand(batch, 1, *s, generator=gen) for v, s in kw["image_size_dict"].items()}
+    import math
+
+    def masks() -> dict:
+        return {v: O.random_patch_mask(batch, math.prod(cfg.grid_size(v)), 0.75, gen) for v in images}
+
+    t0 = time.perf_counter()
+    trainer.step(images, masks())  # warm-up (allocator, thread pool)
+    warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 < budget_s and n < 8):
+        loss, _, _, _ = trainer.step(images, masks())
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} optimisation steps (fwd+bwd+clip+AdamW) of the same Base 4-view config at batch {batch}, fp32 torch-CPU oracle, "
+                      f"after 1 warm-up step ({warm:.1f} s); final loss {float(loss):.4f}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (reference batch_size_per_device, mae/config.yaml:45)")
+    ap.add_argument("--size", default="base")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 disables)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the per-kernel roofline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+
+    import torch.distributed as dist
+
+    from cinema_amd import CineMA
+    from cinema_amd import hip as K
+    from cinema_amd.ddp import GradientSynchronizer, ddp_setup
+    from cinema_amd.optim import TrainStep
+
+    sync = None
+    if world > 1:
+        ddp_setup(rank, world, backend="nccl")
+        sync = GradientSynchronizer(world)
+
+    kw = base_kwargs(args.size)
+    torch.manual_seed(0)  # identical weights on every rank (config.seed, mae/config.yaml:1)
+    model = CineMA(**kw)
+    cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model.to(device)
+    step = TrainStep(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0, synchronizer=sync)
+    torch.manual_seed(1234 + rank)  # per-rank mask / data streams (pretrain.py:309-310)
+    batches = [synthetic_batch(kw, args.batch, 1234 + rank * 100 + i, device) for i in range(2)]
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for i in range(args.warmup):
+        loss, gnorm, _ = step(batches[i % 2], 0.75)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, gnorm, _ = step(batches[i % 2], 0.75)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+
+    # ---- per-kernel roofline: time every GEMM launch with HIP events on the launch stream (extra steps, same workload)
+    roofline = None
+    if rank == 0 and args.profile_steps > 0:
+        K.GEMM_PROFILE = []
+        for i in range(args.profile_steps):
+            step(batches[i % 2], 0.75)
+        torch.cuda.synchronize()
+        prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        agg: dict = {}
+        for kind, flops, e0, e1 in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        kind = max(agg, key=lambda k: agg[k][1])
+        flops, secs, n = agg[kind]
+        achieved = flops / secs / 1e12
+        roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n // args.profile_steps, "avg_launch_us": round(secs / n * 1e6, 2),
+                    "gflop_per_launch": round(flops / n / 1e9, 3),
+                    "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
+                                                                  "launches_per_step": v[2] // args.profile_steps} for k, v in agg.items()}}
+
+    if rank == 0:
+        samples_per_s = world * args.batch * args.steps / dt
+        out = {
+            "metric": "MAE-pretrain samples/sec (4-view cine, 75% mask)", "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX 192x192x16 + LAX 2C/3C/4C 192x192), mask 0.75, "
+                                   f"per-GPU batch {args.batch}, fwd+bwd+clip(5.0)+AdamW, random-init weights",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
+                       "step_tflops_per_gpu": round(samples_per_s / world * STEP_GFLOP_PER_SAMPLE / 1e3, 1),
+                       "step_mfma_frac": round(samples_per_s / world * STEP_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and args.cpu_budget > 0:
+            out["cpu_baseline"] = cpu_baseline(kw, cpu_state, 2, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,1 +1,9 @@
-"""cinema_amd: MI355X-native (gfx950) compute path for the CineMA MAE hot path."""
+"""cinema_amd: MI355X-native (gfx950) compute path for the CineMA MAE hot path.
+
+Public surface mirrors what callers of the reference import (``cinema/__init__.py:23-34``) for this path.
+"""
+
+from cinema_amd.mae.mae import CineMA
+from cinema_amd.vit import patchify, unpatchify
+
+__all__ = ["CineMA", "patchify", "unpatchify"]

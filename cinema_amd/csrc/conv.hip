@@ -10,6 +10,7 @@ namespace {
 struct DwP {
   const bf16_t* x; const bf16_t* dy; const float* w; const float* bias; bf16_t* y;
   float* dw; float* dbias;
+  const uint8_t* out_mask;  // optional per-voxel 0/1 multiplier on the output (masked data gradient)
   int b, X, Y, Z, c, kx, ky, kz;
   int flip;  // 1: correlate with the flipped kernel (data gradient)
 };
@@ -63,6 +64,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwP p) {
         acc[4] = fmaf(w1.x, f[4], acc[4]); acc[5] = fmaf(w1.y, f[5], acc[5]); acc[6] = fmaf(w1.z, f[6], acc[6]); acc[7] = fmaf(w1.w, f[7], acc[7]);
       }
     }
+  }
+  if (p.out_mask && !p.out_mask[vox]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.f;
   }
   uint4 o;
   o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]); o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
@@ -267,11 +272,11 @@ CINEMA_API int cinema_dwconv_fwd(const uint16_t* x, const float* w, const float*
   return dw_launch_fwd(p, (hipStream_t)stream);
 }
 
-CINEMA_API int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, int b, int X, int Y, int Z, int c, int kx, int ky, int kz,
-                                      void* stream) {
+CINEMA_API int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, const uint8_t* out_mask, int b, int X, int Y, int Z, int c,
+                                      int kx, int ky, int kz, void* stream) {
   if (!dy || !w || !dx) return CINEMA_ERR_BAD_ARG;
   if (int e = dw_check(b, X, Y, Z, c, kx, ky, kz)) return e;
-  DwP p{}; p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.flip = 1;
+  DwP p{}; p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.flip = 1; p.out_mask = out_mask;
   return dw_launch_fwd(p, (hipStream_t)stream);
 }
 

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p, int a_rs, in
     }
 }
 
-__global__ void colsum_kernel(const bf16_t* x, int m, int n, int ldx, float* out, int rows_per_block) {
+__global__ void colsum_kernel(const void* x, int is_f32, const int* row_idx, int m, int n, int ldx, float* out, int rows_per_block) {
   // block: 64 columns x 4 row-lanes; grid.x = column groups, grid.y = row chunks
   __shared__ float part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -283,7 +283,10 @@ __global__ void colsum_kernel(const bf16_t* x, int m, int n, int ldx, float* out
   const int r0 = blockIdx.y * rows_per_block, r1 = min(m, r0 + rows_per_block);
   float s = 0.f;
   if (col < n)
-    for (int r = r0 + rl; r < r1; r += 4) s += bf2f(x[(size_t)r * ldx + col]);
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const size_t off = (size_t)(row_idx ? row_idx[r] : r) * ldx + col;
+      s += is_f32 ? reinterpret_cast<const float*>(x)[off] : bf2f(reinterpret_cast<const bf16_t*>(x)[off]);
+    }
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && col < n) unsafeAtomicAdd(out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
@@ -291,7 +294,7 @@ __global__ void colsum_kernel(const bf16_t* x, int m, int n, int ldx, float* out
 
 }  // namespace
 
-CINEMA_API int cinema_gemm_bf16(const cinema_gemm_args* a, void* stream) {
+CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
   if (a->accumulate && !a->out_f32) return CINEMA_ERR_BAD_ARG;
   const int split = a->split_k < 1 ? 1 : a->split_k;
@@ -319,6 +322,7 @@ CINEMA_API int cinema_gemm_bf16(const cinema_gemm_args* a, void* stream) {
     p.ktiles_per_split = (nkt + sp - 1) / sp;
     const int gz = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
     dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, gz);
+    a->kernel_used = (a->a_kmajor && a->b_kmajor) ? 1 : (a->a_kmajor ? 2 : 3);
     if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), 0, st, p);
     else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), 0, st, p);
@@ -331,16 +335,17 @@ CINEMA_API int cinema_gemm_bf16(const cinema_gemm_args* a, void* stream) {
   dim3 grid(((a->m + 63) / 64) * ((a->n + 63) / 64), 1, gz);
   const int a_rs = a->a_kmajor ? a->lda : 1, a_cs = a->a_kmajor ? 1 : a->lda;   // element (m,k) = a[m*a_rs + k*a_cs]
   const int b_rs = a->b_kmajor ? 1 : a->ldb, b_cs = a->b_kmajor ? a->ldb : 1;   // element (k,n) = b[k*b_rs + n*b_cs]
+  a->kernel_used = 0;
   hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, st, p, a_rs, a_cs, b_rs, b_cs);
   return launch_status();
 }
 
-CINEMA_API int cinema_colsum_bf16(const uint16_t* x, int m, int n, int ldx, float* out, void* stream) {
+CINEMA_API int cinema_colsum(const void* x, int x_dtype, const int* row_idx, int m, int n, int ldx, float* out, void* stream) {
   if (!x || !out || m <= 0 || n <= 0) return CINEMA_ERR_BAD_ARG;
   int chunks = (m + 511) / 512;
   if (chunks > 256) chunks = 256;
   const int rpb = (m + chunks - 1) / chunks;
   dim3 grid((n + 63) / 64, (m + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, m, n, ldx, out, rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_dtype, row_idx, m, n, ldx, out, rpb);
   return launch_status();
 }

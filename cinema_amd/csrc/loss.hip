@@ -31,16 +31,26 @@ __device__ __forceinline__ void patch_moments(const float* image, const PatchG& 
   stdv = sqrtf(wave_sum(q) / (float)(F - 1));  // unbiased, as torch.var (mae.py:130)
 }
 
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+  unsigned int old = *a;
+  while (__uint_as_float(old) < v) {
+    const unsigned int prev = atomicCAS(a, old, __float_as_uint(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
 __device__ __forceinline__ float pred_at(const void* pred, int dtype, size_t off) {
   return dtype == 0 ? bf2f(reinterpret_cast<const bf16_t*>(pred)[off]) : reinterpret_cast<const float*>(pred)[off];
 }
 
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* image, PatchG g, const void* pred, int pdt, int ldp, int norm_target, float eps,
-                                                      float inv_count, float* loss_out) {
+                                                      float inv_count, float* loss_out, float* max_out) {
   const int lane = threadIdx.x & 63;
   const int F = g.px * g.py * g.pz * g.c;
   const int nw = gridDim.x * 4;
-  float acc = 0.f;
+  float acc = 0.f, tmax = -INFINITY, pmax = -INFINITY;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < g.n_rows; row += nw) {
     const int tok = g.token_idx ? g.token_idx[row] : row;
     float mean = 0.f, stdv = 1.f;
@@ -48,12 +58,19 @@ __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* image, PatchG
     for (int f = lane; f < F; f += 64) {
       float t = target_at(image, g, tok, f);
       if (norm_target) t = (t - mean) / (stdv + eps);
-      const float d = pred_at(pred, pdt, (size_t)row * ldp + f) - t;
+      const float pv = pred_at(pred, pdt, (size_t)row * ldp + f);
+      const float d = pv - t;
       acc += d * d;
+      tmax = fmaxf(tmax, t);
+      pmax = fmaxf(pmax, pv);
     }
   }
   acc = wave_sum(acc);
   if (lane == 0) unsafeAtomicAdd(loss_out, acc * inv_count);
+  if (max_out) {  // metrics `normed_target_max` / `pred_max` (mae.py:146-150); max_out is pre-filled with -inf by the caller
+    tmax = wave_max(tmax); pmax = wave_max(pmax);
+    if (lane == 0) { atomic_max_f32(max_out, tmax); atomic_max_f32(max_out + 1, pmax); }
+  }
 }
 
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* image, PatchG g, const void* pred, int pdt, int ldp, int norm_target, float eps,
@@ -107,10 +124,10 @@ int rows_grid(int n_rows) { int g = (n_rows + 3) / 4; return g > 4096 ? 4096 : (
 }  // namespace
 
 CINEMA_API int cinema_mse_fwd(const float* image, const cinema_patch_geom* geom, const void* pred, int pred_dtype, int ld_pred, int norm_target,
-                              float eps, float inv_count, float* loss_out, void* stream) {
+                              float eps, float inv_count, float* loss_out, float* max_out, void* stream) {
   if (!image || !geom || !pred || !loss_out || geom->n_rows <= 0) return CINEMA_ERR_BAD_ARG;
   hipLaunchKernelGGL(mse_fwd_kernel, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
-                     norm_target, eps, inv_count, loss_out);
+                     norm_target, eps, inv_count, loss_out, max_out);
   return launch_status();
 }
 

@@ -37,7 +37,14 @@ class GemmArgs(C.Structure):
         ("row_mask", C.c_void_p),
         ("aux_out", C.c_void_p), ("ld_aux", C.c_int),
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
+        ("kernel_used", C.c_int),
     ]
+
+
+GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel", 1: "gemm_mfma_kernel<true,true>", 2: "gemm_mfma_kernel<true,false>", 3: "gemm_mfma_kernel<false,false>"}
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
+# entries are (kernel_used, algorithmic_flops, start_event, end_event)
+GEMM_PROFILE: list | None = None
 
 
 class PatchGeom(C.Structure):
@@ -53,13 +60,13 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 _PROTOS = {
     "cinema_hip_info": [C.POINTER(C.c_int)],
     "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
-    "cinema_colsum_bf16": [_vp, _i, _i, _i, _vp, _vp],
+    "cinema_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "cinema_dwconv_bwd_data": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_dwconv_bwd_data": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_patch_gather": [_vp, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_patch_scatter": [_vp, _i, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
@@ -68,7 +75,7 @@ _PROTOS = {
     "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
     "cinema_gelu_fwd": [_vp, _vp, _ll, _vp],
     "cinema_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
-    "cinema_mse_fwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _f, _vp, _vp],
+    "cinema_mse_fwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "cinema_mse_bwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _vp, _f, _vp, _i, _vp],
     "cinema_patch_stats": [_vp, C.POINTER(PatchGeom), _vp, _vp],
     "cinema_mean_finite": [_vp, _i, _vp, _vp, _vp],
@@ -174,14 +181,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
     g.act, g.out_f32, g.accumulate = act, int(out.dtype == torch.float32), int(accumulate)
     g.split_k, g.force_generic = split_k, int(force_generic or FORCE_GENERIC)
+    if GEMM_PROFILE is None:
+        _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
+        return out
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
+    ev1.record()
+    GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1))
     return out
 
 
-def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """out[n] += sum_m x[m, n] (x bf16 2-D, out fp32)."""
-    _dev(x, out)
-    _check(load().cinema_colsum_bf16(x.data_ptr(), x.shape[0], x.shape[1], _rowmajor(x, "x"), out.data_ptr(), _stream()), "colsum")
+def colsum(x: torch.Tensor, out: torch.Tensor, row_idx: torch.Tensor | None = None) -> torch.Tensor:
+    """out[n] += sum_i x[row(i), n] (x bf16/fp32 2-D, out fp32; ``row_idx`` int32 selects rows)."""
+    _dev(x, out, row_idx)
+    m = x.shape[0] if row_idx is None else row_idx.numel()
+    _check(load().cinema_colsum(x.data_ptr(), _DT[x.dtype], _p(row_idx), m, x.shape[1], _rowmajor(x, "x"), out.data_ptr(), _stream()), "colsum")
     return out
 
 
@@ -270,11 +285,11 @@ def dwconv_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None) -> t
     return y
 
 
-def dwconv_bwd_data(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    _dev(dy, w)
+def dwconv_bwd_data(dy: torch.Tensor, w: torch.Tensor, out_mask: torch.Tensor | None = None) -> torch.Tensor:
+    _dev(dy, w, out_mask)
     dx = torch.empty_like(dy)
     b, X, Y, Z, c, kx, ky, kz = _dw_dims(dy, tuple(w.shape[2:]))  # noqa: N806
-    _check(load().cinema_dwconv_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), b, X, Y, Z, c, kx, ky, kz, _stream()), "dwconv_bwd_data")
+    _check(load().cinema_dwconv_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(out_mask), b, X, Y, Z, c, kx, ky, kz, _stream()), "dwconv_bwd_data")
     return dx
 
 
@@ -302,6 +317,7 @@ def patch_geom(batch: int, chans: int, grid: tuple, patch: tuple, strides: tuple
         if token_idx.dtype != torch.int32:
             raise HipLibraryError("token_idx must be int32")
         g.token_idx = token_idx.data_ptr()
+        g.keepalive = token_idx  # the struct only holds the raw pointer; backward closures outlive the caller's locals
         g.n_rows = token_idx.numel() if n_rows is None else n_rows
     else:
         g.n_rows = n_tok
@@ -373,11 +389,12 @@ def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def mse_fwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_target: bool, eps: float, loss_out: torch.Tensor) -> None:
-    _dev(image, pred, loss_out)
+def mse_fwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_target: bool, eps: float, loss_out: torch.Tensor,
+            max_out: torch.Tensor | None = None) -> None:
+    _dev(image, pred, loss_out, max_out)
     feat = geom.px * geom.py * geom.pz * geom.c
     _check(load().cinema_mse_fwd(image.data_ptr(), C.byref(geom), pred.data_ptr(), _DT[pred.dtype], _rowmajor(pred, "pred"), int(norm_target), eps,
-                                 1.0 / (geom.n_rows * feat), loss_out.data_ptr(), _stream()), "mse_fwd")
+                                 1.0 / (geom.n_rows * feat), loss_out.data_ptr(), _p(max_out), _stream()), "mse_fwd")
 
 
 def mse_bwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_target: bool, eps: float, upstream: torch.Tensor | None,

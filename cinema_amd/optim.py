@@ -1,0 +1,161 @@
+"""Optimisation step of the MAE pre-training hot path on flat HBM buffers (harness semantics of the reference
+``cinema/optim.py`` + ``cinema/mae/pretrain.py:242-269``).
+
+``FlatModel`` re-homes every trainable parameter of a model into ONE contiguous fp32 buffer (weight-decay groups are
+contiguous ranges) and gives every parameter a gradient view into a second flat buffer.  One optimisation step is then
+a handful of kernels regardless of the parameter count: memset(grads) -> [forward/backward accumulate straight into the
+flat gradient buffer] -> (RCCL all-reduce of the flat buffer in a few large buckets) -> squared-norm -> clip coefficient
+-> fused AdamW per decay group.  No per-tensor Python loops, no host synchronisation (the gradient norm stays on the
+device until the caller asks for it).
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from cinema_amd import hip as K
+from cinema_amd import tape as T
+
+
+def adjust_learning_rate(optimizer, step: float, warmup_steps: float, max_n_steps: float, lr: float, min_lr: float) -> float:  # noqa: ANN001
+    """Linear warm-up then half-cosine decay, applied to every param group (``lr_scale`` aware).
+
+    Same schedule as the reference (``cinema/optim.py:21-52``); ``step`` is a fractional epoch (``pretrain.py:243-250``).
+    """
+    if step < warmup_steps:
+        cur = lr * step / warmup_steps
+    else:
+        cur = min_lr + (lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * (step - warmup_steps) / (max_n_steps - warmup_steps)))
+    for group in optimizer.param_groups:
+        group["lr"] = cur * group["lr_scale"] if "lr_scale" in group else cur
+    return cur
+
+
+def get_n_accum_steps(batch_size: int, batch_size_per_device: int, world_size: int) -> int:
+    """Gradient-accumulation factor (reference ``cinema/optim.py:122-143``)."""
+    per_step = batch_size_per_device * world_size
+    if per_step > batch_size:
+        raise ValueError(f"batch_size_per_step {per_step} should be less than batch_size {batch_size}.")
+    if batch_size % per_step != 0:
+        raise ValueError(f"batch_size {batch_size} should be divisible by batch_size_per_step {per_step}.")
+    return batch_size // per_step
+
+
+def param_groups_weight_decay(model: nn.Module, weight_decay: float = 1e-5, no_weight_decay_list: tuple = ()) -> list:
+    """timm's split used by the reference (``pretrain.py:365``): ``ndim <= 1`` or ``*.bias`` -> no decay; tokens are decayed."""
+    skip = set(no_weight_decay_list)
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.ndim <= 1 or name.endswith(".bias") or name in skip) else decay).append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+class FlatModel:
+    """Flat fp32 parameter / gradient storage for a model's trainable parameters, grouped by weight decay."""
+
+    def __init__(self, model: nn.Module, weight_decay: float) -> None:
+        self.model = model
+        self.groups = param_groups_weight_decay(model, weight_decay)
+        params = [p for g in self.groups for p in g["params"]]
+        if not params:
+            raise ValueError("model has no trainable parameters")
+        dev = params[0].device
+        sizes = [((p.numel() + 3) // 4) * 4 for p in params]  # keep every view 16-byte aligned
+        total = sum(sizes)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.ranges = []
+        off = 0
+        it = iter(sizes)
+        for g in self.groups:
+            start = off
+            for p in g["params"]:
+                n = next(it)
+                view = self.flat_param[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+                p._cinema_flat_grad = p.grad  # noqa: SLF001  (tape.PVar accumulates straight into this view)
+                off += n
+            self.ranges.append((start, off))
+        self.numel = total
+
+    def zero_grad(self) -> None:
+        self.flat_grad.zero_()
+
+
+class FusedAdamW:
+    """AdamW (+ global-norm clipping) over a :class:`FlatModel` with ``torch.optim.AdamW`` update semantics.
+
+    ``param_groups`` mimics the torch optimiser attribute so that :func:`adjust_learning_rate` works unchanged.
+    """
+
+    def __init__(self, flat: FlatModel, lr: float = 1e-3, betas: tuple = (0.9, 0.95), eps: float = 1e-8) -> None:
+        self.flat = flat
+        self.param_groups = [{"params": g["params"], "weight_decay": g["weight_decay"], "lr": lr} for g in flat.groups]
+        self.betas, self.eps = tuple(betas), eps
+        self.exp_avg = torch.zeros_like(flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(flat.flat_param)
+        dev = flat.flat_param.device
+        self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002
+        self.flat.zero_grad()
+
+    def step(self, clip_grad: float | None = None) -> torch.Tensor:
+        """One update; returns the pre-clip global gradient norm as a device scalar (``cinema/optim.py:208-210``)."""
+        f = self.flat
+        self.step_count += 1
+        self.sq.zero_()
+        K.sqnorm(f.flat_grad, self.sq)
+        K.clip_coef(self.sq, float(clip_grad) if clip_grad else 0.0, self.coef, self.grad_norm)
+        for group, (a, b) in zip(self.param_groups, f.ranges):
+            if b > a:
+                K.adamw(f.flat_param[a:b], f.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], group["lr"], self.betas[0], self.betas[1],
+                        self.eps, group["weight_decay"], self.step_count, clip=self.coef)
+        T.WEIGHTS.invalidate()  # parameters were written through raw pointers: refresh the bf16 shadows at the next forward
+        return self.grad_norm
+
+    def state_dict(self) -> dict:
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lrs": [g["lr"] for g in self.param_groups]}
+
+    def load_state_dict(self, state: dict) -> None:
+        self.step_count = int(state["step"])
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        for g, lr in zip(self.param_groups, state["lrs"]):
+            g["lr"] = lr
+
+
+class TrainStep:
+    """forward -> backward -> (gradient all-reduce) -> clip -> AdamW -> zero_grad, the body of ``pretrain_one_epoch``
+    (``cinema/mae/pretrain.py:242-269``) without its per-step host synchronisations."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, clip_grad: float | None = 5.0,
+                 synchronizer=None) -> None:  # noqa: ANN001
+        self.model = model
+        self.flat = FlatModel(model, weight_decay)
+        self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas)
+        self.clip_grad = clip_grad
+        self.sync = synchronizer
+        if self.sync is not None:
+            self.sync.attach(self.flat)
+
+    def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
+        loss, _, _, metrics = self.model(image_dict, enc_mask_ratio, enc_mask_dict=enc_mask_dict)
+        (loss / n_accum_steps if n_accum_steps > 1 else loss).backward()
+        grad_norm = None
+        if update_grad:
+            if self.sync is not None:
+                self.sync.all_reduce()
+            grad_norm = self.optimizer.step(self.clip_grad)
+            self.optimizer.zero_grad()
+        return loss.detach(), grad_norm, metrics

@@ -1,0 +1,535 @@
+"""A small static tape for the hand-written HIP kernels.
+
+The reference relies on ``torch.autograd`` over ~2000 ATen ops per step.  Here one top-level module call
+(``CineMA.forward``) is ONE ``torch.autograd.Function`` node: its forward runs the kernel sequence while recording
+backward closures on a :class:`Tape`; its backward replays them in reverse.  All activations are 2-D row-major
+matrices (rows = tokens / voxels in raster order, channels last); fp32 for the residual stream and losses, bf16
+for everything that feeds an MFMA GEMM.  Every op below is a sequence of ``cinema_amd.hip`` launches -- there is no
+ATen compute on this path except index bookkeeping on tiny integer tensors.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Callable
+
+import torch
+
+from cinema_amd import hip as K
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class Var:
+    """An activation on the tape: ``data`` plus its (lazily created) gradient.
+
+    ``grad`` is fp32 for fp32 data and bf16 for bf16 data.  ``grad16`` optionally carries a bf16 copy of an fp32
+    gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
+    """
+
+    __slots__ = ("data", "grad", "grad16", "needs_grad")
+
+    def __init__(self, data: torch.Tensor, needs_grad: bool = True) -> None:
+        self.data = data
+        self.grad: torch.Tensor | None = None
+        self.grad16: torch.Tensor | None = None
+        self.needs_grad = needs_grad
+
+    def add_grad(self, g: torch.Tensor, g16: torch.Tensor | None = None) -> None:
+        if not self.needs_grad:
+            return
+        if self.grad is None:
+            self.grad, self.grad16 = g, g16
+        else:
+            K.row_copy(self.grad.view(-1, self.grad.shape[-1]), g.view(-1, g.shape[-1]), accumulate=True)
+            self.grad16 = None
+
+    def grad_bf16(self) -> torch.Tensor:
+        """bf16 view of the gradient (GEMM operand)."""
+        if self.grad is None:
+            raise RuntimeError("gradient requested before it was produced")
+        if self.grad.dtype == BF16:
+            return self.grad
+        if self.grad16 is None:
+            self.grad16 = K.cast(self.grad, BF16)
+        return self.grad16
+
+
+class PVar:
+    """A parameter on the tape.  ``grad`` (fp32, in the *kernel* layout) is created zeroed on first use."""
+
+    __slots__ = ("param", "grad", "to_param_layout", "direct")
+
+    def __init__(self, param: torch.nn.Parameter) -> None:
+        self.param = param
+        self.grad: torch.Tensor | None = None
+        self.to_param_layout: Callable | None = None
+        self.direct = False
+
+    def grad_buffer(self, shape: tuple, to_param_layout: Callable | None = None) -> torch.Tensor:
+        if self.grad is None:
+            flat = getattr(self.param, "_cinema_flat_grad", None)
+            if flat is not None and to_param_layout is None and flat.data_ptr() == getattr(self.param.grad, "data_ptr", lambda: 0)():
+                # the optimiser owns a flat gradient buffer (cinema_amd.optim.FlatModel): accumulate straight into it
+                self.grad, self.direct = flat.view(shape), True
+            else:
+                self.grad = torch.zeros(shape, dtype=F32, device=self.param.device)
+            self.to_param_layout = to_param_layout
+        return self.grad
+
+    def final_grad(self) -> torch.Tensor | None:
+        if self.grad is None or self.direct:
+            return None
+        g = self.to_param_layout(self.grad) if self.to_param_layout is not None else self.grad
+        return g.reshape(self.param.shape)
+
+
+class WeightCache:
+    """bf16 (and re-laid-out) shadows of the fp32 master parameters, refreshed when a parameter changes.
+
+    Keyed by (parameter identity, kind); validated by ``param._version``, the storage pointer and a global epoch that
+    optimisers writing through raw pointers (``cinema_amd.optim.FusedAdamW``) bump after each step.
+    """
+
+    def __init__(self) -> None:
+        self.epoch = 0
+        self._store: dict = {}
+
+    def invalidate(self) -> None:
+        self.epoch += 1
+
+    def get(self, params: tuple, kind: str, build: Callable) -> torch.Tensor:
+        key = (tuple(id(p) for p in params), kind)
+        stamp = (self.epoch, tuple((p._version, p.data_ptr()) for p in params))  # noqa: SLF001
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        val = build()
+        self._store[key] = (stamp, val)
+        return val
+
+
+WEIGHTS = WeightCache()
+
+
+class Tape:
+    """Backward closures in forward order + the parameter registry of one top-level call."""
+
+    def __init__(self, params: dict | None = None, train: bool = True) -> None:
+        self.ops: list = []
+        self.pvars: dict = {}
+        self.train = train
+
+    def record(self, fn: Callable) -> None:
+        if self.train:
+            self.ops.append(fn)
+
+    def pvar(self, param: torch.nn.Parameter | None) -> PVar | None:
+        if param is None:
+            return None
+        pv = self.pvars.get(id(param))
+        if pv is None:
+            pv = self.pvars[id(param)] = PVar(param)
+        return pv
+
+    def backward(self) -> None:
+        debug = os.environ.get("CINEMA_TAPE_DEBUG") == "1"
+        for i, fn in enumerate(reversed(self.ops)):
+            fn()
+            if debug:  # localise an asynchronous kernel fault to one backward closure
+                torch.cuda.synchronize()
+                print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
+        self.ops = []
+
+
+# --------------------------------------------------------------------------------------------------------------
+# weight shadows
+# --------------------------------------------------------------------------------------------------------------
+def w_plain(weight: torch.nn.Parameter) -> torch.Tensor:
+    """(out, in[,1,1,1]) fp32 -> bf16 [out, in]."""
+    return WEIGHTS.get((weight,), "plain", lambda: K.cast(weight.detach().reshape(weight.shape[0], -1), BF16))
+
+
+def w_patch(weight: torch.nn.Parameter) -> torch.Tensor:
+    """k==s conv weight (out, c, *k) -> bf16 [out, (*k, c)] matching the patch-gather feature order."""
+
+    def build() -> torch.Tensor:
+        w = weight.detach()
+        perm = (0, *range(2, w.dim()), 1)
+        return K.cast(w.permute(perm).reshape(w.shape[0], -1).contiguous(), BF16)
+
+    return WEIGHTS.get((weight,), "patch", build)
+
+
+def patch_grad_to_param(weight: torch.nn.Parameter) -> Callable:
+    shape = weight.shape
+
+    def conv(g: torch.Tensor) -> torch.Tensor:
+        nd = len(shape) - 2
+        g = g.reshape(shape[0], *shape[2:], shape[1])
+        return g.permute(0, nd + 1, *range(1, nd + 1)).contiguous()
+
+    return conv
+
+
+def w_cat(weights: tuple) -> torch.Tensor:
+    return WEIGHTS.get(tuple(weights), "cat", lambda: torch.cat([K.cast(w.detach().reshape(w.shape[0], -1), BF16) for w in weights], dim=0))
+
+
+def b_cat(biases: tuple) -> torch.Tensor:
+    return WEIGHTS.get(tuple(biases), "bcat", lambda: torch.cat([b.detach() for b in biases], dim=0))
+
+
+def _split_k(m_red: int, n_out: int, k_out: int) -> int:
+    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
+    want = max(1, 512 // tiles)
+    return max(1, min(want, (m_red + 255) // 256))
+
+
+def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar | None, wshape: tuple, to_param_layout: Callable | None = None,
+          row_offset: int = 0, total_rows: int | None = None) -> None:
+    """dW[n,k] += dy^T x ; db[n] += colsum(dy).  ``row_offset`` targets a row block of a fused (cat) weight."""
+    n, k = dy16.shape[1], x16.shape[1]
+    full = wv.grad_buffer(wshape if total_rows is None else (total_rows, k), to_param_layout)
+    dst = full.view(-1, k)[row_offset:row_offset + n]
+    K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k))
+    if bv is not None:
+        K.colsum(dy16, bv.grad_buffer((n,) if total_rows is None else (total_rows,))[row_offset:row_offset + n])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# ops
+# --------------------------------------------------------------------------------------------------------------
+def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.Parameter, eps: float, *, act: int = 0, out_f32: bool = False) -> Var:
+    """y = [gelu](LN(x)); x fp32/bf16 [rows, c]; output bf16 (GEMM operand) or fp32 (residual stream)."""
+    y16, y32, mean, rstd = K.layernorm_fwd(x.data, gamma.detach(), beta.detach(), eps, act=act, want_bf16=not out_f32, want_f32=out_f32)
+    y = Var(y32 if out_f32 else y16)
+    gv, bv = tape.pvar(gamma), tape.pvar(beta)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        c = x.data.shape[1]
+        want16 = x.data.dtype == F32  # fp32 residual-stream input: also emit the bf16 copy for the upstream GEMMs
+        res = x.grad if (x.grad is not None and x.grad.dtype == F32) else None
+        dx32, dx16 = K.layernorm_bwd(y.grad, x.data, gamma.detach(), beta.detach(), mean, rstd, act=act, dx_residual=res,
+                                     want_f32=x.data.dtype == F32, want_bf16=want16 or x.data.dtype == BF16,
+                                     dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)))
+        if x.data.dtype == F32:
+            x.grad, x.grad16 = dx32, dx16  # includes the previously accumulated residual gradient
+        else:
+            x.add_grad(dx16)
+
+    tape.record(bwd)
+    return y
+
+
+def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None, *, residual: Var | None = None,
+              out_f32: bool = False, row_mask: torch.Tensor | None = None, w16: torch.Tensor | None = None,
+              to_param_layout: Callable | None = None) -> Var:
+    """y = x W^T + b (+ residual); x bf16 [m,k]; W given as nn.Linear / 1x1-conv weight (or a pre-built shadow ``w16``)."""
+    w = w16 if w16 is not None else w_plain(weight)
+    y = Var(K.gemm(x.data, w, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
+                   out_dtype=F32 if (out_f32 or residual is not None) else BF16, row_mask=row_mask))
+    wv, bv = tape.pvar(weight), tape.pvar(bias)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        if residual is not None:
+            residual.add_grad(y.grad, y.grad16)
+        # row_mask contract: y = mask * (xW^T + b) and the consumer (op_dwconv with in_mask) hands back a gradient whose
+        # masked rows are already zero, so the weight/bias gradients below need no extra masking pass.
+        dy16 = y.grad_bf16()
+        if weight.requires_grad:
+            wgrad(tape, dy16, x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
+        if x.needs_grad:
+            x.add_grad(K.gemm(dy16, w, a_kmajor=True, b_kmajor=False, row_mask=row_mask))
+
+    tape.record(bwd)
+    return y
+
+
+def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parameter, fc2_w: torch.nn.Parameter, fc2_b: torch.nn.Parameter,
+           residual: Var) -> Var:
+    """residual + fc2(gelu(fc1(x))) (timm Mlp / ConvMlp); GELU forward fused into fc1's epilogue, GELU backward into fc2's dgrad."""
+    w1, w2 = w_plain(fc1_w), w_plain(fc2_w)
+    m, hidden = x.data.shape[0], w1.shape[0]
+    h = torch.empty((m, hidden), dtype=BF16, device=x.data.device)
+    a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h)
+    y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=residual.data, out_dtype=F32))
+    pv = [tape.pvar(p) for p in (fc1_w, fc1_b, fc2_w, fc2_b)]
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        residual.add_grad(y.grad, y.grad16)
+        dy16 = y.grad_bf16()
+        wgrad(tape, dy16, a, pv[2], pv[3], tuple(w2.shape))
+        dh = K.gemm(dy16, w2, a_kmajor=True, b_kmajor=False, gelu_in=h)
+        wgrad(tape, dh, x.data, pv[0], pv[1], tuple(w1.shape))
+        if x.needs_grad:
+            x.add_grad(K.gemm(dh, w1, a_kmajor=True, b_kmajor=False))
+
+    tape.record(bwd)
+    return y
+
+
+def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b) -> Var:  # noqa: ANN001
+    """Fused q|k|v projection (one N=3C GEMM on concatenated shadow weights) + flash attention.  x bf16 [b*t, c]."""
+    c = x.data.shape[1]
+    w = w_cat((q_w, kv_w))
+    bias = b_cat((q_b, kv_b)) if q_b is not None else None
+    qkv = K.gemm(x.data, w, bias=bias)
+    t = qkv.shape[0] // batch
+    q3 = qkv.view(batch, t, 3 * c)
+    scale = (c // heads) ** -0.5
+    o, lse = K.attention_fwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], heads, scale)
+    y = Var(o.view(batch * t, c))
+    pv = [tape.pvar(p) for p in (q_w, q_b, kv_w, kv_b)]
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        dqkv = torch.empty_like(qkv)
+        d3 = dqkv.view(batch, t, 3 * c)
+        K.attention_bwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], o, y.grad.view(batch, t, c), lse, heads, scale, d3[..., :c],
+                        d3[..., c:2 * c], d3[..., 2 * c:])
+        wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))
+        wgrad(tape, dqkv[:, c:], x.data, pv[2], pv[3], (2 * c, c))
+        if x.needs_grad:
+            x.add_grad(K.gemm(dqkv, w, a_kmajor=True, b_kmajor=False))
+
+    tape.record(bwd)
+    return y
+
+
+def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b) -> Var:  # noqa: ANN001
+    """q from xq (bf16 [b*tq, c]), k|v from xk (bf16 [b*tk, c], shared by every decoder block, not normed)."""
+    c = xq.data.shape[1]
+    wq, wkv = w_plain(q_w), w_plain(kv_w)
+    q = K.gemm(xq.data, wq, bias=None if q_b is None else q_b.detach())
+    kv = K.gemm(xk.data, wkv, bias=None if kv_b is None else kv_b.detach())
+    tq, tk = q.shape[0] // batch, kv.shape[0] // batch
+    q3, kv3 = q.view(batch, tq, c), kv.view(batch, tk, 2 * c)
+    scale = (c // heads) ** -0.5
+    o, lse = K.attention_fwd(q3, kv3[..., :c], kv3[..., c:], heads, scale)
+    y = Var(o.view(batch * tq, c))
+    pv = [tape.pvar(p) for p in (q_w, q_b, kv_w, kv_b)]
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        dkv3 = dkv.view(batch, tk, 2 * c)
+        K.attention_bwd(q3, kv3[..., :c], kv3[..., c:], o, y.grad.view(batch, tq, c), lse, heads, scale, dq.view(batch, tq, c), dkv3[..., :c],
+                        dkv3[..., c:])
+        wgrad(tape, dq, xq.data, pv[0], pv[1], (c, c))
+        wgrad(tape, dkv, xk.data, pv[2], pv[3], (2 * c, c))
+        if xq.needs_grad:
+            xq.add_grad(K.gemm(dq, wq, a_kmajor=True, b_kmajor=False))
+        if xk.needs_grad:
+            xk.add_grad(K.gemm(dkv, wkv, a_kmajor=True, b_kmajor=False))
+
+    tape.record(bwd)
+    return y
+
+
+def op_cast_bf16(tape: Tape, x: Var) -> Var:
+    y = Var(K.cast(x.data, BF16))
+
+    def bwd() -> None:
+        if y.grad is not None and x.needs_grad:
+            x.add_grad(K.cast(y.grad, F32))
+
+    tape.record(bwd)
+    return y
+
+
+def op_cast_f32(tape: Tape, x: Var) -> Var:
+    y = Var(K.cast(x.data, F32))
+
+    def bwd() -> None:
+        if y.grad is not None and x.needs_grad:
+            x.add_grad(K.cast(y.grad, BF16))
+
+    tape.record(bwd)
+    return y
+
+
+def op_dwconv(tape: Tape, x: Var, spatial: tuple, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None,
+              in_mask: torch.Tensor | None = None) -> Var:
+    """Depthwise 5^n conv on bf16 channels-last rows [b*prod(spatial), c].  ``in_mask`` (uint8 per voxel) marks voxels whose
+    *input* was zeroed by the caller's mask multiply; the data gradient is zeroed there too (conv.py:410-411)."""
+    c = x.data.shape[1]
+    b = x.data.shape[0] // int(torch.Size(spatial).numel())
+    xs = x.data.view(b, *spatial, c)
+    y = Var(K.dwconv_fwd(xs, weight.detach(), None if bias is None else bias.detach()).view(-1, c))
+    wv, bv = tape.pvar(weight), tape.pvar(bias)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        dy = y.grad.view(b, *spatial, c)
+        K.dwconv_bwd_weight(xs, dy, wv.grad_buffer(tuple(weight.shape)), None if bias is None else bv.grad_buffer((c,)))
+        if x.needs_grad:
+            x.add_grad(K.dwconv_bwd_data(dy, weight.detach(), in_mask).view(-1, c))
+
+    tape.record(bwd)
+    return y
+
+
+def op_patch_gather(tape: Tape, x: Var, geom, dst_shape: tuple | None = None) -> Var:  # noqa: ANN001
+    """rows[token, (patch, c)] (bf16) gathered from a volume described by ``geom``; backward scatters (zeros elsewhere)."""
+    y = Var(K.patch_gather(x.data, geom, BF16))
+
+    def bwd() -> None:
+        if y.grad is None or not x.needs_grad:
+            return
+        subset = geom.token_idx is not None
+        dx = (torch.zeros if subset else torch.empty)(x.data.shape, dtype=F32, device=x.data.device)
+        K.patch_scatter(y.grad, dx, geom)
+        x.add_grad(dx)
+
+    tape.record(bwd)
+    return y
+
+
+def op_split_rows(tape: Tape, x: Var, idx_list: list) -> list:
+    """ys[i] = x[idx_list[i]] (int32 row indices, disjoint across the list).  One zeroed gradient buffer is shared."""
+    c = x.data.shape[1]
+    ys = []
+    for idx in idx_list:
+        out = torch.empty((idx.numel(), c), dtype=x.data.dtype, device=x.data.device)
+        ys.append(Var(K.row_copy(out, x.data, src_idx=idx)))
+
+    def bwd() -> None:
+        if not x.needs_grad or all(y.grad is None for y in ys):
+            return
+        dx = torch.zeros(x.data.shape, dtype=x.data.dtype, device=x.data.device)
+        for y, idx in zip(ys, idx_list):
+            if y.grad is not None:
+                K.row_copy(dx, y.grad, dst_idx=idx)
+        x.add_grad(dx)
+
+    tape.record(bwd)
+    return ys
+
+
+class Segment:
+    """One source of rows for :func:`op_assemble`: ``dst[dst_idx[i]] = src[i or src_idx[i]] + add[add_idx[i]]``.
+
+    ``src`` is a :class:`Var` (rows [n, c]) or an ``nn.Parameter`` token of shape (1, 1, c) broadcast to every row.
+    ``add`` is a constant table (frozen sin-cos positional embedding), indexed by ``add_idx``.
+    """
+
+    def __init__(self, dst_idx: torch.Tensor, src=None, add: torch.Tensor | None = None, add_idx: torch.Tensor | None = None) -> None:  # noqa: ANN001
+        self.dst_idx, self.src, self.add, self.add_idx = dst_idx, src, add, add_idx
+
+
+def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.device) -> Var:
+    """Build a token matrix [n_rows, c] (fp32) from row segments (replaces torch.cat / bool-mask selects / pos-embed adds:
+    cinema/vit.py:672-674, cinema/mae/mae.py:98-104,580-585, cinema/convvit.py:205)."""
+    out = torch.empty((n_rows, c), dtype=F32, device=device)
+    zero_idx = {}
+    for s in segments:
+        n = s.dst_idx.numel()
+        if isinstance(s.src, Var):
+            K.row_copy(out, s.src.data, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx)
+        elif s.src is not None:  # broadcast token parameter
+            z = zero_idx.setdefault(n, torch.zeros(n, dtype=torch.int32, device=device))
+            K.row_copy(out, s.src.detach().view(1, c), dst_idx=s.dst_idx, src_idx=z, add=s.add, add_idx=s.add_idx)
+        else:
+            K.row_copy(out, None, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx)
+    y = Var(out)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        for s in segments:
+            if isinstance(s.src, Var):
+                if s.src.needs_grad:
+                    g = torch.empty((s.dst_idx.numel(), c), dtype=F32, device=device)
+                    s.src.add_grad(K.row_copy(g, y.grad, src_idx=s.dst_idx))
+            elif s.src is not None and s.src.requires_grad:
+                K.colsum(y.grad, tape.pvar(s.src).grad_buffer((c,)), row_idx=s.dst_idx)
+
+    tape.record(bwd)
+    return y
+
+
+def op_mse(tape: Tape, pred: Var, image: torch.Tensor, geom_masked, norm_target: bool, eps: float = 1e-6) -> Var:  # noqa: ANN001
+    """Scalar masked-patch MSE (cinema/mae/mae.py:140-143); the target patches are gathered from ``image`` on the fly."""
+    loss = torch.zeros(1, dtype=F32, device=pred.data.device)
+    maxes = torch.full((2,), float("-inf"), dtype=F32, device=pred.data.device) if norm_target else None
+    K.mse_fwd(image, geom_masked, pred.data, norm_target, eps, loss, maxes)
+    y = Var(loss)
+
+    def bwd() -> None:
+        if y.grad is None or not pred.needs_grad:
+            return
+        d = K.mse_bwd(image, geom_masked, pred.data, norm_target, eps, y.grad, 1.0 / pred.data.numel())
+        pred.add_grad(d if pred.data.dtype == BF16 else K.cast(d, F32))
+
+    tape.record(bwd)
+    return y, maxes  # maxes: (normed_target_max, pred_max) metrics of the norm_target mode (mae.py:146-150), else None
+
+
+def op_mean_finite(tape: Tape, losses: list) -> Var:
+    """Mean over the finite per-view losses (cinema/mae/mae.py:604-608) without a host round trip."""
+    dev = losses[0].data.device
+    vals = torch.empty(len(losses), dtype=F32, device=dev)
+    for i, lv in enumerate(losses):
+        K.row_copy(vals[i:i + 1].view(1, 1), lv.data.view(1, 1))
+    mean, coef = torch.empty(1, dtype=F32, device=dev), torch.empty(len(losses), dtype=F32, device=dev)
+    K.mean_finite(vals, mean, coef)
+    y = Var(mean)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        for i, lv in enumerate(losses):
+            lv.add_grad(coef[i:i + 1] * y.grad.reshape(1))  # one-element scalar product: d loss / d loss_i = coef[i] * upstream
+
+    tape.record(bwd)
+    return y
+
+
+# --------------------------------------------------------------------------------------------------------------
+# torch.autograd bridge: one node per top-level call
+# --------------------------------------------------------------------------------------------------------------
+class _TapedCall(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, n_inputs, params, grad_mode, *tensors):  # noqa: ANN001, ANN205
+        inputs = tensors[:n_inputs]
+        train = grad_mode and any(t.requires_grad for t in tensors if isinstance(t, torch.Tensor))
+        tape = Tape(train=train)
+        in_vars = [Var(t, needs_grad=bool(t.requires_grad)) if isinstance(t, torch.Tensor) else t for t in inputs]
+        out_vars, extras = runner(tape, *in_vars)
+        ctx.tape, ctx.in_vars, ctx.out_vars, ctx.params, ctx.n_extras = tape, in_vars, out_vars, params, len(extras)
+        outs = tuple(v.data for v in out_vars) + tuple(extras)
+        ctx.mark_non_differentiable(*[e for e in extras if isinstance(e, torch.Tensor)])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):  # noqa: ANN001, ANN205
+        for v, g in zip(ctx.out_vars, grads):
+            if g is not None:
+                v.grad = g.contiguous().to(v.data.dtype).reshape(v.data.shape)
+        ctx.tape.backward()
+        in_grads = [v.grad.reshape(v.data.shape) if (isinstance(v, Var) and v.needs_grad and v.grad is not None) else None for v in ctx.in_vars]
+        p_grads = []
+        for p in ctx.params:
+            pv = ctx.tape.pvars.get(id(p))
+            p_grads.append(pv.final_grad() if (pv is not None and p.requires_grad) else None)
+        ctx.tape = None
+        return (None, None, None, None, *in_grads, *p_grads)
+
+
+def taped_call(runner: Callable, inputs: list, params: list) -> tuple:
+    """Run ``runner(tape, *input_vars) -> (out_vars, extra_tensors)`` as a single autograd node.
+
+    Returns the output tensors (differentiable) followed by the extras (non-differentiable).
+    """
+    params = [p for p in params if p is not None]
+    return _TapedCall.apply(runner, len(inputs), params, torch.is_grad_enabled(), *inputs, *params)

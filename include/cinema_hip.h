@@ -54,11 +54,13 @@ typedef struct {
   int accumulate;             /* 1: D += result with fp32 atomics (out_f32 must be 1) */
   int split_k;                /* >=1 */
   int force_generic;
+  int kernel_used;            /* OUT: 0 generic FMA, 1 MFMA k-major/k-major, 2 MFMA k-major/n-major (dgrad), 3 MFMA m-major/n-major (wgrad) */
 } cinema_gemm_args;
-int cinema_gemm_bf16(const cinema_gemm_args* args_host, void* stream);
+int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
 
-/* column sums: out[n] += sum_m x[m,n]  (bias gradients).  x bf16 [m][ldx], out fp32 [n] (accumulated atomically) */
-int cinema_colsum_bf16(const uint16_t* x, int m, int n, int ldx, float* out, void* stream);
+/* column sums: out[n] += sum_{i<m} x[row(i), n] with row(i) = row_idx ? row_idx[i] : i  (bias / token-parameter gradients).
+ * x bf16 (x_dtype 0) or fp32 (1), row-major [.][ldx]; out fp32 [n], accumulated atomically */
+int cinema_colsum(const void* x, int x_dtype, const int* row_idx, int m, int n, int ldx, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNorm (reference: nn.LayerNorm norm1/norm2/encoder.norm/fusion.norm/decoder.norm cinema/vit.py:549,564,650,738,
@@ -96,8 +98,9 @@ int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk,
  */
 int cinema_dwconv_fwd(const uint16_t* x, const float* w, const float* bias, uint16_t* y, int b, int X, int Y, int Z, int c, int kx, int ky,
                       int kz, void* stream);
-int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, int b, int X, int Y, int Z, int c, int kx, int ky, int kz,
-                           void* stream);
+/* dx = correlate(dy, flipped w); out_mask (uint8 [b*X*Y*Z] or NULL) zeroes masked voxels of dx (the `mask *` of conv.py:411) */
+int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, const uint8_t* out_mask, int b, int X, int Y, int Z, int c, int kx,
+                           int ky, int kz, void* stream);
 /* dw[c][taps] += sum x*dy ; dbias[c] += sum dy (fp32 atomics) */
 int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, int b, int X, int Y, int Z, int c, int kx,
                              int ky, int kz, void* stream);
@@ -149,7 +152,8 @@ int cinema_gelu_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, long lo
  *                (the per-view `torch.isfinite` filter + mean over views, mae.py:604-608, without a host sync)
  */
 int cinema_mse_fwd(const float* image, const cinema_patch_geom* geom_masked_host, const void* pred, int pred_dtype, int ld_pred,
-                   int norm_target, float eps, float inv_count, float* loss_out, void* stream);
+                   int norm_target, float eps, float inv_count, float* loss_out, float* max_out /* NULL or [2], pre-filled -inf: {max target, max pred} */,
+                   void* stream);
 int cinema_mse_bwd(const float* image, const cinema_patch_geom* geom_masked_host, const void* pred, int pred_dtype, int ld_pred,
                    int norm_target, float eps, const float* upstream, float host_scale, uint16_t* dpred, int ld_dpred, void* stream);
 int cinema_patch_stats(const float* image, const cinema_patch_geom* geom_all_host, float* out2, void* stream);

@@ -1,0 +1,161 @@
+"""End-to-end parity of the HIP path (cinema_amd.CineMA on an MI355X) against
+ (1) golden vectors captured from the upstream reference (tests/golden, fp32 CPU), and
+ (2) the CPU oracle run live on the same seeded inputs.
+
+Stated tolerances (bf16 MFMA compute, fp32 accumulation/residual stream):
+  loss: relative 2e-2;  predictions: max-abs 5e-2 on O(1) values;  metrics (fp32 reductions): relative 1e-4;
+  gradients: max-abs error <= 6 % of the tensor's max-abs gradient (bf16 operands in dgrad/wgrad).
+"""
+
+from __future__ import annotations
+
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cinema_oracle as O  # noqa: E402
+from cinema_amd import CineMA  # noqa: E402
+from cinema_amd.vit import get_vit_config  # noqa: E402
+from conftest import load_golden  # noqa: E402
+
+DEV = "cuda"
+LOSS_RTOL, PRED_ATOL, GRAD_FRAC = 2e-2, 5e-2, 6e-2
+
+
+def split(t: dict, prefix: str) -> dict:
+    return {k[len(prefix):]: v for k, v in t.items() if k.startswith(prefix)}
+
+
+def tiny_kwargs() -> dict:
+    return dict(image_size_dict={"sax": (128, 128, 8)}, in_chans_dict={"sax": 1}, enc_patch_size_dict={"sax": (4, 4, 1)},
+                enc_scale_factor_dict={"sax": (2, 2, 1)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2, **get_vit_config("tiny"))
+
+
+def mini_kwargs(**kw) -> dict:  # noqa: ANN003
+    views = ["sax", "lax_2c", "lax_3c", "lax_4c"]
+    return dict(image_size_dict={v: (32, 32, 4) if v == "sax" else (32, 32) for v in views}, in_chans_dict=dict.fromkeys(views, 1),
+                enc_patch_size_dict={v: (4, 4, 1) if v == "sax" else (4, 4) for v in views},
+                enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views}, enc_conv_chans=[16, 32], enc_conv_n_blocks=1,
+                enc_embed_dim=64, enc_depth=2, enc_n_heads=4, dec_embed_dim=32, dec_depth=2, dec_n_heads=4, **kw)
+
+
+def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tensor, ref_pred: dict, ref_metrics: dict, ref_grads: dict) -> None:
+    model.zero_grad(set_to_none=True)
+    loss, pred, mask_out, metrics = model({k: v.to(DEV) for k, v in images.items()}, 0.75, enc_mask_dict={k: v.to(DEV) for k, v in masks.items()})
+    assert loss.dim() == 0 and torch.isfinite(loss)
+    assert abs(float(loss) - float(ref_loss)) <= LOSS_RTOL * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    for v, t in ref_pred.items():
+        assert pred[v].shape == t.shape, (v, pred[v].shape, t.shape)
+        err = (pred[v].float().cpu() - t).abs().max()
+        assert err <= PRED_ATOL, (v, float(err))
+        assert torch.equal(mask_out[v].cpu(), masks[v])
+    for k, t in ref_metrics.items():
+        tol = LOSS_RTOL if (k.endswith(("mse_loss", "pred_max")) or k == "loss") else 1e-4  # bf16-compute quantities vs fp32 reductions
+        assert abs(float(metrics[k]) - float(t)) <= tol * abs(float(t)) + 1e-6, (k, float(metrics[k]), float(t))
+    loss.backward()
+    named = dict(model.named_parameters())
+    worst = {}
+    for k, t in ref_grads.items():
+        g = named[k].grad
+        assert g is not None, k
+        scale = float(t.abs().max())
+        err = float((g.float().cpu() - t).abs().max())
+        worst[k] = err / max(scale, 1e-12)
+        assert err <= GRAD_FRAC * scale + 1e-7, (k, err, scale)
+    print("worst grad rel err:", max(worst.items(), key=lambda kv: kv[1]))
+
+
+def test_tiny_cfg1_vs_reference_golden() -> None:
+    g = load_golden("tiny_sax.safetensors")
+    model = CineMA(**tiny_kwargs())
+    model.load_state_dict(split(g, "param/"))
+    model.to(DEV)
+    check_against(model, split(g, "image/"), {k: v.bool() for k, v in split(g, "mask/").items()}, g["loss"][0], split(g, "pred/"),
+                  {k: v[0] for k, v in split(g, "metric/").items()}, split(g, "grad/"))
+
+
+@pytest.mark.parametrize(("name", "kw"), [("mini_4view", {}), ("mini_4view_selfattn", {"cross_attn": False}), ("mini_4view_normtarget", {"norm_target": True})])
+def test_mini_4view_vs_reference_golden(name: str, kw: dict) -> None:
+    g = load_golden(f"{name}.safetensors")
+    model = CineMA(**mini_kwargs(**kw))
+    model.load_state_dict(split(load_golden("mini_4view.safetensors"), "param/"))
+    model.to(DEV)
+    check_against(model, split(g, "image/"), {k: v.bool() for k, v in split(g, "mask/").items()}, g["loss"][0], split(g, "pred/"),
+                  {k: v[0] for k, v in split(g, "metric/").items()}, split(g, "grad/"))
+
+
+def test_mini_feature_forward_vs_reference_golden() -> None:
+    g = load_golden("mini_4view.safetensors")
+    model = CineMA(**mini_kwargs())
+    model.load_state_dict(split(g, "param/"))
+    model.to(DEV).eval()
+    with torch.no_grad():
+        feats = model.feature_forward({k: v.to(DEV) for k, v in split(g, "image/").items()})
+    for k, t in split(g, "feature/").items():
+        assert feats[k].shape == t.shape
+        assert (feats[k].float().cpu() - t).abs().max() <= 5e-2, k  # LN-normalised O(1) features, bf16 compute
+
+
+def test_midsize_mfma_path_vs_oracle() -> None:
+    """A config whose shapes take the MFMA kernels (E=256/hd=64 encoder, D=128/hd=32 decoder, stem 64/128 channels),
+    checked against the CPU oracle on seeded random weights, inputs and masks."""
+    views = ["sax", "lax_2c"]
+    kw = dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1),
+              enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)}, enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)},
+              enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=2, enc_n_heads=4, dec_embed_dim=128, dec_depth=2,
+              dec_n_heads=4)
+    torch.manual_seed(3)
+    model = CineMA(**kw)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = O.MAEConfig(**kw)
+    gen = torch.Generator().manual_seed(5)
+    images = {v: torch.rand(3, 1, *kw["image_size_dict"][v], generator=gen) for v in views}
+    masks = {v: O.random_patch_mask(3, math.prod(cfg.grid_size(v)), 0.75, gen) for v in views}
+    p = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+    ref_loss, ref_pred, ref_metrics = O.mae_forward(p, cfg, images, masks)
+    ref_loss.backward()
+    ref_grads = {k: v.grad for k, v in p.items() if v.grad is not None}
+    model.to(DEV)
+    check_against(model, images, masks, ref_loss.detach(), {k: v.detach() for k, v in ref_pred.items()},
+                  {k: v.detach() for k, v in ref_metrics.items()}, ref_grads)
+
+
+def test_random_masks_and_api_contract() -> None:
+    model = CineMA(**mini_kwargs()).to(DEV)
+    images = {v: torch.rand(2, 1, *s, device=DEV) for v, s in model_sizes(model).items()}
+    loss, pred, masks, metrics = model(images, 0.75)
+    assert set(pred) == set(images) == set(masks)
+    for v in images:
+        n = model.enc_down_dict[v].patch_embed.n_patches
+        assert masks[v].shape == (2, n) and masks[v].dtype == torch.bool
+        assert int(masks[v].sum()) == 2 * (n - int(n * 0.25))
+        assert pred[v].shape == (2, n - int(n * 0.25), math.prod(model.dec_patch_size_dict[v]))
+    assert set(metrics) == {f"{v}_{m}" for v in images for m in ("target_mean", "target_std", "mse_loss")} | {"loss"}
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
+    sub = {"sax": images["sax"]}  # a subset of the views is allowed (mae.py:521-523)
+    loss2, pred2, _, _ = model(sub, 0.5)
+    assert set(pred2) == {"sax"} and torch.isfinite(loss2)
+    with pytest.raises(ValueError):
+        model({"bogus": images["sax"]}, 0.75)
+    loss0, pred0, _, _ = model(images, 0.0)  # nothing masked: NaN loss is a value, not an exception (mae.py:604-608)
+    assert math.isnan(float(loss0)) and all(p.shape[1] == 0 for p in pred0.values())
+
+
+def model_sizes(model: CineMA) -> dict:
+    out = {}
+    for v in model.views:
+        enc = model.enc_down_dict[v]
+        out[v] = tuple(g * p for g, p in zip(enc.patch_embed.grid_size, enc.eff_patch_size))
+    return out
+
+
+def test_cpu_tensor_fails_loudly() -> None:
+    from cinema_amd.hip import HipLibraryError
+
+    model = CineMA(**mini_kwargs())  # parameters on the CPU
+    with pytest.raises(HipLibraryError):
+        model({"sax": torch.rand(1, 1, 32, 32, 4)}, 0.75)
