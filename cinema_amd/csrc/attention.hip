@@ -410,6 +410,32 @@ __global__ void attn_delta_kernel(AttnP p) {
   p.delta[idx] = s;
 }
 
+// vectorised delta: one wave per (b, q) token row; 16-byte loads of O and dO across all heads; lanes of one head
+// (hd/8 adjacent lanes) reduce with xor shuffles.  hd in {8,16,32,64,128}.
+__global__ __launch_bounds__(256) void attn_delta_vec_kernel(AttnP p) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)p.b * p.tq) return;
+  const int q = (int)(row % p.tq), b = (int)(row / p.tq);
+  const int lanes_per_head = p.hd >> 3;
+  const int n_chunks = p.h * lanes_per_head;
+  const bf16_t* op = p.o + (size_t)row * p.ldo;
+  const bf16_t* dop = p.d_o + (size_t)row * p.lddo;
+  for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+    const int c = c0 + lane;
+    float s = 0.f;
+    if (c < n_chunks) {
+      const uint4 a = *reinterpret_cast<const uint4*>(op + c * 8), d = *reinterpret_cast<const uint4*>(dop + c * 8);
+      s = bf2f((bf16_t)(a.x & 0xffff)) * bf2f((bf16_t)(d.x & 0xffff)) + bf2f((bf16_t)(a.x >> 16)) * bf2f((bf16_t)(d.x >> 16)) +
+          bf2f((bf16_t)(a.y & 0xffff)) * bf2f((bf16_t)(d.y & 0xffff)) + bf2f((bf16_t)(a.y >> 16)) * bf2f((bf16_t)(d.y >> 16)) +
+          bf2f((bf16_t)(a.z & 0xffff)) * bf2f((bf16_t)(d.z & 0xffff)) + bf2f((bf16_t)(a.z >> 16)) * bf2f((bf16_t)(d.z >> 16)) +
+          bf2f((bf16_t)(a.w & 0xffff)) * bf2f((bf16_t)(d.w & 0xffff)) + bf2f((bf16_t)(a.w >> 16)) * bf2f((bf16_t)(d.w >> 16));
+    }
+    for (int o = lanes_per_head >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (c < n_chunks && (c % lanes_per_head) == 0) p.delta[((size_t)b * p.h + c / lanes_per_head) * p.tq + q] = s;
+  }
+}
+
 // ================================================================================================
 // generic kernels (any head_dim <= 128): one wave per output row, scores staged in LDS
 // ================================================================================================
@@ -550,7 +576,13 @@ CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* 
   p.b = b; p.h = h; p.tq = tq; p.tk = tk; p.hd = hd; p.scale = scale; p.c2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   const long long nq = (long long)b * h * tq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, p);
+  const bool pow2 = (hd & (hd - 1)) == 0 && hd >= 8;
+  if (pow2 && !(ldo & 7) && !(lddo & 7) && !(((uintptr_t)o) & 15) && !(((uintptr_t)d_o) & 15)) {
+    const long long rows = (long long)b * tq;
+    hipLaunchKernelGGL(attn_delta_vec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, p);
+  }
   if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv})) {
     dim3 gq((tq + 127) / 128, h, b), gk((tk + 127) / 128, h, b);
     if (hd == 64) {

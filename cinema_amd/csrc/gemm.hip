@@ -17,6 +17,7 @@ struct GemmP {
   bf16_t* aux_out; int ld_aux;
   int act, out_f32, accumulate;
   int ktiles_per_split;
+  float* ws;  // split-K partial slabs [gridDim.z][m][n] (fp32) or nullptr
 };
 
 // ---- epilogue on 4 consecutive columns (n0..n0+3) of row m; n0 % 4 == 0 and n0+3 < N guaranteed by the caller
@@ -66,6 +67,127 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
   }
 }
 
+// ---- epilogue on W (4 or 8) consecutive columns n0.. of row m (all 16-byte aligned; n0 + W <= N guaranteed by the caller)
+template <int W>
+__device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, float (&v)[W], bool add_bias) {
+#pragma unroll
+  for (int i = 0; i < W; i++) v[i] *= p.alpha;
+  if (p.bias && add_bias) {
+#pragma unroll
+    for (int i = 0; i < W; i += 4) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + i);
+      v[i] += bv.x; v[i + 1] += bv.y; v[i + 2] += bv.z; v[i + 3] += bv.w;
+    }
+  }
+  auto store_bf16 = [&](bf16_t* dst) {
+    if (W == 8) {
+      uint4 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]); pk.z = pack_bf2(v[W - 4], v[W - 3]); pk.w = pack_bf2(v[W - 2], v[W - 1]);
+      *reinterpret_cast<uint4*>(dst) = pk;
+    } else {
+      uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(dst) = pk;
+    }
+  };
+  auto load_bf16 = [&](const bf16_t* src, float (&o)[W]) {
+    if (W == 8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(src);
+      o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16)); o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
+      o[W - 4] = bf2f((bf16_t)(u.z & 0xffff)); o[W - 3] = bf2f((bf16_t)(u.z >> 16)); o[W - 2] = bf2f((bf16_t)(u.w & 0xffff)); o[W - 1] = bf2f((bf16_t)(u.w >> 16));
+    } else {
+      const uint2 u = *reinterpret_cast<const uint2*>(src);
+      o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16)); o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
+    }
+  };
+  if (p.aux_out) store_bf16(p.aux_out + (size_t)m * p.ld_aux + n0);
+  if (p.act == 1) {
+#pragma unroll
+    for (int i = 0; i < W; i++) v[i] = gelu_f(v[i]);
+  }
+  if (p.gelu_in) {
+    float g[W];
+    load_bf16(p.gelu_in + (size_t)m * p.ld_gelu + n0, g);
+#pragma unroll
+    for (int i = 0; i < W; i++) v[i] *= gelu_grad_f(g[i]);
+  }
+  if (p.row_mask) {
+    const float s = p.row_mask[m] ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < W; i++) v[i] *= s;
+  }
+  if (p.res_f32) {
+#pragma unroll
+    for (int i = 0; i < W; i += 4) {
+      const float4 rv = *reinterpret_cast<const float4*>(p.res_f32 + (size_t)m * p.ld_res + n0 + i);
+      v[i] += rv.x; v[i + 1] += rv.y; v[i + 2] += rv.z; v[i + 3] += rv.w;
+    }
+  } else if (p.res_bf16) {
+    float r[W];
+    load_bf16(p.res_bf16 + (size_t)m * p.ld_res + n0, r);
+#pragma unroll
+    for (int i = 0; i < W; i++) v[i] += r[i];
+  }
+  if (p.out_f32) {
+    float* dp = reinterpret_cast<float*>(p.d) + (size_t)m * p.ldd + n0;
+#pragma unroll
+    for (int i = 0; i < W; i += 4) *reinterpret_cast<float4*>(dp + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else {
+    store_bf16(reinterpret_cast<bf16_t*>(p.d) + (size_t)m * p.ldd + n0);
+  }
+}
+
+// Coalesced epilogue of one wave tile (MI x 2 accumulator tiles of 32x32): every 32x32 fp32 block goes through a private
+// 4 KiB LDS staging area (XOR-swizzled float4 columns, no padding) so that a lane ends up with 4 (fp32 out) or 8 (bf16 out)
+// CONSECUTIVE columns of one row and the wave writes whole 64/128-byte row segments.  The direct register epilogue wrote
+// 8 bytes into 64 different cache lines per store instruction and dominated short-K GEMMs (K-sweep intercept 34-48 us).
+template <int MI>
+__device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, int z, float* stg) {
+  const bool to_ws = p.ws != nullptr;
+  const bool add_bias = z == 0;
+  const int ml = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (nw + j * 32 >= p.n) continue;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int col4 = 2 * q + hi;
+        *reinterpret_cast<float4*>(stg + ml * 32 + ((col4 ^ (ml & 7)) << 2)) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
+      const int mb = mw + i * 32, nb = nw + j * 32;
+      if (to_ws || p.out_f32) {
+#pragma unroll
+        for (int pss = 0; pss < 4; pss++) {
+          const int r = pss * 8 + (lane >> 3), col4 = lane & 7;
+          const float4 t = *reinterpret_cast<const float4*>(stg + r * 32 + ((col4 ^ (r & 7)) << 2));
+          const int m = mb + r, n = nb + col4 * 4;
+          if (m < p.m && n < p.n) {
+            if (to_ws) {
+              *reinterpret_cast<float4*>(p.ws + (size_t)z * p.m * p.n + (size_t)m * p.n + n) = t;
+            } else {
+              float v[4] = {t.x, t.y, t.z, t.w};
+              epilogue_row<4>(p, m, n, v, add_bias);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int pss = 0; pss < 2; pss++) {
+          const int r = pss * 16 + (lane >> 2), c8 = lane & 3;
+          const float4 t0 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8) ^ (r & 7)) << 2));
+          const float4 t1 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8 + 1) ^ (r & 7)) << 2));
+          const int m = mb + r, n = nb + c8 * 8;
+          if (m < p.m && n < p.n) {
+            float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            epilogue_row<8>(p, m, n, v, add_bias);
+          }
+        }
+      }
+    }
+  }
+}
+
 // scalar epilogue for the generic kernel
 __device__ __forceinline__ void epilogue1(const GemmP& p, int m, int n, float acc, bool add_bias) {
   float v = acc * p.alpha;
@@ -92,8 +214,23 @@ __device__ __forceinline__ void epilogue1(const GemmP& p, int m, int n, float ac
 // ------------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int KMAJ_BYTES = 128 * BK * 2;        // [128 rows][64 k] bf16, 128-byte rows, XOR swizzled
-constexpr int MNMAJ_STRIDE = 128 * 2 + 64;      // [64 k rows][128 cols] bf16 + 64 B pad (tr-read conflict-free)
-constexpr int MNMAJ_BYTES = BK * MNMAJ_STRIDE;
+constexpr int MNMAJ_STRIDE = 128 * 2;           // [64 k rows][128 cols] bf16; the 64-byte block index is XORed with (k row & 3) so that the
+constexpr int MNMAJ_BYTES = BK * MNMAJ_STRIDE;  // 4 rows x 64 B touched by one 32-lane tr-read group cover all 64 banks (no padding needed)
+__device__ __forceinline__ int mn_off(int kr, int chunk16) { return kr * MNMAJ_STRIDE + ((chunk16 ^ ((kr & 3) << 2)) << 4); }
+
+
+// One LDS-DMA instruction (16 B per lane -> 1 KiB lane-linear at the wave-uniform LDS byte address `lds_addr`), issued
+// from inline asm so that hipcc does NOT see a pending LDS write: with the builtin it inserts s_waitcnt vmcnt(0) in front
+// of the first ds_read_b64_tr_b16 of every k-step (observed in the .s of the dgrad/wgrad variants), which serialises
+// the pipeline.  The loop below counts vmcnt by hand instead.  M0 is saved/restored inside the statement (cdna guide 5.7).
+__device__ __forceinline__ void glds16(uint32_t lds_addr, const void* gsrc) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }  // low 32 bits of a flat LDS pointer = LDS byte address
 
 template <bool KMAJ>
 struct TileIO {
@@ -135,7 +272,7 @@ struct TileIO {
 #pragma unroll
       for (int pss = 0; pss < 4; pss++) {
         const int kr = pss * 16 + (tid >> 4);
-        *reinterpret_cast<uint4*>(lds + kr * MNMAJ_STRIDE + chunk * 16) = r[pss];
+        *reinterpret_cast<uint4*>(lds + mn_off(kr, chunk)) = r[pss];
       }
     }
   }
@@ -148,18 +285,47 @@ struct TileIO {
       const int q4 = lane >> 4, t = lane & 15;
       const int col = base + 16 * (q4 & 1) + 4 * (t & 3);
       const int kr = ks * 16 + 8 * (q4 >> 1) + (t >> 2);
-      const short4v lo = lds_tr16_b64(lds + kr * MNMAJ_STRIDE + col * 2);
-      const short4v hi = lds_tr16_b64(lds + (kr + 4) * MNMAJ_STRIDE + col * 2);
+      const short4v lo = lds_tr16_b64(lds + mn_off(kr, col >> 3) + (col & 7) * 2);
+      const short4v hi = lds_tr16_b64(lds + mn_off(kr + 4, col >> 3) + (col & 7) * 2);
       short8v out;
       out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
       out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
       return out;
     }
   }
+  // global -> LDS directly (LDS-DMA, 16 B per lane, no VGPR staging, no ds_write).  The destination of one wave-instruction
+  // is lane-linear (1 KiB = 8 k-major rows or 4 mn-major rows); the XOR swizzles only permute 16-byte chunks inside a
+  // row, so they are applied to the per-lane SOURCE address and every row segment is still fetched as whole cache lines.
+  // Out-of-range reduction indices read a zero page (M/N tails just re-read a valid row; their outputs are never stored).
+  static __device__ __forceinline__ void glds(char* lds, const bf16_t* base, int ld, int row0, int nrows, int k0, int kdim, int lane, int wave,
+                                              const bf16_t* zero_page) {
+#pragma unroll
+    for (int pss = 0; pss < 4; pss++) {
+      const int blk = pss * 4 + wave;  // 1 KiB block of the 16 KiB tile
+      const bf16_t* src;
+      if (KMAJ) {
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int rg = row0 + row;
+        rg = rg < nrows ? rg : nrows - 1;
+        const int kk = k0 + c * 8;
+        src = kk < kdim ? base + (size_t)rg * ld + kk : zero_page;
+      } else {
+        const int kr = blk * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);
+        int col = row0 + c * 8;
+        col = col < nrows ? col : 0;
+        src = (k0 + kr) < kdim ? base + (size_t)(k0 + kr) * ld + col : zero_page;
+      }
+      glds16(__builtin_amdgcn_readfirstlane(lds_address(lds) + blk * 1024), src);
+    }
+  }
   static constexpr int BYTES = KMAJ ? KMAJ_BYTES : MNMAJ_BYTES;
 };
 
-template <bool A_KMAJ, bool B_KMAJ>
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <bool A_KMAJ, bool B_KMAJ, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
   using AIO = TileIO<A_KMAJ>;
   using BIO = TileIO<B_KMAJ>;
@@ -184,10 +350,18 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   uint4 ra[4], rb[4];
-  AIO::load(ra, p.a, p.lda, m0, p.m, kt_begin * BK, p.k, tid);
-  BIO::load(rb, p.b, p.ldb, n0, p.n, kt_begin * BK, p.k, tid);
-  AIO::store(ra, smem, tid);
-  BIO::store(rb, smem + AIO::BYTES, tid);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
+  if (GLDS) {
+    AIO::glds(smem, p.a, p.lda, m0, p.m, kt_begin * BK, p.k, lane, wave_u, zero_page);
+    BIO::glds(smem + AIO::BYTES, p.b, p.ldb, n0, p.n, kt_begin * BK, p.k, lane, wave_u, zero_page);
+  } else {
+    AIO::load(ra, p.a, p.lda, m0, p.m, kt_begin * BK, p.k, tid);
+    BIO::load(rb, p.b, p.ldb, n0, p.n, kt_begin * BK, p.k, tid);
+    AIO::store(ra, smem, tid);
+    BIO::store(rb, smem + AIO::BYTES, tid);
+  }
+  if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = kt_begin; kt < kt_end; kt++) {
@@ -196,8 +370,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     const char* sb = sa + AIO::BYTES;
     const bool more = kt + 1 < kt_end;
     if (more) {
-      AIO::load(ra, p.a, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid);
-      BIO::load(rb, p.b, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid);
+      if (GLDS) {
+        char* na = smem + (cur ^ 1) * STAGE;
+        AIO::glds(na, p.a, p.lda, m0, p.m, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
+        BIO::glds(na + AIO::BYTES, p.b, p.ldb, n0, p.n, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
+      } else {
+        AIO::load(ra, p.a, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid);
+        BIO::load(rb, p.b, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
@@ -211,27 +391,248 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    if (more) {
+    if (more && !GLDS) {
       char* na = smem + (cur ^ 1) * STAGE;
       AIO::store(ra, na, tid);
       BIO::store(rb, na + AIO::BYTES, tid);
     }
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA must have landed before anyone reads it
     __syncthreads();
   }
 
-  const bool add_bias = blockIdx.z == 0;
+  // epilogue: the stage buffers are free after the last barrier -> 4 KiB of them per wave stage the coalesced stores
+  if (p.accumulate && !p.ws) {  // atomic fallback (no workspace given): register epilogue
+    const bool add_bias = blockIdx.z == 0;
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int m = m0 + wm + i * 32 + (lane & 31);
+    for (int i = 0; i < 2; i++) {
+      const int m = m0 + wm + i * 32 + (lane & 31);
+      if (m >= p.m) continue;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int n = n0 + wn + j * 32 + 8 * q + 4 * (lane >> 5);
+          if (n < p.n) epilogue4(p, m, n, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], add_bias);
+        }
+    }
+    return;
+  }
+  store_wave_tile_staged<2>(p, acc, m0 + wm, n0 + wn, lane, blockIdx.z, reinterpret_cast<float*>(smem + wave * 4096));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-tile kernel: 256(M) x 128(N) x 64(K) block tile, PERSISTENT and WAVE-SPECIALISED.
+//   waves 0-3  consumers: one per SIMD, each owns a 128x64 output tile (4x2 MFMA 32x32x16 accumulators = 128 regs) and
+//              does nothing but ds_read + MFMA (+ the epilogue of a finished tile);
+//   waves 4-7  producers: issue the LDS-DMA (global_load_lds, 12 x 1 KiB pieces per wave per k-tile) into a 3-stage ring,
+//              two k-tiles ahead, and publish a landed tile with a counted s_waitcnt vmcnt + the per-iteration s_barrier.
+// Why: on the 128x128 kernel a K-sweep gave t = 34 us + 0.07 us * K (M=10960, N=3072): (i) ~5 us of un-overlapped
+// prologue/epilogue per round of tiles and (ii) a loop at 38 % of the MFMA rate because every wave both issued 8 LDS-DMA
+// pieces (60-185 issue cycles each, MI355X_MICROARCH "LDS-DMA piece issue cost") and 16 MFMAs per k-tile, in order.
+// Specialisation takes the DMA issue off the MFMA waves; the persistent (tile, k) iteration stream lets the producers
+// prefetch the next tile's first k-tiles while the consumers store the previous tile.
+// ------------------------------------------------------------------------------------------------
+template <bool KMAJ, int ROWS, int NPROD>
+struct BigTile {
+  static constexpr int RB = KMAJ ? 128 : ROWS * 2;           // bytes per LDS row
+  static constexpr int BYTES = KMAJ ? ROWS * 128 : 64 * RB;  // [ROWS][64 k] or [64 k][ROWS]
+  static constexpr int NBLK = BYTES / 1024;                  // 1 KiB LDS-DMA pieces
+  static constexpr int PASSES = NBLK / NPROD;                // pieces per producer wave
+  static __device__ __forceinline__ int mn_off(int kr, int chunk16) { return kr * RB + ((chunk16 ^ ((kr & 3) << 2)) << 4); }
+  static __device__ __forceinline__ void glds(uint32_t lds_addr, const bf16_t* base, int ld, int row0, int nrows, int k0, int kdim, int lane, int pwave,
+                                              const bf16_t* zero_page) {
+#pragma unroll
+    for (int pss = 0; pss < PASSES; pss++) {
+      const int blk = pss * NPROD + pwave;
+      const bf16_t* src;
+      if (KMAJ) {
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int rg = row0 + row;
+        rg = rg < nrows ? rg : nrows - 1;
+        const int kk = k0 + c * 8;
+        src = kk < kdim ? base + (size_t)rg * ld + kk : zero_page;
+      } else {
+        constexpr int CPR = RB / 16;          // 16-byte chunks per row
+        constexpr int RPB = 1024 / RB;        // rows per 1 KiB piece
+        const int kr = blk * RPB + lane / CPR;
+        const int c = (lane % CPR) ^ ((kr & 3) << 2);
+        int col = row0 + c * 8;
+        col = col < nrows ? col : 0;
+        src = (k0 + kr) < kdim ? base + (size_t)(k0 + kr) * ld + col : zero_page;
+      }
+      glds16(lds_addr + blk * 1024, src);
+    }
+  }
+  static __device__ __forceinline__ short8v frag(const char* lds, int base, int ks, int lane) {
+    if (KMAJ) {
+      return *reinterpret_cast<const short8v*>(lds + swz_off<128>(base + (lane & 31), ks * 2 + (lane >> 5)));
+    } else {
+      const int q4 = lane >> 4, t = lane & 15;
+      const int col = base + 16 * (q4 & 1) + 4 * (t & 3);
+      const int kr = ks * 16 + 8 * (q4 >> 1) + (t >> 2);
+      const short4v lo = lds_tr16_b64(lds + mn_off(kr, col >> 3) + (col & 7) * 2);
+      const short4v hi = lds_tr16_b64(lds + mn_off(kr + 4, col >> 3) + (col & 7) * 2);
+      short8v out;
+      out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+      out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+      return out;
+    }
+  }
+};
+
+// epilogue of one wave tile (MI x 2 MFMA tiles); `z` = split index (workspace slab / bias only on split 0)
+template <int MI>
+__device__ __forceinline__ void store_wave_tile(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, int z) {
+  if (p.ws) {
+    float* slab = p.ws + (size_t)z * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+      const int m = mw + i * 32 + (lane & 31);
+      if (m >= p.m) continue;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int n = nw + j * 32 + 8 * q + 4 * (lane >> 5);
+          if (n < p.n)
+            *reinterpret_cast<float4*>(slab + (size_t)m * p.n + n) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+    }
+    return;
+  }
+  const bool add_bias = z == 0;
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    const int m = mw + i * 32 + (lane & 31);
     if (m >= p.m) continue;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int n = n0 + wn + j * 32 + 8 * q + 4 * (lane >> 5);
+        const int n = nw + j * 32 + 8 * q + 4 * (lane >> 5);
         if (n < p.n) epilogue4(p, m, n, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], add_bias);
       }
+  }
+}
+
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items, int tiles_n, int gz) {
+  using AT = BigTile<A_KMAJ, 256, 4>;
+  using BT = BigTile<B_KMAJ, 128, 4>;
+  constexpr int STAGE = AT::BYTES + BT::BYTES;  // 48 KiB
+  static_assert(AT::PASSES + BT::PASSES == 12, "the counted vmcnt below assumes 12 DMA pieces per producer wave per k-tile");
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE + 4 * 4096];  // 3-stage ring + one 4 KiB epilogue staging block per consumer wave
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = (p.k + BK - 1) / BK;
+  // work items of this block: item = blockIdx.x + i * gridDim.x ; item -> (tile = item / gz, z = item % gz)
+  auto item_nt = [&](int item) {
+    const int kb = (item % gz) * p.ktiles_per_split;
+    return min(nkt, kb + p.ktiles_per_split) - kb;
+  };
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int pw = wave - 4;
+    const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
+    int item = blockIdx.x, kt = 0, stage = 0;  // cursor of the NEXT (item, k-tile) to issue
+    int nt = item < n_items ? item_nt(item) : 0;
+    auto issue_next = [&]() -> bool {  // returns false when the stream is exhausted
+      if (item >= n_items) return false;
+      const int tile = item / gz;
+      const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
+      const int k0 = ((item % gz) * p.ktiles_per_split + kt) * BK;
+      const uint32_t s = smem_addr + stage * STAGE;
+      AT::glds(s, p.a, p.lda, m0, p.m, k0, p.k, lane, pw, zero_page);
+      BT::glds(s + AT::BYTES, p.b, p.ldb, n0, p.n, k0, p.k, lane, pw, zero_page);
+      stage = stage == 2 ? 0 : stage + 1;
+      if (++kt == nt) {
+        kt = 0;
+        item += gridDim.x;
+        nt = item < n_items ? item_nt(item) : 0;
+      }
+      return true;
+    };
+    int in_flight = 0;  // k-tiles issued and not yet published
+    if (issue_next()) in_flight++;
+    if (issue_next()) in_flight++;
+    // publish iteration 0
+    if (in_flight == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    in_flight--;
+    // steady state: one barrier per consumer iteration; the stage freed by the barrier we just passed is refilled at once
+    while (true) {
+      const bool issued = issue_next();
+      if (issued) in_flight++;
+      if (in_flight == 0) break;  // nothing left to publish: the consumers are in their last iteration
+      if (in_flight == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // oldest in-flight k-tile landed, newest stays in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      in_flight--;
     }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+  float16v acc[4][2];
+  int stage = 0;
+  bool first = true;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int tile = item / gz, z = item % gz;
+    const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
+    const int nt = item_nt(item);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int t = 0; t < nt; t++) {
+      // wait until the producers have published this k-tile (and, by the same barrier, learnt that the previous stage is free)
+      if (!first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      first = false;
+      const char* sa = smem + stage * STAGE;
+      const char* sb = sa + AT::BYTES;
+      // software-pipelined fragments: the ds_reads of k-step ks+1 are issued BEFORE the MFMAs of k-step ks (one wave per
+      // SIMD has nobody else to hide the LDS latency behind)
+      short8v fa[2][4], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[0][i] = AT::frag(sa, wm + 32 * i, 0, lane);
+      fb[0][0] = BT::frag(sb, wn, 0, lane);
+      fb[0][1] = BT::frag(sb, wn + 32, 0, lane);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ks++) {
+        const int c = ks & 1, nx = c ^ 1;
+        if (ks + 1 < BK / 16) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) fa[nx][i] = AT::frag(sa, wm + 32 * i, ks + 1, lane);
+          fb[nx][0] = BT::frag(sb, wn, ks + 1, lane);
+          fb[nx][1] = BT::frag(sb, wn + 32, ks + 1, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
+        // pin the schedule: the 8 MFMAs of this k-step interleaved 1:1 with the 6 fragment reads of the next one
+        if (ks + 1 < BK / 16) {
+#pragma unroll
+          for (int g = 0; g < 6; g++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, A_KMAJ && B_KMAJ ? 1 : 2, 0);  // DS reads (tr-read fragments take 2 each)
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    if (p.accumulate && !p.ws) store_wave_tile<4>(p, acc, m0 + wm, n0 + wn, lane, z);  // atomic fallback keeps the register epilogue
+    else store_wave_tile_staged<4>(p, acc, m0 + wm, n0 + wn, lane, z, reinterpret_cast<float*>(smem + 3 * STAGE + wave * 4096));
   }
 }
 
@@ -292,25 +693,87 @@ __global__ void colsum_kernel(const void* x, int is_f32, const int* row_idx, int
   if (rl == 0 && col < n) unsafeAtomicAdd(out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// dst[m][n] (+)= alpha * sum_z ws[z][m][n]   (second pass of the workspace split-K; fully coalesced, deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splits, int m, int n, float* dst, int ldd, int accumulate, float alpha) {
+  const long long total4 = (long long)m * n / 4;
+  const size_t slab = (size_t)m * n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const size_t e = (size_t)i * 4;
+    float4 s = *reinterpret_cast<const float4*>(ws + e);
+    for (int z = 1; z < splits; z++) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + z * slab + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int row = (int)(e / n), col = (int)(e % n);
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)row * ldd + col);
+    if (accumulate) { const float4 o = *d; s.x = o.x + alpha * s.x; s.y = o.y + alpha * s.y; s.z = o.z + alpha * s.z; s.w = o.w + alpha * s.w; }
+    else { s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha; }
+    *d = s;
+  }
+}
+
+// Streaming column sum for dense bf16 matrices (bias gradients): 16-byte loads, 8 columns per lane, 32 lanes x 8 row-lanes
+// per block, grid sized to keep >= ~1k blocks in flight; HBM-bound (each element is read exactly once).
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* x, int m, int n, int ldx, float* out, int rows_per_block) {
+  __shared__ float part[8][32][9];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + tx * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(m, r0 + rows_per_block);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < n) {
+    int r = r0 + ty;
+    for (; r + 24 < r1; r += 32) {  // 4 independent 16-byte loads in flight per lane
+      uint4 u[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) u[i] = *reinterpret_cast<const uint4*>(x + (size_t)(r + 8 * i) * ldx + col);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        acc[0] += bf2f((bf16_t)(u[i].x & 0xffff)); acc[1] += bf2f((bf16_t)(u[i].x >> 16));
+        acc[2] += bf2f((bf16_t)(u[i].y & 0xffff)); acc[3] += bf2f((bf16_t)(u[i].y >> 16));
+        acc[4] += bf2f((bf16_t)(u[i].z & 0xffff)); acc[5] += bf2f((bf16_t)(u[i].z >> 16));
+        acc[6] += bf2f((bf16_t)(u[i].w & 0xffff)); acc[7] += bf2f((bf16_t)(u[i].w >> 16));
+      }
+    }
+    for (; r < r1; r += 8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + (size_t)r * ldx + col);
+      acc[0] += bf2f((bf16_t)(u.x & 0xffff)); acc[1] += bf2f((bf16_t)(u.x >> 16));
+      acc[2] += bf2f((bf16_t)(u.y & 0xffff)); acc[3] += bf2f((bf16_t)(u.y >> 16));
+      acc[4] += bf2f((bf16_t)(u.z & 0xffff)); acc[5] += bf2f((bf16_t)(u.z >> 16));
+      acc[6] += bf2f((bf16_t)(u.w & 0xffff)); acc[7] += bf2f((bf16_t)(u.w >> 16));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) part[ty][tx][i] = acc[i];
+  __syncthreads();
+  // 256 threads <-> 256 columns of the block
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += part[j][c >> 3][c & 7];
+    unsafeAtomicAdd(out + blockIdx.x * 256 + c, s);
+  }
+}
+
 }  // namespace
 
 CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
   if (a->accumulate && !a->out_f32) return CINEMA_ERR_BAD_ARG;
   const int split = a->split_k < 1 ? 1 : a->split_k;
-  if (split > 1 && !a->accumulate) return CINEMA_ERR_BAD_ARG;
+  if (split > 1 && !a->accumulate && !a->workspace) return CINEMA_ERR_BAD_ARG;
   GemmP p;
   p.a = (const bf16_t*)a->a; p.b = (const bf16_t*)a->b; p.d = a->d;
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldb = a->ldb; p.ldd = a->ldd;
   p.alpha = a->alpha;
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = a->residual_bf16; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
-  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate;
+  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr;
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
   auto ptr16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-  bool fast = !a->force_generic && al8(a->lda) && al8(a->ldb) && al8(a->ldd) && al8(a->n) && ptr16(a->a) && ptr16(a->b) && ptr16(a->d);
+  bool fast = a->force_generic != 1 && al8(a->lda) && al8(a->ldb) && al8(a->ldd) && al8(a->n) && ptr16(a->a) && ptr16(a->b) && ptr16(a->d);
   fast = fast && (a->a_kmajor ? al8(a->k) : al8(a->m)) && (a->b_kmajor ? al8(a->k) : true);
   fast = fast && (!a->bias || ptr16(a->bias)) && (!a->residual_f32 || (al8(a->ld_res) && ptr16(a->residual_f32)));
   fast = fast && (!a->residual_bf16 || (al8(a->ld_res) && ptr16(a->residual_bf16))) && (!a->gelu_in || (al8(a->ld_gelu) && ptr16(a->gelu_in)));
@@ -321,11 +784,45 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     const int sp = split > nkt ? nkt : split;
     p.ktiles_per_split = (nkt + sp - 1) / sp;
     const int gz = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, gz);
+    // measured (tools/bench_gemm.py): the wave-specialised persistent kernel wins for the long-reduction weight-gradient GEMMs, the
+    // 128x128 two-stage kernel (2 blocks/CU) for the short-K forward / data-gradient GEMMs
+    const bool big = a->force_generic == 4 || (a->force_generic == 0 && !a->a_kmajor && a->m >= 256 && a->n >= 128);
+    dim3 grid(big ? ((a->m + 255) / 256) * ((a->n + 127) / 128) : ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, gz);
+    const bool two_pass = gz > 1 && a->out_f32 && a->workspace && a->workspace_bytes >= (long long)gz * a->m * a->n * 4 && !(((uintptr_t)a->workspace) & 15) &&
+                          !a->bias && !a->residual_f32 && !a->residual_bf16 && !a->gelu_in && !a->row_mask && !a->aux_out && a->act == 0;
+    p.ws = two_pass ? (float*)a->workspace : nullptr;
+    if (gz > 1 && !two_pass && !a->accumulate) return CINEMA_ERR_BAD_ARG;
+    if (gz == 1 && a->accumulate && !a->residual_f32 && !a->residual_bf16) {  // one owner per element: plain read-modify-write, no atomics
+      p.res_f32 = (const float*)a->d; p.ld_res = a->ldd; p.accumulate = 0;
+    }
     a->kernel_used = (a->a_kmajor && a->b_kmajor) ? 1 : (a->a_kmajor ? 2 : 3);
-    if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), 0, st, p);
-    else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), 0, st, p);
+    if (big) {
+      const int tiles_n = (a->n + 127) / 128;
+      const int n_items = ((a->m + 255) / 256) * tiles_n * gz;
+      static int n_cus = 0;
+      if (n_cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+      dim3 pgrid(n_items < n_cus ? n_items : n_cus);
+      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, true>), pgrid, dim3(512), 0, st, p, n_items, tiles_n, gz);
+      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, false>), pgrid, dim3(512), 0, st, p, n_items, tiles_n, gz);
+      else hipLaunchKernelGGL((gemm_mfma_ws_kernel<false, false>), pgrid, dim3(512), 0, st, p, n_items, tiles_n, gz);
+    } else if (a->force_generic == 2) {  // register-staged variant (kept for A/B measurements)
+      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, false>), grid, dim3(256), 0, st, p);
+      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, false>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_mfma_kernel<false, false, false>), grid, dim3(256), 0, st, p);
+    } else {
+      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, true>), grid, dim3(256), 0, st, p);
+      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_mfma_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+    }
+    if (two_pass) {
+      long long blocks = ((long long)a->m * a->n / 4 + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a->workspace, gz, a->m, a->n, (float*)a->d, a->ldd,
+                         a->accumulate, a->alpha);
+    }
     return launch_status();
   }
   const int nkt = (a->k + 15) / 16;
@@ -342,6 +839,15 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
 
 CINEMA_API int cinema_colsum(const void* x, int x_dtype, const int* row_idx, int m, int n, int ldx, float* out, void* stream) {
   if (!x || !out || m <= 0 || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if (x_dtype == 0 && !row_idx && !(n & 7) && !(ldx & 7) && !(((uintptr_t)x) & 15)) {
+    const int col_blocks = (n + 255) / 256;
+    int row_chunks = (1024 + col_blocks - 1) / col_blocks;
+    if (row_chunks > (m + 63) / 64) row_chunks = (m + 63) / 64;
+    const int rpb = (((m + row_chunks - 1) / row_chunks) + 7) / 8 * 8;
+    dim3 grid(col_blocks, (m + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, m, n, ldx, out, rpb);
+    return launch_status();
+  }
   int chunks = (m + 511) / 512;
   if (chunks > 256) chunks = 256;
   const int rpb = (m + chunks - 1) / chunks;

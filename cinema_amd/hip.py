@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("row_mask", C.c_void_p),
         ("aux_out", C.c_void_p), ("ld_aux", C.c_int),
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
         ("kernel_used", C.c_int),
     ]
 
@@ -181,6 +182,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
     g.act, g.out_f32, g.accumulate = act, int(out.dtype == torch.float32), int(accumulate)
     g.split_k, g.force_generic = split_k, int(force_generic or FORCE_GENERIC)
+    ws = None
+    if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
+        ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     if GEMM_PROFILE is None:
         _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
         return out

@@ -54,6 +54,8 @@ typedef struct {
   int accumulate;             /* 1: D += result with fp32 atomics (out_f32 must be 1) */
   int split_k;                /* >=1 */
   int force_generic;
+  void* workspace;            /* optional fp32 scratch for split_k > 1: >= split_k*m*n*4 bytes -> deterministic two-pass reduction instead of atomics */
+  long long workspace_bytes;
   int kernel_used;            /* OUT: 0 generic FMA, 1 MFMA k-major/k-major, 2 MFMA k-major/n-major (dgrad), 3 MFMA m-major/n-major (wgrad) */
 } cinema_gemm_args;
 int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
