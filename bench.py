@@ -146,7 +146,7 @@ def main() -> None:
         torch.cuda.synchronize()
         prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
         agg: dict = {}
-        for kind, flops, e0, e1 in prof:
+        for kind, flops, e0, e1, _shape in prof:
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3

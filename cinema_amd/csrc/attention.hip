@@ -38,10 +38,13 @@ struct TileStage {
     for (int pss = 0; pss < PASSES; pss++) {
       const int cid = pss * 256 + tid;
       const int row = cid / CPR, c = cid % CPR;
-      if (cid < NCH && row0 + row < nrows) r[pss] = *reinterpret_cast<const uint4*>(base + (size_t)(row0 + row) * ld + c * 8);
-      else r[pss] = make_uint4(0, 0, 0, 0);
+      // rows past the end re-read the last valid row (no divergent branch around the load): every consumer masks those
+      // positions (score -> -inf / probability -> 0), so only finiteness of the data matters
+      const int rr = min(row0 + row, nrows - 1);
+      r[pss] = *reinterpret_cast<const uint4*>(base + (size_t)rr * ld + c * 8);
     }
   }
+  static_assert(NCH % 256 == 0, "tile chunks must be a multiple of the block size");
   __device__ __forceinline__ void store(char* lds, int tid) const {
 #pragma unroll
     for (int pss = 0; pss < PASSES; pss++) {
@@ -136,25 +139,29 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnP p) {
     }
     // online softmax (base-2 domain); this lane owns query column lane&31, keys spread over regs (+ partner lane^32)
     float mx = NEG_INF;
-    const int key0 = kt * 64 + 4 * g;
+    if (kt == nkt - 1 && (p.tk & 63)) {  // only the ragged last tile needs the key-range mask (wave-uniform branch)
+      const int key0 = kt * 64 + 4 * g;
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int key = key0 + 32 * u + (r & 3) + 8 * (r >> 2);
+          if (key >= p.tk) s[u][r] = NEG_INF;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 2; u++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = key0 + 32 * u + (r & 3) + 8 * (r >> 2);
-        const float v = key < p.tk ? s[u][r] * p.c2 : NEG_INF;
-        s[u][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * p.c2);  // running max in the scaled base-2 domain (c2 > 0)
+    const float alpha = fast_exp2(m_run - m_new);
     float ps = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; u++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float e = exp2f(s[u][r] - m_new);
+        const float e = fast_exp2(fmaf(s[u][r], p.c2, -m_new));  // one FMA + one v_exp_f32 per score
         s[u][r] = e;
         ps += e;
       }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int key = key0 + 32 * u + (r & 3) + 8 * (r >> 2);
-        const float pr = key < p.tk ? exp2f(s[r] * p.c2 - lse) : 0.f;
+        const float pr = key < p.tk ? fast_exp2(fmaf(s[r], p.c2, -lse)) : 0.f;
         s[r] = pr * (dp[r] - dl);  // dS^T
       }
 #pragma unroll
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const float pr = exp2f(s[4 * j + i] * p.c2 - lv[i]);
+          const float pr = fast_exp2(fmaf(s[4 * j + i], p.c2, -lv[i]));
           s[4 * j + i] = pr;                             // P
           dp[4 * j + i] = pr * (dp[4 * j + i] - dv4[i]);  // dS
         }

@@ -193,7 +193,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ev0.record()
     _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
     ev1.record()
-    GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1))
+    GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k)))
     return out
 
 

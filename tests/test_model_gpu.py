@@ -4,7 +4,8 @@
 
 Stated tolerances (bf16 MFMA compute, fp32 accumulation/residual stream):
   loss: relative 2e-2;  predictions: max-abs 5e-2 on O(1) values;  metrics (fp32 reductions): relative 1e-4;
-  gradients: max-abs error <= 6 % of the tensor's max-abs gradient (bf16 operands in dgrad/wgrad).
+  gradients (bf16 operands in dgrad/wgrad): relative L2 error of every parameter gradient <= 6 %, and no single element off by
+  more than 12 % of the tensor's max-abs gradient.
 """
 
 from __future__ import annotations
@@ -22,7 +23,7 @@ from cinema_amd.vit import get_vit_config  # noqa: E402
 from conftest import load_golden  # noqa: E402
 
 DEV = "cuda"
-LOSS_RTOL, PRED_ATOL, GRAD_FRAC = 2e-2, 5e-2, 6e-2
+LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-2, 5e-2, 6e-2, 12e-2
 
 
 def split(t: dict, prefix: str) -> dict:
@@ -61,10 +62,13 @@ def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tens
     for k, t in ref_grads.items():
         g = named[k].grad
         assert g is not None, k
+        diff = g.float().cpu() - t
         scale = float(t.abs().max())
-        err = float((g.float().cpu() - t).abs().max())
-        worst[k] = err / max(scale, 1e-12)
-        assert err <= GRAD_FRAC * scale + 1e-7, (k, err, scale)
+        err = float(diff.abs().max())
+        l2 = float(diff.norm() / t.norm().clamp_min(1e-12))
+        worst[k] = l2
+        assert l2 <= GRAD_L2, (k, l2)
+        assert err <= GRAD_MAX * scale + 1e-7, (k, err, scale)
     print("worst grad rel err:", max(worst.items(), key=lambda kv: kv[1]))
 
 
