@@ -51,7 +51,9 @@ def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float) -> dic
     sys.path.insert(0, str(ROOT / "oracle"))
     import cinema_oracle as O  # noqa: N812
 
-    cores = os.cpu_count() or 1
+    # intra-op threads actually used: torch's CPU kernels on this graph peak at ~16 threads on the 256-core GPU-box host
+    # (tools/cpu_threads_probe.py: 16 threads 3.6 s/step, 32 -> 4.2 s, 64 -> 7.6 s, 256 -> 640 s at batch 2)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     cfg = O.MAEConfig(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
     trainer = O.Trainer({k: v.detach().float().cpu() for k, v in state_dict.items()}, cfg, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0)

@@ -1,0 +1,267 @@
+"""CPU-side checks (no GPU needed): the C-ABI library loads and exports every symbol the header declares, the host-side
+mirror of the reference interface (state_dict layout, seeded construction, schedules, masks, error behaviour) and the
+multi-process gradient synchroniser over gloo."""
+
+from __future__ import annotations
+
+import ctypes
+import json
+import math
+import os
+import re
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT, load_golden
+
+import cinema_oracle as O  # noqa: E402
+from cinema_amd import CineMA, hip, patchify, unpatchify  # noqa: E402
+from cinema_amd.config import to_config  # noqa: E402
+from cinema_amd.convvit import TokenSelection, upsample_mask  # noqa: E402
+from cinema_amd.mae.mae import get_batch_random_patch_mask, get_decoder_patch_size, get_model  # noqa: E402
+from cinema_amd.optim import FlatModel, adjust_learning_rate, get_n_accum_steps, param_groups_weight_decay  # noqa: E402
+from cinema_amd.vit import get_pos_embed, get_vit_config  # noqa: E402
+
+
+# ---------------------------------------------------------------------------------------------------- C-ABI
+def test_library_exports_every_declared_symbol() -> None:
+    header = (ROOT / "include" / "cinema_hip.h").read_text()
+    declared = set(re.findall(r"^int (cinema_\w+)\(", header, flags=re.M))
+    assert declared, "no declarations parsed from include/cinema_hip.h"
+    assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(str(hip.library_path()))
+    for name in declared:
+        assert hasattr(lib, name), f"libcinema_hip.so does not export {name}"
+    out = (ctypes.c_int * 8)()
+    assert lib.cinema_hip_info(out) == 0 and out[0] == 1  # abi version; no compute call
+
+
+def test_gemm_args_struct_matches_header_field_order() -> None:
+    header = (ROOT / "include" / "cinema_hip.h").read_text()
+    body = header[header.index("typedef struct {"):header.index("} cinema_gemm_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct {", "").strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = names[0].split()[-1].lstrip("*")
+        fields.append(first)
+        fields += [n.strip().lstrip("*") for n in names[1:]]
+    assert fields == [f[0] for f in hip.GemmArgs._fields_]  # noqa: SLF001
+
+
+def test_product_path_never_imports_the_oracle() -> None:
+    for path in (ROOT / "cinema_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "cinema_oracle" not in text and "oracle" not in re.findall(r"^\s*(?:from|import)\s+(\w+)", text, flags=re.M), path
+
+
+def test_cpu_tensors_fail_loudly() -> None:
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+    model = CineMA(**mini_kwargs())
+    with pytest.raises(hip.HipLibraryError):
+        model({"sax": torch.rand(1, 1, 32, 32, 4)}, 0.75)
+
+
+# ---------------------------------------------------------------------------------------------------- module layer
+def mini_kwargs() -> dict:
+    views = ["sax", "lax_2c", "lax_3c", "lax_4c"]
+    return dict(image_size_dict={v: (32, 32, 4) if v == "sax" else (32, 32) for v in views}, in_chans_dict=dict.fromkeys(views, 1),
+                enc_patch_size_dict={v: (4, 4, 1) if v == "sax" else (4, 4) for v in views},
+                enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views}, enc_conv_chans=[16, 32], enc_conv_n_blocks=1,
+                enc_embed_dim=64, enc_depth=2, enc_n_heads=4, dec_embed_dim=32, dec_depth=2, dec_n_heads=4)
+
+
+def base_kwargs(size: str, sax: tuple, lax: tuple) -> dict:
+    views = ["sax", "lax_2c", "lax_3c", "lax_4c"]
+    return dict(image_size_dict={v: sax if v == "sax" else lax for v in views}, in_chans_dict=dict.fromkeys(views, 1),
+                enc_patch_size_dict={v: (4, 4, 1) if v == "sax" else (4, 4) for v in views},
+                enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2,
+                **get_vit_config(size))
+
+
+@pytest.mark.parametrize(("name", "size", "sax", "lax"), [("base_4view_192", "base", (192, 192, 16), (192, 192)),
+                                                         ("large_4view_256", "large", (256, 256, 24), (256, 256))])
+def test_state_dict_layout_matches_reference_manifest(name: str, size: str, sax: tuple, lax: tuple) -> None:
+    man = json.loads((GOLDEN / "state_dict_manifests.json").read_text())[name]
+    with torch.device("meta"):
+        model = CineMA(**base_kwargs(size, sax, lax))
+    sd = model.state_dict()
+    assert list(sd) == list(man["keys"])
+    assert {k: list(v.shape) for k, v in sd.items()} == man["keys"]
+    assert sum(p.numel() for p in model.parameters()) == man["n_params"]
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == man["n_trainable"]
+    groups = param_groups_weight_decay(model, 0.05)
+    names = {id(p): k for k, p in model.named_parameters()}
+    assert sorted(names[id(p)] for p in groups[0]["params"]) == sorted(man["no_decay"])
+    assert "encoder.cls_token" in {names[id(p)] for p in groups[1]["params"]}  # tokens ARE decayed (pretrain.py:365)
+
+
+@pytest.mark.parametrize("name", ["tiny_sax", "mini_4view"])
+def test_seeded_construction_is_identical_to_the_reference(name: str) -> None:
+    fp = json.loads((GOLDEN / f"{name}_init_fingerprint.json").read_text())
+    kw = mini_kwargs() if name == "mini_4view" else dict(
+        image_size_dict={"sax": (128, 128, 8)}, in_chans_dict={"sax": 1}, enc_patch_size_dict={"sax": (4, 4, 1)},
+        enc_scale_factor_dict={"sax": (2, 2, 1)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2, **get_vit_config("tiny"))
+    torch.manual_seed(fp["seed"])
+    sd = CineMA(**kw).state_dict()
+    assert list(sd) == list(fp["params"])
+    for k, ref in fp["params"].items():
+        assert list(sd[k].shape) == ref["shape"], k
+        assert float(sd[k].double().sum()) == pytest.approx(ref["sum"], rel=1e-6, abs=1e-7), k
+        assert [float(x) for x in sd[k].flatten()[:4]] == pytest.approx(ref["head"], rel=1e-6, abs=1e-8), k
+
+
+def test_state_dict_round_trip_with_reference_weights() -> None:
+    g = load_golden("mini_4view.safetensors")
+    params = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    model = CineMA(**mini_kwargs())
+    missing, unexpected = model.load_state_dict(params, strict=True)
+    assert not missing and not unexpected
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, params[k]), k
+
+
+def test_get_model_config_mapping_and_attributes() -> None:
+    cfg = to_config({"grad_ckpt": True, "data": {"sax": {"patch_size": [64, 64, 8], "in_chans": 1}, "lax": {"patch_size": [64, 64], "in_chans": 1}},
+                     "model": {"size": "tiny", "patch_size": [4, 4, 1], "scale_factor": [2, 2, 1], "enc_conv_chans": [16, 32], "enc_conv_n_blocks": 1}})
+    model = get_model(cfg)
+    assert model.views == ["sax", "lax_2c", "lax_3c", "lax_4c"] and model.grad_ckpt is True
+    assert model.enc_down_dict["sax"].patch_embed.grid_size == (4, 4, 8) and model.enc_down_dict["lax_2c"].patch_embed.n_patches == 16
+    assert model.dec_patch_size_dict == {"sax": (16, 16, 1), "lax_2c": (16, 16), "lax_3c": (16, 16), "lax_4c": (16, 16)}
+    assert len(model.encoder.blocks) == 1 and model.cross_attn and not model.norm_target
+    assert get_decoder_patch_size((192, 192, 16), 2, (4, 4, 1), (2, 2, 1)) == (16, 16, 1)
+    with pytest.raises(ValueError):
+        get_vit_config("giant")
+
+
+def test_patchify_tables_and_masks_against_reference_vectors() -> None:
+    g = load_golden("layers.safetensors")
+    assert torch.equal(patchify(g["patchify/image3d"], (2, 3, 1)), g["patchify/out3d"])
+    assert torch.equal(patchify(g["patchify/image2d"], (2, 2)), g["patchify/out2d"])
+    assert torch.equal(unpatchify(g["patchify/out3d"], (2, 3, 1), (2, 2, 2)), g["patchify/image3d"])
+    assert torch.equal(unpatchify(g["patchify/out2d"], (2, 2), (2, 3)), g["patchify/image2d"])
+    with pytest.raises(ValueError):
+        patchify(torch.zeros(1, 1, 5, 4), (2, 2))
+    with pytest.raises(ValueError):
+        unpatchify(torch.zeros(1, 4, 8), (2, 2), (2, 3))
+    for name, dim, grid in [("sax768", 768, (12, 12, 16)), ("lax768", 768, (12, 12)), ("odd", 20, (2, 3, 4)), ("odd2d", 10, (3, 2))]:
+        pe = get_pos_embed(dim, grid)
+        assert not pe.requires_grad
+        pe = pe[:, ::37] if pe.shape[1] > 64 else pe
+        assert torch.allclose(pe, g[f"pos_embed/{name}"], atol=1e-6), name
+    for i in range(4):
+        out = upsample_mask(g[f"upsample_mask/{i}/in"].bool(), tuple(g[f"upsample_mask/{i}/scale"].tolist()))
+        assert torch.equal(out, g[f"upsample_mask/{i}/out"].bool())
+    for n, r in [(16, 0.75), (10, 0.5), (7, 0.3), (512, 0.75), (2304, 0.75)]:
+        mask = get_batch_random_patch_mask(3, n, r, torch.device("cpu"))
+        assert mask.shape == (3, n) and int((~mask).sum()) == int(n * (1 - r)) * 3  # exact keep count (mae_test.py:30-32)
+    assert not get_batch_random_patch_mask(2, 5, 0.0, torch.device("cpu")).any()
+    with pytest.raises(ValueError):
+        get_batch_random_patch_mask(2, 5, -0.1, torch.device("cpu"))
+
+
+def test_token_selection_is_raster_order_like_boolean_indexing() -> None:
+    mask = get_batch_random_patch_mask(4, 48, 0.75, torch.device("cpu"))
+    sel = TokenSelection(mask, 4, 48, torch.device("cpu"), n_masked=36)
+    flat = torch.arange(4 * 48).reshape(4, 48)
+    assert torch.equal(sel.keep.long(), flat[~mask]) and torch.equal(sel.drop.long(), flat[mask])
+    assert torch.equal(sel.keep_pos.long(), flat[~mask] % 48) and (sel.n_keep, sel.n_drop) == (12, 36)
+    sel2 = TokenSelection(mask, 4, 48, torch.device("cpu"))  # count read back from the mask
+    assert sel2.n_drop == 36
+    full = TokenSelection(None, 2, 5, torch.device("cpu"))
+    assert full.all_tokens and full.keep.tolist() == list(range(10))
+
+
+def test_lr_schedule_accumulation_and_reference_errors() -> None:
+    for row in json.loads((GOLDEN / "lr_schedule.json").read_text()):
+        opt = torch.optim.SGD([{"params": [torch.zeros(1, requires_grad=True)]}, {"params": [torch.zeros(1, requires_grad=True)], "lr_scale": 0.5}], lr=0.1)
+        assert adjust_learning_rate(opt, *row["args"]) == pytest.approx(row["lr"], rel=1e-12, abs=1e-18)
+        assert [g["lr"] for g in opt.param_groups] == pytest.approx(row["group_lrs"], rel=1e-12, abs=1e-18)
+    assert get_n_accum_steps(64, 16, 2) == 2 and get_n_accum_steps(64, 16, 4) == 1
+    with pytest.raises(ValueError):
+        get_n_accum_steps(16, 16, 2)
+    with pytest.raises(ValueError):
+        get_n_accum_steps(48, 16, 2)
+    model = CineMA(**mini_kwargs())
+    with pytest.raises(ValueError):
+        model({"bogus": torch.zeros(1, 1, 32, 32)}, 0.75)
+
+
+def test_flat_model_views_share_storage() -> None:
+    model = CineMA(**mini_kwargs())
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    flat = FlatModel(model, 0.05)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert flat.numel >= n_train and flat.numel - n_train < 4 * len(list(model.parameters()))
+    p = model.encoder.blocks[0].attn.q.weight
+    flat.flat_grad.fill_(2.0)
+    assert float(p.grad.sum()) == 2.0 * p.numel()
+    flat.flat_param.zero_()
+    assert float(p.abs().sum()) == 0.0
+    (a0, b0), (a1, b1) = flat.ranges
+    assert a0 == 0 and b0 == a1 and b1 == flat.numel  # [no-decay | decay] contiguous ranges
+
+
+# ---------------------------------------------------------------------------------------------------- N > 1 path on gloo
+def _ddp_worker(rank: int, world: int, port: int, tmp: str) -> None:
+    sys.path.insert(0, str(ROOT))
+    from cinema_amd.ddp import GradientSynchronizer, ddp_setup
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    ddp_setup(rank, world, port=port, backend="gloo")
+    torch.manual_seed(100 + rank)  # different initial weights per rank: the broadcast must make them equal to rank 0's
+    model = CineMA(**mini_kwargs())
+    flat = FlatModel(model, 0.05)
+    sync = GradientSynchronizer(world, bucket_bytes=64 << 10)  # small buckets -> several collectives
+    sync.attach(flat)
+    assert len(sync.buckets) > 1
+    torch.save(flat.flat_param.clone(), f"{tmp}/param{rank}.pt")
+    flat.flat_grad.copy_(torch.arange(flat.numel, dtype=torch.float32) * (rank + 1))
+    sync.all_reduce()
+    torch.save(flat.flat_grad.clone(), f"{tmp}/grad{rank}.pt")
+    ok = sync.all_finite(torch.tensor(float("nan") if rank == 1 else 1.0))
+    torch.save(ok, f"{tmp}/finite{rank}.pt")
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_synchronizer_world_size_2_gloo(tmp_path: Path) -> None:
+    from cinema_amd.ddp import get_free_port
+
+    mp.spawn(_ddp_worker, args=(2, get_free_port(), str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "param0.pt"), torch.load(tmp_path / "param1.pt")
+    assert torch.equal(p0, p1)  # rank 0's parameters everywhere
+    g0, g1 = torch.load(tmp_path / "grad0.pt"), torch.load(tmp_path / "grad1.pt")
+    expect = torch.arange(g0.numel(), dtype=torch.float32) * 1.5  # mean of 1x and 2x
+    assert torch.equal(g0, g1) and torch.allclose(g0, expect)
+    assert float(torch.load(tmp_path / "finite0.pt")) == 0.0 and float(torch.load(tmp_path / "finite1.pt")) == 0.0  # collective NaN decision
+
+
+def test_oracle_two_rank_average_equals_full_batch_gradient() -> None:
+    """Data-parallel semantics the synchroniser implements: mean over ranks of per-rank mean-loss gradients == full-batch gradient
+    (equal per-rank batch sizes, same masks), checked with the CPU oracle on the mini config."""
+    g = load_golden("mini_4view.safetensors")
+    params = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    images = {k[len("image/"):]: v for k, v in g.items() if k.startswith("image/")}
+    masks = {k[len("mask/"):]: v.bool() for k, v in g.items() if k.startswith("mask/")}
+    cfg = O.MAEConfig(**mini_kwargs())
+
+    def grads(sl: slice) -> dict:
+        p = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in params.items()}
+        loss, _, _ = O.mae_forward(p, cfg, {k: v[sl] for k, v in images.items()}, {k: v[sl] for k, v in masks.items()})
+        loss.backward()
+        return {k: v.grad for k, v in p.items() if v.grad is not None}
+
+    full, r0, r1 = grads(slice(0, 2)), grads(slice(0, 1)), grads(slice(1, 2))
+    for k in full:
+        assert torch.allclose(full[k], 0.5 * (r0[k] + r1[k]), rtol=1e-4, atol=1e-7), k
+    assert math.isfinite(float(sum(v.abs().sum() for v in full.values())))
