@@ -11,6 +11,7 @@ struct DwP {
   const bf16_t* x; const bf16_t* dy; const float* w; const float* bias; bf16_t* y;
   float* dw; float* dbias;
   const uint8_t* out_mask;  // optional per-voxel 0/1 multiplier on the output (masked data gradient)
+  float* ws;                // weight-gradient partial slabs [gridDim.x][c * (taps + 1)] or nullptr (atomic fallback)
   int b, X, Y, Z, c, kx, ky, kz;
   int flip;  // 1: correlate with the flipped kernel (data gradient)
 };
@@ -72,6 +73,92 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwP p) {
   uint4 o;
   o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]); o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
   *reinterpret_cast<uint4*>(p.y + (size_t)vox * p.c + ch) = o;
+}
+
+// Register-blocked forward / data-gradient for kz == 5: a thread owns a column of ZB = 16 consecutive z outputs of one
+// (b, x, y) position and 8 channels (128 fp32 accumulators).  For each of the kx*ky in-plane taps it streams the
+// (ZB + 4)-long input column once (16-byte loads) and every loaded vector feeds the 5 z-taps: 40 FMAs per load + unpack
+// instead of 8 in the per-voxel kernel (which was VALU/L1-bound at ~400 VALU instructions per output element).
+// 2-D maps are passed as (X=1, Y=H, Z=W): the walked axis is then W.
+template <int ZB, bool FULLZ>  // FULLZ: Z == ZB, every z-range test is resolved at compile time (the SAX volumes, Z = 16)
+__global__ __launch_bounds__(256) void dwconv_zcol_kernel(DwP p) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* wl = reinterpret_cast<float*>(dyn_smem);  // [kx*ky][5][64] fp32 (64-channel slab)
+  const int nxy = p.kx * p.ky, taps = nxy * 5;
+  const int c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < taps * 64; i += 256) {
+    const int t = i >> 6, cc = i & 63;
+    const int ts = p.flip ? taps - 1 - t : t;
+    wl[i] = (c0 + cc < p.c) ? p.w[(size_t)(c0 + cc) * taps + ts] : 0.f;
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 7;            // 8 channel groups of 8 = 64 channels: one 128-byte line per voxel
+  const int ch = c0 + cg * 8;
+  const long long npos = (long long)p.b * p.X * p.Y;
+  const long long pos = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (pos >= npos || ch >= p.c) return;
+  const int y = (int)(pos % p.Y), x = (int)((pos / p.Y) % p.X);
+  const long long bb = pos / ((long long)p.Y * p.X);
+  const int z0 = FULLZ ? 0 : blockIdx.z * ZB;  // wave-uniform z block
+  const int rx = p.kx >> 1, ry = p.ky >> 1;
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {  // two vector loads once (a per-accumulator `bias ? load : 0` compiles to 128 serialised branch+load+wait)
+    const float4 a = *reinterpret_cast<const float4*>(p.bias + ch), b4 = *reinterpret_cast<const float4*>(p.bias + ch + 4);
+    bv[0] = a.x; bv[1] = a.y; bv[2] = a.z; bv[3] = a.w; bv[4] = b4.x; bv[5] = b4.y; bv[6] = b4.z; bv[7] = b4.w;
+  }
+  float acc[ZB][8];
+#pragma unroll
+  for (int z = 0; z < ZB; z++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[z][i] = bv[i];
+  for (int i = 0; i < p.kx; i++) {
+    const int xx = x + i - rx;
+    if (xx < 0 || xx >= p.X) continue;
+    for (int j = 0; j < p.ky; j++) {
+      const int yy = y + j - ry;
+      if (yy < 0 || yy >= p.Y) continue;
+      float w5[5][8];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const float* wt = wl + ((i * p.ky + j) * 5 + k) * 64 + cg * 8;
+        const float4 a = *reinterpret_cast<const float4*>(wt), b4 = *reinterpret_cast<const float4*>(wt + 4);
+        w5[k][0] = a.x; w5[k][1] = a.y; w5[k][2] = a.z; w5[k][3] = a.w; w5[k][4] = b4.x; w5[k][5] = b4.y; w5[k][6] = b4.z; w5[k][7] = b4.w;
+      }
+      const uint4* colp = reinterpret_cast<const uint4*>(__builtin_assume_aligned(p.x + ((((size_t)bb * p.X + xx) * p.Y + yy) * p.Z) * p.c + ch, 16));
+      const int cstride = p.c >> 3;  // uint4 per voxel
+#pragma unroll
+      for (int zi = 0; zi < ZB + 4; zi++) {  // input z = z0 + zi - 2
+        const int zin = z0 + zi - 2;
+        if (FULLZ) { if (zi < 2 || zi >= ZB + 2) continue; }
+        else if (zin < 0 || zin >= p.Z) continue;
+        float f[8];
+        { const uint4 u = colp[(size_t)zin * cstride]; unpack8(u, f); }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          const int zo = zi - k;  // output z (relative) fed through z-tap k:  zin = zout + k - 2
+          if (zo < 0 || zo >= ZB) continue;
+#pragma unroll
+          for (int c = 0; c < 8; c++) acc[zo][c] = fmaf(w5[k][c], f[c], acc[zo][c]);
+        }
+      }
+    }
+  }
+  const size_t vox0 = (((size_t)bb * p.X + x) * p.Y + y) * p.Z + z0;
+  uint32_t keep = 0xffffffffu;  // bit z: output voxel z0+z is visible
+  if (p.out_mask) {
+    keep = 0u;
+#pragma unroll
+    for (int z = 0; z < ZB; z++)
+      if (FULLZ || z0 + z < p.Z) keep |= (p.out_mask[vox0 + z] ? 1u : 0u) << z;
+  }
+#pragma unroll
+  for (int z = 0; z < ZB; z++) {
+    if (!FULLZ && z0 + z >= p.Z) continue;
+    uint4 o;
+    o.x = pack_bf2(acc[z][0], acc[z][1]); o.y = pack_bf2(acc[z][2], acc[z][3]); o.z = pack_bf2(acc[z][4], acc[z][5]); o.w = pack_bf2(acc[z][6], acc[z][7]);
+    if (!((keep >> z) & 1u)) o = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(p.y + (vox0 + z) * p.c + ch) = o;
+  }
 }
 
 // Weight gradient with a sliding window along z (kz == KZ): thread = (tap_xy, channel group of 8); it walks whole z
@@ -142,6 +229,18 @@ __global__ void dwconv_wgrad_walk_kernel(DwP p, int cols_per_block) {
     }
   }
   const int taps = nxy * KZ;
+  if (p.ws) {  // deterministic two-pass: this block's partial sums to its slab, dwconv_wgrad_reduce_kernel adds the slabs up
+    float* slab = p.ws + (size_t)blockIdx.x * p.c * (taps + 1);
+#pragma unroll
+    for (int k = 0; k < KZ; k++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) slab[(size_t)(ch + i) * taps + txy * KZ + k] = acc[k][i];
+    if (center) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) slab[(size_t)p.c * taps + ch + i] = accb[i];
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < KZ; k++)
 #pragma unroll
@@ -150,6 +249,19 @@ __global__ void dwconv_wgrad_walk_kernel(DwP p, int cols_per_block) {
 #pragma unroll
     for (int i = 0; i < 8; i++) unsafeAtomicAdd(p.dbias + ch + i, accb[i]);
   }
+}
+
+// dw[i] += sum_blocks slab[block][i]  (i < c*taps), dbias[j] += sum_blocks slab[block][c*taps + j]
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* ws, int nblocks, int n_w, int n_b, float* dw, float* dbias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = n_w + n_b;
+  if (i >= total) return;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float s = 0.f;
+  for (int b = b0; b < b1; b++) s += ws[(size_t)b * total + i];
+  if (i < n_w) unsafeAtomicAdd(dw + i, s);   // 16 slices per element
+  else if (dbias) unsafeAtomicAdd(dbias + (i - n_w), s);
 }
 
 // naive weight gradient for other kernel extents: thread = (tap, channel); each block reduces a voxel chunk
@@ -259,6 +371,15 @@ static int dw_check(int b, int X, int Y, int Z, int c, int kx, int ky, int kz) {
 static int dw_launch_fwd(const DwP& p, hipStream_t st) {
   const long long nvox = (long long)p.b * p.X * p.Y * p.Z;
   dim3 grid((unsigned)((nvox + 63) / 64), (p.c + 31) / 32);
+  if (p.kz == 5 && (size_t)p.kx * p.ky * 5 * 64 * sizeof(float) <= 64 * 1024) {
+    const int nzb = (p.Z + 15) / 16;
+    const long long npos = (long long)p.b * p.X * p.Y;
+    dim3 zgrid((unsigned)((npos + 31) / 32), (p.c + 63) / 64, nzb);
+    const size_t wsmem = (size_t)p.kx * p.ky * 5 * 64 * sizeof(float);
+    if (p.Z == 16) hipLaunchKernelGGL((dwconv_zcol_kernel<16, true>), zgrid, dim3(256), wsmem, st, p);
+    else hipLaunchKernelGGL((dwconv_zcol_kernel<16, false>), zgrid, dim3(256), wsmem, st, p);
+    return launch_status();
+  }
   const size_t smem = (size_t)p.kx * p.ky * p.kz * 32 * sizeof(float);
   hipLaunchKernelGGL(dwconv_fwd_kernel, grid, dim3(256), smem, st, p);
   return launch_status();
@@ -280,8 +401,8 @@ CINEMA_API int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16
   return dw_launch_fwd(p, (hipStream_t)stream);
 }
 
-CINEMA_API int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, int b, int X, int Y, int Z, int c, int kx,
-                                        int ky, int kz, void* stream) {
+CINEMA_API int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes,
+                                        int b, int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream) {
   if (!x || !dy || !dw) return CINEMA_ERR_BAD_ARG;
   if (int e = dw_check(b, X, Y, Z, c, kx, ky, kz)) return e;
   DwP p{}; p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz;
@@ -293,7 +414,14 @@ CINEMA_API int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, f
     dim3 grid((unsigned)((ncols + cpb - 1) / cpb), (c + 63) / 64);
     int threads = kx * ky * 8;
     threads = ((threads + 63) / 64) * 64;
+    const int taps = kx * ky * kz;
+    const long long need = (long long)grid.x * c * (taps + 1) * 4;
+    p.ws = (workspace && workspace_bytes >= need && !(c & 63)) ? workspace : nullptr;  // every (block, channel, tap) slot is written when c % 64 == 0
     hipLaunchKernelGGL(dwconv_wgrad_walk_kernel<5>, grid, dim3(threads), 0, st, p, cpb);
+    if (p.ws) {
+      const int total = c * (taps + 1);
+      hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((total + 255) / 256, 16), dim3(256), 0, st, (const float*)p.ws, (int)grid.x, c * taps, c, dw, dbias);
+    }
     return launch_status();
   }
   const long long nvox = (long long)b * X * Y * Z;

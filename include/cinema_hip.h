@@ -103,9 +103,10 @@ int cinema_dwconv_fwd(const uint16_t* x, const float* w, const float* bias, uint
 /* dx = correlate(dy, flipped w); out_mask (uint8 [b*X*Y*Z] or NULL) zeroes masked voxels of dx (the `mask *` of conv.py:411) */
 int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, const uint8_t* out_mask, int b, int X, int Y, int Z, int c, int kx,
                            int ky, int kz, void* stream);
-/* dw[c][taps] += sum x*dy ; dbias[c] += sum dy (fp32 atomics) */
-int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, int b, int X, int Y, int Z, int c, int kx,
-                             int ky, int kz, void* stream);
+/* dw[c][taps] += sum x*dy ; dbias[c] += sum dy.  workspace (fp32, >= 1024 * c * (taps+1) * 4 bytes) makes the reduction a deterministic
+ * two-pass (per-block slabs + reduce kernel); without it the kernel falls back to fp32 atomics. */
+int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes, int b,
+                             int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Non-overlapping patch gather / scatter (reference: patchify cinema/vit.py:67-161 and the im2col of the k==s
