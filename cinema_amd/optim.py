@@ -69,7 +69,11 @@ class FlatModel:
         total = sum(sizes)
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        # bf16 shadow of every parameter in the SAME order: the AdamW kernel writes it together with the fp32 master, so the
+        # forward needs no per-weight cast kernels, and adjacent weights (attn.q | attn.kv) form one fused GEMM operand for free
+        self.flat_shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         self.ranges = []
+        self.params = params
         off = 0
         it = iter(sizes)
         for g in self.groups:
@@ -81,12 +85,24 @@ class FlatModel:
                 p.data = view
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
                 p._cinema_flat_grad = p.grad  # noqa: SLF001  (tape.PVar accumulates straight into this view)
+                if self.flat_shadow is not None:
+                    p._cinema_shadow = self.flat_shadow[off:off + p.numel()]  # noqa: SLF001
                 off += n
             self.ranges.append((start, off))
         self.numel = total
+        self.refresh_shadows()
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
+
+    def refresh_shadows(self) -> None:
+        """Re-derive every bf16 shadow from the fp32 masters (after construction / ``load_state_dict``); the optimiser keeps
+        them in sync afterwards.  A shadow is trusted only while the parameter's autograd version is the one stamped here."""
+        if self.flat_shadow is None:
+            return
+        K.cast(self.flat_param, torch.bfloat16, out=self.flat_shadow)
+        for p in self.params:
+            p._cinema_shadow_version = p._version  # noqa: SLF001
 
 
 class FusedAdamW:
@@ -120,8 +136,9 @@ class FusedAdamW:
         for group, (a, b) in zip(self.param_groups, f.ranges):
             if b > a:
                 K.adamw(f.flat_param[a:b], f.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], group["lr"], self.betas[0], self.betas[1],
-                        self.eps, group["weight_decay"], self.step_count, clip=self.coef)
-        T.WEIGHTS.invalidate()  # parameters were written through raw pointers: refresh the bf16 shadows at the next forward
+                        self.eps, group["weight_decay"], self.step_count, clip=self.coef,
+                        shadow=None if f.flat_shadow is None else f.flat_shadow[a:b])
+        T.WEIGHTS.invalidate()  # parameters were written through raw pointers: re-laid-out shadows (patch convs) are rebuilt next forward
         return self.grad_norm
 
     def state_dict(self) -> dict:

@@ -145,8 +145,23 @@ class Tape:
 # --------------------------------------------------------------------------------------------------------------
 # weight shadows
 # --------------------------------------------------------------------------------------------------------------
+def _flat_shadow(p: torch.nn.Parameter) -> torch.Tensor | None:
+    """The optimiser-maintained bf16 copy of ``p`` (cinema_amd.optim.FlatModel), if it is still in sync with the master."""
+    sh = getattr(p, "_cinema_shadow", None)
+    if sh is not None and getattr(p, "_cinema_shadow_version", -1) == p._version:  # noqa: SLF001
+        return sh
+    return None
+
+
+def _adjacent(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a.data_ptr() + a.numel() * a.element_size() == b.data_ptr()
+
+
 def w_plain(weight: torch.nn.Parameter) -> torch.Tensor:
     """(out, in[,1,1,1]) fp32 -> bf16 [out, in]."""
+    sh = _flat_shadow(weight)
+    if sh is not None:
+        return sh.view(weight.shape[0], -1)
     return WEIGHTS.get((weight,), "plain", lambda: K.cast(weight.detach().reshape(weight.shape[0], -1), BF16))
 
 
@@ -173,11 +188,19 @@ def patch_grad_to_param(weight: torch.nn.Parameter) -> Callable:
 
 
 def w_cat(weights: tuple) -> torch.Tensor:
+    """Row-concatenation of Linear weights as one bf16 [sum(out), in] operand; a zero-copy view when the flat shadows are adjacent."""
+    shs = [_flat_shadow(w) for w in weights]
+    if all(s is not None for s in shs) and all(_adjacent(a, b) for a, b in zip(shs, shs[1:])):
+        k = weights[0].shape[1]
+        return shs[0].as_strided((sum(w.shape[0] for w in weights), k), (k, 1))
     return WEIGHTS.get(tuple(weights), "cat", lambda: torch.cat([K.cast(w.detach().reshape(w.shape[0], -1), BF16) for w in weights], dim=0))
 
 
 def b_cat(biases: tuple) -> torch.Tensor:
-    return WEIGHTS.get(tuple(biases), "bcat", lambda: torch.cat([b.detach() for b in biases], dim=0))
+    ds = [b.detach() for b in biases]
+    if all(_adjacent(a, b) for a, b in zip(ds, ds[1:])):
+        return ds[0].as_strided((sum(b.numel() for b in ds),), (1,))
+    return WEIGHTS.get(tuple(biases), "bcat", lambda: torch.cat(ds, dim=0))
 
 
 def _split_k(m_red: int, n_out: int, k_out: int) -> int:
@@ -295,8 +318,17 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
         d3 = dqkv.view(batch, t, 3 * c)
         K.attention_bwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], o, y.grad.view(batch, t, c), lse, heads, scale, d3[..., :c],
                         d3[..., c:2 * c], d3[..., 2 * c:])
-        wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))
-        wgrad(tape, dqkv[:, c:], x.data, pv[2], pv[3], (2 * c, c))
+        gq, gkv = pv[0].grad_buffer((c, c)), pv[2].grad_buffer((2 * c, c))
+        if q_b is not None and pv[0].direct and pv[2].direct and _adjacent(gq, gkv):
+            bq, bkv = pv[1].grad_buffer((c,)), pv[3].grad_buffer((2 * c,))
+            if pv[1].direct and pv[3].direct and _adjacent(bq, bkv):  # one [3c, c] weight-gradient GEMM + one column sum
+                K.gemm(dqkv, x.data, a_kmajor=False, b_kmajor=False, out=gq.as_strided((3 * c, c), (c, 1)), accumulate=True,
+                       split_k=_split_k(dqkv.shape[0], 3 * c, c))
+                K.colsum(dqkv, bq.as_strided((3 * c,), (1,)))
+                gq = None
+        if gq is not None:
+            wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))
+            wgrad(tape, dqkv[:, c:], x.data, pv[2], pv[3], (2 * c, c))
         if x.needs_grad:
             x.add_grad(K.gemm(dqkv, w, a_kmajor=True, b_kmajor=False))
 

@@ -163,3 +163,32 @@ def test_cpu_tensor_fails_loudly() -> None:
     model = CineMA(**mini_kwargs())  # parameters on the CPU
     with pytest.raises(HipLibraryError):
         model({"sax": torch.rand(1, 1, 32, 32, 4)}, 0.75)
+
+
+def test_three_step_optimisation_trajectory_vs_reference_golden() -> None:
+    """cinema_amd.optim.TrainStep (fused clip + AdamW on flat buffers, 2-group weight decay, LR schedule) against 3 steps of the
+    reference harness (GradScaler + adjust_learning_rate + AdamW) captured on cfg 1.  Adam's first updates are ~lr * sign(g), so
+    parameters are compared through their mean absolute deviation (<= 0.25 * cumulative lr) rather than element-wise."""
+    from cinema_amd.optim import TrainStep, adjust_learning_rate
+
+    g = load_golden("tiny_sax_trajectory.safetensors")
+    init = split(load_golden("tiny_sax.safetensors"), "param/")
+    model = CineMA(**tiny_kwargs())
+    model.load_state_dict(init)
+    model.to(DEV)
+    step = TrainStep(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0)
+    gen = torch.Generator().manual_seed(7)
+    named = dict(model.named_parameters())
+    lr_sum = 0.0
+    for i in range(3):
+        lr = adjust_learning_rate(step.optimizer, i / 4, 1, 5, 1e-3, 1e-6)
+        assert lr == pytest.approx(float(g[f"step{i}/lr"][0]), rel=1e-12, abs=1e-15)
+        lr_sum += lr
+        image = torch.rand(2, 1, 128, 128, 8, generator=gen)
+        assert torch.equal(image.flatten()[:64], g[f"step{i}/image_head"])
+        loss, norm, _ = step({"sax": image.to(DEV)}, 0.75, enc_mask_dict={"sax": g[f"step{i}/mask"].bool().to(DEV)})
+        assert abs(float(loss) - float(g[f"step{i}/loss"][0])) <= 3e-2 * float(g[f"step{i}/loss"][0]), (i, float(loss))
+        assert abs(float(norm) - float(g[f"step{i}/grad_norm"][0])) <= 6e-2 * float(g[f"step{i}/grad_norm"][0]), (i, float(norm))
+        for k, t in split(g, f"step{i}/param/").items():
+            dev = (named[k].detach().float().cpu() - t).abs().mean()
+            assert float(dev) <= 0.25 * lr_sum + 1e-7, (i, k, float(dev), lr_sum)
