@@ -18,7 +18,15 @@ struct GemmP {
   int act, out_f32, accumulate;
   int ktiles_per_split;
   float* ws;  // split-K partial slabs [gridDim.z][m][n] (fp32) or nullptr
+  float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m][k] (the bias gradient of a weight-gradient GEMM), fused into the MFMA loop
 };
+
+__device__ __forceinline__ float frag_sum8(const short8v& f) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) s += bf2f((bf16_t)f[e]);
+  return s;
+}
 
 // ---- epilogue on 4 consecutive columns (n0..n0+3) of row m; n0 % 4 == 0 and n0+3 < N guaranteed by the caller
 __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v0, float v1, float v2, float v3, bool add_bias) {
@@ -349,6 +357,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  float rs[2] = {0.f, 0.f};
+  const bool do_rowsum = p.a_rowsum != nullptr && wn == 0 && n0 == 0;  // one wave column of the first n-tile covers every A row once
   uint4 ra[4], rb[4];
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
@@ -390,6 +400,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if (!A_KMAJ && do_rowsum) { rs[0] += frag_sum8(fa[0]); rs[1] += frag_sum8(fa[1]); }  // VALU work in the shadow of the MFMAs
     }
     if (more && !GLDS) {
       char* na = smem + (cur ^ 1) * STAGE;
@@ -400,6 +411,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     __syncthreads();
   }
 
+  if (!A_KMAJ && do_rowsum) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float t = rs[i] + __shfl_xor(rs[i], 32, 64);
+      const int m = m0 + wm + i * 32 + lane;
+      if (lane < 32 && m < p.m) unsafeAtomicAdd(p.a_rowsum + m, t);
+    }
+  }
   // epilogue: the stage buffers are free after the last barrier -> 4 KiB of them per wave stage the coalesced stores
   if (p.accumulate && !p.ws) {  // atomic fallback (no workspace given): register epilogue
     const bool add_bias = blockIdx.z == 0;
@@ -586,6 +605,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
     const int tile = item / gz, z = item % gz;
     const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
     const int nt = item_nt(item);
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = p.a_rowsum != nullptr && wn == 0 && n0 == 0;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -619,6 +640,10 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
+        if (!A_KMAJ && do_rowsum) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) rs[i] += frag_sum8(fa[c][i]);
+        }
         // pin the schedule: the 8 MFMAs of this k-step interleaved 1:1 with the 6 fragment reads of the next one
         if (ks + 1 < BK / 16) {
 #pragma unroll
@@ -630,6 +655,14 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
         }
       }
       stage = stage == 2 ? 0 : stage + 1;
+    }
+    if (!A_KMAJ && do_rowsum) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float t = rs[i] + __shfl_xor(rs[i], 32, 64);
+        const int m = m0 + wm + i * 32 + lane;
+        if (lane < 32 && m < p.m) unsafeAtomicAdd(p.a_rowsum + m, t);
+      }
     }
     if (p.accumulate && !p.ws) store_wave_tile<4>(p, acc, m0 + wm, n0 + wn, lane, z);  // atomic fallback keeps the register epilogue
     else store_wave_tile_staged<4>(p, acc, m0 + wm, n0 + wn, lane, z, reinterpret_cast<float*>(smem + 3 * STAGE + wave * 4096));
@@ -768,7 +801,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.alpha = a->alpha;
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = a->residual_bf16; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
-  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr;
+  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -788,6 +821,8 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     // 128x128 two-stage kernel (2 blocks/CU) for the short-K forward / data-gradient GEMMs
     const bool big = a->force_generic == 4 || (a->force_generic == 0 && !a->a_kmajor && a->m >= 256 && a->n >= 128);
     dim3 grid(big ? ((a->m + 255) / 256) * ((a->n + 127) / 128) : ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, gz);
+    p.a_rowsum = (!a->a_kmajor) ? a->a_rowsum : nullptr;
+    if (a->a_rowsum && a->a_kmajor) return CINEMA_ERR_UNSUPPORTED;
     const bool two_pass = gz > 1 && a->out_f32 && a->workspace && a->workspace_bytes >= (long long)gz * a->m * a->n * 4 && !(((uintptr_t)a->workspace) & 15) &&
                           !a->bias && !a->residual_f32 && !a->residual_bf16 && !a->gelu_in && !a->row_mask && !a->aux_out && a->act == 0;
     p.ws = two_pass ? (float*)a->workspace : nullptr;
@@ -830,6 +865,14 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.ktiles_per_split = (nkt + sp - 1) / sp;
   const int gz = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
   dim3 grid(((a->m + 63) / 64) * ((a->n + 63) / 64), 1, gz);
+  if (a->a_rowsum) {  // the generic kernel does not fuse the row sums: one column-sum launch over the stored [K][M] operand
+    if (a->a_kmajor) return CINEMA_ERR_UNSUPPORTED;
+    int chunks = (a->k + 511) / 512;
+    if (chunks > 256) chunks = 256;
+    const int rpb = (a->k + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((a->m + 63) / 64, (a->k + rpb - 1) / rpb), dim3(256), 0, st, a->a, 0, (const int*)nullptr, a->k, a->m, a->lda,
+                       a->a_rowsum, rpb);
+  }
   const int a_rs = a->a_kmajor ? a->lda : 1, a_cs = a->a_kmajor ? 1 : a->lda;   // element (m,k) = a[m*a_rs + k*a_cs]
   const int b_rs = a->b_kmajor ? 1 : a->ldb, b_cs = a->b_kmajor ? a->ldb : 1;   // element (k,n) = b[k*b_rs + n*b_cs]
   a->kernel_used = 0;

@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("row_mask", C.c_void_p),
         ("aux_out", C.c_void_p), ("ld_aux", C.c_int),
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
         ("kernel_used", C.c_int),
     ]
 
@@ -141,7 +141,8 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True, out: torch.Tensor | None = None,
          out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None,
          gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, aux_out: torch.Tensor | None = None,
-         act: int = 0, accumulate: bool = False, split_k: int = 1, alpha: float = 1.0, force_generic: bool = False) -> torch.Tensor:
+         act: int = 0, accumulate: bool = False, split_k: int = 1, alpha: float = 1.0, force_generic: bool = False,
+         a_rowsum: torch.Tensor | None = None) -> torch.Tensor:
     """D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N]."""
     lib = load()
     _dev(a, b, out, bias, residual, gelu_in, row_mask, aux_out)
@@ -182,6 +183,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
     g.act, g.out_f32, g.accumulate = act, int(out.dtype == torch.float32), int(accumulate)
     g.split_k, g.force_generic = split_k, int(force_generic or FORCE_GENERIC)
+    if a_rowsum is not None:  # fp32 [m], accumulated: sum_k A[m, k] (bias gradient of a weight-gradient GEMM)
+        _dev(a_rowsum)
+        g.a_rowsum = a_rowsum.data_ptr()
     ws = None
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
         ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device)

@@ -215,9 +215,8 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
     n, k = dy16.shape[1], x16.shape[1]
     full = wv.grad_buffer(wshape if total_rows is None else (total_rows, k), to_param_layout)
     dst = full.view(-1, k)[row_offset:row_offset + n]
-    K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k))
-    if bv is not None:
-        K.colsum(dy16, bv.grad_buffer((n,) if total_rows is None else (total_rows,))[row_offset:row_offset + n])
+    bias_grad = None if bv is None else bv.grad_buffer((n,) if total_rows is None else (total_rows,))[row_offset:row_offset + n]
+    K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k), a_rowsum=bias_grad)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -323,8 +322,7 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
             bq, bkv = pv[1].grad_buffer((c,)), pv[3].grad_buffer((2 * c,))
             if pv[1].direct and pv[3].direct and _adjacent(bq, bkv):  # one [3c, c] weight-gradient GEMM + one column sum
                 K.gemm(dqkv, x.data, a_kmajor=False, b_kmajor=False, out=gq.as_strided((3 * c, c), (c, 1)), accumulate=True,
-                       split_k=_split_k(dqkv.shape[0], 3 * c, c))
-                K.colsum(dqkv, bq.as_strided((3 * c,), (1,)))
+                       split_k=_split_k(dqkv.shape[0], 3 * c, c), a_rowsum=bq.as_strided((3 * c,), (1,)))
                 gq = None
         if gq is not None:
             wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))

@@ -56,6 +56,7 @@ typedef struct {
   int force_generic;
   void* workspace;            /* optional fp32 scratch for split_k > 1: >= split_k*m*n*4 bytes -> deterministic two-pass reduction instead of atomics */
   long long workspace_bytes;
+  float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
   int kernel_used;            /* OUT: 0 generic FMA, 1 MFMA k-major/k-major, 2 MFMA k-major/n-major (dgrad), 3 MFMA m-major/n-major (wgrad) */
 } cinema_gemm_args;
 int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);

@@ -66,6 +66,12 @@ def test_gemm_dgrad_and_wgrad_layouts(m: int, n: int, k: int, generic: bool) -> 
     acc = torch.ones(n, k, dtype=torch.float32, device=DEV)
     K.gemm(dy, x, a_kmajor=False, b_kmajor=False, out=acc, accumulate=True, split_k=5, force_generic=generic)
     close(acc, dw_ref + 1.0, 2e-4, 1e-2, "wgrad split-k accumulate")
+    # fused bias gradient: a_rowsum[n] += sum_m dy[m, n], accumulated on top of existing content
+    rs = torch.full((n,), 0.5, dtype=torch.float32, device=DEV)
+    acc2 = torch.zeros(n, k, dtype=torch.float32, device=DEV)
+    K.gemm(dy, x, a_kmajor=False, b_kmajor=False, out=acc2, accumulate=True, split_k=3, force_generic=generic, a_rowsum=rs)
+    close(acc2, dw_ref, 2e-4, 1e-2, "wgrad with fused row sums")
+    close(rs, dy.float().sum(0) + 0.5, 1e-3, 2e-2, "fused bias gradient")
 
 
 @pytest.mark.parametrize("generic", [False, True])
