@@ -728,20 +728,36 @@ __global__ void colsum_kernel(const void* x, int is_f32, const int* row_idx, int
 
 // dst[m][n] (+)= alpha * sum_z ws[z][m][n]   (second pass of the workspace split-K; fully coalesced, deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splits, int m, int n, float* dst, int ldd, int accumulate, float alpha) {
+  // grid.y slices the split range (tiny outputs come with hundreds of splits: a single thread summing them serially was
+  // latency-bound); slices > 1 combine with fp32 atomics (only ever used with accumulate=1), one slice does a plain RMW
   const long long total4 = (long long)m * n / 4;
   const size_t slab = (size_t)m * n;
+  const int per = (splits + gridDim.y - 1) / gridDim.y;
+  const int z0 = blockIdx.y * per, z1 = min(splits, z0 + per);
+  if (z0 >= z1) return;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     const size_t e = (size_t)i * 4;
-    float4 s = *reinterpret_cast<const float4*>(ws + e);
-    for (int z = 1; z < splits; z++) {
-      const float4 v = *reinterpret_cast<const float4*>(ws + z * slab + e);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {  // 4 independent loads in flight
+      const float4 a = *reinterpret_cast<const float4*>(ws + (size_t)z * slab + e), b = *reinterpret_cast<const float4*>(ws + (size_t)(z + 1) * slab + e);
+      const float4 c = *reinterpret_cast<const float4*>(ws + (size_t)(z + 2) * slab + e), d4 = *reinterpret_cast<const float4*>(ws + (size_t)(z + 3) * slab + e);
+      s.x += (a.x + b.x) + (c.x + d4.x); s.y += (a.y + b.y) + (c.y + d4.y); s.z += (a.z + b.z) + (c.z + d4.z); s.w += (a.w + b.w) + (c.w + d4.w);
+    }
+    for (; z < z1; z++) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)z * slab + e);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const int row = (int)(e / n), col = (int)(e % n);
-    float4* d = reinterpret_cast<float4*>(dst + (size_t)row * ldd + col);
-    if (accumulate) { const float4 o = *d; s.x = o.x + alpha * s.x; s.y = o.y + alpha * s.y; s.z = o.z + alpha * s.z; s.w = o.w + alpha * s.w; }
-    else { s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha; }
-    *d = s;
+    float* dp = dst + (size_t)row * ldd + col;
+    if (gridDim.y > 1) {
+      unsafeAtomicAdd(dp, alpha * s.x); unsafeAtomicAdd(dp + 1, alpha * s.y); unsafeAtomicAdd(dp + 2, alpha * s.z); unsafeAtomicAdd(dp + 3, alpha * s.w);
+    } else {
+      float4* d = reinterpret_cast<float4*>(dp);
+      if (accumulate) { const float4 o = *d; s.x = o.x + alpha * s.x; s.y = o.y + alpha * s.y; s.z = o.z + alpha * s.z; s.w = o.w + alpha * s.w; }
+      else { s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha; }
+      *d = s;
+    }
   }
 }
 
@@ -855,7 +871,13 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     if (two_pass) {
       long long blocks = ((long long)a->m * a->n / 4 + 255) / 256;
       if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a->workspace, gz, a->m, a->n, (float*)a->d, a->ldd,
+      int slices = 1;
+      if (a->accumulate && blocks < 256) {  // few output elements, many splits: parallelise over the split range too
+        slices = (int)(512 / blocks);
+        if (slices > (gz + 7) / 8) slices = (gz + 7) / 8;
+        if (slices < 1) slices = 1;
+      }
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks, slices), dim3(256), 0, st, (const float*)a->workspace, gz, a->m, a->n, (float*)a->d, a->ldd,
                          a->accumulate, a->alpha);
     }
     return launch_status();
