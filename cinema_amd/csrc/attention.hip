@@ -94,14 +94,31 @@ __device__ __forceinline__ void zero16(float16v& a) {
 // ================================================================================================
 // forward: block = 4 waves x 32 queries; K/V tiles of 64 keys
 // ================================================================================================
+// (tile, head, batch) of this workgroup: the linear dispatch id goes through xcd_remap() so that the tiles of one
+// (batch, head) pair - which share K/V (forward, dQ) or Q/dO (dK/dV) - run on ONE XCD and meet in its L2 (PMC: the plain
+// grid fetched the shared operands once per XCD, 4x the operand bytes on the decoder shapes).
+struct BlockCoord { int t, h, b; };
+__device__ __forceinline__ BlockCoord block_coord() {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int l = xcd_remap(lin, gx * gy * (int)gridDim.z);
+  BlockCoord c;
+  c.t = l % gx;
+  const int r = l / gx;
+  c.h = r % gy;
+  c.b = r / gy;
+  return c;
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnP p) {
   using Stage = TileStage<HD, 64>;
   constexpr int TB = Stage::BYTES;
   __shared__ __attribute__((aligned(16))) char smem[4 * TB];  // [2 stages][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const BlockCoord bc = block_coord();
+  const int b = bc.b, h = bc.h;
+  const int qrow = bc.t * 128 + wave * 32 + (lane & 31);
   const int qc = qrow < p.tq ? qrow : p.tq - 1;
   const bf16_t* kbase = p.k + (size_t)b * p.tk * p.ldk + h * HD;
   const bf16_t* vbase = p.v + (size_t)b * p.tk * p.ldv + h * HD;
@@ -214,8 +231,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnP p) {
   constexpr int TB = Stage::BYTES;
   __shared__ __attribute__((aligned(16))) char smem[4 * TB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const BlockCoord bc = block_coord();
+  const int b = bc.b, h = bc.h;
+  const int qrow = bc.t * 128 + wave * 32 + (lane & 31);
   const int qc = qrow < p.tq ? qrow : p.tq - 1;
   const bf16_t* kbase = p.k + (size_t)b * p.tk * p.ldk + h * HD;
   const bf16_t* vbase = p.v + (size_t)b * p.tk * p.ldv + h * HD;
@@ -299,8 +317,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
   constexpr int ST = 2 * TB + 512;  // Q | dO | lse[64] | delta[64]
   __shared__ __attribute__((aligned(16))) char smem[2 * ST];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int krow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const BlockCoord bc = block_coord();
+  const int b = bc.b, h = bc.h;
+  const int krow = bc.t * 128 + wave * 32 + (lane & 31);
   const int kc = krow < p.tk ? krow : p.tk - 1;
   const bf16_t* qbase = p.q + (size_t)b * p.tq * p.ldq + h * HD;
   const bf16_t* dobase = p.d_o + (size_t)b * p.tq * p.lddo + h * HD;

@@ -87,3 +87,11 @@ __device__ __forceinline__ int swz_off(int r, int c) {
 __device__ __forceinline__ short4v lds_tr16_b64(const void* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(lds_ptr));
 }
+
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private 4 MiB L2.  xcd_remap() is a bijection
+// of [0, n) that hands XCD x the CONTIGUOUS logical range [~x*n/8, ~(x+1)*n/8), so that neighbouring work items (shared
+// operand rows, stencil halos) meet in one L2.  Placement is a speed hint only, never a correctness assumption.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return x * q + min(x, r) + i;
+}

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void dwconv_zcol_kernel(DwP p) {
   const int cg = threadIdx.x & 7;            // 8 channel groups of 8 = 64 channels: one 128-byte line per voxel
   const int ch = c0 + cg * 8;
   const long long npos = (long long)p.b * p.X * p.Y;
-  const long long pos = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const long long pos = (long long)xcd_remap(blockIdx.x, gridDim.x) * 32 + (threadIdx.x >> 3);  // stencil halos meet in one L2
   if (pos >= npos || ch >= p.c) return;
   const int y = (int)(pos % p.Y), x = (int)((pos / p.Y) % p.X);
   const long long bb = pos / ((long long)p.Y * p.X);
@@ -184,7 +184,7 @@ __global__ void dwconv_wgrad_walk_kernel(DwP p, int cols_per_block) {
   for (int i = 0; i < 8; i++) accb[i] = 0.f;
   const bool center = (ti == rx && tj == ry);
   const long long ncols = (long long)p.b * p.X * p.Y;
-  const long long col_begin = (long long)blockIdx.x * cols_per_block;
+  const long long col_begin = (long long)xcd_remap(blockIdx.x, gridDim.x) * cols_per_block;
   const long long col_end = min(ncols, col_begin + cols_per_block);
   for (long long col = col_begin; col < col_end; col++) {
     const int y = (int)(col % p.Y), x = (int)((col / p.Y) % p.X);

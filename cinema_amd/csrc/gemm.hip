@@ -333,6 +333,21 @@ struct TileIO {
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
 
+// XCD-aware work order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private 4 MiB L2, so
+// neighbouring ids never share a cache: with the plain row-major map the 6 column tiles of one A row block were fetched
+// by 6 different L2s (PMC: fabric reads 3-4x the operand bytes).  xcd_remap() hands XCD x the CONTIGUOUS logical range
+// [x*n/8, (x+1)*n/8); tile_of() then walks groups of 8 row tiles with m fastest, so the ~64 tiles resident on one XCD
+// form an 8x8 patch (8 A blocks + 8 B blocks feed 64 tiles).  Placement is a speed hint only, never a correctness one.
+__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+  constexpr int G = 8;
+  const int per_group = G * tiles_n;
+  const int g = t / per_group, first_m = g * G;
+  const int gsz = min(G, tiles_m - first_m);
+  const int in_g = t - g * per_group;
+  tn = in_g / gsz;
+  tm = first_m + in_g - tn * gsz;
+}
+
 template <bool A_KMAJ, bool B_KMAJ, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
   using AIO = TileIO<A_KMAJ>;
@@ -342,10 +357,15 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int tiles_n = (p.n + BN - 1) / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
+  // linear dispatch id (x fastest, then z) -> logical work item, split-major so that one XCD sees one k-range
+  const int logical = xcd_remap(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x * gridDim.z);
+  const int zsplit = logical / (int)gridDim.x;
+  int tm, tn;
+  tile_of(logical - zsplit * (int)gridDim.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   const int nkt = (p.k + BK - 1) / BK;
-  const int kt_begin = blockIdx.z * p.ktiles_per_split;
+  const int kt_begin = zsplit * p.ktiles_per_split;
   const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
   if (kt_begin >= kt_end) return;
 
@@ -421,7 +441,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
   }
   // epilogue: the stage buffers are free after the last barrier -> 4 KiB of them per wave stage the coalesced stores
   if (p.accumulate && !p.ws) {  // atomic fallback (no workspace given): register epilogue
-    const bool add_bias = blockIdx.z == 0;
+    const bool add_bias = zsplit == 0;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int m = m0 + wm + i * 32 + (lane & 31);
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     }
     return;
   }
-  store_wave_tile_staged<2>(p, acc, m0 + wm, n0 + wn, lane, blockIdx.z, reinterpret_cast<float*>(smem + wave * 4096));
+  store_wave_tile_staged<2>(p, acc, m0 + wm, n0 + wn, lane, zsplit, reinterpret_cast<float*>(smem + wave * 4096));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,9 +566,22 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkt = (p.k + BK - 1) / BK;
-  // work items of this block: item = blockIdx.x + i * gridDim.x ; item -> (tile = item / gz, z = item % gz)
+  // work items of this block: slot = blockIdx.x + i * gridDim.x, remapped inside its round so that the workgroups of one
+  // XCD own a contiguous range; item -> (z = item / n_tiles, tile = item % n_tiles): one XCD sees one k-range and a compact
+  // patch of tiles (walked along the shorter side of the tile grid first)
+  const int n_tiles = n_items / gz, tiles_m = n_tiles / tiles_n;
+  auto item_of = [&](int slot) {
+    const int round0 = (slot / (int)gridDim.x) * (int)gridDim.x;
+    return round0 + xcd_remap(slot - round0, min((int)gridDim.x, n_items - round0));
+  };
+  auto item_z = [&](int item) { return item / n_tiles; };
+  auto item_tile = [&](int item, int& m0, int& n0) {
+    const int t = item % n_tiles;
+    if (tiles_m <= tiles_n) { m0 = (t % tiles_m) * 256; n0 = (t / tiles_m) * 128; }
+    else { m0 = (t / tiles_n) * 256; n0 = (t % tiles_n) * 128; }
+  };
   auto item_nt = [&](int item) {
-    const int kb = (item % gz) * p.ktiles_per_split;
+    const int kb = item_z(item) * p.ktiles_per_split;
     return min(nkt, kb + p.ktiles_per_split) - kb;
   };
 
@@ -557,21 +590,23 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
     const int pw = wave - 4;
     const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
     const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
-    int item = blockIdx.x, kt = 0, stage = 0;  // cursor of the NEXT (item, k-tile) to issue
-    int nt = item < n_items ? item_nt(item) : 0;
+    int slot = blockIdx.x, kt = 0, stage = 0;  // cursor of the NEXT (item, k-tile) to issue
+    int item = slot < n_items ? item_of(slot) : 0;
+    int nt = slot < n_items ? item_nt(item) : 0;
     auto issue_next = [&]() -> bool {  // returns false when the stream is exhausted
-      if (item >= n_items) return false;
-      const int tile = item / gz;
-      const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
-      const int k0 = ((item % gz) * p.ktiles_per_split + kt) * BK;
+      if (slot >= n_items) return false;
+      int m0, n0;
+      item_tile(item, m0, n0);
+      const int k0 = (item_z(item) * p.ktiles_per_split + kt) * BK;
       const uint32_t s = smem_addr + stage * STAGE;
       AT::glds(s, p.a, p.lda, m0, p.m, k0, p.k, lane, pw, zero_page);
       BT::glds(s + AT::BYTES, p.b, p.ldb, n0, p.n, k0, p.k, lane, pw, zero_page);
       stage = stage == 2 ? 0 : stage + 1;
       if (++kt == nt) {
         kt = 0;
-        item += gridDim.x;
-        nt = item < n_items ? item_nt(item) : 0;
+        slot += gridDim.x;
+        item = slot < n_items ? item_of(slot) : 0;
+        nt = slot < n_items ? item_nt(item) : 0;
       }
       return true;
     };
@@ -601,9 +636,10 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
   float16v acc[4][2];
   int stage = 0;
   bool first = true;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int tile = item / gz, z = item % gz;
-    const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
+  for (int slot = blockIdx.x; slot < n_items; slot += gridDim.x) {
+    const int item = item_of(slot), z = item_z(item);
+    int m0, n0;
+    item_tile(item, m0, n0);
     const int nt = item_nt(item);
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = p.a_rowsum != nullptr && wn == 0 && n0 == 0;

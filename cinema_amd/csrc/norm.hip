@@ -95,7 +95,9 @@ struct LnBwdP {
   int lpr;
 };
 
-template <int CPL>
+// RG = independent row groups per wave iteration: narrow rows (CPL <= 2) carry only 2-4 16-byte loads per lane, too few
+// bytes in flight to cover the HBM latency (measured 2.5 TB/s at C = 64), so those instantiations interleave RG groups.
+template <int CPL, int RG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   float* red = reinterpret_cast<float*>(dyn_smem);  // [n_waves_in_block][2][c]
@@ -110,50 +112,80 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
 #pragma unroll
   for (int i = 0; i < CPL; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
 
-  for (int row0 = wave_global * rows_per_wave; row0 < p.rows; row0 += n_waves * rows_per_wave) {
-    const int row = row0 + lane / p.lpr;
-    const bool rv = row < p.rows;
-    const float mu = rv ? p.mean[row] : 0.f, rs = rv ? p.rstd[row] : 0.f;
-    float4 xh[CPL], dxh[CPL];
-    float s1 = 0.f, s2 = 0.f;
+  for (int row0 = wave_global * rows_per_wave * RG; row0 < p.rows; row0 += n_waves * rows_per_wave * RG) {
+    float4 xh[RG][CPL], dxh[RG][CPL];
+    float s1[RG], s2[RG], rsv[RG];
+    bool rvv[RG];
+    // phase 1: every load of the RG groups is issued before the first use
+    float4 xv[RG][CPL], dv[RG][CPL];
 #pragma unroll
-    for (int i = 0; i < CPL; i++) {
-      const int ch = sub + i * p.lpr;
-      xh[i] = make_float4(0, 0, 0, 0); dxh[i] = make_float4(0, 0, 0, 0);
-      if (rv && ch < nch) {
-        const float4 xv = load4(p.x, p.x_bf16, (size_t)row * p.ldx + ch * 4);
-        float4 d = load4(p.dy, p.dy_bf16, (size_t)row * p.lddy + ch * 4);
-        const float4 g = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        if (p.act == 1) {
-          const float4 b = *reinterpret_cast<const float4*>(p.beta + ch * 4);
-          d.x *= gelu_grad_f(xh[i].x * g.x + b.x); d.y *= gelu_grad_f(xh[i].y * g.y + b.y);
-          d.z *= gelu_grad_f(xh[i].z * g.z + b.z); d.w *= gelu_grad_f(xh[i].w * g.w + b.w);
+    for (int g = 0; g < RG; g++) {
+      const int row = row0 + g * rows_per_wave + lane / p.lpr;
+      rvv[g] = row < p.rows;
+#pragma unroll
+      for (int i = 0; i < CPL; i++) {
+        const int ch = sub + i * p.lpr;
+        xv[g][i] = make_float4(0, 0, 0, 0); dv[g][i] = make_float4(0, 0, 0, 0);
+        if (rvv[g] && ch < nch) {
+          xv[g][i] = load4(p.x, p.x_bf16, (size_t)row * p.ldx + ch * 4);
+          dv[g][i] = load4(p.dy, p.dy_bf16, (size_t)row * p.lddy + ch * 4);
         }
-        ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
-        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-        dxh[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-        s1 += dxh[i].x + dxh[i].y + dxh[i].z + dxh[i].w;
-        s2 += dxh[i].x * xh[i].x + dxh[i].y * xh[i].y + dxh[i].z * xh[i].z + dxh[i].w * xh[i].w;
       }
     }
-    s1 = group_sum(s1, p.lpr) * inv_c;
-    s2 = group_sum(s2, p.lpr) * inv_c;
-    if (!rv) continue;
 #pragma unroll
-    for (int i = 0; i < CPL; i++) {
-      const int ch = sub + i * p.lpr;
-      if (ch >= nch) continue;
-      float4 dx;
-      dx.x = rs * (dxh[i].x - s1 - xh[i].x * s2); dx.y = rs * (dxh[i].y - s1 - xh[i].y * s2);
-      dx.z = rs * (dxh[i].z - s1 - xh[i].z * s2); dx.w = rs * (dxh[i].w - s1 - xh[i].w * s2);
-      const size_t off = (size_t)row * p.lddx + ch * 4;
-      if (p.dx_res) {
-        const float4 r = *reinterpret_cast<const float4*>(p.dx_res + off);
-        dx.x += r.x; dx.y += r.y; dx.z += r.z; dx.w += r.w;
+    for (int g = 0; g < RG; g++) {
+      const int row = row0 + g * rows_per_wave + lane / p.lpr;
+      const bool rv = rvv[g];
+      const float mu = rv ? p.mean[row] : 0.f, rs = rv ? p.rstd[row] : 0.f;
+      rsv[g] = rs;
+      s1[g] = 0.f; s2[g] = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; i++) {
+        const int ch = sub + i * p.lpr;
+        xh[g][i] = make_float4(0, 0, 0, 0); dxh[g][i] = make_float4(0, 0, 0, 0);
+        if (rv && ch < nch) {
+          const float4 x4 = xv[g][i];
+          float4 d = dv[g][i];
+          const float4 gm = *reinterpret_cast<const float4*>(p.gamma + ch * 4);
+          xh[g][i] = make_float4((x4.x - mu) * rs, (x4.y - mu) * rs, (x4.z - mu) * rs, (x4.w - mu) * rs);
+          if (p.act == 1) {
+            const float4 b = *reinterpret_cast<const float4*>(p.beta + ch * 4);
+            d.x *= gelu_grad_f(xh[g][i].x * gm.x + b.x); d.y *= gelu_grad_f(xh[g][i].y * gm.y + b.y);
+            d.z *= gelu_grad_f(xh[g][i].z * gm.z + b.z); d.w *= gelu_grad_f(xh[g][i].w * gm.w + b.w);
+          }
+          ag[i].x += d.x * xh[g][i].x; ag[i].y += d.y * xh[g][i].y; ag[i].z += d.z * xh[g][i].z; ag[i].w += d.w * xh[g][i].w;
+          ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+          dxh[g][i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+          s1[g] += dxh[g][i].x + dxh[g][i].y + dxh[g][i].z + dxh[g][i].w;
+          s2[g] += dxh[g][i].x * xh[g][i].x + dxh[g][i].y * xh[g][i].y + dxh[g][i].z * xh[g][i].z + dxh[g][i].w * xh[g][i].w;
+        }
       }
-      if (p.dx_f32) *reinterpret_cast<float4*>(p.dx_f32 + off) = dx;
-      if (p.dx_bf16) store4_bf16(p.dx_bf16 + off, dx);
+    }
+#pragma unroll
+    for (int g = 0; g < RG; g++) {
+      s1[g] = group_sum(s1[g], p.lpr) * inv_c;
+      s2[g] = group_sum(s2[g], p.lpr) * inv_c;
+    }
+#pragma unroll
+    for (int g = 0; g < RG; g++) {
+      if (!rvv[g]) continue;
+      const int row = row0 + g * rows_per_wave + lane / p.lpr;
+      const float rs = rsv[g];
+#pragma unroll
+      for (int i = 0; i < CPL; i++) {
+        const int ch = sub + i * p.lpr;
+        if (ch >= nch) continue;
+        float4 dx;
+        dx.x = rs * (dxh[g][i].x - s1[g] - xh[g][i].x * s2[g]); dx.y = rs * (dxh[g][i].y - s1[g] - xh[g][i].y * s2[g]);
+        dx.z = rs * (dxh[g][i].z - s1[g] - xh[g][i].z * s2[g]); dx.w = rs * (dxh[g][i].w - s1[g] - xh[g][i].w * s2[g]);
+        const size_t off = (size_t)row * p.lddx + ch * 4;
+        if (p.dx_res) {
+          const float4 r = *reinterpret_cast<const float4*>(p.dx_res + off);
+          dx.x += r.x; dx.y += r.y; dx.z += r.z; dx.w += r.w;
+        }
+        if (p.dx_f32) *reinterpret_cast<float4*>(p.dx_f32 + off) = dx;
+        if (p.dx_bf16) store4_bf16(p.dx_bf16 + off, dx);
+      }
     }
   }
   if (!p.dgamma && !p.dbeta) return;
@@ -227,12 +259,15 @@ CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, co
   LnBwdP p{dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
            pick_lpr(c)};
   const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
-  const int rows_per_block = 4 * (64 / p.lpr);
-  int grid = (rows + rows_per_block - 1) / rows_per_block;
-  if (grid > 1024) grid = 1024;
   const size_t smem = (size_t)4 * 2 * c * sizeof(float);
   return dispatch_cpl<LnBwdP>(cpl, [&](auto tag) {
-    hipLaunchKernelGGL((ln_bwd_kernel<decltype(tag)::value>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    constexpr int CPL = decltype(tag)::value;
+    constexpr int RG = CPL == 1 ? 4 : 1;  // RG = 2 at CPL 2-3 measured 30 % slower (registers)
+    const int rows_per_block = 4 * (64 / p.lpr) * RG;
+    int grid = (rows + rows_per_block - 1) / rows_per_block;
+    const int cap = CPL == 1 ? 2048 : 1024;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL((ln_bwd_kernel<CPL, RG>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
     return launch_status();
   });
 }
