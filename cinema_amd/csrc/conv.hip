@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwP p) {
 // instead of 8 in the per-voxel kernel (which was VALU/L1-bound at ~400 VALU instructions per output element).
 // 2-D maps are passed as (X=1, Y=H, Z=W): the walked axis is then W.
 template <int ZB, bool FULLZ>  // FULLZ: Z == ZB, every z-range test is resolved at compile time (the SAX volumes, Z = 16)
-__global__ __launch_bounds__(256) void dwconv_zcol_kernel(DwP p) {
+__global__ __launch_bounds__(256, 2) void dwconv_zcol_kernel(DwP p) {  // 2 waves/SIMD: the unconstrained build took 270 registers = 1 wave/SIMD
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   float* wl = reinterpret_cast<float*>(dyn_smem);  // [kx*ky][5][64] fp32 (64-channel slab)
   const int nxy = p.kx * p.ky, taps = nxy * 5;
@@ -163,8 +163,9 @@ __global__ __launch_bounds__(256) void dwconv_zcol_kernel(DwP p) {
 
 // Weight gradient with a sliding window along z (kz == KZ): thread = (tap_xy, channel group of 8); it walks whole z
 // columns of its block's (b, x, y) set, re-using the KZ-wide x window in registers: 2 loads per KZ*8 FMAs.
-template <int KZ>
+template <int KZ, int ZC>  // ZC > 0: Z == ZC known at compile time (address arithmetic and range tests fold)
 __global__ void dwconv_wgrad_walk_kernel(DwP p, int cols_per_block) {
+  const int Z = ZC > 0 ? ZC : p.Z;
   const int ncg = min(8, (p.c - blockIdx.y * 64) / 8);
   const int nxy = p.kx * p.ky;
   const int role = threadIdx.x;
@@ -191,20 +192,20 @@ __global__ void dwconv_wgrad_walk_kernel(DwP p, int cols_per_block) {
     const long long bb = col / ((long long)p.Y * p.X);
     const int xx = x + ti - rx, yy = y + tj - ry;
     if (xx < 0 || xx >= p.X || yy < 0 || yy >= p.Y) continue;
-    const bf16_t* xcol = p.x + ((((size_t)bb * p.X + xx) * p.Y + yy) * p.Z) * p.c + ch;
-    const bf16_t* dcol = p.dy + ((size_t)col * p.Z) * p.c + ch;
+    const bf16_t* xcol = p.x + ((((size_t)bb * p.X + xx) * p.Y + yy) * Z) * p.c + ch;
+    const bf16_t* dcol = p.dy + ((size_t)col * Z) * p.c + ch;
     // window win[k] = x[z + k - RZ]
     float win[KZ][8];
 #pragma unroll
     for (int k = 0; k < KZ; k++) {
       const int zz = k - RZ;
-      if (zz >= 0 && zz < p.Z) { const uint4 u = *reinterpret_cast<const uint4*>(xcol + (size_t)zz * p.c); unpack8(u, win[k]); }
+      if (zz >= 0 && zz < Z) { const uint4 u = *reinterpret_cast<const uint4*>(xcol + (size_t)zz * p.c); unpack8(u, win[k]); }
       else {
 #pragma unroll
         for (int i = 0; i < 8; i++) win[k][i] = 0.f;
       }
     }
-    for (int z = 0; z < p.Z; z++) {
+    for (int z = 0; z < Z; z++) {  // kept rolled: unrolling by 5 or fully (to rename the window slide away) spilled and measured 1.6x slower
       float d[8];
       { const uint4 u = *reinterpret_cast<const uint4*>(dcol + (size_t)z * p.c); unpack8(u, d); }
 #pragma unroll
@@ -221,7 +222,7 @@ __global__ void dwconv_wgrad_walk_kernel(DwP p, int cols_per_block) {
 #pragma unroll
         for (int i = 0; i < 8; i++) win[k][i] = win[k + 1][i];
       const int zn = z + 1 + RZ;
-      if (zn < p.Z) { const uint4 u = *reinterpret_cast<const uint4*>(xcol + (size_t)zn * p.c); unpack8(u, win[KZ - 1]); }
+      if (zn < Z) { const uint4 u = *reinterpret_cast<const uint4*>(xcol + (size_t)zn * p.c); unpack8(u, win[KZ - 1]); }
       else {
 #pragma unroll
         for (int i = 0; i < 8; i++) win[KZ - 1][i] = 0.f;
@@ -417,7 +418,8 @@ CINEMA_API int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, f
     const int taps = kx * ky * kz;
     const long long need = (long long)grid.x * c * (taps + 1) * 4;
     p.ws = (workspace && workspace_bytes >= need && !(c & 63)) ? workspace : nullptr;  // every (block, channel, tap) slot is written when c % 64 == 0
-    hipLaunchKernelGGL(dwconv_wgrad_walk_kernel<5>, grid, dim3(threads), 0, st, p, cpb);
+    if (Z == 16) hipLaunchKernelGGL((dwconv_wgrad_walk_kernel<5, 16>), grid, dim3(threads), 0, st, p, cpb);
+    else hipLaunchKernelGGL((dwconv_wgrad_walk_kernel<5, 0>), grid, dim3(threads), 0, st, p, cpb);
     if (p.ws) {
       const int total = c * (taps + 1);
       hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((total + 255) / 256, 16), dim3(256), 0, st, (const float*)p.ws, (int)grid.x, c * taps, c, dw, dbias);

@@ -19,6 +19,11 @@ struct GemmP {
   int ktiles_per_split;
   float* ws;  // split-K partial slabs [gridDim.z][m][n] (fp32) or nullptr
   float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m][k] (the bias gradient of a weight-gradient GEMM), fused into the MFMA loop
+  // split tail (128x128 kernel, gridDim.z == 1): logical tiles >= tail_begin do not fill the last round of workgroup slots, so each
+  // is cut into tail_split k-slices (tail_ktiles k-tiles each) whose fp32 partial tiles go to tail_ws[(tile - tail_begin) * tail_split
+  // + slice][128][128]; tail_fixup_kernel sums the slices and runs the fused epilogue.  tail_split == 0: off.
+  int tail_begin, tail_split, tail_ktiles;
+  float* tail_ws;
 };
 
 __device__ __forceinline__ float frag_sum8(const short8v& f) {
@@ -148,8 +153,11 @@ __device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, floa
 // CONSECUTIVE columns of one row and the wave writes whole 64/128-byte row segments.  The direct register epilogue wrote
 // 8 bytes into 64 different cache lines per store instruction and dominated short-K GEMMs (K-sweep intercept 34-48 us).
 template <int MI>
-__device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, int z, float* stg) {
-  const bool to_ws = p.ws != nullptr;
+__device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, int z, float* stg,
+                                                       float* ws_base = nullptr, long long ws_ld = 0) {
+  // fp32 partial destination: an explicit one (split-tail slice), else the split-K slab of slice z
+  if (!ws_base && p.ws) { ws_base = p.ws + (size_t)z * p.m * p.n; ws_ld = p.n; }
+  const bool to_ws = ws_base != nullptr;
   const bool add_bias = z == 0;
   const int ml = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -172,7 +180,7 @@ __device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const flo
           const int m = mb + r, n = nb + col4 * 4;
           if (m < p.m && n < p.n) {
             if (to_ws) {
-              *reinterpret_cast<float4*>(p.ws + (size_t)z * p.m * p.n + (size_t)m * p.n + n) = t;
+              *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n) = t;
             } else {
               float v[4] = {t.x, t.y, t.z, t.w};
               epilogue_row<4>(p, m, n, v, add_bias);
@@ -359,14 +367,29 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
   // linear dispatch id (x fastest, then z) -> logical work item, split-major so that one XCD sees one k-range
-  const int logical = xcd_remap(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x * gridDim.z);
-  const int zsplit = logical / (int)gridDim.x;
-  int tm, tn;
-  tile_of(logical - zsplit * (int)gridDim.x, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
   const int nkt = (p.k + BK - 1) / BK;
-  const int kt_begin = zsplit * p.ktiles_per_split;
-  const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+  int zsplit = 0, tile, kt_begin, kt_end;
+  float* tail_dst = nullptr;
+  if (p.tail_split > 0 && (int)blockIdx.x >= p.tail_begin) {
+    // split tail: dispatched last (highest ids), dealt round-robin over the XCDs as they drain
+    const int j = (int)blockIdx.x - p.tail_begin;
+    tile = p.tail_begin + j / p.tail_split;
+    const int slice = j - (tile - p.tail_begin) * p.tail_split;
+    kt_begin = slice * p.tail_ktiles;
+    kt_end = min(nkt, kt_begin + p.tail_ktiles);
+    tail_dst = p.tail_ws + (size_t)j * (BM * BN);
+    zsplit = slice;  // bias-gradient row sums / nothing else depends on it in this mode
+  } else {
+    const int n_main = p.tail_split > 0 ? p.tail_begin : (int)gridDim.x;
+    const int logical = xcd_remap(blockIdx.z * n_main + blockIdx.x, n_main * gridDim.z);
+    zsplit = logical / n_main;
+    tile = logical - zsplit * n_main;
+    kt_begin = zsplit * p.ktiles_per_split;
+    kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+  }
+  int tm, tn;
+  tile_of(tile, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   if (kt_begin >= kt_end) return;
 
   float16v acc[2][2];
@@ -456,7 +479,36 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     }
     return;
   }
+  if (tail_dst) {  // fp32 partial of this k-slice, plain [128][128] rows (address = base + m * 128 + n with the tile origin folded into base)
+    store_wave_tile_staged<2>(p, acc, m0 + wm, n0 + wn, lane, 0, reinterpret_cast<float*>(smem + wave * 4096),
+                              tail_dst - ((long long)m0 * BN + n0), BN);
+    return;
+  }
   store_wave_tile_staged<2>(p, acc, m0 + wm, n0 + wn, lane, zsplit, reinterpret_cast<float*>(smem + wave * 4096));
+}
+
+// Sums the k-slices of the split-tail tiles and applies the fused epilogue: thread = 8 consecutive columns of one row.
+__global__ __launch_bounds__(256) void tail_fixup_kernel(GemmP p, int tiles_m, int tiles_n) {
+  const int r = blockIdx.x >> 3;
+  const int idx = (blockIdx.x & 7) * 256 + threadIdx.x;
+  const int row = idx >> 4, c8 = (idx & 15) * 8;
+  int tm, tn;
+  tile_of(p.tail_begin + r, tiles_m, tiles_n, tm, tn);
+  const int m = tm * BM + row, n = tn * BN + c8;
+  if (m >= p.m || n >= p.n) return;
+  const float* src = p.tail_ws + (size_t)r * p.tail_split * (BM * BN) + row * BN + c8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.tail_split; z++) {
+    const float4 a = *reinterpret_cast<const float4*>(src + (size_t)z * (BM * BN)), b = *reinterpret_cast<const float4*>(src + (size_t)z * (BM * BN) + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (p.out_f32) {
+    float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+    epilogue_row<4>(p, m, n, lo, true);
+    epilogue_row<4>(p, m, n + 4, hi, true);
+  } else {
+    epilogue_row<8>(p, m, n, v, true);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -883,6 +935,30 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       p.res_f32 = (const float*)a->d; p.ld_res = a->ldd; p.accumulate = 0;
     }
     a->kernel_used = (a->a_kmajor && a->b_kmajor) ? 1 : (a->a_kmajor ? 2 : 3);
+    // split tail (measured: 516 tiles on 512 slots cost 1.64 rounds, the 4 left-over tiles run alone at the end): worth a second
+    // launch only for long reductions and when the left-over tiles can be cut at least in two
+    p.tail_split = 0; p.tail_begin = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+    bool tail = false;
+    if (!big && gz == 1 && a->force_generic == 0 && !p.accumulate && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= 24) {
+      static int slots = 0;
+      if (slots == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        slots = 2 * ((hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256);
+      }
+      const int tiles = (int)grid.x, rem = tiles % slots;
+      if (rem > 0 && rem <= slots / 2) {
+        int sp2 = slots / rem;
+        if (sp2 > nkt / 4) sp2 = nkt / 4;  // >= 4 k-tiles per slice
+        if (sp2 > 16) sp2 = 16;
+        const int kts = (nkt + sp2 - 1) / sp2;
+        sp2 = (nkt + kts - 1) / kts;
+        if (sp2 >= 2 && a->workspace_bytes >= (long long)rem * sp2 * BM * BN * 4) {
+          p.tail_begin = tiles - rem; p.tail_split = sp2; p.tail_ktiles = kts; p.tail_ws = (float*)a->workspace;
+          grid.x = p.tail_begin + rem * sp2;
+          tail = true;
+        }
+      }
+    }
     if (big) {
       const int tiles_n = (a->n + 127) / 128;
       const int n_items = ((a->m + 255) / 256) * tiles_n * gz;
@@ -903,6 +979,10 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, true>), grid, dim3(256), 0, st, p);
       else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, true>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((gemm_mfma_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+    }
+    if (tail) {
+      const int rem = ((int)grid.x - p.tail_begin) / p.tail_split;
+      hipLaunchKernelGGL(tail_fixup_kernel, dim3(rem * 8), dim3(256), 0, st, p, (a->m + BM - 1) / BM, (a->n + BN - 1) / BN);
     }
     if (two_pass) {
       long long blocks = ((long long)a->m * a->n / 4 + 255) / 256;

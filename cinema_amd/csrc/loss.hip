@@ -45,63 +45,163 @@ __device__ __forceinline__ float pred_at(const void* pred, int dtype, size_t off
   return dtype == 0 ? bf2f(reinterpret_cast<const bf16_t*>(pred)[off]) : reinterpret_cast<const float*>(pred)[off];
 }
 
+// Fast path (patch features F <= 64 * MAXI): the feature -> image offset of a lane's features does not depend on the token, so
+// it is decomposed ONCE per thread (the per-element div/mod chain of target_at() made these kernels ALU-bound: 157 us to
+// read 38 MB); a wave then holds its whole patch in registers for the moments, the loss and the gradient.
+constexpr int MAXI = 8;
+__device__ __forceinline__ void feat_offsets(const PatchG& g, int F, int lane, long long (&o)[MAXI]) {
+#pragma unroll
+  for (int i = 0; i < MAXI; i++) {
+    const int f = lane + 64 * i;
+    const int cc = f % g.c, pf = f / g.c;
+    const int kz = pf % g.pz, ky = (pf / g.pz) % g.py, kx = pf / (g.pz * g.py);
+    o[i] = f < F ? (long long)kx * g.sx + (long long)ky * g.sy + (long long)kz * g.sz + (long long)cc * g.sc : 0;
+  }
+}
+__device__ __forceinline__ long long tok_base(const PatchG& g, int tok) {
+  const int G = g.gx * g.gy * g.gz;
+  const int bb = tok / G, gi = tok % G;
+  const int iz = gi % g.gz, iy = (gi / g.gz) % g.gy, ix = gi / (g.gz * g.gy);
+  return (long long)bb * g.sb + (long long)(ix * g.px) * g.sx + (long long)(iy * g.py) * g.sy + (long long)(iz * g.pz) * g.sz;
+}
+__device__ __forceinline__ void load_patch(const float* image, long long base, const long long (&o)[MAXI], int F, int lane, float (&t)[MAXI]) {
+#pragma unroll
+  for (int i = 0; i < MAXI; i++) t[i] = (lane + 64 * i < F) ? image[base + o[i]] : 0.f;
+}
+__device__ __forceinline__ void reg_moments(const float (&t)[MAXI], int F, int lane, float& mean, float& stdv) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; i++) s += t[i];
+  mean = wave_sum(s) / (float)F;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; i++) { const float d = t[i] - mean; q += (lane + 64 * i < F) ? d * d : 0.f; }
+  stdv = sqrtf(wave_sum(q) / (float)(F - 1));  // unbiased, as torch.var (mae.py:130)
+}
+
+// per-block combine of the 4 waves' partials -> ONE atomic per block and output (16k waves hammering three addresses
+// serialised the forward kernel: 74 us for 11 MB)
+__device__ __forceinline__ void block_add_max(float acc, float tmax, float pmax, float* loss_out, float* max_out) {
+  __shared__ float red[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  acc = wave_sum(acc); tmax = wave_max(tmax); pmax = wave_max(pmax);
+  if (lane == 0) { red[0][wave] = acc; red[1][wave] = tmax; red[2][wave] = pmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(loss_out, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    if (max_out) {  // metrics `normed_target_max` / `pred_max` (mae.py:146-150); max_out is pre-filled with -inf by the caller
+      atomic_max_f32(max_out, fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+      atomic_max_f32(max_out + 1, fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3])));
+    }
+  }
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* image, PatchG g, const void* pred, int pdt, int ldp, int norm_target, float eps,
                                                       float inv_count, float* loss_out, float* max_out) {
   const int lane = threadIdx.x & 63;
   const int F = g.px * g.py * g.pz * g.c;
   const int nw = gridDim.x * 4;
   float acc = 0.f, tmax = -INFINITY, pmax = -INFINITY;
+  long long offs[MAXI];
+  if (FAST) feat_offsets(g, F, lane, offs);
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < g.n_rows; row += nw) {
     const int tok = g.token_idx ? g.token_idx[row] : row;
     float mean = 0.f, stdv = 1.f;
-    if (norm_target) patch_moments(image, g, tok, F, lane, mean, stdv);
-    for (int f = lane; f < F; f += 64) {
-      float t = target_at(image, g, tok, f);
-      if (norm_target) t = (t - mean) / (stdv + eps);
-      const float pv = pred_at(pred, pdt, (size_t)row * ldp + f);
-      const float d = pv - t;
-      acc += d * d;
-      tmax = fmaxf(tmax, t);
-      pmax = fmaxf(pmax, pv);
+    if (FAST) {
+      float t[MAXI];
+      load_patch(image, tok_base(g, tok), offs, F, lane, t);
+      if (norm_target) reg_moments(t, F, lane, mean, stdv);
+#pragma unroll
+      for (int i = 0; i < MAXI; i++) {
+        const int f = lane + 64 * i;
+        if (f < F) {
+          const float tt = norm_target ? (t[i] - mean) / (stdv + eps) : t[i];
+          const float pv = pred_at(pred, pdt, (size_t)row * ldp + f);
+          const float d = pv - tt;
+          acc += d * d;
+          tmax = fmaxf(tmax, tt);
+          pmax = fmaxf(pmax, pv);
+        }
+      }
+    } else {
+      if (norm_target) patch_moments(image, g, tok, F, lane, mean, stdv);
+      for (int f = lane; f < F; f += 64) {
+        float t = target_at(image, g, tok, f);
+        if (norm_target) t = (t - mean) / (stdv + eps);
+        const float pv = pred_at(pred, pdt, (size_t)row * ldp + f);
+        const float d = pv - t;
+        acc += d * d;
+        tmax = fmaxf(tmax, t);
+        pmax = fmaxf(pmax, pv);
+      }
     }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) unsafeAtomicAdd(loss_out, acc * inv_count);
-  if (max_out) {  // metrics `normed_target_max` / `pred_max` (mae.py:146-150); max_out is pre-filled with -inf by the caller
-    tmax = wave_max(tmax); pmax = wave_max(pmax);
-    if (lane == 0) { atomic_max_f32(max_out, tmax); atomic_max_f32(max_out + 1, pmax); }
-  }
+  block_add_max(acc * inv_count, tmax, pmax, loss_out, max_out);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* image, PatchG g, const void* pred, int pdt, int ldp, int norm_target, float eps,
                                                       const float* upstream, float host_scale, bf16_t* dpred, int ldd) {
   const int lane = threadIdx.x & 63;
   const int F = g.px * g.py * g.pz * g.c;
   const int nw = gridDim.x * 4;
   const float coef = 2.f * host_scale * (upstream ? upstream[0] : 1.f);
+  long long offs[MAXI];
+  if (FAST) feat_offsets(g, F, lane, offs);
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < g.n_rows; row += nw) {
     const int tok = g.token_idx ? g.token_idx[row] : row;
     float mean = 0.f, stdv = 1.f;
-    if (norm_target) patch_moments(image, g, tok, F, lane, mean, stdv);
-    for (int f = lane; f < F; f += 64) {
-      float t = target_at(image, g, tok, f);
-      if (norm_target) t = (t - mean) / (stdv + eps);
-      dpred[(size_t)row * ldd + f] = f2bf(coef * (pred_at(pred, pdt, (size_t)row * ldp + f) - t));
+    if (FAST) {
+      float t[MAXI];
+      load_patch(image, tok_base(g, tok), offs, F, lane, t);
+      if (norm_target) reg_moments(t, F, lane, mean, stdv);
+#pragma unroll
+      for (int i = 0; i < MAXI; i++) {
+        const int f = lane + 64 * i;
+        if (f < F) {
+          const float tt = norm_target ? (t[i] - mean) / (stdv + eps) : t[i];
+          dpred[(size_t)row * ldd + f] = f2bf(coef * (pred_at(pred, pdt, (size_t)row * ldp + f) - tt));
+        }
+      }
+    } else {
+      if (norm_target) patch_moments(image, g, tok, F, lane, mean, stdv);
+      for (int f = lane; f < F; f += 64) {
+        float t = target_at(image, g, tok, f);
+        if (norm_target) t = (t - mean) / (stdv + eps);
+        dpred[(size_t)row * ldd + f] = f2bf(coef * (pred_at(pred, pdt, (size_t)row * ldp + f) - t));
+      }
     }
   }
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void patch_stats_kernel(const float* image, PatchG g, float inv_n, float* out2) {
   const int lane = threadIdx.x & 63;
   const int F = g.px * g.py * g.pz * g.c;
   const int nw = gridDim.x * 4;
   float am = 0.f, as = 0.f;
+  long long offs[MAXI];
+  if (FAST) feat_offsets(g, F, lane, offs);
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < g.n_rows; row += nw) {
+    const int tok = g.token_idx ? g.token_idx[row] : row;
     float mean, stdv;
-    patch_moments(image, g, g.token_idx ? g.token_idx[row] : row, F, lane, mean, stdv);
+    if (FAST) {
+      float t[MAXI];
+      load_patch(image, tok_base(g, tok), offs, F, lane, t);
+      reg_moments(t, F, lane, mean, stdv);
+    } else {
+      patch_moments(image, g, tok, F, lane, mean, stdv);
+    }
     am += mean; as += stdv;
   }
-  if (lane == 0) { unsafeAtomicAdd(out2, am * inv_n); unsafeAtomicAdd(out2 + 1, as * inv_n); }
+  __shared__ float red[2][4];
+  if (lane == 0) { red[0][threadIdx.x >> 6] = am; red[1][threadIdx.x >> 6] = as; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(out2, ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * inv_n);
+    unsafeAtomicAdd(out2 + 1, ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * inv_n);
+  }
 }
 
 // mean over the finite entries (reference: `if torch.isfinite(loss_view)` mae.py:604-608); coef[i] = d mean / d vals[i]
@@ -119,30 +219,43 @@ PatchG to_dev(const cinema_patch_geom* g) {
   p.sb = g->sb; p.sc = g->sc; p.sx = g->sx; p.sy = g->sy; p.sz = g->sz; p.n_rows = g->n_rows; p.token_idx = g->token_idx;
   return p;
 }
-int rows_grid(int n_rows) { int g = (n_rows + 3) / 4; return g > 4096 ? 4096 : (g < 1 ? 1 : g); }
+int rows_grid(int n_rows) { int g = (n_rows + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+bool fast_patch(const cinema_patch_geom* g) { return (long long)g->px * g->py * g->pz * g->c <= 64 * MAXI; }
 
 }  // namespace
 
 CINEMA_API int cinema_mse_fwd(const float* image, const cinema_patch_geom* geom, const void* pred, int pred_dtype, int ld_pred, int norm_target,
                               float eps, float inv_count, float* loss_out, float* max_out, void* stream) {
   if (!image || !geom || !pred || !loss_out || geom->n_rows <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(mse_fwd_kernel, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
-                     norm_target, eps, inv_count, loss_out, max_out);
+  if (fast_patch(geom))
+    hipLaunchKernelGGL(mse_fwd_kernel<true>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+                       norm_target, eps, inv_count, loss_out, max_out);
+  else
+    hipLaunchKernelGGL(mse_fwd_kernel<false>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+                       norm_target, eps, inv_count, loss_out, max_out);
   return launch_status();
 }
 
 CINEMA_API int cinema_mse_bwd(const float* image, const cinema_patch_geom* geom, const void* pred, int pred_dtype, int ld_pred, int norm_target,
                               float eps, const float* upstream, float host_scale, uint16_t* dpred, int ld_dpred, void* stream) {
   if (!image || !geom || !pred || !dpred || geom->n_rows <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(mse_bwd_kernel, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
-                     norm_target, eps, upstream, host_scale, dpred, ld_dpred);
+  if (fast_patch(geom))
+    hipLaunchKernelGGL(mse_bwd_kernel<true>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+                       norm_target, eps, upstream, host_scale, dpred, ld_dpred);
+  else
+    hipLaunchKernelGGL(mse_bwd_kernel<false>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+                       norm_target, eps, upstream, host_scale, dpred, ld_dpred);
   return launch_status();
 }
 
 CINEMA_API int cinema_patch_stats(const float* image, const cinema_patch_geom* geom_all, float* out2, void* stream) {
   if (!image || !geom_all || !out2 || geom_all->n_rows <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(patch_stats_kernel, dim3(rows_grid(geom_all->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom_all),
-                     1.f / (float)geom_all->n_rows, out2);
+  if (fast_patch(geom_all))
+    hipLaunchKernelGGL(patch_stats_kernel<true>, dim3(rows_grid(geom_all->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom_all),
+                       1.f / (float)geom_all->n_rows, out2);
+  else
+    hipLaunchKernelGGL(patch_stats_kernel<false>, dim3(rows_grid(geom_all->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom_all),
+                       1.f / (float)geom_all->n_rows, out2);
   return launch_status();
 }
 

@@ -137,6 +137,19 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
     return t.stride(0)
 
 
+_TAIL_WS: dict = {}
+
+
+def _tail_workspace(device: torch.device) -> torch.Tensor:
+    """32 MiB of fp32 scratch per (device, stream): 512 workgroup slots x one 128x128 partial tile.  Use is stream-ordered
+    (GEMM kernel -> fix-up kernel), so one buffer per stream serves every GEMM launched on it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _TAIL_WS.get(key)
+    if ws is None:
+        ws = _TAIL_WS[key] = torch.empty(512 * 128 * 128, dtype=torch.float32, device=device)
+    return ws
+
+
 # --------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True, out: torch.Tensor | None = None,
          out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None,
@@ -189,6 +202,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ws = None
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
         ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    elif split_k == 1 and k >= 1536:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
+        ws = _tail_workspace(a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     if GEMM_PROFILE is None:
         _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")

@@ -54,7 +54,9 @@ typedef struct {
   int accumulate;             /* 1: D += result with fp32 atomics (out_f32 must be 1) */
   int split_k;                /* >=1 */
   int force_generic;
-  void* workspace;            /* optional fp32 scratch for split_k > 1: >= split_k*m*n*4 bytes -> deterministic two-pass reduction instead of atomics */
+  void* workspace;            /* optional fp32 scratch. split_k > 1: >= split_k*m*n*4 bytes -> deterministic two-pass reduction instead of atomics.
+                                 split_k == 1: >= 32 MiB lets the library cut the tiles left over after the last full round of workgroup slots
+                                 into k-slices (partial tiles here, a fix-up launch applies the epilogue); contents are scratch, use is stream-ordered */
   long long workspace_bytes;
   float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
   int kernel_used;            /* OUT: 0 generic FMA, 1 MFMA k-major/k-major, 2 MFMA k-major/n-major (dgrad), 3 MFMA m-major/n-major (wgrad) */

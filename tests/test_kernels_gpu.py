@@ -103,6 +103,25 @@ def test_gemm_epilogues(generic: bool) -> None:
     close(out, (a.float() @ w.float().t()) * hx.grad, 5e-4, 5e-3, "gelu' epilogue")
 
 
+@pytest.mark.parametrize(("m", "n", "k"), [(10960, 768, 3072), (8300, 512, 2048), (10960, 768, 2304)])
+def test_gemm_split_tail_full_size(m: int, n: int, k: int) -> None:
+    """BASELINE config-2 shapes whose tile count just exceeds the 512 workgroup slots (516 / 260 tiles): the left-over tiles
+    run as k-slices + fix-up launch.  Same fused epilogues, same tolerances as the single-launch path."""
+    a, w = rnd(m, k, scale=0.5, seed=11), rnd(n, k, scale=0.05, seed=12)
+    bias = rnd(n, dtype=torch.float32, seed=13)
+    res = rnd(m, n, dtype=torch.float32, seed=14)
+    ref = a.float() @ w.float().t() + bias
+    out = K.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32)
+    close(out, ref + res, 2e-4, 2e-3, "tail f32 + residual")
+    pre = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    act = K.gemm(a, w, bias=bias, act=1, aux_out=pre)
+    close(pre, ref, 1e-2, 2e-2, "tail pre-activation")
+    close(act, F.gelu(ref), 1e-2, 2e-2, "tail gelu")
+    wt = w.t().contiguous()  # dgrad layout: B stored [k][n]
+    out2 = K.gemm(a, wt, b_kmajor=False, out_dtype=torch.float32)
+    close(out2, ref - bias, 2e-4, 2e-3, "tail dgrad layout")
+
+
 def test_gemm_strided_views_and_colsum() -> None:
     big = rnd(300, 3 * 256, seed=13)
     a = big[:, 256:512]  # column slice of a fused buffer
