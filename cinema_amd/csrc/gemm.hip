@@ -152,7 +152,9 @@ __device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, floa
 // 4 KiB LDS staging area (XOR-swizzled float4 columns, no padding) so that a lane ends up with 4 (fp32 out) or 8 (bf16 out)
 // CONSECUTIVE columns of one row and the wave writes whole 64/128-byte row segments.  The direct register epilogue wrote
 // 8 bytes into 64 different cache lines per store instruction and dominated short-K GEMMs (K-sweep intercept 34-48 us).
-template <int MI>
+// SIMPLE: fp32 output with at most alpha and an fp32 residual (the weight-gradient kernel): keeps the fully unrolled epilogue small - with the
+// general one the compiler left the (i, j) loop rolled, indexed the accumulators dynamically and moved all 128 of them through scratch.
+template <int MI, bool SIMPLE = false>
 __device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, int z, float* stg,
                                                        float* ws_base = nullptr, long long ws_ld = 0) {
   // fp32 partial destination: an explicit one (split-tail slice), else the split-K slab of slice z
@@ -181,13 +183,20 @@ __device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const flo
           if (m < p.m && n < p.n) {
             if (to_ws) {
               *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n) = t;
+            } else if (SIMPLE) {
+              float4 o = make_float4(t.x * p.alpha, t.y * p.alpha, t.z * p.alpha, t.w * p.alpha);
+              if (p.res_f32) {
+                const float4 r = *reinterpret_cast<const float4*>(p.res_f32 + (size_t)m * p.ld_res + n);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+              }
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.d) + (size_t)m * p.ldd + n) = o;
             } else {
               float v[4] = {t.x, t.y, t.z, t.w};
               epilogue_row<4>(p, m, n, v, add_bias);
             }
           }
         }
-      } else {
+      } else if (!SIMPLE) {
 #pragma unroll
         for (int pss = 0; pss < 2; pss++) {
           const int r = pss * 16 + (lane >> 2), c8 = lane & 3;
@@ -687,7 +696,6 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
   const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
   float16v acc[4][2];
   int stage = 0;
-  bool first = true;
   for (int slot = blockIdx.x; slot < n_items; slot += gridDim.x) {
     const int item = item_of(slot), z = item_z(item);
     int m0, n0;
@@ -703,9 +711,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     for (int t = 0; t < nt; t++) {
       // wait until the producers have published this k-tile (and, by the same barrier, learnt that the previous stage is free)
-      if (!first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      first = false;
       const char* sa = smem + stage * STAGE;
       const char* sb = sa + AT::BYTES;
       // software-pipelined fragments: the ds_reads of k-step ks+1 are issued BEFORE the MFMAs of k-step ks (one wave per
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
       }
     }
     if (p.accumulate && !p.ws) store_wave_tile<4>(p, acc, m0 + wm, n0 + wn, lane, z);  // atomic fallback keeps the register epilogue
-    else store_wave_tile_staged<4>(p, acc, m0 + wm, n0 + wn, lane, z, reinterpret_cast<float*>(smem + 3 * STAGE + wave * 4096));
+    else store_wave_tile_staged<4, true>(p, acc, m0 + wm, n0 + wn, lane, z, reinterpret_cast<float*>(smem + 3 * STAGE + wave * 4096));
   }
 }
 
@@ -923,7 +930,8 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     const int gz = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
     // measured (tools/bench_gemm.py): the wave-specialised persistent kernel wins for the long-reduction weight-gradient GEMMs, the
     // 128x128 two-stage kernel (2 blocks/CU) for the short-K forward / data-gradient GEMMs
-    const bool big = a->force_generic == 4 || (a->force_generic == 0 && !a->a_kmajor && a->m >= 256 && a->n >= 128);
+    const bool plain_f32 = a->out_f32 && !a->bias && !a->act && !a->aux_out && !a->gelu_in && !a->row_mask && !a->residual_bf16;  // its epilogue is the simple one
+    const bool big = plain_f32 && (a->force_generic == 4 || (a->force_generic == 0 && !a->a_kmajor && a->m >= 256 && a->n >= 128));
     dim3 grid(big ? ((a->m + 255) / 256) * ((a->n + 127) / 128) : ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, gz);
     p.a_rowsum = (!a->a_kmajor) ? a->a_rowsum : nullptr;
     if (a->a_rowsum && a->a_kmajor) return CINEMA_ERR_UNSUPPORTED;
