@@ -45,6 +45,22 @@ struct TileStage {
     }
   }
   static_assert(NCH % 256 == 0, "tile chunks must be a multiple of the block size");
+  // LDS-DMA variant: no staging registers (the register-staged tiles were spilled to scratch inside the key/query loop of the
+  // HD = 64 kernels), asynchronous; 1 KiB lane-linear pieces, the XOR swizzle of swz_off<HD*2>() applied to the SOURCE chunk.
+  // Callers drain with s_waitcnt vmcnt(0) before the barrier that publishes the tile.
+  static __device__ __forceinline__ void glds(char* lds, const bf16_t* base, int ld, int row0, int nrows, int lane, int wave) {
+    constexpr int RB = HD * 2, RPP = 1024 / RB, PIECES = BYTES / 1024;  // bytes per row, rows per piece
+    static_assert(PIECES % 4 == 0, "pieces are dealt to the block's 4 waves");
+    const uint32_t a0 = __builtin_amdgcn_readfirstlane(lds_address(lds));
+#pragma unroll
+    for (int pss = 0; pss < PIECES / 4; pss++) {
+      const int blk = pss * 4 + wave;
+      const int row = blk * RPP + lane / CPR;
+      const int c = (lane % CPR) ^ ((row / (256 / RB)) & (CPR - 1));
+      const int rr = min(row0 + row, nrows - 1);
+      glds16(__builtin_amdgcn_readfirstlane(a0 + blk * 1024), base + (size_t)rr * ld + c * 8);
+    }
+  }
   __device__ __forceinline__ void store(char* lds, int tid) const {
 #pragma unroll
     for (int pss = 0; pss < PASSES; pss++) {
@@ -111,7 +127,7 @@ __device__ __forceinline__ BlockCoord block_coord() {
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_mfma(AttnP p) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
   using Stage = TileStage<HD, 64>;
   constexpr int TB = Stage::BYTES;
   __shared__ __attribute__((aligned(16))) char smem[4 * TB];  // [2 stages][K | V]
@@ -132,20 +148,20 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnP p) {
   float m_run = NEG_INF, l_run = 0.f;
 
   const int nkt = (p.tk + 63) / 64;
-  Stage sk, sv;
-  sk.load(kbase, p.ldk, 0, p.tk, tid);
-  sv.load(vbase, p.ldv, 0, p.tk, tid);
-  sk.store(smem, tid);
-  sv.store(smem + TB, tid);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  Stage::glds(smem, kbase, p.ldk, 0, p.tk, lane, wave_u);
+  Stage::glds(smem + TB, vbase, p.ldv, 0, p.tk, lane, wave_u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < nkt; kt++) {
     const char* ks_ = smem + (kt & 1) * 2 * TB;
     const char* vs_ = ks_ + TB;
     const bool more = kt + 1 < nkt;
-    if (more) {
-      sk.load(kbase, p.ldk, (kt + 1) * 64, p.tk, tid);
-      sv.load(vbase, p.ldv, (kt + 1) * 64, p.tk, tid);
+    if (more) {  // the other stage was last read before the barrier that ended the previous iteration
+      char* nk = smem + ((kt + 1) & 1) * 2 * TB;
+      Stage::glds(nk, kbase, p.ldk, (kt + 1) * 64, p.tk, lane, wave_u);
+      Stage::glds(nk + TB, vbase, p.ldv, (kt + 1) * 64, p.tk, lane, wave_u);
     }
     float16v s[2];
 #pragma unroll
@@ -198,11 +214,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnP p) {
         for (int dt = 0; dt < HD / 32; dt++)
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(vs_, 32 * u + 16 * st, 32 * dt, lane), pf, o[dt], 0, 0, 0);
       }
-    if (more) {
-      char* nk = smem + ((kt + 1) & 1) * 2 * TB;
-      sk.store(nk, tid);
-      sv.store(nk + TB, tid);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed
     __syncthreads();
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnP p) {
 // backward, dQ: block = 4 waves x 32 queries; loop over K/V tiles of 64 keys
 // ================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnP p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
   using Stage = TileStage<HD, 64>;
   constexpr int TB = Stage::BYTES;
   __shared__ __attribute__((aligned(16))) char smem[4 * TB];
@@ -248,19 +260,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnP p) {
   for (int i = 0; i < HD / 32; i++) zero16(dq[i]);
 
   const int nkt = (p.tk + 63) / 64;
-  Stage sk, sv;
-  sk.load(kbase, p.ldk, 0, p.tk, tid);
-  sv.load(vbase, p.ldv, 0, p.tk, tid);
-  sk.store(smem, tid);
-  sv.store(smem + TB, tid);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  Stage::glds(smem, kbase, p.ldk, 0, p.tk, lane, wave_u);
+  Stage::glds(smem + TB, vbase, p.ldv, 0, p.tk, lane, wave_u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nkt; kt++) {
     const char* ks_ = smem + (kt & 1) * 2 * TB;
     const char* vs_ = ks_ + TB;
     const bool more = kt + 1 < nkt;
-    if (more) {
-      sk.load(kbase, p.ldk, (kt + 1) * 64, p.tk, tid);
-      sv.load(vbase, p.ldv, (kt + 1) * 64, p.tk, tid);
+    if (more) {  // the other stage was last read before the barrier that ended the previous iteration
+      char* nk = smem + ((kt + 1) & 1) * 2 * TB;
+      Stage::glds(nk, kbase, p.ldk, (kt + 1) * 64, p.tk, lane, wave_u);
+      Stage::glds(nk + TB, vbase, p.ldv, (kt + 1) * 64, p.tk, lane, wave_u);
     }
     const int key0 = kt * 64 + 4 * g;
 #pragma unroll
@@ -286,11 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnP p) {
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ks_, 32 * u + 16 * st, 32 * dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    if (more) {
-      char* nk = smem + ((kt + 1) & 1) * 2 * TB;
-      sk.store(nk, tid);
-      sv.store(nk + TB, tid);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed
     __syncthreads();
   }
   if (qrow < p.tq) {
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(AttnP p) {
 // backward, dK/dV: block = 4 waves x 32 keys; loop over Q/dO tiles of 64 queries
 // ================================================================================================
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
   using Stage = TileStage<HD, 64>;
   constexpr int TB = Stage::BYTES;
   constexpr int ST = 2 * TB + 512;  // Q | dO | lse[64] | delta[64]
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
   for (int i = 0; i < HD / 32; i++) { zero16(dk[i]); zero16(dv[i]); }
 
   const int nqt = (p.tq + 63) / 64;
-  Stage sq, sdo;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   float st_l = 0.f;  // threads 0..63: lse, 64..127: delta
   auto load_stats = [&](int q0) {
     if (tid < 128) {
@@ -345,12 +353,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
   auto store_stats = [&](char* base) {
     if (tid < 128) reinterpret_cast<float*>(base + 2 * TB)[tid] = st_l;
   };
-  sq.load(qbase, p.ldq, 0, p.tq, tid);
-  sdo.load(dobase, p.lddo, 0, p.tq, tid);
+  Stage::glds(smem, qbase, p.ldq, 0, p.tq, lane, wave_u);
+  Stage::glds(smem + TB, dobase, p.lddo, 0, p.tq, lane, wave_u);
   load_stats(0);
-  sq.store(smem, tid);
-  sdo.store(smem + TB, tid);
   store_stats(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int qt = 0; qt < nqt; qt++) {
     const char* qs_ = smem + (qt & 1) * ST;
@@ -358,8 +365,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
     const float* stats = reinterpret_cast<const float*>(qs_ + 2 * TB);
     const bool more = qt + 1 < nqt;
     if (more) {
-      sq.load(qbase, p.ldq, (qt + 1) * 64, p.tq, tid);
-      sdo.load(dobase, p.lddo, (qt + 1) * 64, p.tq, tid);
+      char* nb = smem + ((qt + 1) & 1) * ST;
+      Stage::glds(nb, qbase, p.ldq, (qt + 1) * 64, p.tq, lane, wave_u);
+      Stage::glds(nb + TB, dobase, p.lddo, (qt + 1) * 64, p.tq, lane, wave_u);
       load_stats((qt + 1) * 64);
     }
 #pragma unroll
@@ -395,12 +403,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(AttnP p) {
         }
       }
     }
-    if (more) {
-      char* nb = smem + ((qt + 1) & 1) * ST;
-      sq.store(nb, tid);
-      sdo.store(nb + TB, tid);
-      store_stats(nb);
-    }
+    if (more) store_stats(smem + ((qt + 1) & 1) * ST);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (krow < p.tk) {

@@ -88,6 +88,19 @@ __device__ __forceinline__ short4v lds_tr16_b64(const void* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(lds_ptr));
 }
 
+// One LDS-DMA instruction (16 B per lane -> 1 KiB lane-linear at the wave-uniform LDS byte address `lds_addr`), issued
+// from inline asm so that hipcc does NOT see a pending LDS write: with the builtin it inserts s_waitcnt vmcnt(0) in front
+// of the first ds_read_b64_tr_b16 of every k-step (observed in the .s of the dgrad/wgrad variants), which serialises
+// the pipeline.  The loop below counts vmcnt by hand instead.  M0 is saved/restored inside the statement (cdna guide 5.7).
+__device__ __forceinline__ void glds16(uint32_t lds_addr, const void* gsrc) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }  // low 32 bits of a flat LDS pointer = LDS byte address
+
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private 4 MiB L2.  xcd_remap() is a bijection
 // of [0, n) that hands XCD x the CONTIGUOUS logical range [~x*n/8, ~(x+1)*n/8), so that neighbouring work items (shared
 // operand rows, stencil halos) meet in one L2.  Placement is a speed hint only, never a correctness assumption.

@@ -244,19 +244,6 @@ constexpr int MNMAJ_BYTES = BK * MNMAJ_STRIDE;  // 4 rows x 64 B touched by one 
 __device__ __forceinline__ int mn_off(int kr, int chunk16) { return kr * MNMAJ_STRIDE + ((chunk16 ^ ((kr & 3) << 2)) << 4); }
 
 
-// One LDS-DMA instruction (16 B per lane -> 1 KiB lane-linear at the wave-uniform LDS byte address `lds_addr`), issued
-// from inline asm so that hipcc does NOT see a pending LDS write: with the builtin it inserts s_waitcnt vmcnt(0) in front
-// of the first ds_read_b64_tr_b16 of every k-step (observed in the .s of the dgrad/wgrad variants), which serialises
-// the pipeline.  The loop below counts vmcnt by hand instead.  M0 is saved/restored inside the statement (cdna guide 5.7).
-__device__ __forceinline__ void glds16(uint32_t lds_addr, const void* gsrc) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_addr)
-               : "memory");
-}
-__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }  // low 32 bits of a flat LDS pointer = LDS byte address
-
 template <bool KMAJ>
 struct TileIO {
   // global -> registers (4 x 16 B per thread) for the 128(rows of M or N) x 64(k) operand tile
