@@ -1,6 +1,7 @@
 // bf16 GEMM with fused epilogues for gfx950: MFMA 32x32x16 tiles, register-staged double-buffered LDS,
 // XOR-swizzled K-major tiles, ds_read_b64_tr_b16 transpose reads for reduction-strided operands
 // (dgrad / wgrad), fp32-atomic split-K for the weight gradients.  See include/cinema_hip.h for the contract.
+#include <cstdlib>
 #include "common.cuh"
 #include "../../include/cinema_hip.h"
 
@@ -80,18 +81,53 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
   }
 }
 
-// ---- epilogue on W (4 or 8) consecutive columns n0.. of row m (all 16-byte aligned; n0 + W <= N guaranteed by the caller)
+// ---- epilogue on W (4 or 8) consecutive columns n0.. of row m (all 16-byte aligned; n0 + W <= N guaranteed by the caller), split into
+// a LOAD half and an APPLY half: the staged tile epilogue issues the loads of all its sub-blocks up front, so the residual / GELU-input
+// reads are in flight while the accumulators go through LDS (as one function the loads sat in the dependency chain of every 32x32
+// sub-block: +20 us for a bias, +130 us for bias + fp32 residual on the 32848x2048 decoder GEMM).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int W>
-__device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, float (&v)[W], bool add_bias) {
+struct EpiPre {   // plain vector members (arrays inside the struct were left in scratch memory by the compiler)
+  u32x4 ra, rb;   // fp32 residual words 0-3 / 4-7, or packed bf16 residual in ra (W/2 words)
+  u32x4 g;        // packed bf16 GELU input (pre-activation of the forward pass), W/2 words
+  float keep;     // row mask as 0/1
+};
+__device__ __forceinline__ u32x4 ldg128(const void* ptr) { return *reinterpret_cast<const u32x4*>(ptr); }
+__device__ __forceinline__ u32x4 ldg64(const void* ptr) {
+  const uint2 u = *reinterpret_cast<const uint2*>(ptr);
+  u32x4 r = {u.x, u.y, 0u, 0u};
+  return r;
+}
+template <int W>
+__device__ __forceinline__ void epi_load_bias(const GemmP& p, int n0, bool add_bias, float (&bv)[W]) {
 #pragma unroll
-  for (int i = 0; i < W; i++) v[i] *= p.alpha;
-  if (p.bias && add_bias) {
+  for (int i = 0; i < W; i++) bv[i] = 0.f;
+  if (p.bias && add_bias && n0 < p.n) {
 #pragma unroll
     for (int i = 0; i < W; i += 4) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + i);
-      v[i] += bv.x; v[i + 1] += bv.y; v[i + 2] += bv.z; v[i + 3] += bv.w;
+      const float4 t = *reinterpret_cast<const float4*>(p.bias + n0 + i);
+      bv[i] = t.x; bv[i + 1] = t.y; bv[i + 2] = t.z; bv[i + 3] = t.w;
     }
   }
+}
+template <int W>
+__device__ __forceinline__ void epi_load(const GemmP& p, int m, int n0, EpiPre<W>& e) {
+  e.keep = 1.f;
+  if (p.gelu_in) e.g = W == 8 ? ldg128(p.gelu_in + (size_t)m * p.ld_gelu + n0) : ldg64(p.gelu_in + (size_t)m * p.ld_gelu + n0);
+  if (p.row_mask) e.keep = p.row_mask[m] ? 1.f : 0.f;
+  if (p.res_f32) {
+    e.ra = ldg128(p.res_f32 + (size_t)m * p.ld_res + n0);
+    if (W == 8) e.rb = ldg128(p.res_f32 + (size_t)m * p.ld_res + n0 + 4);
+  } else if (p.res_bf16) {
+    e.ra = W == 8 ? ldg128(p.res_bf16 + (size_t)m * p.ld_res + n0) : ldg64(p.res_bf16 + (size_t)m * p.ld_res + n0);
+  }
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+template <int W>
+__device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (&v)[W], const float (&bv)[W], const EpiPre<W>& e) {
+#pragma unroll
+  for (int i = 0; i < W; i++) v[i] = fmaf(v[i], p.alpha, bv[i]);
   auto store_bf16 = [&](bf16_t* dst) {
     if (W == 8) {
       uint4 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]); pk.z = pack_bf2(v[W - 4], v[W - 3]); pk.w = pack_bf2(v[W - 2], v[W - 1]);
@@ -101,43 +137,25 @@ __device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, floa
       *reinterpret_cast<uint2*>(dst) = pk;
     }
   };
-  auto load_bf16 = [&](const bf16_t* src, float (&o)[W]) {
-    if (W == 8) {
-      const uint4 u = *reinterpret_cast<const uint4*>(src);
-      o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16)); o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
-      o[W - 4] = bf2f((bf16_t)(u.z & 0xffff)); o[W - 3] = bf2f((bf16_t)(u.z >> 16)); o[W - 2] = bf2f((bf16_t)(u.w & 0xffff)); o[W - 1] = bf2f((bf16_t)(u.w >> 16));
-    } else {
-      const uint2 u = *reinterpret_cast<const uint2*>(src);
-      o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16)); o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
-    }
-  };
   if (p.aux_out) store_bf16(p.aux_out + (size_t)m * p.ld_aux + n0);
   if (p.act == 1) {
 #pragma unroll
     for (int i = 0; i < W; i++) v[i] = gelu_f(v[i]);
   }
   if (p.gelu_in) {
-    float g[W];
-    load_bf16(p.gelu_in + (size_t)m * p.ld_gelu + n0, g);
 #pragma unroll
-    for (int i = 0; i < W; i++) v[i] *= gelu_grad_f(g[i]);
+    for (int i = 0; i < W / 2; i++) { v[2 * i] *= gelu_grad_f(bf_lo(e.g[i])); v[2 * i + 1] *= gelu_grad_f(bf_hi(e.g[i])); }
   }
   if (p.row_mask) {
-    const float s = p.row_mask[m] ? 1.f : 0.f;
 #pragma unroll
-    for (int i = 0; i < W; i++) v[i] *= s;
+    for (int i = 0; i < W; i++) v[i] *= e.keep;
   }
   if (p.res_f32) {
 #pragma unroll
-    for (int i = 0; i < W; i += 4) {
-      const float4 rv = *reinterpret_cast<const float4*>(p.res_f32 + (size_t)m * p.ld_res + n0 + i);
-      v[i] += rv.x; v[i + 1] += rv.y; v[i + 2] += rv.z; v[i + 3] += rv.w;
-    }
+    for (int i = 0; i < W; i++) v[i] += __uint_as_float(i < 4 ? e.ra[i & 3] : e.rb[i & 3]);
   } else if (p.res_bf16) {
-    float r[W];
-    load_bf16(p.res_bf16 + (size_t)m * p.ld_res + n0, r);
 #pragma unroll
-    for (int i = 0; i < W; i++) v[i] += r[i];
+    for (int i = 0; i < W / 2; i++) { v[2 * i] += bf_lo(e.ra[i]); v[2 * i + 1] += bf_hi(e.ra[i]); }
   }
   if (p.out_f32) {
     float* dp = reinterpret_cast<float*>(p.d) + (size_t)m * p.ldd + n0;
@@ -145,6 +163,61 @@ __device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, floa
     for (int i = 0; i < W; i += 4) *reinterpret_cast<float4*>(dp + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
   } else {
     store_bf16(reinterpret_cast<bf16_t*>(p.d) + (size_t)m * p.ldd + n0);
+  }
+}
+template <int W>
+__device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, float (&v)[W], bool add_bias) {
+  float bv[W];
+  EpiPre<W> e;
+  epi_load_bias<W>(p, n0, add_bias, bv);
+  epi_load<W>(p, m, n0, e);
+  epi_apply<W>(p, m, n0, v, bv, e);
+}
+
+// General fused epilogue of one wave tile through the LDS staging block: W = 4 columns per lane (fp32 output, 4 row passes per 32x32
+// sub-block) or 8 (bf16 output, 2 passes).  Operand loads of ALL sub-blocks first, then stage / apply / store sub-block by sub-block.
+template <int MI, int W>
+__device__ __forceinline__ void staged_general_epilogue(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, bool add_bias, float* stg) {
+  constexpr int PASSES = W == 4 ? 4 : 2, RPP = 32 / PASSES, LPR = 32 / W;  // rows per pass, lanes per row
+  const int ml = lane & 31, hi = lane >> 5;
+  const int rl = lane / LPR, cl = (lane % LPR) * W;  // this lane's row within a pass and first column within the sub-block
+  float bv[2][W];
+  EpiPre<W> pre[MI][2][PASSES];
+#pragma unroll
+  for (int j = 0; j < 2; j++) epi_load_bias<W>(p, nw + j * 32 + cl, add_bias, bv[j]);
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int pss = 0; pss < PASSES; pss++) {
+        const int m = mw + i * 32 + pss * RPP + rl, n = nw + j * 32 + cl;
+        if (m < p.m && n < p.n) epi_load<W>(p, m, n, pre[i][j][pss]);
+      }
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (nw + j * 32 >= p.n) continue;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int col4 = 2 * q + hi;
+        *reinterpret_cast<float4*>(stg + ml * 32 + ((col4 ^ (ml & 7)) << 2)) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
+#pragma unroll
+      for (int pss = 0; pss < PASSES; pss++) {
+        const int r = pss * RPP + rl;
+        const int m = mw + i * 32 + r, n = nw + j * 32 + cl;
+        float v[W];
+#pragma unroll
+        for (int c = 0; c < W / 4; c++) {
+          const float4 t = *reinterpret_cast<const float4*>(stg + r * 32 + ((((cl >> 2) + c) ^ (r & 7)) << 2));
+          v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+        }
+        if (m < p.m && n < p.n) epi_apply<W>(p, m, n, v, bv[j], pre[i][j][pss]);
+      }
+    }
   }
 }
 
@@ -161,6 +234,11 @@ __device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const flo
   if (!ws_base && p.ws) { ws_base = p.ws + (size_t)z * p.m * p.n; ws_ld = p.n; }
   const bool to_ws = ws_base != nullptr;
   const bool add_bias = z == 0;
+  if (!SIMPLE && !to_ws) {
+    if (p.out_f32) staged_general_epilogue<MI, 4>(p, acc, mw, nw, lane, add_bias, stg);
+    else staged_general_epilogue<MI, 8>(p, acc, mw, nw, lane, add_bias, stg);
+    return;
+  }
   const int ml = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int i = 0; i < MI; i++) {
@@ -174,7 +252,7 @@ __device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const flo
             make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
       }
       const int mb = mw + i * 32, nb = nw + j * 32;
-      if (to_ws || p.out_f32) {
+      {
 #pragma unroll
         for (int pss = 0; pss < 4; pss++) {
           const int r = pss * 8 + (lane >> 3), col4 = lane & 7;
@@ -190,22 +268,7 @@ __device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const flo
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
               }
               *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.d) + (size_t)m * p.ldd + n) = o;
-            } else {
-              float v[4] = {t.x, t.y, t.z, t.w};
-              epilogue_row<4>(p, m, n, v, add_bias);
             }
-          }
-        }
-      } else if (!SIMPLE) {
-#pragma unroll
-        for (int pss = 0; pss < 2; pss++) {
-          const int r = pss * 16 + (lane >> 2), c8 = lane & 3;
-          const float4 t0 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8) ^ (r & 7)) << 2));
-          const float4 t1 = *reinterpret_cast<const float4*>(stg + r * 32 + (((2 * c8 + 1) ^ (r & 7)) << 2));
-          const int m = mb + r, n = nb + c8 * 8;
-          if (m < p.m && n < p.n) {
-            float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            epilogue_row<8>(p, m, n, v, add_bias);
           }
         }
       }
@@ -353,7 +416,7 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
 }
 
 template <bool A_KMAJ, bool B_KMAJ, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
   using AIO = TileIO<A_KMAJ>;
   using BIO = TileIO<B_KMAJ>;
   constexpr int STAGE = AIO::BYTES + BIO::BYTES;
