@@ -276,6 +276,48 @@ __device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const flo
   }
 }
 
+// fp32-only epilogue of the weight-gradient kernel through a 2 KiB staging block per wave (32 rows x 16 columns: half a 32x32
+// accumulator tile at a time): destination = split-K slab / explicit partial buffer, or D = alpha * acc (+ fp32 residual).
+template <int MI>
+__device__ __forceinline__ void store_wave_tile_half_staged(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, int z, float* stg) {
+  float* ws_base = p.ws ? p.ws + (size_t)z * p.m * p.n : nullptr;
+  const int ml = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (nw + j * 32 >= p.n) continue;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {  // columns 16h .. 16h+15 of the sub-block
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int c4 = 2 * q + hi;  // 16-byte chunk within the 64-byte staging row
+          *reinterpret_cast<float4*>(stg + ml * 16 + ((c4 ^ (ml & 3)) << 2)) =
+              make_float4(acc[i][j][8 * h + 4 * q], acc[i][j][8 * h + 4 * q + 1], acc[i][j][8 * h + 4 * q + 2], acc[i][j][8 * h + 4 * q + 3]);
+        }
+#pragma unroll
+        for (int pss = 0; pss < 2; pss++) {
+          const int r = pss * 16 + (lane >> 2), c4 = lane & 3;
+          const float4 t = *reinterpret_cast<const float4*>(stg + r * 16 + ((c4 ^ (r & 3)) << 2));
+          const int m = mw + i * 32 + r, n = nw + j * 32 + 16 * h + c4 * 4;
+          if (m < p.m && n < p.n) {
+            if (ws_base) {
+              *reinterpret_cast<float4*>(ws_base + (size_t)m * p.n + n) = t;
+            } else {
+              float4 o = make_float4(t.x * p.alpha, t.y * p.alpha, t.z * p.alpha, t.w * p.alpha);
+              if (p.res_f32) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.res_f32 + (size_t)m * p.ld_res + n);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+              }
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.d) + (size_t)m * p.ldd + n) = o;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // scalar epilogue for the generic kernel
 __device__ __forceinline__ void epilogue1(const GemmP& p, int m, int n, float acc, bool add_bias) {
   float v = acc * p.alpha;
@@ -667,12 +709,13 @@ __device__ __forceinline__ void store_wave_tile(const GemmP& p, const float16v (
 }
 
 template <bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items, int tiles_n, int gz) {
+__global__ __launch_bounds__(768) void gemm_mfma_ws_kernel(GemmP p, int n_items, int tiles_n, int gz) {
   using AT = BigTile<A_KMAJ, 256, 4>;
   using BT = BigTile<B_KMAJ, 128, 4>;
   constexpr int STAGE = AT::BYTES + BT::BYTES;  // 48 KiB
+  constexpr int NCONS = 8;                      // consumer waves (4 x 2 grid of 64x64 wave tiles), two per SIMD
   static_assert(AT::PASSES + BT::PASSES == 12, "the counted vmcnt below assumes 12 DMA pieces per producer wave per k-tile");
-  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE + 4 * 4096];  // 3-stage ring + one 4 KiB epilogue staging block per consumer wave
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE + NCONS * 2048];  // 3-stage ring + one 2 KiB epilogue staging block per consumer wave = 160 KiB
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -696,9 +739,9 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
     return min(nkt, kb + p.ktiles_per_split) - kb;
   };
 
-  if (wave >= 4) {
+  if (wave >= NCONS) {
     // ------------------------------------------------------------------ producers
-    const int pw = wave - 4;
+    const int pw = wave - NCONS;
     const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
     const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
     int slot = blockIdx.x, kt = 0, stage = 0;  // cursor of the NEXT (item, k-tile) to issue
@@ -743,18 +786,21 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
   }
 
   // -------------------------------------------------------------------- consumers
-  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
-  float16v acc[4][2];
+  // 8 waves, each a 64x64 wave tile (2x2 MFMA 32x32x16 accumulators): two consumer waves per SIMD, so that one wave's LDS fragment
+  // latency (transposing b64 reads reach their rate only with several waves per SIMD) hides behind the other's MFMAs.  With
+  // 4 consumers of 128x64 the loop ran at 23 % of the MFMA rate.
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  float16v acc[2][2];
   int stage = 0;
   for (int slot = blockIdx.x; slot < n_items; slot += gridDim.x) {
     const int item = item_of(slot), z = item_z(item);
     int m0, n0;
     item_tile(item, m0, n0);
     const int nt = item_nt(item);
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    float rs[2] = {0.f, 0.f};
     const bool do_rowsum = p.a_rowsum != nullptr && wn == 0 && n0 == 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -765,54 +811,37 @@ __global__ __launch_bounds__(512) void gemm_mfma_ws_kernel(GemmP p, int n_items,
       __builtin_amdgcn_s_barrier();
       const char* sa = smem + stage * STAGE;
       const char* sb = sa + AT::BYTES;
-      // software-pipelined fragments: the ds_reads of k-step ks+1 are issued BEFORE the MFMAs of k-step ks (one wave per
-      // SIMD has nobody else to hide the LDS latency behind)
-      short8v fa[2][4], fb[2][2];
+      short8v fa[2][2], fb[2][2];
 #pragma unroll
-      for (int i = 0; i < 4; i++) fa[0][i] = AT::frag(sa, wm + 32 * i, 0, lane);
-      fb[0][0] = BT::frag(sb, wn, 0, lane);
-      fb[0][1] = BT::frag(sb, wn + 32, 0, lane);
+      for (int i = 0; i < 2; i++) { fa[0][i] = AT::frag(sa, wm + 32 * i, 0, lane); fb[0][i] = BT::frag(sb, wn + 32 * i, 0, lane); }
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ks++) {
         const int c = ks & 1, nx = c ^ 1;
         if (ks + 1 < BK / 16) {
 #pragma unroll
-          for (int i = 0; i < 4; i++) fa[nx][i] = AT::frag(sa, wm + 32 * i, ks + 1, lane);
-          fb[nx][0] = BT::frag(sb, wn, ks + 1, lane);
-          fb[nx][1] = BT::frag(sb, wn + 32, ks + 1, lane);
+          for (int i = 0; i < 2; i++) { fa[nx][i] = AT::frag(sa, wm + 32 * i, ks + 1, lane); fb[nx][i] = BT::frag(sb, wn + 32 * i, ks + 1, lane); }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
-        if (!A_KMAJ && do_rowsum) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) rs[i] += frag_sum8(fa[c][i]);
-        }
-        // pin the schedule: the 8 MFMAs of this k-step interleaved 1:1 with the 6 fragment reads of the next one
-        if (ks + 1 < BK / 16) {
-#pragma unroll
-          for (int g = 0; g < 6; g++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, A_KMAJ && B_KMAJ ? 1 : 2, 0);  // DS reads (tr-read fragments take 2 each)
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
+        if (!A_KMAJ && do_rowsum) { rs[0] += frag_sum8(fa[c][0]); rs[1] += frag_sum8(fa[c][1]); }
       }
       stage = stage == 2 ? 0 : stage + 1;
     }
     if (!A_KMAJ && do_rowsum) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < 2; i++) {
         const float t = rs[i] + __shfl_xor(rs[i], 32, 64);
         const int m = m0 + wm + i * 32 + lane;
         if (lane < 32 && m < p.m) unsafeAtomicAdd(p.a_rowsum + m, t);
       }
     }
-    if (p.accumulate && !p.ws) store_wave_tile<4>(p, acc, m0 + wm, n0 + wn, lane, z);  // atomic fallback keeps the register epilogue
-    else store_wave_tile_staged<4, true>(p, acc, m0 + wm, n0 + wn, lane, z, reinterpret_cast<float*>(smem + 3 * STAGE + wave * 4096));
+    if (p.accumulate && !p.ws) store_wave_tile<2>(p, acc, m0 + wm, n0 + wn, lane, z);  // atomic fallback keeps the register epilogue
+    else store_wave_tile_half_staged<2>(p, acc, m0 + wm, n0 + wn, lane, z, reinterpret_cast<float*>(smem + 3 * STAGE + wave * 2048));
   }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Generic kernel: any shape / alignment, fp32 FMA on bf16 inputs, 64x64 tile, 16x16 threads x (4x4).
@@ -1026,9 +1055,9 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
         n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
       }
       dim3 pgrid(n_items < n_cus ? n_items : n_cus);
-      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, true>), pgrid, dim3(512), 0, st, p, n_items, tiles_n, gz);
-      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, false>), pgrid, dim3(512), 0, st, p, n_items, tiles_n, gz);
-      else hipLaunchKernelGGL((gemm_mfma_ws_kernel<false, false>), pgrid, dim3(512), 0, st, p, n_items, tiles_n, gz);
+      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, true>), pgrid, dim3(768), 0, st, p, n_items, tiles_n, gz);
+      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, false>), pgrid, dim3(768), 0, st, p, n_items, tiles_n, gz);
+      else hipLaunchKernelGGL((gemm_mfma_ws_kernel<false, false>), pgrid, dim3(768), 0, st, p, n_items, tiles_n, gz);
     } else if (a->force_generic == 2) {  // register-staged variant (kept for A/B measurements)
       if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, false>), grid, dim3(256), 0, st, p);
       else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, false>), grid, dim3(256), 0, st, p);
