@@ -109,6 +109,22 @@ class Volume:
         return (acc, 1, *reversed(sp))
 
 
+class CompactVolume:
+    """Visible-voxel activation of the conv stem in an MAE step: ``var.data`` is [n_tok * prod(block), chans] (fp32), token-major
+    compact rows (see ``csrc/sparse_conv.hip``); ``geom`` is the ``hip.sparse_geom`` of this stage."""
+
+    def __init__(self, var: T.Var, n_tok: int, block: tuple, chans: int, geom, pos: torch.Tensor, inv_pos: torch.Tensor) -> None:  # noqa: ANN001
+        self.var, self.n_tok, self.block, self.chans, self.geom, self.pos, self.inv_pos = var, n_tok, tuple(block), chans, geom, pos, inv_pos
+
+    @property
+    def block_voxels(self) -> int:
+        return math.prod(self.block)
+
+    def token_rows(self, tp: T.Tape) -> T.Var:
+        """bf16 [n_tok, block_voxels * chans]: one row per kept token (GEMM operand of a k == s conv over the token's block)."""
+        return T.op_cast_bf16(tp, T.op_view(tp, self.var, (self.n_tok, self.block_voxels * self.chans)))
+
+
 class ConvNormActBlock(nn.Module, _CkptFlag):
     """conv(kernel == stride, 'valid') -> ConvLayerNorm -> GELU  (reference ``cinema/conv.py:212-273``)."""
 
@@ -145,6 +161,12 @@ class ConvNormActBlock(nn.Module, _CkptFlag):
                         to_param_layout=T.patch_grad_to_param(self.conv.weight))
         out = T.op_layernorm(tp, y, self.norm.weight, self.norm.bias, self.norm.eps, act=1, out_f32=True)
         return Volume(out, batch, grid, self.conv.out_channels)
+
+    def tape_forward_rows(self, tp: T.Tape, rows: T.Var) -> T.Var:
+        """The same block on already gathered bf16 patch rows [n, prod(kernel) * in_chans] (visible-voxel stem)."""
+        y = T.op_linear(tp, rows, self.conv.weight, self.conv.bias, w16=T.w_patch(self.conv.weight),
+                        to_param_layout=T.patch_grad_to_param(self.conv.weight))
+        return T.op_layernorm(tp, y, self.norm.weight, self.norm.bias, self.norm.eps, act=1, out_f32=True)
 
 
 class ConvMlp(nn.Module, _CkptFlag):
@@ -212,6 +234,17 @@ class MaskedConvBlock(nn.Module, _CkptFlag):
         xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x2 = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1)
         return Volume(x2, x.batch, x.spatial, x.chans)
+
+    def tape_forward_compact(self, tp: T.Tape, x: CompactVolume) -> CompactVolume:
+        """The block on the visible voxels only: every row is visible, so the mask multiply disappears and the depthwise conv
+        looks its neighbours up through the token rank map (masked neighbours contribute the zeros the reference multiplies in)."""
+        xn = T.op_layernorm(tp, x.var, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        h = T.op_linear(tp, xn, self.conv1.weight, self.conv1.bias)
+        h = T.op_sparse_dwconv(tp, h, x.geom, self.dw_conv.weight, self.dw_conv.bias)
+        x1 = T.op_linear(tp, h, self.conv2.weight, self.conv2.bias, residual=x.var)
+        xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x2 = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1)
+        return CompactVolume(x2, x.n_tok, x.block, x.chans, x.geom, x.pos, x.inv_pos)
 
     def forward(self, x: torch.Tensor, mask: torch.Tensor | None = None) -> torch.Tensor:
         """Channels-first (b, C, *S) in/out like the reference; layout converted at the boundary."""

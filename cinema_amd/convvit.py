@@ -1,5 +1,10 @@
 """Conv stem and multi-scale fusion on the HIP tape (interface of the reference ``cinema/convvit.py:24-291``).
 
+In an MAE step (a mask with dropped tokens) the stem runs on the VISIBLE voxels only (``CINEMA_DENSE_STEM=1`` forces the
+dense path): the reference evaluates every voxel and then reads the kept tokens (``cinema/mae/mae.py:548-550``); every stem op
+except the depthwise conv is per-voxel and the depthwise conv input is zero at masked voxels (``cinema/conv.py:405-411``), so
+the kept tokens, the loss and every gradient are the same numbers - 4x fewer rows for 75 % masking.
+
 ``DownsampleEncoder`` runs the stem on channels-last rows (fp32 residual stream, bf16 GEMM operands) and then embeds
 ONLY the kept tokens: the reference embeds all tokens and throws 75 % away (``cinema/mae/mae.py:548-550``); the result for
 the kept ones is identical.  ``MultiScaleFusion`` likewise projects only the kept patches of each skip map.
@@ -8,6 +13,7 @@ the kept ones is identical.  ``MultiScaleFusion`` likewise projects only the kep
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F  # noqa: N812
@@ -15,7 +21,7 @@ from torch import nn
 
 from cinema_amd import hip as K
 from cinema_amd import tape as T
-from cinema_amd.conv import Conv2d, Conv3d, ConvNormActBlock, Linear, MaskedConvBlock, Volume, _CkptFlag
+from cinema_amd.conv import CompactVolume, Conv2d, Conv3d, ConvNormActBlock, Linear, MaskedConvBlock, Volume, _CkptFlag
 from cinema_amd.vit import PatchEmbed, get_pos_embed, init_weights
 
 
@@ -26,6 +32,35 @@ def upsample_mask(mask: torch.Tensor, scale_factor: tuple) -> torch.Tensor:
     for axis, f in enumerate(scale_factor):
         mask = mask.repeat_interleave(int(f), dim=axis + 1)
     return mask
+
+
+DENSE_STEM = bool(int(os.environ.get("CINEMA_DENSE_STEM", "0")))
+
+
+def _raster(u: tuple, dims: tuple) -> int:
+    r = 0
+    for a, d in zip(u, dims):
+        r = r * d + a
+    return r
+
+
+def hierarchical_positions(patch_sizes: list, level: int) -> list:
+    """Row offset inside a token's block for every stage-``level`` voxel (raster order over the block): voxels are nested
+    coarse -> fine so that the children of a stage-(level+1) voxel are contiguous, in raster order (then a k == s conv over
+    them is a plain reshape of the compact rows)."""
+    n = len(patch_sizes) - 1
+    block = tuple(math.prod(ps[d] for ps in patch_sizes[level:]) for d in range(len(patch_sizes[0])))
+
+    def off(lv: int, u: tuple) -> int:
+        if lv == n:
+            return _raster(u, patch_sizes[n])
+        f = patch_sizes[lv]
+        return off(lv + 1, tuple(a // b for a, b in zip(u, f))) * math.prod(f) + _raster(tuple(a % b for a, b in zip(u, f)), f)
+
+    coords = [()]
+    for d in block:
+        coords = [c + (i,) for c in coords for i in range(d)]
+    return [off(level, u) for u in coords]
 
 
 class TokenSelection:
@@ -110,6 +145,8 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
         """-> (skips: list[Volume], tokens: Var fp32 [b*n_keep, E] WITHOUT the positional table, which the caller adds while
         assembling the encoder sequence)."""
         batch, chans, *size = image.shape
+        if sel.mask is not None and not sel.all_tokens and not DENSE_STEM and sel.n_keep > 0:
+            return self.tape_forward_visible(tp, image, sel, grid)
         vis_masks: list = [None] * len(self.conv_blocks)
         if sel.mask is not None:
             m = sel.mask.reshape(batch, *grid)
@@ -129,6 +166,74 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
         geom = K.patch_geom(batch, src_chans, grid, self.patch_sizes[-1], src_strides, token_idx=None if sel.all_tokens else sel.keep)
         rows = T.op_patch_gather(tp, src, geom)
         tok = T.op_linear(tp, rows, self.patch_embed.proj.weight, self.patch_embed.proj.bias)
+        tok = T.op_linear(tp, tok, self.linear.weight, self.linear.bias, out_f32=True)
+        return skips, tok
+
+    def _stage_tables(self, device: torch.device) -> list:
+        """Per stage: (block, pos, inv_pos) - voxels per token and the hierarchical row-offset table (constant per model)."""
+        cache = getattr(self, "_stage_tables_cache", None)
+        if cache is not None and cache[0] == device:
+            return cache[1]
+        n = len(self.conv_blocks)
+        n_dims = len(self.patch_sizes[0])
+        tables = []
+        for lvl in range(1, n + 1):
+            block = tuple(math.prod(ps[d] for ps in self.patch_sizes[lvl:]) for d in range(n_dims))
+            pos = hierarchical_positions(self.patch_sizes, lvl)
+            inv = [0] * len(pos)
+            for u, q in enumerate(pos):
+                inv[q] = u
+            tables.append((block, torch.tensor(pos, dtype=torch.int32, device=device), torch.tensor(inv, dtype=torch.int32, device=device)))
+        self._stage_tables_cache = (device, tables)
+        return tables
+
+    def tape_forward_visible(self, tp: T.Tape, image: torch.Tensor, sel: TokenSelection, grid: tuple):  # noqa: ANN201
+        """The stem on the visible voxels (see the module docstring): -> (skips: list[CompactVolume], tokens [b*n_keep, E])."""
+        batch, chans, *size = image.shape
+        dev = image.device
+        n_dims = len(size)
+        n_tok_all = math.prod(grid)
+        n_tok = sel.keep.numel()
+        tables = self._stage_tables(dev)
+        rank = torch.full((batch * n_tok_all,), -1, dtype=torch.int32, device=dev)
+        rank[sel.keep.long()] = torch.arange(n_tok, dtype=torch.int32, device=dev)
+        # stage-1 voxels of the kept tokens, in compact row order, as flat ids of the (batch, *grid1) stage-1 volume
+        block1, pos1, inv1 = tables[0]
+        grid1 = tuple(g * b for g, b in zip(grid, block1))
+        t = sel.keep.long() % n_tok_all
+        bb = sel.keep.long() // n_tok_all
+        tcoord = []
+        for g in reversed(grid):
+            tcoord.append(t % g)
+            t = t // g
+        tcoord.reverse()
+        u = inv1.long()  # raster voxel index stored at row offset q
+        ucoord = []
+        for bdim in reversed(block1):
+            ucoord.append(u % bdim)
+            u = u // bdim
+        ucoord.reverse()
+        vid = bb[:, None]
+        for d in range(n_dims):
+            vid = vid * grid1[d] + (tcoord[d][:, None] * block1[d] + ucoord[d][None, :])
+        idx1 = vid.reshape(-1).to(torch.int32).contiguous()
+
+        skips = []
+        vol = None
+        for lvl, (block, (blk, pos, inv)) in enumerate(zip(self.conv_blocks, tables)):
+            if lvl == 0:
+                geom = K.patch_geom(batch, chans, grid1, self.patch_sizes[0], tuple(image.stride()), token_idx=idx1)
+                rows = T.op_patch_gather(tp, T.Var(image, needs_grad=False), geom)
+            else:
+                per = math.prod(self.patch_sizes[lvl])
+                rows = T.op_cast_bf16(tp, T.op_view(tp, vol.var, (vol.var.data.shape[0] // per, per * vol.chans)))
+            out = block.patch_embed.tape_forward_rows(tp, rows)
+            sg = K.sparse_geom(batch, grid, blk, sel.keep, rank, pos)
+            vol = CompactVolume(out, n_tok, blk, block.patch_embed.conv.out_channels, sg, pos, inv)
+            for conv in block.conv:
+                vol = conv.tape_forward_compact(tp, vol)
+            skips.append(vol)
+        tok = T.op_linear(tp, vol.token_rows(tp), self.patch_embed.proj.weight, self.patch_embed.proj.bias)
         tok = T.op_linear(tp, tok, self.linear.weight, self.linear.bias, out_f32=True)
         return skips, tok
 
@@ -186,6 +291,10 @@ class MultiScaleFusion(nn.Module, _CkptFlag):
     def tape_forward(self, tp: T.Tape, skips: list, x: T.Var, sel: TokenSelection, grid: tuple, out_f32: bool = False) -> T.Var:
         """x: fp32 [b*n_keep, E] rows of this view (after ``encoder.norm``).  Output bf16 (decoder path) or fp32 (features)."""
         for vol, conv in zip(skips, self.down_convs):
+            if isinstance(vol, CompactVolume):  # visible-voxel stem: one row per kept token already, voxels in hierarchical order
+                x = T.op_linear(tp, vol.token_rows(tp), conv.weight, conv.bias, residual=x, w16=T.w_patch_perm(conv.weight, vol.inv_pos),
+                                to_param_layout=T.patch_grad_to_param_perm(conv.weight, vol.pos))
+                continue
             geom = K.patch_geom(vol.batch, vol.chans, grid, tuple(conv.kernel_size), vol.strides(), token_idx=None if sel.all_tokens else sel.keep)
             rows = T.op_patch_gather(tp, vol.var, geom)
             x = T.op_linear(tp, rows, conv.weight, conv.bias, residual=x, w16=T.w_patch(conv.weight), to_param_layout=T.patch_grad_to_param(conv.weight))

@@ -57,6 +57,15 @@ class PatchGeom(C.Structure):
     ]
 
 
+class SparseGeom(C.Structure):
+    """Mirror of ``cinema_sparse_geom``: visible-voxel (token-major compact row) geometry of one stem stage."""
+
+    _fields_ = [
+        ("b", C.c_int), ("tx", C.c_int), ("ty", C.c_int), ("tz", C.c_int), ("bx", C.c_int), ("by", C.c_int), ("bz", C.c_int), ("n_tok", C.c_int),
+        ("keep", C.c_void_p), ("rank", C.c_void_p), ("pos", C.c_void_p),
+    ]
+
+
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 _PROTOS = {
     "cinema_hip_info": [C.POINTER(C.c_int)],
@@ -69,6 +78,11 @@ _PROTOS = {
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_data": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_sparse_nbr_ints": [_i],
+    "cinema_sparse_nbr_build": [C.POINTER(SparseGeom), _i, _i, _i, _vp, _vp, _vp],
+    "cinema_sparse_dwconv_fwd": [_vp, _vp, _vp, _vp, C.POINTER(SparseGeom), _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cinema_sparse_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, C.POINTER(SparseGeom), _i, _i, _i, _i, _vp],
+    "cinema_sparse_dwconv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i],
     "cinema_patch_gather": [_vp, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_patch_scatter": [_vp, _i, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_row_copy": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
@@ -106,7 +120,7 @@ def load():  # noqa: ANN201
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints")) else C.c_int
     _lib = lib
     return lib
 
@@ -325,6 +339,63 @@ def dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dbias
     ws = torch.empty(1024 * c * (kx * ky * kz + 1), dtype=torch.float32, device=x.device)  # per-block partial slabs (deterministic two-pass)
     _check(load().cinema_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), ws.numel() * 4, b, X, Y, Z, c, kx, ky,
                                            kz, _stream()), "dwconv_bwd_weight")
+
+
+def sparse_geom(batch: int, tok_grid: tuple, block: tuple, keep: torch.Tensor, rank: torch.Tensor, pos: torch.Tensor) -> SparseGeom:
+    """``tok_grid`` / ``block``: 2-D or 3-D (token grid per sample, voxels per token); 2-D maps use a leading axis of 1 like the dense kernels."""
+    _dev(keep, rank, pos)
+    tg = (1,) * (3 - len(tok_grid)) + tuple(int(v) for v in tok_grid)
+    bl = (1,) * (3 - len(block)) + tuple(int(v) for v in block)
+    for t in (keep, rank, pos):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise HipLibraryError("sparse_geom index tensors must be contiguous int32")
+    g = SparseGeom()
+    g.b, (g.tx, g.ty, g.tz), (g.bx, g.by, g.bz) = batch, tg, bl
+    g.n_tok, g.keep, g.rank, g.pos = keep.numel(), keep.data_ptr(), rank.data_ptr(), pos.data_ptr()
+    g.keepalive = (keep, rank, pos)
+    g.nbr_lists = {}  # kernel extent -> (nbr, cnt), built on first use for this mask
+    return g
+
+
+def _sparse_nbr(geom: SparseGeom, kdims: tuple, device: torch.device) -> tuple:
+    hit = geom.nbr_lists.get(kdims)
+    if hit is None:
+        rows = geom.n_tok * geom.bx * geom.by * geom.bz
+        buf = torch.empty(load().cinema_sparse_nbr_ints(rows), dtype=torch.int32, device=device)
+        nbr, cnt = buf[:rows * 128], buf[rows * 128:]
+        _check(load().cinema_sparse_nbr_build(C.byref(geom), *kdims, nbr.data_ptr(), cnt.data_ptr(), _stream()), "sparse_nbr_build")
+        hit = geom.nbr_lists[kdims] = (nbr, cnt)
+    return hit
+
+
+def _kernel3(w: torch.Tensor) -> tuple:
+    ks = tuple(w.shape[2:])
+    return (1,) * (3 - len(ks)) + ks
+
+
+def sparse_dwconv(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, geom: SparseGeom, flip: bool = False) -> torch.Tensor:
+    """Depthwise conv on visible-voxel compact rows x bf16 [n_tok * block, c]; w fp32 [c, 1, *k]; flip=True: data gradient."""
+    _dev(x, w, bias)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or w.dtype != torch.float32 or not w.is_contiguous():
+        raise HipLibraryError("sparse_dwconv: x must be contiguous bf16 rows, w contiguous fp32")
+    c = x.shape[1]
+    kx, ky, kz = _kernel3(w)
+    y = torch.empty_like(x)
+    nbr, cnt = _sparse_nbr(geom, (kx, ky, kz), x.device)
+    _check(load().cinema_sparse_dwconv_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), C.byref(geom), nbr.data_ptr(), cnt.data_ptr(), c, kx, ky, kz,
+                                           int(flip), _stream()), "sparse_dwconv")
+    return y
+
+
+def sparse_dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, w_shape: tuple, dw: torch.Tensor, dbias: torch.Tensor | None, geom: SparseGeom) -> None:
+    _dev(x, dy, dw, dbias)
+    c = x.shape[1]
+    ks = tuple(w_shape[2:])
+    kx, ky, kz = (1,) * (3 - len(ks)) + ks
+    need = load().cinema_sparse_dwconv_wgrad_workspace_bytes(geom.n_tok, c, kx, ky, kz)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    _check(load().cinema_sparse_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), need, C.byref(geom), c, kx, ky, kz,
+                                                  _stream()), "sparse_dwconv_bwd_weight")
 
 
 def patch_geom(batch: int, chans: int, grid: tuple, patch: tuple, strides: tuple, token_idx: torch.Tensor | None = None,

@@ -187,6 +187,30 @@ def patch_grad_to_param(weight: torch.nn.Parameter) -> Callable:
     return conv
 
 
+def w_patch_perm(weight: torch.nn.Parameter, inv_pos: torch.Tensor) -> torch.Tensor:
+    """Like :func:`w_patch` for rows whose patch voxels are stored in a permuted order: feature block q of a row holds
+    the voxel with raster index ``inv_pos[q]`` (the visible-voxel stem keeps coarser-stage children contiguous)."""
+
+    def build() -> torch.Tensor:
+        w = weight.detach()
+        perm = (0, *range(2, w.dim()), 1)
+        w3 = w.permute(perm).reshape(w.shape[0], -1, w.shape[1])
+        return K.cast(w3[:, inv_pos.long(), :].reshape(w.shape[0], -1).contiguous(), BF16)
+
+    return WEIGHTS.get((weight,), "patch_perm", build)
+
+
+def patch_grad_to_param_perm(weight: torch.nn.Parameter, pos: torch.Tensor) -> Callable:
+    shape = weight.shape
+    base = patch_grad_to_param(weight)
+
+    def conv(g: torch.Tensor) -> torch.Tensor:
+        g3 = g.reshape(shape[0], -1, shape[1])
+        return base(g3[:, pos.long(), :].contiguous())  # raster voxel u sits at row block pos[u]
+
+    return conv
+
+
 def w_cat(weights: tuple) -> torch.Tensor:
     """Row-concatenation of Linear weights as one bf16 [sum(out), in] operand; a zero-copy view when the flat shadows are adjacent."""
     shs = [_flat_shadow(w) for w in weights]
@@ -404,6 +428,37 @@ def op_dwconv(tape: Tape, x: Var, spatial: tuple, weight: torch.nn.Parameter, bi
         K.dwconv_bwd_weight(xs, dy, wv.grad_buffer(tuple(weight.shape)), None if bias is None else bv.grad_buffer((c,)))
         if x.needs_grad:
             x.add_grad(K.dwconv_bwd_data(dy, weight.detach(), in_mask).view(-1, c))
+
+    tape.record(bwd)
+    return y
+
+
+def op_sparse_dwconv(tape: Tape, x: Var, geom, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None) -> Var:  # noqa: ANN001
+    """Depthwise conv on the visible-voxel compact rows of an MAE step (``hip.sparse_geom``): exactly the dense masked conv
+    of ``op_dwconv`` evaluated at the visible voxels, whose inputs at masked voxels are zero by construction."""
+    y = Var(K.sparse_dwconv(x.data, weight.detach(), None if bias is None else bias.detach(), geom))
+    wv, bv = tape.pvar(weight), tape.pvar(bias)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        c = x.data.shape[1]
+        K.sparse_dwconv_bwd_weight(x.data, y.grad, tuple(weight.shape), wv.grad_buffer(tuple(weight.shape)), None if bias is None else bv.grad_buffer((c,)),
+                                   geom)
+        if x.needs_grad:
+            x.add_grad(K.sparse_dwconv(y.grad, weight.detach(), None, geom, flip=True))
+
+    tape.record(bwd)
+    return y
+
+
+def op_view(tape: Tape, x: Var, shape: tuple) -> Var:
+    """Zero-copy reshape of contiguous rows (e.g. [n*4, c] -> [n, 4*c]); the gradient is reshaped back."""
+    y = Var(x.data.view(shape), needs_grad=x.needs_grad)
+
+    def bwd() -> None:
+        if y.grad is not None and x.needs_grad:
+            x.add_grad(y.grad.reshape(x.data.shape), None if y.grad16 is None else y.grad16.reshape(x.data.shape))
 
     tape.record(bwd)
     return y

@@ -111,6 +111,33 @@ int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, con
 int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes, int b,
                              int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream);
 
+/* ---- the same depthwise conv restricted to the VISIBLE voxels of an MAE step (exactly the reference result at those voxels: every other op of
+ * cinema/conv.py:349-415 is per-voxel and the conv input is zero at masked voxels, so visible outputs depend on visible voxels only; the
+ * reference computes all voxels and discards 75 % of them, cinema/mae/mae.py:548-550).
+ * Activations are token-major compact rows: row = token_row * (bx*by*bz) + pos[voxel within token, raster (x,y,z)].
+ *   keep[n_tok]       flat token id  sample * (tx*ty*tz) + token  of every kept token, in row order
+ *   rank[b*tx*ty*tz]  row of that token, or -1 when it is masked
+ *   pos[bx*by*bz]     raster voxel-in-token -> row offset inside the token's block (lets the caller keep coarser-stage children contiguous) */
+typedef struct {
+  int b, tx, ty, tz;  /* samples, token grid per sample */
+  int bx, by, bz;     /* voxels per token along each axis at this stage */
+  int n_tok;          /* kept tokens over all samples */
+  const int* keep;
+  const int* rank;
+  const int* pos;
+} cinema_sparse_geom;
+/* neighbour lists of a stage for one kernel extent: nbr[rows][128] packed (tap << 24 | source row) of the visible stencil neighbours in tap
+ * order, cnt[rows]; rows = n_tok*bx*by*bz; both together need cinema_sparse_nbr_ints(rows) ints.  Built once per mask, reused by every conv. */
+long long cinema_sparse_nbr_ints(int n_rows);
+int cinema_sparse_nbr_build(const cinema_sparse_geom* geom, int kx, int ky, int kz, int* nbr, int* cnt, void* stream);
+/* y = bias + dwconv(x) on compact rows; flip = 1 evaluates the data gradient (taps reversed, pass bias = NULL) */
+int cinema_sparse_dwconv_fwd(const uint16_t* x, const float* w, const float* bias, uint16_t* y, const cinema_sparse_geom* geom, const int* nbr,
+                             const int* cnt, int c, int kx, int ky, int kz, int flip, void* stream);
+/* dw[c][taps] += sum x*dy, dbias[c] += sum dy over the visible voxels; workspace >= cinema_sparse_dwconv_wgrad_workspace_bytes(...) */
+int cinema_sparse_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes,
+                                    const cinema_sparse_geom* geom, int c, int kx, int ky, int kz, void* stream);
+long long cinema_sparse_dwconv_wgrad_workspace_bytes(int n_tok, int c, int kx, int ky, int kz);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Non-overlapping patch gather / scatter (reference: patchify cinema/vit.py:67-161 and the im2col of the k==s
  * ConvNd layers cinema/convvit.py:94-102,252).  Source is addressed by element strides (sb, sc, sx, sy, sz) so both

@@ -30,7 +30,7 @@ from cinema_amd.vit import get_pos_embed, get_vit_config  # noqa: E402
 # ---------------------------------------------------------------------------------------------------- C-ABI
 def test_library_exports_every_declared_symbol() -> None:
     header = (ROOT / "include" / "cinema_hip.h").read_text()
-    declared = set(re.findall(r"^int (cinema_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|long long) (cinema_\w+)\(", header, flags=re.M))
     assert declared, "no declarations parsed from include/cinema_hip.h"
     assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
     lib = ctypes.CDLL(str(hip.library_path()))

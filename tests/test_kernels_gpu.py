@@ -241,6 +241,81 @@ def test_dwconv(shape: tuple, c: int) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ patches / rows
+@pytest.mark.parametrize(("tok_grid", "block", "c", "levels"), [((3, 3, 4), (4, 4, 1), 64, 2), ((3, 4), (2, 2), 128, 1), ((2, 3, 2), (2, 2, 2), 64, 1), ((3, 5), (4, 4), 64, 2)])
+def test_sparse_dwconv_matches_dense_masked_conv(tok_grid: tuple, block: tuple, c: int, levels: int) -> None:
+    """Visible-voxel depthwise conv (forward, data gradient, weight gradient) == the dense kernels applied to a volume
+    whose masked voxels are zero, read back at the visible voxels (the identity the MAE stem relies on)."""
+    from cinema_amd.convvit import hierarchical_positions
+
+    nd = len(tok_grid)
+    b = 2
+    n_tok_all = math.prod(tok_grid)
+    n_keep = max(2, n_tok_all // 4)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    keep_pos = torch.stack([torch.randperm(n_tok_all, generator=g)[:n_keep].sort().values for _ in range(b)])
+    keep = (torch.arange(b)[:, None] * n_tok_all + keep_pos).reshape(-1).to(torch.int32).to(DEV)
+    rank = torch.full((b * n_tok_all,), -1, dtype=torch.int32, device=DEV)
+    rank[keep.long()] = torch.arange(keep.numel(), dtype=torch.int32, device=DEV)
+    if levels == 2:
+        half = tuple(max(1, v // 2) for v in block)
+        ps = [tuple(1 for _ in block), tuple(v // h for v, h in zip(block, half)), half]
+    else:
+        ps = [tuple(1 for _ in block), block]
+    pos_l = hierarchical_positions(ps, 1)
+    bv = math.prod(block)
+    assert sorted(pos_l) == list(range(bv))
+    pos = torch.tensor(pos_l, dtype=torch.int32, device=DEV)
+    geom = K.sparse_geom(b, tok_grid, block, keep, rank, pos)
+    # dense <-> compact index map
+    spatial = tuple(t * k for t, k in zip(tok_grid, block))
+    dense_of_row = torch.empty(keep.numel() * bv, dtype=torch.long)
+    kp = keep.cpu().long()
+    for r in range(kp.numel()):
+        bb, t = int(kp[r]) // n_tok_all, int(kp[r]) % n_tok_all
+        tc = []
+        for gdim in reversed(tok_grid):
+            tc.append(t % gdim)
+            t //= gdim
+        tc.reverse()
+        for u in range(bv):
+            uu, uc = u, []
+            for bdim in reversed(block):
+                uc.append(uu % bdim)
+                uu //= bdim
+            uc.reverse()
+            vid = bb
+            for d in range(nd):
+                vid = vid * spatial[d] + tc[d] * block[d] + uc[d]
+            dense_of_row[r * bv + pos_l[u]] = vid
+    dense_of_row = dense_of_row.to(DEV)
+    nvox = b * math.prod(spatial)
+    ks = (5,) * nd
+    w = rnd(c, 1, *ks, scale=0.2, dtype=torch.float32, seed=21)
+    bias = rnd(c, dtype=torch.float32, seed=22)
+    xc = rnd(keep.numel() * bv, c, seed=23)
+    dyc = rnd(keep.numel() * bv, c, seed=24)
+    xd = torch.zeros(nvox, c, dtype=torch.bfloat16, device=DEV)
+    xd[dense_of_row] = xc
+    dyd = torch.zeros(nvox, c, dtype=torch.bfloat16, device=DEV)
+    dyd[dense_of_row] = dyc
+    xd5, dyd5 = xd.view(b, *spatial, c), dyd.view(b, *spatial, c)
+    # forward
+    y_ref = K.dwconv_fwd(xd5, w, bias).view(nvox, c)[dense_of_row]
+    y = K.sparse_dwconv(xc, w, bias, geom)
+    close(y, y_ref, 1e-2, 1e-2, "sparse dwconv fwd")  # same fp32 taps, different summation order, one bf16 rounding
+    # data gradient (taps flipped), read at visible voxels
+    dx_ref = K.dwconv_bwd_data(dyd5, w).view(nvox, c)[dense_of_row]
+    dx = K.sparse_dwconv(dyc, w, None, geom, flip=True)
+    close(dx, dx_ref, 1e-2, 1e-2, "sparse dwconv bwd data")
+    # weight gradient
+    dw_ref, db_ref = torch.zeros_like(w), torch.zeros(c, device=DEV)
+    K.dwconv_bwd_weight(xd5, dyd5, dw_ref, db_ref)
+    dw, db = torch.zeros_like(w), torch.zeros(c, device=DEV)
+    K.sparse_dwconv_bwd_weight(xc, dyc, tuple(w.shape), dw, db, geom)
+    close(dw, dw_ref, 1e-3, 1e-2 * float(dw_ref.abs().max()), "sparse dwconv wgrad")
+    close(db, db_ref, 1e-3, 1e-3 * float(db_ref.abs().max()), "sparse dwconv bias grad")
+
+
 def test_patch_gather_scatter_channels_first_image() -> None:
     img = rnd(2, 3, 8, 12, 4, dtype=torch.float32, seed=50)
     patch, grid = (4, 4, 1), (2, 3, 4)
