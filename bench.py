@@ -77,6 +77,18 @@ def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float) -> dic
                       f"after 1 warm-up step ({warm:.1f} s); final loss {float(loss):.4f}"}
 
 
+def pmc_traffic(kernel: str):  # noqa: ANN201
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command (tools/gpu_pmc_bench.sh ->
+    profiles/pmc_hbm_traffic.json; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); None when no capture is committed."""
+    path = Path(__file__).resolve().parent / "profiles" / "pmc_hbm_traffic.json"
+    try:
+        k = json.loads(path.read_text())["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    hit = k.get(kernel)
+    return None if hit is None else hit["hbm_bytes_per_launch"]
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +151,21 @@ def main() -> None:
         dt = float(t)
     final_loss = float(loss)
 
+    # the same steps with the stem evaluated on every voxel like the reference (information only; single process)
+    from cinema_amd import convvit
+    dense_stem, dense_ms = convvit.DENSE_STEM, None
+    if world == 1 and not dense_stem and args.profile_steps > 0:
+        convvit.DENSE_STEM = True
+        for i in range(2):
+            step(batches[i % 2], 0.75)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        for i in range(args.steps):
+            step(batches[i % 2], 0.75)
+        torch.cuda.synchronize()
+        dense_ms = round((time.perf_counter() - td) / args.steps * 1e3, 3)
+        convvit.DENSE_STEM = False
+
     # ---- per-kernel roofline: time every GEMM launch with HIP events on the launch stream (extra steps, same workload)
     roofline = None
     if rank == 0 and args.profile_steps > 0:
@@ -157,7 +184,7 @@ def main() -> None:
         flops, secs, n = agg[kind]
         achieved = flops / secs / 1e12
         roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(K.GEMM_KERNEL_NAMES[kind]),
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(secs / n * 1e6, 2),
                     "gflop_per_launch": round(flops / n / 1e9, 3),
                     "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
@@ -172,8 +199,11 @@ def main() -> None:
             "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX 192x192x16 + LAX 2C/3C/4C 192x192), mask 0.75, "
                                    f"per-GPU batch {args.batch}, fwd+bwd+clip(5.0)+AdamW, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
-                       "step_tflops_per_gpu": round(samples_per_s / world * STEP_GFLOP_PER_SAMPLE / 1e3, 1),
-                       "step_mfma_frac": round(samples_per_s / world * STEP_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
+                       "stem": "dense (every voxel, as the reference)" if dense_stem else
+                               "visible voxels only - exact: masked voxels never reach a kept token (DESIGN.md 3a); CINEMA_DENSE_STEM=1 runs every voxel",
+                       "dense_stem_ms_per_step": dense_ms,
+                       # the REFERENCE's dense FLOP count per sample x samples/s: a reference-equivalent rate, not executed FLOPs
+                       "reference_equiv_tflops_per_gpu": round(samples_per_s / world * STEP_GFLOP_PER_SAMPLE / 1e3, 1)},
             "roofline": roofline,
         }
         if world == 1 and args.cpu_budget > 0:

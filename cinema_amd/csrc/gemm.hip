@@ -1021,7 +1021,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     if (gz == 1 && a->accumulate && !a->residual_f32 && !a->residual_bf16) {  // one owner per element: plain read-modify-write, no atomics
       p.res_f32 = (const float*)a->d; p.ld_res = a->ldd; p.accumulate = 0;
     }
-    a->kernel_used = (a->a_kmajor && a->b_kmajor) ? 1 : (a->a_kmajor ? 2 : 3);
+    a->kernel_used = big ? 4 : ((a->a_kmajor && a->b_kmajor) ? 1 : (a->a_kmajor ? 2 : 3));
     // split tail (measured: 516 tiles on 512 slots cost 1.64 rounds, the 4 left-over tiles run alone at the end): worth a second
     // launch only for long reductions and when the left-over tiles can be cut at least in two
     p.tail_split = 0; p.tail_begin = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;

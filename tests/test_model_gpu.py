@@ -127,6 +127,43 @@ def test_midsize_mfma_path_vs_oracle() -> None:
                   {k: v.detach() for k, v in ref_metrics.items()}, ref_grads)
 
 
+def test_visible_voxel_stem_equals_dense_stem() -> None:
+    """The MAE step evaluates the conv stem on the visible voxels only (cinema_amd/convvit.py); forcing the reference's dense
+    evaluation must give the same loss, predictions and parameter gradients up to bf16 summation-order noise."""
+    from cinema_amd import convvit
+
+    views = ["sax", "lax_2c"]
+    kw = dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1),
+              enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)}, enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)},
+              enc_conv_chans=[64, 128], enc_conv_n_blocks=2, enc_embed_dim=256, enc_depth=2, enc_n_heads=4, dec_embed_dim=128, dec_depth=2,
+              dec_n_heads=4)
+    torch.manual_seed(11)
+    model = CineMA(**kw).to(DEV)
+    gen = torch.Generator().manual_seed(6)
+    images = {v: torch.rand(3, 1, *kw["image_size_dict"][v], generator=gen).to(DEV) for v in views}
+    cfg = O.MAEConfig(**kw)
+    masks = {v: O.random_patch_mask(3, math.prod(cfg.grid_size(v)), 0.75, gen).to(DEV) for v in views}
+    results = []
+    for dense in (False, True):
+        convvit.DENSE_STEM = dense
+        try:
+            model.zero_grad(set_to_none=True)
+            loss, pred, _, _ = model(images, 0.75, enc_mask_dict=masks)
+            loss.backward()
+            results.append((loss.detach().float(), {k: v.detach().float() for k, v in pred.items()},
+                            {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            convvit.DENSE_STEM = False
+    (l0, p0, g0), (l1, p1, g1) = results
+    assert abs(float(l0) - float(l1)) <= 2e-3 * abs(float(l1)), (float(l0), float(l1))  # bf16 activations, different row order in the GEMMs
+    for k in p1:
+        assert (p0[k] - p1[k]).abs().max() <= 2e-2 * max(1.0, float(p1[k].abs().max())), k
+    assert set(g0) == set(g1)
+    for k in g1:
+        rel = float((g0[k] - g1[k]).norm() / (g1[k].norm() + 1e-12))
+        assert rel <= 3e-2, (k, rel)  # relative L2 per parameter tensor
+
+
 def test_random_masks_and_api_contract() -> None:
     model = CineMA(**mini_kwargs()).to(DEV)
     images = {v: torch.rand(2, 1, *s, device=DEV) for v, s in model_sizes(model).items()}
