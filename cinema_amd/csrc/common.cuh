@@ -39,7 +39,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ void gelu_terms(float x, float& cdf, float& gauss) {
   const float ax = fabsf(x);
   gauss = __expf(-0.5f * x * x);  // exp(-z^2)
-  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));  // v_rcp_f32 (1 ulp): __frcp_rn expands to the 11-instruction IEEE division sequence, and the epilogue GELU is VALU-bound (72 clk per element measured)
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);

@@ -93,6 +93,7 @@ struct LnBwdP {
   const float* dx_res; float* dx_f32; bf16_t* dx_bf16; int lddx;
   float* dgamma; float* dbeta;
   int lpr;
+  float* ws;  // per-block partial sums [gridDim.x][2][c] (then ln_param_reduce_kernel) or nullptr: atomics from every block
 };
 
 // RG = independent row groups per wave iteration: narrow rows (CPL <= 2) carry only 2-4 16-byte loads per lane, too few
@@ -208,8 +209,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   for (int col = threadIdx.x; col < p.c; col += blockDim.x) {
     float g = 0.f, b = 0.f;
     for (int w = 0; w < nw; w++) { g += red[(size_t)(w * 2 + 0) * p.c + col]; b += red[(size_t)(w * 2 + 1) * p.c + col]; }
-    if (p.dgamma) unsafeAtomicAdd(p.dgamma + col, g);
-    if (p.dbeta) unsafeAtomicAdd(p.dbeta + col, b);
+    if (p.ws) {  // plain coalesced stores; 1024 blocks x 2c fp32 atomics on 2c addresses cost as much as the whole streaming pass
+      p.ws[((size_t)blockIdx.x * 2 + 0) * p.c + col] = g;
+      p.ws[((size_t)blockIdx.x * 2 + 1) * p.c + col] = b;
+    } else {
+      if (p.dgamma) unsafeAtomicAdd(p.dgamma + col, g);
+      if (p.dbeta) unsafeAtomicAdd(p.dbeta + col, b);
+    }
+  }
+}
+
+// dgamma[col] += sum_blocks ws[block][0][col], dbeta likewise.  Workgroup = 64 columns of the [2c] row x 4 sub-slices of the block range
+// (combined through LDS), grid.y = 16 slices: 64 independent partial rows per column group in flight, 16 atomics per column.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* ws, int nblocks, int c, float* dgamma, float* dbeta) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int slices = gridDim.y * 4;
+  const int per = (nblocks + slices - 1) / slices;
+  const int b0 = (blockIdx.y * 4 + sub) * per, b1 = min(nblocks, b0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < 2 * c) {
+    const float* src = ws + col;
+    const size_t ld = (size_t)2 * c;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) { s0 += src[b * ld]; s1 += src[(b + 1) * ld]; s2 += src[(b + 2) * ld]; s3 += src[(b + 3) * ld]; }
+    for (; b < b1; b++) s0 += src[b * ld];
+  }
+  red[sub][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0 && col < 2 * c) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float* dst = col < c ? dgamma : dbeta;
+    if (dst) unsafeAtomicAdd(dst + (col < c ? col : col - c), t);
   }
 }
 
@@ -252,12 +283,12 @@ CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const
 CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
                                     const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                                     const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
-                                    void* stream) {
+                                    float* workspace, long long workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
   if (act == 1 && !beta) return CINEMA_ERR_BAD_ARG;
   if ((c & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CINEMA_ERR_UNSUPPORTED;
   LnBwdP p{dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
-           pick_lpr(c)};
+           pick_lpr(c), nullptr};
   const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
   const size_t smem = (size_t)4 * 2 * c * sizeof(float);
   return dispatch_cpl<LnBwdP>(cpl, [&](auto tag) {
@@ -267,7 +298,10 @@ CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, co
     int grid = (rows + rows_per_block - 1) / rows_per_block;
     const int cap = CPL == 1 ? 2048 : 1024;
     if (grid > cap) grid = cap;
+    const bool two_pass = (dgamma || dbeta) && workspace && workspace_bytes >= (long long)grid * 2 * c * 4 && grid >= 64;
+    if (two_pass) p.ws = workspace;
     hipLaunchKernelGGL((ln_bwd_kernel<CPL, RG>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    if (two_pass) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, grid, c, dgamma, dbeta);
     return launch_status();
   });
 }

@@ -73,7 +73,7 @@ _PROTOS = {
     "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "cinema_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
-    "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _vp],
     "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -264,10 +264,11 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: 
     dx16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
         raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
+    ws = torch.empty(2048 * 2 * c, dtype=torch.float32, device=x.device) if (dgamma is not None or dbeta is not None) else None
     _check(load().cinema_layernorm_bwd(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
                                        int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
                                        rstd.data_ptr(), rows, c, act, _p(dx_residual), _p(dx32), _p(dx16), c, _p(dgamma), _p(dbeta),
-                                       _stream()), "layernorm_bwd")
+                                       ws.data_ptr() if ws is not None else None, 0 if ws is None else ws.numel() * 4, _stream()), "layernorm_bwd")
     return dx32, dx16
 
 

@@ -72,7 +72,8 @@ int cinema_colsum(const void* x, int x_dtype, const int* row_idx, int m, int n, 
  * cinema/convvit.py:254; ConvLayerNorm + nn.GELU cinema/conv.py:169-187,271-272).
  * fwd: y = LN(x)*gamma+beta over the last dim (c), optional exact GELU; x fp32 or bf16, y bf16 and/or fp32;
  *      mean/rstd (fp32 [rows]) saved for the backward.
- * bwd: dx = LN'(dy) (+ dx_residual);  writes dx_f32 and/or dx_bf16; dgamma/dbeta accumulated atomically (fp32).
+ * bwd: dx = LN'(dy) (+ dx_residual);  writes dx_f32 and/or dx_bf16; dgamma/dbeta accumulated (fp32): with a workspace of
+ *      >= 2048*2*c*4 bytes the blocks store partial sums and a second small kernel adds them up, without one every block adds atomically.
  *      If act==1 the incoming dy is w.r.t. gelu(LN(x)) and is chained through gelu' (recomputed from x, stats).
  */
 int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
@@ -80,7 +81,7 @@ int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gam
 int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
                          const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                          const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
-                         void* stream);
+                         float* workspace, long long workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Attention (reference: F.scaled_dot_product_attention / matmul-softmax-matmul cinema/vit.py:505-517, no mask, no
