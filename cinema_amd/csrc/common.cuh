@@ -58,6 +58,38 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.39894228040143268f, g, cdf);
 }
 
+// Two elements at a time on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32): the fused GEMM epilogues are VALU-bound on these terms.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_terms2(f32x2 x, f32x2& cdf, f32x2& gauss) {
+  f32x2 ax;
+  ax.x = fabsf(x.x); ax.y = fabsf(x.y);
+  const f32x2 e = x * x * (-0.5f * 1.4426950408889634f);
+  gauss.x = __builtin_amdgcn_exp2f(e.x); gauss.y = __builtin_amdgcn_exp2f(e.y);
+  const f32x2 d = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+  f32x2 poly = t * 1.061405429f + (-1.453152027f);
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + (-0.284496736f);
+  poly = poly * t + 0.254829592f;
+  const f32x2 half_erfc = poly * t * gauss * 0.5f;
+  cdf.x = x.x >= 0.f ? 1.0f - half_erfc.x : half_erfc.x;
+  cdf.y = x.y >= 0.f ? 1.0f - half_erfc.y : half_erfc.y;
+}
+__device__ __forceinline__ void gelu2(float& a, float& b) {
+  f32x2 x = {a, b}, cdf, g;
+  gelu_terms2(x, cdf, g);
+  x = x * cdf;
+  a = x.x; b = x.y;
+}
+// (ga, gb) = gelu'(a), gelu'(b)
+__device__ __forceinline__ void gelu_grad2(float a, float b, float& ga, float& gb) {
+  f32x2 x = {a, b}, cdf, g;
+  gelu_terms2(x, cdf, g);
+  const f32x2 r = x * 0.39894228040143268f * g + cdf;
+  ga = r.x; gb = r.y;
+}
+
 // wave64 reductions (all 64 lanes participate)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -140,11 +140,15 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
   if (p.aux_out) store_bf16(p.aux_out + (size_t)m * p.ld_aux + n0);
   if (p.act == 1) {
 #pragma unroll
-    for (int i = 0; i < W; i++) v[i] = gelu_f(v[i]);
+    for (int i = 0; i < W; i += 2) gelu2(v[i], v[i + 1]);
   }
   if (p.gelu_in) {
 #pragma unroll
-    for (int i = 0; i < W / 2; i++) { v[2 * i] *= gelu_grad_f(bf_lo(e.g[i])); v[2 * i + 1] *= gelu_grad_f(bf_hi(e.g[i])); }
+    for (int i = 0; i < W / 2; i++) {
+      float ga, gb;
+      gelu_grad2(bf_lo(e.g[i]), bf_hi(e.g[i]), ga, gb);
+      v[2 * i] *= ga; v[2 * i + 1] *= gb;
+    }
   }
   if (p.row_mask) {
 #pragma unroll

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) {
       float4 y;
       y.x = (v[i].x - mu) * rs * g.x + b.x; y.y = (v[i].y - mu) * rs * g.y + b.y;
       y.z = (v[i].z - mu) * rs * g.z + b.z; y.w = (v[i].w - mu) * rs * g.w + b.w;
-      if (p.act == 1) { y.x = gelu_f(y.x); y.y = gelu_f(y.y); y.z = gelu_f(y.z); y.w = gelu_f(y.w); }
+      if (p.act == 1) { gelu2(y.x, y.y); gelu2(y.z, y.w); }
       if (p.y_bf16) store4_bf16(p.y_bf16 + (size_t)row * p.ldy + ch * 4, y);
       if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + (size_t)row * p.ldy + ch * 4) = y;
     }
@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
           xh[g][i] = make_float4((x4.x - mu) * rs, (x4.y - mu) * rs, (x4.z - mu) * rs, (x4.w - mu) * rs);
           if (p.act == 1) {
             const float4 b = *reinterpret_cast<const float4*>(p.beta + ch * 4);
-            d.x *= gelu_grad_f(xh[g][i].x * gm.x + b.x); d.y *= gelu_grad_f(xh[g][i].y * gm.y + b.y);
-            d.z *= gelu_grad_f(xh[g][i].z * gm.z + b.z); d.w *= gelu_grad_f(xh[g][i].w * gm.w + b.w);
+            float g0, g1, g2, g3;
+            gelu_grad2(xh[g][i].x * gm.x + b.x, xh[g][i].y * gm.y + b.y, g0, g1);
+            gelu_grad2(xh[g][i].z * gm.z + b.z, xh[g][i].w * gm.w + b.w, g2, g3);
+            d.x *= g0; d.y *= g1; d.z *= g2; d.w *= g3;
           }
           ag[i].x += d.x * xh[g][i].x; ag[i].y += d.y * xh[g][i].y; ag[i].z += d.z * xh[g][i].z; ag[i].w += d.w * xh[g][i].w;
           ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
