@@ -97,6 +97,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (reference batch_size_per_device, mae/config.yaml:45)")
     ap.add_argument("--size", default="base")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 disables)")
+    ap.add_argument("--force-sync", action="store_true", help="N=1 only: still issue the gradient collectives (RCCL path check)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the per-kernel roofline")
     args = ap.parse_args()
 
@@ -121,6 +122,10 @@ def main() -> None:
     if world > 1:
         ddp_setup(rank, world, backend="nccl")
         sync = GradientSynchronizer(world)
+    elif args.force_sync:  # one-process RCCL group: runs the overlapped all-reduce schedule on one GPU (path check, not a metric)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        ddp_setup(0, 1, backend="nccl")
+        sync = GradientSynchronizer(1, force_collectives=True)
 
     kw = base_kwargs(args.size)
     torch.manual_seed(0)  # identical weights on every rank (config.seed, mae/config.yaml:1)
@@ -209,7 +214,7 @@ def main() -> None:
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(kw, cpu_state, 2, args.cpu_budget)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_sync:
         dist.destroy_process_group()
 
 

@@ -2,10 +2,12 @@
 
 Replaces ``torch.nn.parallel.DistributedDataParallel`` as used by the reference (``cinema/device.py:35-48,86-104``,
 ``cinema/mae/pretrain.py:304-305,343``): one process per GPU, the model replicated, the *flat* fp32 gradient buffer of
-:class:`cinema_amd.optim.FlatModel` all-reduced (mean) once per optimisation step in a few large buckets.  On the
-8-GPU MI355X mesh every GPU has 7 point-to-point xGMI links, so a handful of >= 64 MB messages (RCCL picks its direct
-algorithms for those) beat DDP's ~20 buckets of 25 MiB; gradient accumulation steps skip the collective entirely
-(the reference all-reduces on every micro-step because it never uses ``no_sync``).
+:class:`cinema_amd.optim.FlatModel` all-reduced (mean) once per optimisation step: the ranges of each transformer block go
+out as soon as the block's backward kernels are launched (~28 MB per encoder block, overlapped with the rest of the
+backward), the remainder in a few large buckets at the end.  On the 8-GPU MI355X mesh every GPU has 7 point-to-point
+xGMI links, so tens-of-MB messages (RCCL picks its direct algorithms for those) beat DDP's ~20 buckets of 25 MiB; gradient
+accumulation steps skip the collective entirely (the reference all-reduces on every micro-step because it never uses
+``no_sync``).
 """
 
 from __future__ import annotations
@@ -38,37 +40,91 @@ def ddp_setup(rank: int, world_size: int, port: int | None = None, backend: str 
 
 
 class GradientSynchronizer:
-    """Mean all-reduce of a flat gradient buffer in ``n_buckets`` contiguous chunks, plus the one-off parameter broadcast."""
+    """Mean all-reduce of the flat gradient buffer, overlapped with the backward pass, plus the one-off parameter broadcast.
 
-    def __init__(self, world_size: int | None = None, bucket_bytes: int = 128 << 20, group=None) -> None:  # noqa: ANN001
+    ``cinema_amd.tape.mark_params`` tells :meth:`params_done`, during the backward pass, when every gradient kernel of a
+    transformer block has been launched; the block's flat ranges are all-reduced right away (``async_op``: RCCL's stream
+    waits for the work queued so far and then runs beside the rest of the backward).  :meth:`all_reduce` reduces what is
+    left (stem, fusion, heads, tokens) in buckets and waits for everything before the optimiser reads the gradients.
+    """
+
+    def __init__(self, world_size: int | None = None, bucket_bytes: int = 128 << 20, group=None, overlap: bool = True,
+                 force_collectives: bool = False) -> None:  # noqa: ANN001
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.bucket_bytes = bucket_bytes
         self.group = group
         self.flat = None
         self.buckets: list = []
+        self.overlap = overlap
+        self.force = force_collectives  # issue the collectives even in a one-process group (exercises the RCCL path on one GPU)
+        self.armed = False
+        self.min_early = 1 << 18  # elements (1 MiB)
+        self._early: list = []   # (begin, end) ranges already handed to a collective in this backward pass
+        self._works: list = []
 
     def attach(self, flat) -> None:  # noqa: ANN001
         self.flat = flat
         per = max(1, self.bucket_bytes // 4)
         n = flat.flat_grad.numel()
         self.buckets = [flat.flat_grad[i:min(n, i + per)] for i in range(0, n, per)]
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force:
             dist.broadcast(flat.flat_param, src=0, group=self.group)  # rank 0's weights everywhere (DDP's _sync_module_states)
+        if self.overlap:
+            from cinema_amd import tape as T
+
+            T.PARAMS_DONE_HOOK = self.params_done
+
+    def _launch(self, t: torch.Tensor) -> None:
+        op = dist.ReduceOp.AVG if dist.get_backend(self.group) == "nccl" else dist.ReduceOp.SUM  # gloo (CPU tests) has no AVG
+        self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+
+    def arm(self, on: bool) -> None:
+        """Called before ``backward()``: only the micro-step that ends with the optimiser update all-reduces."""
+        self.armed = bool(on) and (self.world_size > 1 or self.force) and self.flat is not None
+        self._early, self._works = [], []
+
+    def params_done(self, tape, params: list) -> None:  # noqa: ANN001
+        """Backward-pass hook: all gradient kernels of ``params`` are in the stream -> start their all-reduce.  Every rank
+        takes the same decisions (they depend on the model only), so the collectives stay matched."""
+        if not self.armed:
+            return
+        ranges = []
+        for p in params:
+            r = self.flat.offsets.get(id(p))
+            pv = tape.pvars.get(id(p))
+            if r is None or pv is None or not pv.direct:  # gradient not accumulated straight into the flat buffer: leave it for the end
+                return
+            ranges.append(r)
+        ranges.sort()
+        merged = []
+        for a, b in ranges:
+            if merged and merged[-1][1] == a:
+                merged[-1][1] = b
+            else:
+                merged.append([a, b])
+        for a, b in merged:
+            if b - a < self.min_early:  # biases / LayerNorm vectors: latency-bound as separate collectives, they ride in the final buckets
+                continue
+            self._launch(self.flat.flat_grad[a:b])
+            self._early.append((a, b))
 
     def all_reduce(self) -> None:
-        if self.world_size <= 1:
+        if self.world_size <= 1 and not self.force:
             return
-        backend = dist.get_backend(self.group)
-        works = []
-        for b in self.buckets:
-            if backend == "nccl":
-                works.append(dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-            else:  # gloo (CPU tests) has no AVG
-                works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
+        n = self.flat.flat_grad.numel()
+        per = max(1, self.bucket_bytes // 4)
+        pos = 0
+        for a, b in sorted(self._early) + [(n, n)]:  # the complement of what went out early, in buckets
+            while pos < a:
+                e = min(a, pos + per)
+                self._launch(self.flat.flat_grad[pos:e])
+                pos = e
+            pos = max(pos, b)
+        for w in self._works:
             w.wait()
-        if backend != "nccl":
+        if dist.get_backend(self.group) != "nccl":
             self.flat.flat_grad.div_(self.world_size)
+        self._early, self._works, self.armed = [], [], False
 
     def all_finite(self, loss: torch.Tensor) -> torch.Tensor:
         """Collective NaN decision (a rank-local ``continue`` as in ``pretrain.py:255-257`` would dead-lock DDP)."""

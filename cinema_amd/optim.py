@@ -74,6 +74,7 @@ class FlatModel:
         self.flat_shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         self.ranges = []
         self.params = params
+        self.offsets: dict = {}  # id(param) -> (begin, end) element range in the flat buffers (end includes the alignment pad)
         off = 0
         it = iter(sizes)
         for g in self.groups:
@@ -87,6 +88,7 @@ class FlatModel:
                 p._cinema_flat_grad = p.grad  # noqa: SLF001  (tape.PVar accumulates straight into this view)
                 if self.flat_shadow is not None:
                     p._cinema_shadow = self.flat_shadow[off:off + p.numel()]  # noqa: SLF001
+                self.offsets[id(p)] = (off, off + n)
                 off += n
             self.ranges.append((start, off))
         self.numel = total
@@ -168,6 +170,8 @@ class TrainStep:
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
         loss, _, _, metrics = self.model(image_dict, enc_mask_ratio, enc_mask_dict=enc_mask_dict)
+        if self.sync is not None:
+            self.sync.arm(update_grad)  # on the micro-step that ends with the optimiser update, blocks all-reduce as their gradients complete
         (loss / n_accum_steps if n_accum_steps > 1 else loss).backward()
         grad_norm = None
         if update_grad:

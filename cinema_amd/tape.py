@@ -111,6 +111,18 @@ class WeightCache:
 
 WEIGHTS = WeightCache()
 
+# Data-parallel overlap: when set (cinema_amd.ddp.GradientSynchronizer), called in the BACKWARD pass as hook(tape, params) at the
+# point where every gradient contribution of ``params`` has been launched (see mark_params).
+PARAMS_DONE_HOOK: Callable | None = None
+
+
+def mark_params(tape: "Tape", params: list) -> None:
+    """Record, at the START of a module's forward ops, that ``params`` are used by these ops only: in the reversed backward order the
+    marker runs after all of their gradient kernels, which is where their gradient all-reduce may start."""
+    hook = PARAMS_DONE_HOOK
+    if hook is not None and tape.train:
+        tape.record(lambda: hook(tape, params))
+
 
 class Tape:
     """Backward closures in forward order + the parameter registry of one top-level call."""

@@ -239,8 +239,15 @@ class Block(nn.Module, _CkptFlag):
         self.ls2 = nn.Identity()
         self.drop_path2 = nn.Identity()
 
+    def _param_list(self) -> list:
+        pl = self.__dict__.get("_plist")
+        if pl is None:
+            pl = self.__dict__["_plist"] = [p for p in self.parameters() if p.requires_grad]
+        return pl
+
     def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int) -> T.Var:
         """xq: fp32 residual stream [b*tq, c]; xk: bf16 un-normed keys [b*tk, c] or None (``vit.py:589``)."""
+        T.mark_params(tp, self._param_list())  # gradient all-reduce of this block may start once its backward ops are launched
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = self.attn.tape_forward(tp, qn, xk, batch)
         x1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, residual=xq)

@@ -229,6 +229,27 @@ def _ddp_worker(rank: int, world: int, port: int, tmp: str) -> None:
     flat.flat_grad.copy_(torch.arange(flat.numel, dtype=torch.float32) * (rank + 1))
     sync.all_reduce()
     torch.save(flat.flat_grad.clone(), f"{tmp}/grad{rank}.pt")
+    # overlapped path: two encoder blocks report "gradients complete" during the backward pass (a non-direct parameter set is refused),
+    # the remainder goes out at the end; every element must be reduced exactly once
+    from types import SimpleNamespace
+
+    flat.flat_grad.copy_(torch.arange(flat.numel, dtype=torch.float32) * (rank + 1))
+    blocks = [list(model.encoder.blocks[i].parameters()) for i in (1, 0)]
+    fake_tape = SimpleNamespace(pvars={id(p): SimpleNamespace(direct=True) for b in blocks for p in b})
+    sync.min_early = 64  # the mini model's blocks are tiny
+    sync.arm(True)
+    for b in blocks:
+        sync.params_done(fake_tape, b)
+    assert len(sync._early) >= 2  # noqa: SLF001
+    n_early = len(sync._early)  # noqa: SLF001
+    head = list(model.decoder.blocks[0].parameters())
+    sync.params_done(SimpleNamespace(pvars={id(p): SimpleNamespace(direct=False) for p in head}), head)
+    assert len(sync._early) == n_early  # noqa: SLF001
+    sync.all_reduce()
+    torch.save(flat.flat_grad.clone(), f"{tmp}/grad_overlap{rank}.pt")
+    sync.arm(False)  # accumulation micro-step: the hook must stay silent
+    sync.params_done(fake_tape, blocks[0])
+    assert not sync._early and not sync._works  # noqa: SLF001
     ok = sync.all_finite(torch.tensor(float("nan") if rank == 1 else 1.0))
     torch.save(ok, f"{tmp}/finite{rank}.pt")
     torch.distributed.destroy_process_group()
@@ -243,6 +264,8 @@ def test_gradient_synchronizer_world_size_2_gloo(tmp_path: Path) -> None:
     g0, g1 = torch.load(tmp_path / "grad0.pt"), torch.load(tmp_path / "grad1.pt")
     expect = torch.arange(g0.numel(), dtype=torch.float32) * 1.5  # mean of 1x and 2x
     assert torch.equal(g0, g1) and torch.allclose(g0, expect)
+    for r in (0, 1):
+        assert torch.equal(torch.load(tmp_path / f"grad_overlap{r}.pt"), g0)  # overlapped schedule == plain bucketed schedule
     assert float(torch.load(tmp_path / "finite0.pt")) == 0.0 and float(torch.load(tmp_path / "finite1.pt")) == 0.0  # collective NaN decision
 
 
