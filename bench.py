@@ -92,8 +92,8 @@ def pmc_traffic(kernel: str):  # noqa: ANN201
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (reference batch_size_per_device, mae/config.yaml:45)")
     ap.add_argument("--size", default="base")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 disables)")

@@ -11,6 +11,7 @@ ATen compute on this path except index bookkeeping on tiny integer tensors.
 from __future__ import annotations
 
 import os
+from collections import deque
 from typing import Callable
 
 import torch
@@ -116,12 +117,43 @@ WEIGHTS = WeightCache()
 PARAMS_DONE_HOOK: Callable | None = None
 
 
+# Weight-gradient GEMMs on a second HIP stream (default; CINEMA_SIDE_WGRAD=0 keeps one stream): nothing in the backward chain waits for them, so they can fill the
+# compute units left idle by the tails of the kernels on the main stream.  Each launch waits for an event recorded on the main stream
+# (its dy / x operands are complete); Tape.backward() and the all-reduce hook join the side stream before anyone reads the gradients.
+SIDE_WGRAD = bool(int(os.environ.get("CINEMA_SIDE_WGRAD", "1")))
+_SIDE_STREAMS: dict = {}
+
+
+def side_stream() -> "torch.cuda.Stream":
+    dev = torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(dev)
+    if st is None:
+        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+_SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient launches still (possibly) running on the side stream
+
+
+def join_side_stream(release: bool = False) -> None:
+    """Make the current stream wait for the side stream.  ``release`` (end of the backward pass): the operands kept alive for the side
+    stream may go back to the allocator - their next user is ordered after this wait."""
+    if SIDE_WGRAD and _SIDE_STREAMS:
+        torch.cuda.current_stream().wait_stream(side_stream())
+    if release:
+        _SIDE_KEEP.clear()
+
+
 def mark_params(tape: "Tape", params: list) -> None:
     """Record, at the START of a module's forward ops, that ``params`` are used by these ops only: in the reversed backward order the
     marker runs after all of their gradient kernels, which is where their gradient all-reduce may start."""
     hook = PARAMS_DONE_HOOK
     if hook is not None and tape.train:
-        tape.record(lambda: hook(tape, params))
+        def fire() -> None:
+            join_side_stream()  # the block's weight gradients may still be running beside the main stream
+            hook(tape, params)
+
+        tape.record(fire)
 
 
 class Tape:
@@ -151,6 +183,7 @@ class Tape:
             if debug:  # localise an asynchronous kernel fault to one backward closure
                 torch.cuda.synchronize()
                 print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
+        join_side_stream(release=True)
         self.ops = []
 
 
@@ -248,6 +281,26 @@ def _split_k(m_red: int, n_out: int, k_out: int) -> int:
     return max(1, min(want, (m_red + 255) // 256))
 
 
+def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
+    """Run a weight-gradient launch on the side stream (after everything queued on the main stream so far) or inline.  ``operands``
+    are the activation / gradient tensors the launch reads: they were allocated on the main stream, so they are kept alive until the
+    backward pass joins the side stream (a closure may drop its last reference right away and the allocator would reuse the memory)."""
+    if SIDE_WGRAD and operands[0].is_cuda:
+        main, side = torch.cuda.current_stream(), side_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):  # the split-K workspace is allocated under the side stream too
+            side.wait_event(ev)
+            fn()
+            done = torch.cuda.Event()
+            done.record(side)
+        _SIDE_KEEP.append((done, operands))  # cheaper than record_stream (allocator events on every free of these blocks)
+        while _SIDE_KEEP and _SIDE_KEEP[0][0].query():  # finished launches give their operands back (holding everything to the end of
+            _SIDE_KEEP.popleft()                        # the backward pass kept ~4 GB more live and cost 2 ms/step of cache locality)
+        return
+    fn()
+
+
 def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar | None, wshape: tuple, to_param_layout: Callable | None = None,
           row_offset: int = 0, total_rows: int | None = None) -> None:
     """dW[n,k] += dy^T x ; db[n] += colsum(dy).  ``row_offset`` targets a row block of a fused (cat) weight."""
@@ -255,7 +308,8 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
     full = wv.grad_buffer(wshape if total_rows is None else (total_rows, k), to_param_layout)
     dst = full.view(-1, k)[row_offset:row_offset + n]
     bias_grad = None if bv is None else bv.grad_buffer((n,) if total_rows is None else (total_rows,))[row_offset:row_offset + n]
-    K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k), a_rowsum=bias_grad)
+    _wgrad_launch(lambda: K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k),
+                                 a_rowsum=bias_grad), dy16, x16)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -360,8 +414,9 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
         if q_b is not None and pv[0].direct and pv[2].direct and _adjacent(gq, gkv):
             bq, bkv = pv[1].grad_buffer((c,)), pv[3].grad_buffer((2 * c,))
             if pv[1].direct and pv[3].direct and _adjacent(bq, bkv):  # one [3c, c] weight-gradient GEMM + one column sum
-                K.gemm(dqkv, x.data, a_kmajor=False, b_kmajor=False, out=gq.as_strided((3 * c, c), (c, 1)), accumulate=True,
-                       split_k=_split_k(dqkv.shape[0], 3 * c, c), a_rowsum=bq.as_strided((3 * c,), (1,)))
+                g3, b3 = gq.as_strided((3 * c, c), (c, 1)), bq.as_strided((3 * c,), (1,))
+                _wgrad_launch(lambda: K.gemm(dqkv, x.data, a_kmajor=False, b_kmajor=False, out=g3, accumulate=True,
+                                             split_k=_split_k(dqkv.shape[0], 3 * c, c), a_rowsum=b3), dqkv, x.data)
                 gq = None
         if gq is not None:
             wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))
@@ -621,7 +676,15 @@ class _TapedCall(torch.autograd.Function):
         p_grads = []
         for p in ctx.params:
             pv = ctx.tape.pvars.get(id(p))
-            p_grads.append(pv.final_grad() if (pv is not None and p.requires_grad) else None)
+            g = pv.final_grad() if (pv is not None and p.requires_grad) else None
+            flat = getattr(p, "_cinema_flat_grad", None)
+            if g is not None and flat is not None and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)():
+                # the optimiser's flat buffer: add here, on the current stream, instead of through autograd's AccumulateGrad node (which
+                # runs on the parameter's creation stream - a cross-stream launch that breaks HIP-graph capture of the step)
+                n = g.shape[-1] if g.dim() > 1 else g.numel()
+                K.row_copy(flat.view(-1, n), g.contiguous().view(-1, n), accumulate=True)
+                g = None
+            p_grads.append(g)
         ctx.tape = None
         return (None, None, None, None, *in_grads, *p_grads)
 
