@@ -3,7 +3,8 @@
 Public surface mirrors what callers of the reference import (``cinema/__init__.py:23-34``) for this path.
 """
 
+from cinema_amd.convvit import ConvViT
 from cinema_amd.mae.mae import CineMA
 from cinema_amd.vit import patchify, unpatchify
 
-__all__ = ["CineMA", "patchify", "unpatchify"]
+__all__ = ["CineMA", "ConvViT", "patchify", "unpatchify"]

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import math
 import os
+from pathlib import Path
 
 import torch
 import torch.nn.functional as F  # noqa: N812
@@ -299,3 +300,278 @@ class MultiScaleFusion(nn.Module, _CkptFlag):
             rows = T.op_patch_gather(tp, vol.var, geom)
             x = T.op_linear(tp, rows, conv.weight, conv.bias, residual=x, w16=T.w_patch(conv.weight), to_param_layout=T.patch_grad_to_param(conv.weight))
         return T.op_layernorm(tp, x, self.norm.weight, self.norm.bias, self.norm.eps, out_f32=out_f32)
+
+
+def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids: dict):  # noqa: ANN001, ANN201
+    """Stem -> kept-token embedding (+ positional table) -> [cls | view tokens] sequence -> ``model.encoder`` -> LN, shared by
+    ``CineMA`` and ``ConvViT`` (reference ``mae.py:535-562``, ``convvit.py:478-493``).
+    Returns (x fp32 [b*T, E], skips per view, cls row indices, row indices per view)."""
+    batch = sels[views[0]].batch
+    dev = images[views[0]].device
+    e = model.encoder.cls_token.shape[-1]
+    n_keep = [sels[v].n_keep for v in views]
+    t_e = 1 + sum(n_keep)
+    b_ar = torch.arange(batch, dtype=torch.int32, device=dev)
+    cls_rows = b_ar * t_e
+    segs, skips_all, view_rows = [T.Segment(cls_rows, src=model.encoder.cls_token)], {}, {}
+    off = 1
+    for v, nk in zip(views, n_keep):
+        enc = model.enc_down_dict[v]
+        skips, tok = enc.tape_forward(tp, images[v], sels[v], grids[v])
+        skips_all[v] = skips
+        rows = (b_ar[:, None] * t_e + off + torch.arange(nk, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous()
+        view_rows[v] = rows
+        pe = enc.interpolate_pos_encoding(grids[v]).detach().reshape(-1, e)
+        segs.append(T.Segment(rows, src=tok, add=pe, add_idx=sels[v].keep_pos))
+        off += nk
+    x = T.op_assemble(tp, batch * t_e, e, segs, dev)
+    x = model.encoder.tape_forward(tp, x, batch)
+    return x, skips_all, cls_rows, view_rows
+
+
+# --------------------------------------------------------------------------------------------------------------
+# ConvViT: multi-view classifier / regressor on the same stem + encoder + fusion (reference cinema/convvit.py:294-810)
+# --------------------------------------------------------------------------------------------------------------
+def get_model(config) -> "ConvViT":  # noqa: ANN001
+    """Same config mapping as the reference ``get_model`` (``convvit.py:294-334``); ``config`` needs attribute access."""
+    from cinema_amd.vit import get_vit_config
+
+    views = [config.model.views] if isinstance(config.model.views, str) else list(config.model.views)
+    vit = get_vit_config(config.model.convvit.size)
+    in_chans_dict = {v: config.data.sax.in_chans if v == "sax" else config.data.lax.in_chans for v in views}
+    if hasattr(config.data, "class_column"):
+        out_chans = len(config.data[config.data.class_column])
+    elif hasattr(config.data, "regression_column"):
+        out_chans = 1
+    else:
+        out_chans = config.model.out_chans
+    image_size_dict = {v: tuple(config.data.sax.patch_size if v == "sax" else config.data.lax.patch_size) for v in views}
+    ndim = {v: 3 if v == "sax" else 2 for v in views}
+    model = ConvViT(image_size_dict=image_size_dict, n_frames=config.model.n_frames, in_chans_dict=in_chans_dict, out_chans=out_chans,
+                    enc_patch_size_dict={v: tuple(config.model.convvit.enc_patch_size[:n]) for v, n in ndim.items()},
+                    enc_scale_factor_dict={v: tuple(config.model.convvit.enc_scale_factor[:n]) for v, n in ndim.items()},
+                    enc_conv_chans=list(config.model.convvit.enc_conv_chans), enc_conv_n_blocks=config.model.convvit.enc_conv_n_blocks,
+                    enc_embed_dim=vit["enc_embed_dim"], enc_depth=vit["enc_depth"], enc_n_heads=vit["enc_n_heads"],
+                    drop_path=config.model.convvit.drop_path)
+    model.set_grad_ckpt(config.grad_ckpt)
+    return model
+
+
+class ConvViT(nn.Module):
+    """Multi-view ViT with the ConvMAE stem for classification / regression (reference ``cinema/convvit.py:337-614``)."""
+
+    def __init__(self, image_size_dict: dict, in_chans_dict: dict, n_frames: int, out_chans: int, enc_patch_size_dict: dict,
+                 enc_scale_factor_dict: dict, enc_conv_chans: list, enc_conv_n_blocks: int, enc_embed_dim: int, enc_depth: int, enc_n_heads: int,
+                 mlp_ratio: int = 4, qkv_bias: bool = True, norm_layer: type = nn.LayerNorm, norm_eps: float = 1e-5, rotary: bool = False,
+                 act_layer: type = nn.GELU, mlp_layer: type | None = None, drop_path: float = 0.0, norm: str = "layer",
+                 head_layer: type | None = nn.Linear) -> None:
+        from cinema_amd.vit import Mlp, ViTEncoder
+
+        super().__init__()
+        self.grad_ckpt = False
+        self.views = list(image_size_dict.keys())
+        self.n_frames = n_frames
+        self.enc_down_dict = nn.ModuleDict({
+            v: DownsampleEncoder(image_size=tuple(image_size_dict[v]), in_chans=n_frames * in_chans_dict[v], patch_size=tuple(enc_patch_size_dict[v]),
+                                 scale_factor=tuple(enc_scale_factor_dict[v]), conv_chans=enc_conv_chans, conv_n_blocks=enc_conv_n_blocks,
+                                 embed_dim=enc_embed_dim, norm=norm) for v in self.views})
+        self.enc_fusion_dict = nn.ModuleDict({
+            v: MultiScaleFusion(image_size=tuple(image_size_dict[v]), patch_size=tuple(enc_patch_size_dict[v]),
+                                scale_factor=tuple(enc_scale_factor_dict[v]), conv_chans=enc_conv_chans, embed_dim=enc_embed_dim,
+                                norm_layer=norm_layer, norm_eps=norm_eps) for v in self.views})
+        self.encoder = ViTEncoder(embed_dim=enc_embed_dim, depth=enc_depth, n_heads=enc_n_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                  norm_layer=norm_layer, norm_eps=norm_eps, rotary=rotary, act_layer=act_layer, mlp_layer=mlp_layer or Mlp,
+                                  drop_path=drop_path)
+        self.apply(init_weights)
+        # heads are created AFTER apply(init_weights): they keep torch's default Linear init (reference convvit.py:439-445)
+        self.pred_head_dict = nn.ModuleDict()
+        if head_layer is not None:
+            for v in [*self.views, "cls"]:
+                self.pred_head_dict[v] = head_layer(enc_embed_dim, out_chans)
+
+    def set_grad_ckpt(self, enable: bool = True) -> None:
+        """Accepted for API compatibility (``convvit.py:447-457``); nothing is recomputed on this path."""
+        self.grad_ckpt = enable
+        for v in self.views:
+            self.enc_down_dict[v].set_grad_ckpt(enable)
+            self.enc_fusion_dict[v].set_grad_ckpt(enable)
+        self.encoder.set_grad_ckpt(enable)
+
+    def _features(self, tp: T.Tape, views: list, images: dict, mask_dict: dict | None):  # noqa: ANN202
+        """-> (cls rows Var [b, E], {view: Var [b*n_view, E]}, n tokens per view): all tokens are embedded, ``mask_dict`` only masks
+        the conv stem; the fusion sees every token (``mask=None``, reference ``convvit.py:501``)."""
+        batch = images[views[0]].shape[0]
+        dev = images[views[0]].device
+        grids = {v: self.enc_down_dict[v].grid_for(tuple(images[v].shape[2:])) for v in views}
+        sels = {}
+        for v in views:
+            sels[v] = TokenSelection(None, batch, math.prod(grids[v]), dev)
+            if mask_dict is not None:
+                sels[v].mask = mask_dict[v].to(device=dev, dtype=torch.bool)
+        x, skips_all, cls_rows, view_rows = encode_views(self, tp, views, images, sels, grids)
+        parts = T.op_split_rows(tp, x, [cls_rows] + [view_rows[v] for v in views])
+        feats = {}
+        for i, v in enumerate(views):
+            feats[v] = self.enc_fusion_dict[v].tape_forward(tp, skips_all[v], parts[i + 1], sels[v], grids[v], out_f32=True)
+        return parts[0], feats, {v: sels[v].n_keep for v in views}
+
+    def _check(self, image_dict: dict) -> list:
+        views = list(image_dict.keys())
+        if any(v not in self.views for v in views):
+            raise ValueError(f"views {views} must be in self.input_keys {self.views}.")
+        return views
+
+    def feature_forward(self, image_dict: dict, mask_dict: dict | None) -> dict:
+        """{"cls": (b, 1, E), view: (b, n_patches_view, E)} (reference ``convvit.py:459-503``)."""
+        views = self._check(image_dict)
+        batch = image_dict[views[0]].shape[0]
+        images = {v: image_dict[v].float().contiguous() for v in views}
+
+        def run(tp: T.Tape):  # noqa: ANN202
+            cls, feats, _ = self._features(tp, views, images, mask_dict)
+            return [cls] + [feats[v] for v in views], []
+
+        res = T.taped_call(run, [], [p for p in self.parameters() if p.requires_grad])
+        return {k: r.reshape(batch, -1, r.shape[-1]) for k, r in zip(["cls", *views], res)}
+
+    def forward(self, image_dict: dict, mask_dict: dict | None = None, reduce: str = "all") -> torch.Tensor:
+        """logits (batch, out_chans); ``reduce`` in {"patch", "all", "cls"} (reference ``convvit.py:505-558``)."""
+        if reduce not in {"patch", "all", "cls"}:
+            raise NotImplementedError(f"Unsupported reduce method {reduce}.")
+        views = self._check(image_dict)
+        if reduce != "cls" and any(v not in image_dict for v in self.views):
+            raise KeyError(f"reduce='{reduce}' averages the heads of all model views {self.views}")  # the reference indexes x_dict[view] for every view
+        batch = image_dict[views[0]].shape[0]
+        images = {v: image_dict[v].float().contiguous() for v in views}
+
+        def run(tp: T.Tape):  # noqa: ANN202
+            cls, feats, _ = self._features(tp, views, images, mask_dict)
+            if reduce == "cls":
+                head = self.pred_head_dict["cls"]
+                return [T.op_linear(tp, T.op_cast_bf16(tp, cls), head.weight, head.bias, out_f32=True)], []
+            acc = None
+            for v in self.views:  # mean over tokens, head, then mean over the heads
+                head = self.pred_head_dict[v]
+                pooled = T.op_cast_bf16(tp, T.op_segment_mean(tp, feats[v], batch))
+                acc = T.op_linear(tp, pooled, head.weight, head.bias, out_f32=True, residual=acc)
+            k = len(self.views)
+            if reduce == "all":
+                head = self.pred_head_dict["cls"]
+                acc = T.op_linear(tp, T.op_cast_bf16(tp, cls), head.weight, head.bias, out_f32=True, residual=acc)
+                k += 1
+            return [T.op_scale(tp, acc, 1.0 / k)], []
+
+        (logits,) = T.taped_call(run, [], [p for p in self.parameters() if p.requires_grad])
+        return logits.reshape(batch, -1)
+
+    @classmethod
+    def from_finetuned(cls, repo_id: str | None = None, model_filename: str | None = None, config_filename: str | None = None, *,
+                       model_path: str | Path | None = None, config_path: str | Path | None = None, **kwargs) -> "ConvViT":  # noqa: ANN003
+        """Fine-tuned weights + config (reference ``convvit.py:560-593``); pass local ``model_path`` / ``config_path`` on an air-gapped box."""
+        import yaml
+        from safetensors.torch import load_file
+
+        from cinema_amd.config import to_config
+
+        if model_path is None or config_path is None:
+            from huggingface_hub import hf_hub_download
+
+            model_path = model_path or hf_hub_download(repo_id=repo_id, filename=model_filename, **kwargs)
+            config_path = config_path or hf_hub_download(repo_id=repo_id, filename=config_filename, **kwargs)
+        with open(config_path, encoding="utf-8") as f:
+            config = to_config(yaml.safe_load(f))
+        model = get_model(config)
+        model.load_state_dict(load_file(str(model_path)))
+        return model
+
+    @classmethod
+    def from_pretrained(cls, config, freeze: bool, model_path: str | Path | None = None, **kwargs) -> "ConvViT":  # noqa: ANN001, ANN003
+        """MAE-pretrained stem / encoder / fusion weights into a fresh classifier (reference ``convvit.py:595-613``)."""
+        if model_path is None:
+            from huggingface_hub import hf_hub_download
+
+            model_path = hf_hub_download(repo_id="mathpluscode/CineMA", filename="pretrained/cinema.safetensors", **kwargs)
+        return load_pretrain_weights(model=get_model(config), views=config.model.views, ckpt_path=Path(model_path), freeze=freeze)
+
+
+def load_pretrain_weights(model: nn.Module, views, ckpt_path: Path, freeze: bool) -> nn.Module:  # noqa: ANN001
+    """Load MAE weights into a downstream model (reference ``convvit.py:616-704``): decoder / heads / other views / positional tables
+    are dropped, the first stem conv is tiled over extra input channels, the only keys allowed to be missing are the views' ``pos_embed``."""
+    ckpt_path = Path(ckpt_path)
+    if ckpt_path.suffix == ".pt":
+        pretrained = torch.load(ckpt_path, map_location="cpu")["model"]
+    elif ckpt_path.suffix == ".safetensors":
+        from safetensors.torch import load_file
+
+        pretrained = load_file(str(ckpt_path))
+    else:
+        raise ValueError(f"Unsupported checkpoint type {ckpt_path.suffix}.")
+    keys_to_drop = ["mask", "decoder", "_head", "sax", "lax_2c", "lax_3c", "lax_4c", "fusion", "dec_linear", "pos_embed"]
+    if hasattr(model, "enc_fusion_dict"):
+        keys_to_drop.remove("fusion")
+    views = [views] if isinstance(views, str) else list(views)
+    expected_missing = []
+    for v in views:
+        keys_to_drop.remove(v)
+        expected_missing.append(f"enc_down_dict.{v}.pos_embed")
+    state = {}
+    for k, val in pretrained.items():
+        if any(x in k for x in keys_to_drop):
+            continue
+        for v in views:
+            if k == f"enc_down_dict.{v}.conv_blocks.0.patch_embed.conv.weight":
+                chans = model.enc_down_dict[v].conv_blocks[0].patch_embed.conv.weight.shape[1]
+                if val.shape[1] != chans:  # video / multi-modality input: tile the single-channel filter (convvit.py:663-681)
+                    if val.dim() not in (4, 5):
+                        raise ValueError(f"Unsupported weight shape {val.shape}.")
+                    val = val.repeat(1, chans, *([1] * (val.dim() - 2)))
+        state[k] = val
+    incompatible = model.load_state_dict(state, strict=False)
+    missing = [x for x in incompatible.missing_keys if ("decoder" not in x) and (not x.startswith("dec_")) and ("head" not in x)]
+    if set(missing) != set(expected_missing):
+        raise ValueError(f"Missing keys from checkpoint: {missing}, expected {expected_missing}")
+    if len(incompatible.unexpected_keys) > 0:
+        raise ValueError(f"Unexpected keys in checkpoint: {incompatible.unexpected_keys}")
+    if freeze:
+        for name, param in model.named_parameters():
+            if name in state:
+                param.requires_grad = False
+    return model
+
+
+def get_layer_id_for_vit(name: str, n_layers: int) -> int:
+    """Layer id for layer-wise lr decay, first layer is 1 (reference ``convvit.py:707-738``)."""
+    if name.startswith("enc_"):
+        return 0
+    if any(x in name for x in ["cls_token", "pos_embed", "patch_embed", "view_embed"]):
+        return 0
+    if name.startswith("encoder.blocks"):
+        return int(name.split(".")[2]) + 1
+    return n_layers
+
+
+def param_groups_lr_decay(model: nn.Module, no_weight_decay_list: list, weight_decay: float, layer_decay: float, out_dir: Path | None = None) -> list:
+    """Parameter groups with layer-wise lr decay (reference ``convvit.py:741-810``): ``lr_scale = layer_decay ** (n_layers - layer_id)``."""
+    import json
+
+    names: dict = {}
+    groups: dict = {}
+    n_layers = len(model.encoder.blocks) + 1
+    scales = [layer_decay ** (n_layers - i) for i in range(n_layers + 1)]
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        decay_name, this_decay = ("no_decay", 0.0) if (p.ndim == 1 or n in no_weight_decay_list) else ("decay", weight_decay)
+        layer_id = get_layer_id_for_vit(n, n_layers)
+        key = f"layer_{layer_id}_{decay_name}"
+        if key not in groups:
+            names[key] = {"lr_scale": scales[layer_id], "weight_decay": this_decay, "params": []}
+            groups[key] = {"lr_scale": scales[layer_id], "weight_decay": this_decay, "params": []}
+        names[key]["params"].append(n)
+        groups[key]["params"].append(p)
+    if out_dir is not None:
+        out_dir = Path(out_dir)
+        out_dir.mkdir(parents=True, exist_ok=True)
+        with open(out_dir / "param_group_names.json", "w", encoding="utf-8") as f:
+            json.dump(names, f, indent=2)
+    return list(groups.values())

@@ -107,6 +107,34 @@ int grid_for(long long total, int block) {
 }
 bool a16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Segment mean over consecutive row blocks (token pooling of the classification heads, reference cinema/convvit.py:523-547):
+// out[s][c] = scale * sum_{r < seg_rows} x[s * seg_rows + r][c]; thread = one column of one segment, grid.y = segment.
+__global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* x, int ldx, int seg_rows, int c, float scale, float* out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  const float* src = x + (size_t)blockIdx.y * seg_rows * ldx + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < seg_rows; r += 4) { s0 += src[(size_t)r * ldx]; s1 += src[(size_t)(r + 1) * ldx]; s2 += src[(size_t)(r + 2) * ldx]; s3 += src[(size_t)(r + 3) * ldx]; }
+  for (; r < seg_rows; r++) s0 += src[(size_t)r * ldx];
+  out[(size_t)blockIdx.y * c + col] = ((s0 + s1) + (s2 + s3)) * scale;
+}
+// dx[s * seg_rows + r][c] (+)= scale * dy[s][c]
+__global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* dy, int seg_rows, int c, float scale, float* dx, int lddx, int accumulate) {
+  const long long total = (long long)gridDim.y * seg_rows * c;
+  (void)total;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  const float g = dy[(size_t)blockIdx.y * c + col] * scale;
+  float* dst = dx + (size_t)blockIdx.y * seg_rows * lddx + col;
+  for (int r = 0; r < seg_rows; r++) {
+    if (accumulate) dst[(size_t)r * lddx] += g; else dst[(size_t)r * lddx] = g;
+  }
+}
+__global__ __launch_bounds__(256) void scale_f32_kernel(const float* x, float alpha, float* y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * alpha;
+}
+
 }  // namespace
 
 CINEMA_API int cinema_hip_info(int* out) {
@@ -156,5 +184,23 @@ CINEMA_API int cinema_gelu_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* 
   if (!x || !dy || !dx || n <= 0) return CINEMA_ERR_BAD_ARG;
   if (!a16(x) || !a16(dy) || !a16(dx)) return CINEMA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+  return launch_status();
+}
+
+CINEMA_API int cinema_segment_mean_fwd(const float* x, int ldx, int n_seg, int seg_rows, int c, float scale, float* out, void* stream) {
+  if (!x || !out || n_seg <= 0 || seg_rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3((c + 255) / 256, n_seg), dim3(256), 0, (hipStream_t)stream, x, ldx, seg_rows, c, scale, out);
+  return launch_status();
+}
+
+CINEMA_API int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, float scale, float* dx, int lddx, int accumulate, void* stream) {
+  if (!dy || !dx || n_seg <= 0 || seg_rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3((c + 255) / 256, n_seg), dim3(256), 0, (hipStream_t)stream, dy, seg_rows, c, scale, dx, lddx, accumulate);
+  return launch_status();
+}
+
+CINEMA_API int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream) {
+  if (!x || !y || n <= 0) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, n);
   return launch_status();
 }

@@ -87,6 +87,9 @@ _PROTOS = {
     "cinema_patch_gather": [_vp, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_patch_scatter": [_vp, _i, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_row_copy": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "cinema_segment_mean_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp],
+    "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
+    "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
     "cinema_cast": [_vp, _i, _vp, _i, _ll, _vp],
     "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
     "cinema_gelu_fwd": [_vp, _vp, _ll, _vp],
@@ -230,6 +233,37 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ev1.record()
     GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k)))
     return out
+
+
+def segment_mean(x: torch.Tensor, n_seg: int, scale: float | None = None) -> torch.Tensor:
+    """x fp32 [n_seg * seg_rows, c] -> [n_seg, c]: scale (default 1/seg_rows) times the sum over each block of consecutive rows."""
+    _dev(x)
+    if x.dtype != torch.float32:
+        raise HipLibraryError("segment_mean: x must be fp32")
+    rows, c = x.shape
+    seg_rows = rows // n_seg
+    out = torch.empty((n_seg, c), dtype=torch.float32, device=x.device)
+    _check(load().cinema_segment_mean_fwd(x.data_ptr(), _rowmajor(x, "x"), n_seg, seg_rows, c, 1.0 / seg_rows if scale is None else scale, out.data_ptr(),
+                                          _stream()), "segment_mean_fwd")
+    return out
+
+
+def segment_mean_bwd(dy: torch.Tensor, seg_rows: int, scale: float | None = None) -> torch.Tensor:
+    _dev(dy)
+    n_seg, c = dy.shape
+    dx = torch.empty((n_seg * seg_rows, c), dtype=torch.float32, device=dy.device)
+    _check(load().cinema_segment_mean_bwd(dy.data_ptr(), n_seg, seg_rows, c, 1.0 / seg_rows if scale is None else scale, dx.data_ptr(), c, 0, _stream()),
+           "segment_mean_bwd")
+    return dx
+
+
+def scale(x: torch.Tensor, alpha: float) -> torch.Tensor:
+    _dev(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise HipLibraryError("scale: contiguous fp32 only")
+    y = torch.empty_like(x)
+    _check(load().cinema_scale_f32(x.data_ptr(), alpha, y.data_ptr(), x.numel(), _stream()), "scale")
+    return y
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, row_idx: torch.Tensor | None = None) -> torch.Tensor:

@@ -26,7 +26,7 @@ from torch import nn
 from cinema_amd import hip as K
 from cinema_amd import tape as T
 from cinema_amd.conv import Linear
-from cinema_amd.convvit import DownsampleEncoder, MultiScaleFusion, TokenSelection
+from cinema_amd.convvit import DownsampleEncoder, MultiScaleFusion, TokenSelection, encode_views
 from cinema_amd.vit import Mlp, ViTDecoder, ViTEncoder, get_pos_embed, get_tokens, get_vit_config, init_weights, patchify
 
 
@@ -134,28 +134,7 @@ class CineMA(nn.Module):
         return views
 
     def _encode(self, tp: T.Tape, views: list, images: dict, sels: dict, grids: dict):  # noqa: ANN202
-        """Stem -> kept-token embedding -> encoder -> LN.  Returns (xln fp32 [b*T_e, E], skips per view, row-index tensors)."""
-        batch = sels[views[0]].batch
-        dev = images[views[0]].device
-        e = self.encoder.cls_token.shape[-1]
-        n_keep = [sels[v].n_keep for v in views]
-        t_e = 1 + sum(n_keep)
-        b_ar = torch.arange(batch, dtype=torch.int32, device=dev)
-        cls_rows = b_ar * t_e
-        segs, skips_all, view_rows = [T.Segment(cls_rows, src=self.encoder.cls_token)], {}, {}
-        off = 1
-        for v, nk in zip(views, n_keep):
-            enc = self.enc_down_dict[v]
-            skips, tok = enc.tape_forward(tp, images[v], sels[v], grids[v])
-            skips_all[v] = skips
-            rows = (b_ar[:, None] * t_e + off + torch.arange(nk, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous()
-            view_rows[v] = rows
-            pe = enc.interpolate_pos_encoding(grids[v]).detach().reshape(-1, e)
-            segs.append(T.Segment(rows, src=tok, add=pe, add_idx=sels[v].keep_pos))
-            off += nk
-        x = T.op_assemble(tp, batch * t_e, e, segs, dev)
-        x = self.encoder.tape_forward(tp, x, batch)
-        return x, skips_all, cls_rows, view_rows
+        return encode_views(self, tp, views, images, sels, grids)
 
     def _forward_tape(self, tp: T.Tape, images: dict, masks: dict, n_masked: dict):  # noqa: ANN202
         views = list(images.keys())

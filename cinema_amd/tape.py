@@ -534,6 +534,30 @@ def op_view(tape: Tape, x: Var, shape: tuple) -> Var:
     return y
 
 
+def op_segment_mean(tape: Tape, x: Var, n_seg: int) -> Var:
+    """fp32 [n_seg * rows, c] -> [n_seg, c]: mean over each block of consecutive rows (token pooling, ``convvit.py:523-547``)."""
+    seg_rows = x.data.shape[0] // n_seg
+    y = Var(K.segment_mean(x.data, n_seg))
+
+    def bwd() -> None:
+        if y.grad is not None and x.needs_grad:
+            x.add_grad(K.segment_mean_bwd(y.grad, seg_rows))
+
+    tape.record(bwd)
+    return y
+
+
+def op_scale(tape: Tape, x: Var, alpha: float) -> Var:
+    y = Var(K.scale(x.data, alpha))
+
+    def bwd() -> None:
+        if y.grad is not None and x.needs_grad:
+            x.add_grad(K.scale(y.grad.contiguous(), alpha))
+
+    tape.record(bwd)
+    return y
+
+
 def op_patch_gather(tape: Tape, x: Var, geom, dst_shape: tuple | None = None) -> Var:  # noqa: ANN001
     """rows[token, (patch, c)] (bf16) gathered from a volume described by ``geom``; backward scatters (zeros elsewhere)."""
     y = Var(K.patch_gather(x.data, geom, BF16))

@@ -167,6 +167,13 @@ int cinema_row_copy(void* dst, int dst_dtype, int ld_dst, const int* dst_idx, co
                     const int* src_idx, const void* add, int add_dtype, int ld_add, const int* add_idx, int n_rows, int c,
                     int accumulate, void* stream);
 
+/* Token pooling of the ConvViT heads (reference cinema/convvit.py:523-547, `x.mean(dim=1, keepdim=True)` and the mean over head outputs):
+ * out[s][:] = scale * sum of the seg_rows consecutive rows of segment s of x (fp32 [n_seg*seg_rows][c]); bwd broadcasts scale * dy[s] back. */
+int cinema_segment_mean_fwd(const float* x, int ldx, int n_seg, int seg_rows, int c, float scale, float* out, void* stream);
+int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, float scale, float* dx, int lddx, int accumulate, void* stream);
+/* y = alpha * x (fp32) */
+int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream);
+
 /* elementwise: dtype codes as above */
 int cinema_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
 /* dst[c][r] = src[r][c] (bf16 out); src fp32 or bf16 */

@@ -336,6 +336,44 @@ def feature_forward(p: Params, cfg: MAEConfig, image_dict: dict) -> dict:
     return dict(zip(["cls", *image_dict], parts))
 
 
+def convvit_features(p: Params, cfg: MAEConfig, image_dict: dict, mask_dict: dict | None) -> dict:
+    """``ConvViT.feature_forward`` (``cinema/convvit.py:459-503``): every token is embedded, ``mask_dict`` only masks the conv stem,
+    the fusion runs with ``mask=None``."""
+    views = list(image_dict)
+    if any(v not in cfg.views for v in views):
+        raise ValueError(f"views {views} must be in self.input_keys {cfg.views}.")
+    b = image_dict[views[0]].shape[0]
+    toks, skips_all, n_tok = [], [], []
+    for v in views:
+        m = None if mask_dict is None else mask_dict[v]
+        skips, x = downsample_encoder(image_dict[v], m, p, f"enc_down_dict.{v}", cfg, v)
+        toks.append(x)
+        skips_all.append(skips)
+        n_tok.append(x.shape[1])
+    x = torch.cat([p["encoder.cls_token"].expand(b, -1, -1), *toks], dim=1)
+    for i in range(cfg.enc_depth):
+        x = block(x, None, p, f"encoder.blocks.{i}", cfg.enc_n_heads, cfg.norm_eps)
+    x = _ln(x, p, "encoder.norm", cfg.norm_eps)
+    parts = list(torch.split(x, [1, *n_tok], dim=1))
+    out = {"cls": parts[0]}
+    for i, v in enumerate(views):
+        out[v] = multi_scale_fusion(skips_all[i], parts[i + 1], None, p, f"enc_fusion_dict.{v}", cfg.norm_eps)
+    return out
+
+
+def convvit_forward(p: Params, cfg: MAEConfig, image_dict: dict, mask_dict: dict | None = None, reduce: str = "all") -> Tensor:
+    """``ConvViT.forward`` (``cinema/convvit.py:505-558``): per-view head on the token mean (+ the cls head), averaged."""
+    x = convvit_features(p, cfg, image_dict, mask_dict)
+    if reduce == "cls":
+        return _lin(x["cls"], p, "pred_head_dict.cls")[:, 0]
+    if reduce not in {"patch", "all"}:
+        raise NotImplementedError(f"Unsupported reduce method {reduce}.")
+    outs = [_lin(x[v].mean(dim=1, keepdim=True), p, f"pred_head_dict.{v}") for v in cfg.views]
+    if reduce == "all":
+        outs.append(_lin(x["cls"], p, "pred_head_dict.cls"))
+    return torch.cat(outs, dim=1).mean(dim=1)
+
+
 def mae_forward(p: Params, cfg: MAEConfig, image_dict: dict, mask_dict: dict):  # noqa: ANN201
     """``CineMA.forward`` (``cinema/mae/mae.py:504-612``) with the random masks injected.
 

@@ -288,3 +288,74 @@ def test_oracle_two_rank_average_equals_full_batch_gradient() -> None:
     for k in full:
         assert torch.allclose(full[k], 0.5 * (r0[k] + r1[k]), rtol=1e-4, atol=1e-7), k
     assert math.isfinite(float(sum(v.abs().sum() for v in full.values())))
+
+
+# ---------------------------------------------------------------------------------------------------- ConvViT host logic
+def _convvit_kwargs() -> dict:
+    kw = json.loads((GOLDEN / "convvit_meta.json").read_text())["kwargs"]
+    for key in ("image_size_dict", "enc_patch_size_dict", "enc_scale_factor_dict"):
+        kw[key] = {v: tuple(s) for v, s in kw[key].items()}
+    return kw
+
+
+def test_convvit_seeded_construction_and_state_dict_match_the_reference() -> None:
+    from cinema_amd.convvit import ConvViT
+
+    g = load_golden("convvit_mini.safetensors")
+    ref = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    torch.manual_seed(0)
+    sd = ConvViT(**_convvit_kwargs()).state_dict()
+    assert set(sd) == set(ref)  # heads are created after apply(init_weights) (convvit.py:439-445)
+    for k, v in sd.items():
+        assert torch.equal(v, ref[k]), k  # same RNG draw order -> bit-identical initial weights, heads with torch's default init
+
+
+def test_convvit_param_groups_lr_decay_match_the_reference() -> None:
+    from cinema_amd.convvit import ConvViT, get_layer_id_for_vit, param_groups_lr_decay
+
+    meta = json.loads((GOLDEN / "convvit_meta.json").read_text())
+    model = ConvViT(**_convvit_kwargs())
+    groups = param_groups_lr_decay(model, no_weight_decay_list=[], weight_decay=0.05, layer_decay=0.75)
+    names = {id(p): n for n, p in model.named_parameters()}
+    got = [{"lr_scale": g["lr_scale"], "weight_decay": g["weight_decay"], "params": [names[id(p)] for p in g["params"]]} for g in groups]
+    assert got == meta["param_groups"]
+    assert get_layer_id_for_vit("encoder.blocks.1.attn.q.weight", 3) == 2 and get_layer_id_for_vit("enc_down_dict.sax.linear.weight", 3) == 0
+    assert get_layer_id_for_vit("pred_head_dict.cls.weight", 3) == 3 and get_layer_id_for_vit("encoder.cls_token", 3) == 0
+
+
+def test_convvit_load_pretrain_weights_matches_the_reference(tmp_path: Path) -> None:
+    from safetensors.torch import save_file
+
+    from cinema_amd.convvit import ConvViT, load_pretrain_weights
+
+    meta = json.loads((GOLDEN / "convvit_meta.json").read_text())["load_pretrain"]
+    ck = GOLDEN / "convvit_mae_ckpt.safetensors"
+    mae_sd = load_golden("convvit_mae_ckpt.safetensors")
+    torch.manual_seed(2)
+    fresh = ConvViT(**_convvit_kwargs())
+    before = {k: v.detach().clone() for k, v in fresh.state_dict().items()}
+    loaded = load_pretrain_weights(fresh, views=["sax", "lax_2c"], ckpt_path=ck, freeze=True)
+    after = loaded.state_dict()
+    assert sorted(k for k in after if not torch.equal(after[k], before[k])) == meta["changed"]
+    assert sorted(n for n, p in loaded.named_parameters() if not p.requires_grad) == meta["frozen"]
+    w = after["enc_down_dict.sax.conv_blocks.0.patch_embed.conv.weight"]  # single-frame filter tiled over the 2 frames
+    assert torch.equal(w[:, 0], w[:, 1]) and torch.equal(w[:, :1], mae_sd["enc_down_dict.sax.conv_blocks.0.patch_embed.conv.weight"])
+    with pytest.raises(ValueError, match="Missing keys from checkpoint"):  # a 2-view model cannot be filled from one view (reference behaviour)
+        load_pretrain_weights(ConvViT(**_convvit_kwargs()), views=["sax"], ckpt_path=ck, freeze=False)
+    bad = dict(mae_sd)
+    bad["encoder.not_a_key"] = torch.zeros(1)
+    save_file(bad, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(ValueError, match="Unexpected keys"):
+        load_pretrain_weights(ConvViT(**_convvit_kwargs()), views=["sax", "lax_2c"], ckpt_path=tmp_path / "bad.safetensors", freeze=False)
+
+
+def test_convvit_api_errors_on_cpu() -> None:
+    from cinema_amd.convvit import ConvViT
+
+    model = ConvViT(**_convvit_kwargs())
+    with pytest.raises(ValueError):
+        model.feature_forward({"bogus": torch.zeros(1, 2, 32, 32)}, None)
+    with pytest.raises(NotImplementedError):
+        model({"sax": torch.zeros(1, 2, 32, 32, 4), "lax_2c": torch.zeros(1, 2, 32, 32)}, None, reduce="none")
+    with pytest.raises(hip.HipLibraryError):  # no CPU fallback
+        model({"sax": torch.zeros(1, 2, 32, 32, 4), "lax_2c": torch.zeros(1, 2, 32, 32)}, None, reduce="cls")

@@ -229,3 +229,50 @@ def test_three_step_optimisation_trajectory_vs_reference_golden() -> None:
         for k, t in split(g, f"step{i}/param/").items():
             dev = (named[k].detach().float().cpu() - t).abs().mean()
             assert float(dev) <= 0.25 * lr_sum + 1e-7, (i, k, float(dev), lr_sum)
+
+
+# ------------------------------------------------------------------------------------------------ ConvViT
+def _convvit_model():  # noqa: ANN202
+    import json
+
+    from cinema_amd.convvit import ConvViT
+    from conftest import GOLDEN
+
+    kw = json.loads((GOLDEN / "convvit_meta.json").read_text())["kwargs"]
+    for key in ("image_size_dict", "enc_patch_size_dict", "enc_scale_factor_dict"):
+        kw[key] = {v: tuple(s) for v, s in kw[key].items()}
+    g = load_golden("convvit_mini.safetensors")
+    model = ConvViT(**kw)
+    model.load_state_dict(split(g, "param/"))
+    return model.to(DEV), g
+
+
+def test_convvit_logits_and_features_vs_reference_golden() -> None:
+    """``ConvViT.feature_forward`` / ``forward`` (all reduce modes, with and without stem masks, 2 frames per view) against the reference.
+    Tolerances: bf16 MFMA operands, fp32 accumulation - features (LayerNorm-normalised, O(1)) max-abs 5e-2, logits max-abs 3e-2."""
+    model, g = _convvit_model()
+    images = {k: v.to(DEV) for k, v in split(g, "image/").items()}
+    masks = {k: v.bool().to(DEV) for k, v in split(g, "mask/").items()}
+    for tag, md in (("nomask", None), ("mask", masks)):
+        feats = model.feature_forward(images, md)
+        for k, t in split(g, f"feature_{tag}/").items():
+            assert feats[k].shape == t.shape, (tag, k)
+            assert (feats[k].float().cpu() - t).abs().max() <= 5e-2, (tag, k)
+        for reduce, t in split(g, f"logits_{tag}/").items():
+            out = model(images, md, reduce=reduce)
+            assert out.shape == t.shape, (tag, reduce)
+            assert (out.float().cpu() - t).abs().max() <= 3e-2, (tag, reduce, float((out.float().cpu() - t).abs().max()))
+
+
+def test_convvit_gradients_vs_reference_golden() -> None:
+    model, g = _convvit_model()
+    images = {k: v.to(DEV) for k, v in split(g, "image/").items()}
+    masks = {k: v.bool().to(DEV) for k, v in split(g, "mask/").items()}
+    (model(images, masks, reduce="all") * g["grad/coef"].to(DEV)).sum().backward()
+    named = dict(model.named_parameters())
+    for k, t in split(g, "grad/").items():
+        if k == "coef":
+            continue
+        got = named[k].grad.float().cpu()
+        rel = float((got - t).norm() / (t.norm() + 1e-12))
+        assert rel <= 6e-2, (k, rel)  # relative L2, same bound as the MAE gradient checks

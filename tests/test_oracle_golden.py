@@ -186,3 +186,35 @@ def test_reference_value_tables() -> None:
         O.patchify(torch.zeros(1, 1, 5, 4), (2, 2))
     with pytest.raises(ValueError):
         O.unpatchify(torch.zeros(1, 4, 8), (2, 2), (2, 3))
+
+
+# ------------------------------------------------------------------------------------------------ ConvViT
+def convvit_cfg() -> O.MAEConfig:
+    meta = json.loads((GOLDEN / "convvit_meta.json").read_text())["kwargs"]
+    return O.MAEConfig(image_size_dict=meta["image_size_dict"], in_chans_dict=meta["in_chans_dict"], enc_patch_size_dict=meta["enc_patch_size_dict"],
+                       enc_scale_factor_dict=meta["enc_scale_factor_dict"], enc_conv_chans=meta["enc_conv_chans"],
+                       enc_conv_n_blocks=meta["enc_conv_n_blocks"], enc_embed_dim=meta["enc_embed_dim"], enc_depth=meta["enc_depth"],
+                       enc_n_heads=meta["enc_n_heads"], dec_embed_dim=16, dec_depth=1, dec_n_heads=2)
+
+
+def test_convvit_logits_features_and_gradients() -> None:
+    """Oracle restatement of ``ConvViT.feature_forward`` / ``forward`` against the reference (all reduce modes, with and without stem masks)."""
+    g = load_golden("convvit_mini.safetensors")
+    cfg = convvit_cfg()
+    params = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in split(g, "param/").items()}
+    images = split(g, "image/")
+    masks = {k: v.bool() for k, v in split(g, "mask/").items()}
+    for tag, md in (("nomask", None), ("mask", masks)):
+        feats = O.convvit_features(params, cfg, images, md)
+        for k, t in split(g, f"feature_{tag}/").items():
+            assert torch.allclose(feats[k], t, rtol=1e-4, atol=2e-5), (tag, k)
+        for reduce, t in split(g, f"logits_{tag}/").items():
+            out = O.convvit_forward(params, cfg, images, md, reduce=reduce)
+            assert out.shape == t.shape and torch.allclose(out, t, rtol=1e-4, atol=2e-5), (tag, reduce)
+    (O.convvit_forward(params, cfg, images, masks, reduce="all") * g["grad/coef"]).sum().backward()
+    for k, t in split(g, "grad/").items():
+        if k == "coef":
+            continue
+        assert torch.allclose(params[k].grad, t, rtol=1e-3, atol=1e-6), k
+    with pytest.raises(NotImplementedError):
+        O.convvit_forward(params, cfg, images, None, reduce="none")
