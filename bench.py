@@ -92,8 +92,8 @@ def pmc_traffic(kernel: str):  # noqa: ANN201
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (reference batch_size_per_device, mae/config.yaml:45)")
     ap.add_argument("--size", default="base")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 disables)")
@@ -174,11 +174,16 @@ def main() -> None:
     # ---- per-kernel roofline: time every GEMM launch with HIP events on the launch stream (extra steps, same workload)
     roofline = None
     if rank == 0 and args.profile_steps > 0:
+        from cinema_amd import tape as T_
+
+        side, T_.SIDE_WGRAD = T_.SIDE_WGRAD, False  # one stream while timing single launches: a kernel sharing the chip with the
+        step(batches[0], 0.75)                      # side-stream weight gradients would be charged for the overlap
         K.GEMM_PROFILE = []
         for i in range(args.profile_steps):
             step(batches[i % 2], 0.75)
         torch.cuda.synchronize()
         prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        T_.SIDE_WGRAD = side
         agg: dict = {}
         for kind, flops, e0, e1, _shape in prof:
             a = agg.setdefault(kind, [0.0, 0.0, 0])
