@@ -69,6 +69,14 @@ class Conv3d(_ConvBase, nn.Conv3d):
     """Parameter container (reference ``cinema/conv.py:57-72``)."""
 
 
+class ConvTranspose2d(_ConvBase, nn.ConvTranspose2d):
+    """Parameter container (reference ``cinema/conv.py:75-90``)."""
+
+
+class ConvTranspose3d(_ConvBase, nn.ConvTranspose3d):
+    """Parameter container (reference ``cinema/conv.py:93-108``)."""
+
+
 class ConvLayerNorm(nn.LayerNorm):
     """LayerNorm over the channel axis of a channels-first tensor (reference ``cinema/conv.py:169-187``)."""
 
@@ -261,3 +269,59 @@ class MaskedConvBlock(nn.Module, _CkptFlag):
 
 def n_voxels(spatial: tuple) -> int:
     return math.prod(spatial)
+
+
+class ConvResBlock(nn.Module, _CkptFlag):
+    """norm -> GELU -> conv -> norm -> GELU -> (dropout) -> conv, plus a 1x1 shortcut when the channel count changes
+    (reference ``cinema/conv.py:276-348``).  The two dense "same" convs run as im2col + MFMA GEMM (``tape.op_conv_same``), the
+    LayerNorm + GELU pairs are one fused kernel each, the shortcut is the fp32 residual of the second GEMM."""
+
+    def __init__(self, n_dims: int, in_chans: int, out_chans: int, norm: str, dropout: float = 0.0, kernel_size: KernelSizeType = 3,
+                 act_layer: type = nn.GELU) -> None:
+        if n_dims not in {2, 3}:
+            raise ValueError(f"Invalid n_dims, must be 2 or 3, got {n_dims}.")
+        if not isinstance(kernel_size, int) and len(kernel_size) != n_dims:
+            raise ValueError(f"Invalid kernel_size {kernel_size}, must be an integer or a tuple of {n_dims} integers.")
+        super().__init__()
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("cinema_amd ConvResBlock: GELU only (what every CineMA model uses).")
+        conv_cls = Conv2d if n_dims == 2 else Conv3d
+        self.norm1 = get_conv_norm(n_dims=n_dims, in_chans=in_chans, norm=norm)
+        self.norm2 = get_conv_norm(n_dims=n_dims, in_chans=out_chans, norm=norm)
+        self.conv1 = conv_cls(in_chans, out_chans, kernel_size=kernel_size, padding="same")
+        self.conv2 = conv_cls(out_chans, out_chans, kernel_size=kernel_size, padding="same")
+        self.dropout = nn.Dropout(dropout)
+        self.act = act_layer()
+        self.shortcut = conv_cls(in_chans, out_chans, kernel_size=1) if in_chans != out_chans else nn.Identity()
+
+    def set_grad_ckpt(self, enable: bool = True) -> None:
+        self.grad_ckpt = enable
+        self.conv1.set_grad_ckpt(enable)
+        self.conv2.set_grad_ckpt(enable)
+        if hasattr(self.shortcut, "set_grad_ckpt"):
+            self.shortcut.set_grad_ckpt(enable)
+
+    def tape_forward(self, tp: T.Tape, x: Volume) -> Volume:
+        """x: fp32 channels-last rows; returns fp32 rows with ``out_chans`` channels."""
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("dropout > 0 in training mode has no HIP path yet (evaluation / dropout = 0 only).")
+        h = T.op_layernorm(tp, x.var, self.norm1.weight, self.norm1.bias, self.norm1.eps, act=1)
+        h = T.op_conv_same(tp, h, x.batch, x.spatial, self.conv1.weight, self.conv1.bias, out_f32=True)
+        h = T.op_layernorm(tp, h, self.norm2.weight, self.norm2.bias, self.norm2.eps, act=1)
+        if isinstance(self.shortcut, nn.Identity):
+            res = x.var
+        else:
+            res = T.op_linear(tp, T.op_cast_bf16(tp, x.var), self.shortcut.weight, self.shortcut.bias, out_f32=True)
+        y = T.op_conv_same(tp, h, x.batch, x.spatial, self.conv2.weight, self.conv2.bias, residual=res)
+        return Volume(y, x.batch, x.spatial, self.conv2.out_channels)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Channels-first (b, C, *S) in/out like the reference."""
+        b, c, *sp = x.shape
+        rows = x.movedim(1, -1).contiguous().float().reshape(-1, c)
+
+        def run(tp: T.Tape, xv: T.Var):  # noqa: ANN202
+            return [self.tape_forward(tp, Volume(xv, b, tuple(sp), c)).var], []
+
+        (y,) = T.taped_call(run, [rows], list(self.parameters()))
+        return y.reshape(b, *sp, -1).movedim(-1, 1).contiguous()

@@ -476,3 +476,109 @@ CINEMA_API int cinema_patch_scatter(const void* rows, int rows_dtype, int ld_row
 #undef CINEMA_PS
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Dense k^n "same" convolution of the segmentation decoder (reference ConvResBlock, cinema/conv.py:276-348) as
+// im2col + MFMA GEMM.  cols[v][(tap, c)] = x[v + tap - r][c] (zero outside the volume), rows padded to ld (multiple of 8)
+// with zeros so that the GEMM's 16-byte alignment rules hold for any channel count (the raw-image conv has C = 1).
+// The data gradient is the mirrored GATHER: dx[v][c] = sum_tap dcols[v - (tap - r)][(tap, c)] - no atomics.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct ColP {
+  const bf16_t* x; bf16_t* cols; const bf16_t* dcols; bf16_t* dx;
+  int b, X, Y, Z, c, kx, ky, kz, ld;
+};
+
+__global__ __launch_bounds__(256) void im2col_kernel(ColP p) {
+  const int taps = p.kx * p.ky * p.kz, F = taps * p.c;
+  const long long nvox = (long long)p.b * p.X * p.Y * p.Z;
+  const int rx = p.kx >> 1, ry = p.ky >> 1, rz = p.kz >> 1;
+  const bool vec = (p.c & 7) == 0;
+  const int per_row = vec ? p.ld / 8 : p.ld;  // work items per output row
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvox * per_row; i += (long long)gridDim.x * 256) {
+    const long long v = i / per_row;
+    const int j = (int)(i - v * per_row);
+    const int z = (int)(v % p.Z), y = (int)((v / p.Z) % p.Y), x = (int)((v / ((long long)p.Z * p.Y)) % p.X);
+    const long long bb = v / ((long long)p.Z * p.Y * p.X);
+    if (vec) {
+      const int f = j * 8;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if (f < F) {
+        const int t = f / p.c, cc = f - t * p.c;
+        const int k = t % p.kz, jj = (t / p.kz) % p.ky, ii = t / (p.kz * p.ky);
+        const int xx = x + ii - rx, yy = y + jj - ry, zz = z + k - rz;
+        if (xx >= 0 && xx < p.X && yy >= 0 && yy < p.Y && zz >= 0 && zz < p.Z)
+          val = *reinterpret_cast<const uint4*>(p.x + ((((size_t)bb * p.X + xx) * p.Y + yy) * p.Z + zz) * p.c + cc);
+      }
+      *reinterpret_cast<uint4*>(p.cols + (size_t)v * p.ld + f) = val;
+    } else {
+      bf16_t val = 0;
+      if (j < F) {
+        const int t = j / p.c, cc = j - t * p.c;
+        const int k = t % p.kz, jj = (t / p.kz) % p.ky, ii = t / (p.kz * p.ky);
+        const int xx = x + ii - rx, yy = y + jj - ry, zz = z + k - rz;
+        if (xx >= 0 && xx < p.X && yy >= 0 && yy < p.Y && zz >= 0 && zz < p.Z) val = p.x[((((size_t)bb * p.X + xx) * p.Y + yy) * p.Z + zz) * p.c + cc];
+      }
+      p.cols[(size_t)v * p.ld + j] = val;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void col2im_kernel(ColP p) {
+  const int taps = p.kx * p.ky * p.kz;
+  const long long nvox = (long long)p.b * p.X * p.Y * p.Z;
+  const int rx = p.kx >> 1, ry = p.ky >> 1, rz = p.kz >> 1;
+  const bool vec = (p.c & 7) == 0;
+  const int per_vox = vec ? p.c / 8 : p.c;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvox * per_vox; i += (long long)gridDim.x * 256) {
+    const long long v = i / per_vox;
+    const int cg = (int)(i - v * per_vox);
+    const int z = (int)(v % p.Z), y = (int)((v / p.Z) % p.Y), x = (int)((v / ((long long)p.Z * p.Y)) % p.X);
+    const long long bb = v / ((long long)p.Z * p.Y * p.X);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < taps; t++) {
+      const int k = t % p.kz, jj = (t / p.kz) % p.ky, ii = t / (p.kz * p.ky);
+      const int xx = x - (ii - rx), yy = y - (jj - ry), zz = z - (k - rz);  // the output voxel whose tap t reads this input voxel
+      if (xx < 0 || xx >= p.X || yy < 0 || yy >= p.Y || zz < 0 || zz >= p.Z) continue;
+      const size_t row = (((size_t)bb * p.X + xx) * p.Y + yy) * p.Z + zz;
+      if (vec) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.dcols + row * p.ld + (size_t)t * p.c + cg * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += f[e];
+      } else {
+        acc[0] += bf2f(p.dcols[row * p.ld + (size_t)t * p.c + cg]);
+      }
+    }
+    if (vec) {
+      uint4 o;
+      o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]); o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
+      *reinterpret_cast<uint4*>(p.dx + (size_t)v * p.c + cg * 8) = o;
+    } else {
+      p.dx[(size_t)v * p.c + cg] = f2bf(acc[0]);
+    }
+  }
+}
+
+}  // namespace
+
+CINEMA_API int cinema_im2col(const uint16_t* x, uint16_t* cols, int ld_cols, int b, int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream) {
+  if (!x || !cols || b <= 0 || X <= 0 || Y <= 0 || Z <= 0 || c <= 0 || kx <= 0 || ky <= 0 || kz <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!(kx & 1) || !(ky & 1) || !(kz & 1) || (ld_cols & 7) || ld_cols < kx * ky * kz * c || (((uintptr_t)cols) & 15) || (!(c & 7) && (((uintptr_t)x) & 15)))
+    return CINEMA_ERR_UNSUPPORTED;
+  ColP p{}; p.x = x; p.cols = cols; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.ld = ld_cols;
+  const long long items = (long long)b * X * Y * Z * ((c & 7) ? ld_cols : ld_cols / 8);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+CINEMA_API int cinema_col2im(const uint16_t* dcols, int ld_cols, uint16_t* dx, int b, int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream) {
+  if (!dcols || !dx || b <= 0 || X <= 0 || Y <= 0 || Z <= 0 || c <= 0 || kx <= 0 || ky <= 0 || kz <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!(kx & 1) || !(ky & 1) || !(kz & 1) || (ld_cols & 7) || ld_cols < kx * ky * kz * c || (!(c & 7) && ((((uintptr_t)dcols) & 15) || (((uintptr_t)dx) & 15))))
+    return CINEMA_ERR_UNSUPPORTED;
+  ColP p{}; p.dcols = dcols; p.dx = dx; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.ld = ld_cols;
+  const long long items = (long long)b * X * Y * Z * ((c & 7) ? c : c / 8);
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}

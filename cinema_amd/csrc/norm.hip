@@ -246,6 +246,65 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* ws, i
   }
 }
 
+// Channel counts that are not a multiple of 4 (the raw-image block of the segmentation decoder normalises ONE channel, reference
+// cinema/segmentation/convunetr.py:320-329): one thread per row, scalar accesses, c <= 64.  Same math as the vector kernels.
+__device__ __forceinline__ float ld1(const void* base, int is_bf16, size_t i) {
+  return is_bf16 ? bf2f(reinterpret_cast<const bf16_t*>(base)[i]) : reinterpret_cast<const float*>(base)[i];
+}
+__global__ __launch_bounds__(256) void ln_fwd_small_kernel(LnFwdP p) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.rows) return;
+  float s = 0.f;
+  for (int j = 0; j < p.c; j++) s += ld1(p.x, p.x_bf16, (size_t)row * p.ldx + j);
+  const float mu = s / (float)p.c;
+  float q = 0.f;
+  for (int j = 0; j < p.c; j++) { const float d = ld1(p.x, p.x_bf16, (size_t)row * p.ldx + j) - mu; q += d * d; }
+  const float rs = rsqrtf(q / (float)p.c + p.eps);
+  if (p.mean) p.mean[row] = mu;
+  if (p.rstd) p.rstd[row] = rs;
+  for (int j = 0; j < p.c; j++) {
+    float y = (ld1(p.x, p.x_bf16, (size_t)row * p.ldx + j) - mu) * rs * p.gamma[j] + p.beta[j];
+    if (p.act == 1) y = gelu_f(y);
+    if (p.y_bf16) p.y_bf16[(size_t)row * p.ldy + j] = f2bf(y);
+    if (p.y_f32) p.y_f32[(size_t)row * p.ldy + j] = y;
+  }
+}
+__global__ __launch_bounds__(256) void ln_bwd_small_kernel(LnBwdP p) {
+  __shared__ float red[2][64];
+  if (threadIdx.x < 128) red[threadIdx.x >> 6][threadIdx.x & 63] = 0.f;
+  __syncthreads();
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row < p.rows) {
+    const float mu = p.mean[row], rs = p.rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < p.c; j++) {
+      const float xh = (ld1(p.x, p.x_bf16, (size_t)row * p.ldx + j) - mu) * rs;
+      float d = ld1(p.dy, p.dy_bf16, (size_t)row * p.lddy + j);
+      if (p.act == 1) d *= gelu_grad_f(xh * p.gamma[j] + p.beta[j]);
+      const float dxh = d * p.gamma[j];
+      s1 += dxh; s2 += dxh * xh;
+      atomicAdd(&red[0][j], d * xh);
+      atomicAdd(&red[1][j], d);
+    }
+    s1 /= (float)p.c; s2 /= (float)p.c;
+    for (int j = 0; j < p.c; j++) {
+      const float xh = (ld1(p.x, p.x_bf16, (size_t)row * p.ldx + j) - mu) * rs;
+      float d = ld1(p.dy, p.dy_bf16, (size_t)row * p.lddy + j);
+      if (p.act == 1) d *= gelu_grad_f(xh * p.gamma[j] + p.beta[j]);
+      float dx = rs * (d * p.gamma[j] - s1 - xh * s2);
+      const size_t off = (size_t)row * p.lddx + j;
+      if (p.dx_res) dx += p.dx_res[off];
+      if (p.dx_f32) p.dx_f32[off] = dx;
+      if (p.dx_bf16) p.dx_bf16[off] = f2bf(dx);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < p.c) {
+    if (p.dgamma) unsafeAtomicAdd(p.dgamma + threadIdx.x, red[0][threadIdx.x]);
+    if (p.dbeta) unsafeAtomicAdd(p.dbeta + threadIdx.x, red[1][threadIdx.x]);
+  }
+}
+
 int pick_lpr(int c) {
   int nch = c >> 2, l = 1;
   while (l < nch && l < 64) l <<= 1;
@@ -270,8 +329,12 @@ int dispatch_cpl(int cpl, F&& f) {
 CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
                                     int act, uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, void* stream) {
   if (!x || !gamma || !beta || rows <= 0 || c <= 0 || (!y_bf16 && !y_f32)) return CINEMA_ERR_BAD_ARG;
-  if ((c & 3) || (ldx & 3) || (ldy & 3)) return CINEMA_ERR_UNSUPPORTED;
   LnFwdP p{x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, pick_lpr(c)};
+  if ((c & 3) || (ldx & 3) || (ldy & 3)) {
+    if (c > 64) return CINEMA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ln_fwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status();
+  }
   const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
   const int rows_per_block = 4 * (64 / p.lpr);
   int grid = (rows + rows_per_block - 1) / rows_per_block;
@@ -288,9 +351,13 @@ CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, co
                                     float* workspace, long long workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
   if (act == 1 && !beta) return CINEMA_ERR_BAD_ARG;
-  if ((c & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CINEMA_ERR_UNSUPPORTED;
   LnBwdP p{dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
            pick_lpr(c), nullptr};
+  if ((c & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) {
+    if (c > 64) return CINEMA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ln_bwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status();
+  }
   const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
   const size_t smem = (size_t)4 * 2 * c * sizeof(float);
   return dispatch_cpl<LnBwdP>(cpl, [&](auto tag) {

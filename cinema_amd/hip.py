@@ -79,6 +79,8 @@ _PROTOS = {
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_data": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_im2col": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_col2im": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_sparse_nbr_ints": [_i],
     "cinema_sparse_nbr_build": [C.POINTER(SparseGeom), _i, _i, _i, _vp, _vp, _vp],
     "cinema_sparse_dwconv_fwd": [_vp, _vp, _vp, _vp, C.POINTER(SparseGeom), _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -150,6 +152,8 @@ def _dev(*ts: torch.Tensor | None) -> None:
 
 
 def _rowmajor(t: torch.Tensor, name: str) -> int:
+    if t.dim() == 2 and t.shape[1] == 1:  # a single column: the inner stride is meaningless (torch may report anything for it)
+        return t.stride(0)
     if t.dim() != 2 or t.stride(1) != 1:
         raise HipLibraryError(f"{name} must be 2-D with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
     return t.stride(0)
@@ -375,6 +379,35 @@ def dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dbias
     ws = torch.empty(1024 * c * (kx * ky * kz + 1), dtype=torch.float32, device=x.device)  # per-block partial slabs (deterministic two-pass)
     _check(load().cinema_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), ws.numel() * 4, b, X, Y, Z, c, kx, ky,
                                            kz, _stream()), "dwconv_bwd_weight")
+
+
+def _vol_dims(shape: tuple, ks: tuple) -> tuple:
+    """(b, *spatial, c) with 2 or 3 spatial dims -> (b, X, Y, Z, c, kx, ky, kz); 2-D maps get a leading axis of 1."""
+    b, c = shape[0], shape[-1]
+    sp = (1,) * (3 - len(shape[1:-1])) + tuple(shape[1:-1])
+    k3 = (1,) * (3 - len(ks)) + tuple(ks)
+    return (b, *sp, c, *k3)
+
+
+def im2col(x: torch.Tensor, ks: tuple) -> torch.Tensor:
+    """x bf16 channels-last [b, *spatial, c] -> cols bf16 [b*prod(spatial), ld], ld = taps*c rounded up to 8 (zero tail)."""
+    _dev(x)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        raise HipLibraryError("im2col: x must be contiguous bf16 channels-last")
+    b, X, Y, Z, c, kx, ky, kz = _vol_dims(tuple(x.shape), ks)  # noqa: N806
+    ld = (kx * ky * kz * c + 7) // 8 * 8
+    cols = torch.empty((b * X * Y * Z, ld), dtype=torch.bfloat16, device=x.device)
+    _check(load().cinema_im2col(x.data_ptr(), cols.data_ptr(), ld, b, X, Y, Z, c, kx, ky, kz, _stream()), "im2col")
+    return cols
+
+
+def col2im(dcols: torch.Tensor, shape: tuple, ks: tuple) -> torch.Tensor:
+    """Data gradient of :func:`im2col`: dcols bf16 [b*prod(spatial), ld] -> dx bf16 [b, *spatial, c]."""
+    _dev(dcols)
+    b, X, Y, Z, c, kx, ky, kz = _vol_dims(tuple(shape), ks)  # noqa: N806
+    dx = torch.empty(shape, dtype=torch.bfloat16, device=dcols.device)
+    _check(load().cinema_col2im(dcols.data_ptr(), _rowmajor(dcols, "dcols"), dx.data_ptr(), b, X, Y, Z, c, kx, ky, kz, _stream()), "col2im")
+    return dx
 
 
 def sparse_geom(batch: int, tok_grid: tuple, block: tuple, keep: torch.Tensor, rank: torch.Tensor, pos: torch.Tensor) -> SparseGeom:

@@ -10,6 +10,7 @@ ATen compute on this path except index bookkeeping on tiny integer tensors.
 
 from __future__ import annotations
 
+import math
 import os
 from collections import deque
 from typing import Callable
@@ -255,6 +256,32 @@ def patch_grad_to_param_perm(weight: torch.nn.Parameter, pos: torch.Tensor) -> C
     def conv(g: torch.Tensor) -> torch.Tensor:
         g3 = g.reshape(shape[0], -1, shape[1])
         return base(g3[:, pos.long(), :].contiguous())  # raster voxel u sits at row block pos[u]
+
+    return conv
+
+
+def w_conv_same(weight: torch.nn.Parameter) -> torch.Tensor:
+    """Dense conv weight (out, c, *k) -> bf16 [out, ld] in the im2col feature order (*k, c), zero-padded to ld = ceil(taps*c / 8) * 8."""
+
+    def build() -> torch.Tensor:
+        w = weight.detach()
+        perm = (0, *range(2, w.dim()), 1)
+        flat = w.permute(perm).reshape(w.shape[0], -1)
+        ld = (flat.shape[1] + 7) // 8 * 8
+        if ld != flat.shape[1]:
+            flat = torch.nn.functional.pad(flat, (0, ld - flat.shape[1]))
+        return K.cast(flat.contiguous(), BF16)
+
+    return WEIGHTS.get((weight,), "conv_same", build)
+
+
+def conv_same_grad_to_param(weight: torch.nn.Parameter) -> Callable:
+    shape = weight.shape
+    base = patch_grad_to_param(weight)
+
+    def conv(g: torch.Tensor) -> torch.Tensor:
+        f = math.prod(shape[1:])
+        return base(g[:, :f].contiguous())
 
     return conv
 
@@ -532,6 +559,108 @@ def op_view(tape: Tape, x: Var, shape: tuple) -> Var:
 
     tape.record(bwd)
     return y
+
+
+def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None, *,
+                 residual: Var | None = None, out_f32: bool = False) -> Var:
+    """Dense "same"-padded conv on bf16 channels-last rows x [batch*prod(spatial), c] (``ConvResBlock`` convs, ``cinema/conv.py:320-345``):
+    im2col + MFMA GEMM (+ bias, + fp32 residual).  The column matrix is not kept: the backward pass rebuilds it for the weight gradient."""
+    ks = tuple(weight.shape[2:])
+    c = x.data.shape[1]
+    w16 = w_conv_same(weight)
+    xs = x.data.view(batch, *spatial, c)
+    cols = K.im2col(xs, ks)
+    y = Var(K.gemm(cols, w16, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
+                   out_dtype=F32 if (out_f32 or residual is not None) else BF16))
+    del cols
+    wv, bv = tape.pvar(weight), tape.pvar(bias)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        if residual is not None:
+            residual.add_grad(y.grad, y.grad16)
+        dy16 = y.grad_bf16()
+        if weight.requires_grad:
+            wgrad(tape, dy16, K.im2col(xs, ks), wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w16.shape),
+                  conv_same_grad_to_param(weight))
+        if x.needs_grad:
+            dcols = K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False)
+            x.add_grad(K.col2im(dcols, (batch, *spatial, c), ks).view(-1, c))
+
+    tape.record(bwd)
+    return y
+
+
+def _chan_last_strides(chans: int, spatial: tuple) -> tuple:
+    sp, acc = [], chans
+    for d in reversed(spatial):
+        sp.append(acc)
+        acc *= d
+    return (acc, 1, *reversed(sp))
+
+
+def w_conv_transpose(weight: torch.nn.Parameter) -> torch.Tensor:
+    """ConvTranspose weight (c_in, c_out, *k) -> bf16 [(*k, c_out), c_in]: one GEMM gives every output voxel of a k == s up-sampling."""
+
+    def build() -> torch.Tensor:
+        w = weight.detach()
+        perm = (*range(2, w.dim()), 1, 0)
+        return K.cast(w.permute(perm).reshape(-1, w.shape[0]).contiguous(), BF16)
+
+    return WEIGHTS.get((weight,), "conv_transpose", build)
+
+
+def conv_transpose_grad_to_param(weight: torch.nn.Parameter) -> Callable:
+    shape = weight.shape
+
+    def conv(g: torch.Tensor) -> torch.Tensor:
+        nd = len(shape) - 2
+        g = g.reshape(*shape[2:], shape[1], shape[0])
+        return g.permute(nd + 1, nd, *range(nd)).contiguous()
+
+    return conv
+
+
+def op_conv_transpose(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None,
+                      skip: Var | None = None) -> tuple:
+    """k == s transposed conv (``UpsampleDecoder.up``, ``cinema/segmentation/convunetr.py:62-101``) on bf16 channels-last rows
+    x [batch*prod(spatial), c_in]: one GEMM to rows [(*k, c_out)] per input voxel, scattered to the up-sampled fp32 volume
+    (+ ``skip``, the encoder feature added right after the up-sampling).  Returns (Var fp32 [batch*prod(out_spatial), c_out], out_spatial)."""
+    ks = tuple(weight.shape[2:])
+    c_out = weight.shape[1]
+    k_vol = math.prod(ks)
+    wt = w_conv_transpose(weight)
+    bias_t = None if bias is None else WEIGHTS.get((bias,), f"tile{k_vol}", lambda: bias.detach().repeat(k_vol).contiguous())
+    rows = K.gemm(x.data, wt, bias=bias_t)
+    out_spatial = tuple(s * k for s, k in zip(spatial, ks))
+    n_out = batch * math.prod(out_spatial)
+    geom = K.patch_geom(batch, c_out, spatial, ks, _chan_last_strides(c_out, out_spatial))
+    if skip is not None:
+        dst = torch.empty((n_out, c_out), dtype=F32, device=x.data.device)
+        K.row_copy(dst, skip.data)
+        K.patch_scatter(rows, dst, geom, accumulate=True)
+    else:
+        dst = torch.empty((n_out, c_out), dtype=F32, device=x.data.device)
+        K.patch_scatter(rows, dst, geom)
+    y = Var(dst)
+    wv, bv = tape.pvar(weight), tape.pvar(bias)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        if skip is not None:
+            skip.add_grad(y.grad, y.grad16)
+        drows = K.patch_gather(y.grad, geom, BF16)  # [n_in_vox, k_vol * c_out]
+        if weight.requires_grad:
+            wgrad(tape, drows, x.data, wv, None, tuple(wt.shape), conv_transpose_grad_to_param(weight))
+            if bias is not None and bias.requires_grad:
+                K.colsum(drows.view(-1, c_out), bv.grad_buffer((c_out,)))
+        if x.needs_grad:
+            x.add_grad(K.gemm(drows, wt, a_kmajor=True, b_kmajor=False))
+
+    tape.record(bwd)
+    return y, out_spatial
 
 
 def op_segment_mean(tape: Tape, x: Var, n_seg: int) -> Var:

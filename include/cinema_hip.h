@@ -112,6 +112,13 @@ int cinema_dwconv_bwd_data(const uint16_t* dy, const float* w, uint16_t* dx, con
 int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes, int b,
                              int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream);
 
+/* Dense k^n "same"-padded convolution of the segmentation decoder (reference ConvResBlock conv1/conv2, cinema/conv.py:276-348, called from
+ * cinema/segmentation/convunetr.py:320-345,455-485) = im2col + cinema_gemm_bf16:
+ *   cols[v][(tap, c)] = x[v + tap - r][c], zero outside the volume; rows are ld_cols (multiple of 8, >= taps*c) wide, the tail is zero-filled.
+ *   col2im is the data-gradient gather dx[v][c] = sum_tap dcols[v - (tap - r)][(tap, c)].  x / dx: bf16 channels-last [b][X][Y][Z][c]. */
+int cinema_im2col(const uint16_t* x, uint16_t* cols, int ld_cols, int b, int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream);
+int cinema_col2im(const uint16_t* dcols, int ld_cols, uint16_t* dx, int b, int X, int Y, int Z, int c, int kx, int ky, int kz, void* stream);
+
 /* ---- the same depthwise conv restricted to the VISIBLE voxels of an MAE step (exactly the reference result at those voxels: every other op of
  * cinema/conv.py:349-415 is per-voxel and the conv input is zero at masked voxels, so visible outputs depend on visible voxels only; the
  * reference computes all voxels and discards 75 % of them, cinema/mae/mae.py:548-550).

@@ -374,6 +374,68 @@ def convvit_forward(p: Params, cfg: MAEConfig, image_dict: dict, mask_dict: dict
     return torch.cat(outs, dim=1).mean(dim=1)
 
 
+def conv_res_block(x: Tensor, p: Params, key: str) -> Tensor:
+    """``ConvResBlock.forward`` (``cinema/conv.py:328-348``), dropout = 0: norm-GELU-conv-norm-GELU-conv + (1x1 conv | identity) shortcut."""
+    pad = tuple(k // 2 for k in p[f"{key}.conv1.weight"].shape[2:])
+    h = _conv(F.gelu(_conv_ln(x, p, f"{key}.norm1")), p, f"{key}.conv1", padding=pad)
+    h = _conv(F.gelu(_conv_ln(h, p, f"{key}.norm2")), p, f"{key}.conv2", padding=pad)
+    return h + (_conv(x, p, f"{key}.shortcut") if f"{key}.shortcut.weight" in p else x)
+
+
+def _conv_transpose(x: Tensor, p: Params, key: str) -> Tensor:
+    w = p[f"{key}.weight"]
+    fn = F.conv_transpose3d if x.ndim == 5 else F.conv_transpose2d
+    return fn(x, w, p.get(f"{key}.bias"), stride=tuple(w.shape[2:]))
+
+
+def upsample_decoder(embeddings: list, p: Params, key: str, n_levels: int, n_blocks: int = 2) -> Tensor:
+    """``UpsampleDecoder.forward`` (``cinema/segmentation/convunetr.py:89-106``)."""
+    embeddings = list(embeddings)
+    x = embeddings.pop()
+    for i in range(n_levels):
+        x = _conv_transpose(x, p, f"{key}.blocks.{i}.up")
+        skip = embeddings.pop()
+        if skip is not None:
+            x = x + skip
+        for j in range(n_blocks):
+            x = conv_res_block(x, p, f"{key}.blocks.{i}.conv.{j}")
+    return x
+
+
+def convunetr_forward(p: Params, cfg: MAEConfig, dec_chans: tuple, n_layers_wo_skip: int, n_downsample_layers: int, image_dict: dict) -> dict:
+    """``ConvUNetR.forward`` (``cinema/segmentation/convunetr.py:422-485``): logits (b, out_chans, *image_size) per view."""
+    views = list(image_dict)
+    if any(v not in cfg.views for v in views):
+        raise ValueError(f"views {views} must be in self.input_keys {cfg.views}.")
+    b = image_dict[views[0]].shape[0]
+    toks, skips_all, n_tok = [], [], []
+    for v in views:
+        skips, x = downsample_encoder(image_dict[v], None, p, f"enc_down_dict.{v}", cfg, v)
+        toks.append(x)
+        skips_all.append(skips)
+        n_tok.append(x.shape[1])
+    x = torch.cat([p["encoder.cls_token"].expand(b, -1, -1), *toks], dim=1)
+    for i in range(cfg.enc_depth):
+        x = block(x, None, p, f"encoder.blocks.{i}", cfg.enc_n_heads, cfg.norm_eps)
+    x = _ln(x, p, "encoder.norm", cfg.norm_eps)
+    parts = torch.split(x, [1, *n_tok], dim=1)[1:]
+    preds = {}
+    for i, v in enumerate(views):
+        grid = tuple(s // e for s, e in zip(image_dict[v].shape[2:], [math.prod(q[d] for q in cfg.patch_sizes(v)) for d in range(len(cfg.patch_sizes(v)[0]))]))
+        xv = parts[i].permute(0, 2, 1).reshape(b, -1, *grid)
+        skips_view = list(skips_all[i]) + [xv]
+        for j in range(n_downsample_layers):
+            w = p[f"dec_down_blocks_dict.{v}.{j}.weight"]
+            xv = _conv(xv, p, f"dec_down_blocks_dict.{v}.{j}", stride=tuple(w.shape[2:]))
+            skips_view.append(xv)
+        emb = [conv_res_block(image_dict[v], p, f"dec_image_conv_block_dict.{v}")] + [None] * n_layers_wo_skip
+        for j in range(len(skips_view)):
+            emb.append(conv_res_block(skips_view[j], p, f"dec_conv_blocks_dict.{v}.{j}"))
+        y = upsample_decoder(emb, p, f"decoder_dict.{v}", len(dec_chans))
+        preds[v] = _conv(y, p, f"pred_head_dict.{v}")
+    return preds
+
+
 def mae_forward(p: Params, cfg: MAEConfig, image_dict: dict, mask_dict: dict):  # noqa: ANN201
     """``CineMA.forward`` (``cinema/mae/mae.py:504-612``) with the random masks injected.
 

@@ -359,3 +359,36 @@ def test_convvit_api_errors_on_cpu() -> None:
         model({"sax": torch.zeros(1, 2, 32, 32, 4), "lax_2c": torch.zeros(1, 2, 32, 32)}, None, reduce="none")
     with pytest.raises(hip.HipLibraryError):  # no CPU fallback
         model({"sax": torch.zeros(1, 2, 32, 32, 4), "lax_2c": torch.zeros(1, 2, 32, 32)}, None, reduce="cls")
+
+
+# ---------------------------------------------------------------------------------------------------- ConvUNetR host logic
+def _unetr_kwargs() -> dict:
+    kw = json.loads((GOLDEN / "convunetr_meta.json").read_text())["kwargs"]
+    for key in ("image_size_dict", "enc_patch_size_dict", "enc_scale_factor_dict", "dec_patch_size_dict", "dec_scale_factor_dict"):
+        kw[key] = {v: tuple(s) for v, s in kw[key].items()}
+    kw["dec_chans"] = tuple(kw["dec_chans"])
+    return kw
+
+
+def test_convunetr_state_dict_seeded_init_and_compat_checks_match_the_reference() -> None:
+    from cinema_amd.segmentation.convunetr import ConvUNetR, check_conv_unetr_enc_dec_compatiblity
+
+    meta = json.loads((GOLDEN / "convunetr_meta.json").read_text())
+    g = load_golden("convunetr_mini.safetensors")
+    ref = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    torch.manual_seed(0)
+    model = ConvUNetR(**_unetr_kwargs())
+    sd = model.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["state_dict"]
+    for k, v in sd.items():
+        assert torch.equal(v, ref[k]), k  # same RNG draw order as the reference constructor
+    assert model.n_layers_wo_skip == meta["n_layers_wo_skip"] and len(model.dec_down_blocks_dict["sax"]) == meta["n_downsample_layers"]
+    assert list(check_conv_unetr_enc_dec_compatiblity((4, 4, 1), (2, 2, 1), 2, 5, (2, 2, 1), (2, 2, 1))) == meta["compat"]["acdc"]
+    with pytest.raises(ValueError, match="must be less than dec_depth"):
+        check_conv_unetr_enc_dec_compatiblity((4, 4, 1), (2, 2, 1), 5, 5, (2, 2, 1), (2, 2, 1))
+    with pytest.raises(ValueError, match="must be greater than dec_patch_size"):
+        check_conv_unetr_enc_dec_compatiblity((2, 2, 1), (2, 2, 1), 2, 5, (4, 4, 1), (2, 2, 1))
+    with pytest.raises(ValueError, match="must be equal to"):
+        check_conv_unetr_enc_dec_compatiblity((6, 6, 1), (2, 2, 1), 2, 5, (2, 2, 1), (2, 2, 1))
+    with pytest.raises(ValueError):
+        model({"bogus": torch.zeros(1, 1, 64, 64)})

@@ -218,3 +218,33 @@ def test_convvit_logits_features_and_gradients() -> None:
         assert torch.allclose(params[k].grad, t, rtol=1e-3, atol=1e-6), k
     with pytest.raises(NotImplementedError):
         O.convvit_forward(params, cfg, images, None, reduce="none")
+
+
+# ------------------------------------------------------------------------------------------------ ConvUNetR
+def _unetr_setup():  # noqa: ANN202
+    meta = json.loads((GOLDEN / "convunetr_meta.json").read_text())
+    kw = meta["kwargs"]
+    cfg = O.MAEConfig(image_size_dict=kw["image_size_dict"], in_chans_dict=kw["in_chans_dict"], enc_patch_size_dict=kw["enc_patch_size_dict"],
+                      enc_scale_factor_dict=kw["enc_scale_factor_dict"], enc_conv_chans=kw["enc_conv_chans"], enc_conv_n_blocks=kw["enc_conv_n_blocks"],
+                      enc_embed_dim=kw["enc_embed_dim"], enc_depth=kw["enc_depth"], enc_n_heads=kw["enc_n_heads"], dec_embed_dim=16, dec_depth=1,
+                      dec_n_heads=2)
+    return meta, cfg
+
+
+def test_convunetr_logits_gradients_and_layer_kats() -> None:
+    """Oracle restatement of ``ConvUNetR.forward`` / ``ConvResBlock`` / ``UpsampleDecoder`` against the reference."""
+    g = load_golden("convunetr_mini.safetensors")
+    meta, cfg = _unetr_setup()
+    params = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in split(g, "param/").items() if not k.startswith(("resblock", "updec"))}
+    images = split(g, "image/")
+    out = O.convunetr_forward(params, cfg, tuple(meta["kwargs"]["dec_chans"]), meta["n_layers_wo_skip"], meta["n_downsample_layers"], images)
+    for v, t in split(g, "logits/").items():
+        assert out[v].shape == t.shape and torch.allclose(out[v], t, rtol=1e-4, atol=5e-5), v
+    sum((out[v] * g[f"coef/{v}"]).sum() for v in images).backward()
+    for k, t in split(g, "grad/").items():
+        assert torch.allclose(params[k].grad, t, rtol=2e-3, atol=1e-5 * float(t.abs().max()) + 1e-7), k
+    rp = split(g, "resblock/param/")
+    assert torch.allclose(O.conv_res_block(g["resblock/x"], {f"b.{k}": v for k, v in rp.items()}, "b"), g["resblock/y"], rtol=1e-4, atol=2e-5)
+    up = {f"d.{k}": v for k, v in split(g, "updec/param/").items()}
+    y = O.upsample_decoder([g["updec/e0"], None, g["updec/e2"]], up, "d", 2)
+    assert torch.allclose(y, g["updec/y"], rtol=1e-4, atol=2e-5)
