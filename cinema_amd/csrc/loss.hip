@@ -264,3 +264,123 @@ CINEMA_API int cinema_mean_finite(const float* vals, int n, float* mean_out, flo
   hipLaunchKernelGGL(mean_finite_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vals, n, mean_out, coef_out);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Segmentation loss of one view (reference _segmentation_loss, cinema/segmentation/train.py:77-103):
+//   cross_entropy(logits, labels, ignore_index = -1)  +  monai DiceLoss(include_background=False, softmax=True) against one_hot(max(labels, 0))
+// (monai defaults: smooth_nr = smooth_dr = 1e-5, reduced over the spatial axes per (sample, class), mean over samples x foreground classes).
+// logits: fp32 channels-last rows [b * vox][c] (c <= 16), labels int32 [b * vox].
+//   pass 1  per (sample, class) sums of p*t, p, t  + CE sum / count            -> acc[b][c][3], acc_ce[2]
+//   finish  loss, metrics and the coefficients d dice / d (sum p*t), d dice / d (sum p)   -> out[3], coef[b][c][2], inv_count
+//   pass 2  d loss / d logits (softmax Jacobian applied per voxel)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int SEG_MAXC = 16;
+
+__device__ __forceinline__ void row_softmax(const float* row, int c, float (&p)[SEG_MAXC], float& lse) {
+  float mx = -INFINITY;
+  for (int j = 0; j < c; j++) mx = fmaxf(mx, row[j]);
+  float s = 0.f;
+  for (int j = 0; j < c; j++) { p[j] = __expf(row[j] - mx); s += p[j]; }
+  const float inv = 1.f / s;
+  for (int j = 0; j < c; j++) p[j] *= inv;
+  lse = mx + __logf(s);
+}
+
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* logits, const int* labels, int vox, int c, float* acc, float* acc_ce) {
+  __shared__ float red[SEG_MAXC * 3 + 2];
+  for (int i = threadIdx.x; i < c * 3 + 2; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.y;
+  float li[SEG_MAXC], lp[SEG_MAXC], lt[SEG_MAXC], ce = 0.f, cnt = 0.f;
+  for (int j = 0; j < c; j++) { li[j] = 0.f; lp[j] = 0.f; lt[j] = 0.f; }
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < vox; v += gridDim.x * 256) {
+    const size_t r = (size_t)b * vox + v;
+    float p[SEG_MAXC], lse;
+    row_softmax(logits + r * c, c, p, lse);
+    const int lab = labels[r];
+    const int tcls = lab < 0 ? 0 : lab;  // one_hot(labels.clamp(min=0))
+    for (int j = 0; j < c; j++) { lp[j] += p[j]; if (j == tcls) { li[j] += p[j]; lt[j] += 1.f; } }
+    if (lab >= 0) { ce += lse - logits[r * c + lab]; cnt += 1.f; }
+  }
+  for (int j = 0; j < c; j++) {
+    const float a = wave_sum(li[j]), bb = wave_sum(lp[j]), t = wave_sum(lt[j]);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[j * 3], a); atomicAdd(&red[j * 3 + 1], bb); atomicAdd(&red[j * 3 + 2], t); }
+  }
+  ce = wave_sum(ce); cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&red[c * 3], ce); atomicAdd(&red[c * 3 + 1], cnt); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c * 3; i += 256) unsafeAtomicAdd(acc + (size_t)b * c * 3 + i, red[i]);
+  if (threadIdx.x < 2) unsafeAtomicAdd(acc_ce + threadIdx.x, red[c * 3 + threadIdx.x]);
+}
+
+// out[0] = loss, out[1] = cross entropy, out[2] = mean dice loss; coef[b][c][0] = d dice / d I, coef[b][c][1] = d dice / d P; out[3] = 1 / count
+__global__ void seg_loss_finish_kernel(const float* acc, const float* acc_ce, int b, int c, float smooth_nr, float smooth_dr, float* out, float* coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float n = (float)(b * (c - 1));
+  float dice = 0.f;
+  for (int i = 0; i < b; i++)
+    for (int j = 0; j < c; j++) {
+      const float I = acc[(i * c + j) * 3], P = acc[(i * c + j) * 3 + 1], G = acc[(i * c + j) * 3 + 2];
+      const float den = G + P + smooth_dr;
+      float dI = 0.f, dP = 0.f;
+      if (j >= 1) {
+        dice += 1.f - (2.f * I + smooth_nr) / den;
+        dI = -2.f / den / n;
+        dP = (2.f * I + smooth_nr) / (den * den) / n;
+      }
+      coef[(i * c + j) * 2] = dI;
+      coef[(i * c + j) * 2 + 1] = dP;
+    }
+  dice /= n;
+  const float ce = acc_ce[0] / acc_ce[1];
+  out[0] = dice + ce; out[1] = ce; out[2] = dice; out[3] = 1.f / acc_ce[1];
+}
+
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* logits, const int* labels, int vox, int c, const float* coef, const float* out,
+                                                           const float* upstream, float* dlogits) {
+  const int b = blockIdx.y;
+  const float up = upstream ? upstream[0] : 1.f, inv_cnt = out[3];
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < vox; v += gridDim.x * 256) {
+    const size_t r = (size_t)b * vox + v;
+    float p[SEG_MAXC], lse;
+    row_softmax(logits + r * c, c, p, lse);
+    const int lab = labels[r];
+    const int tcls = lab < 0 ? 0 : lab;
+    float g[SEG_MAXC], dot = 0.f;
+    for (int j = 0; j < c; j++) {
+      g[j] = coef[(b * c + j) * 2 + 1] + (j == tcls ? coef[(b * c + j) * 2] : 0.f);  // d dice / d p_j
+      dot += g[j] * p[j];
+    }
+    for (int j = 0; j < c; j++) {
+      float d = p[j] * (g[j] - dot);
+      if (lab >= 0) d += (p[j] - (j == lab ? 1.f : 0.f)) * inv_cnt;
+      dlogits[r * c + j] = d * up;
+    }
+  }
+}
+
+}  // namespace
+
+CINEMA_API int cinema_seg_loss_fwd(const float* logits, const int* labels, int b, int vox, int c, float* acc, float* out4, float* coef, void* stream) {
+  if (!logits || !labels || !acc || !out4 || !coef || b <= 0 || vox <= 0 || c < 2) return CINEMA_ERR_BAD_ARG;
+  if (c > SEG_MAXC) return CINEMA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(acc, 0, ((size_t)b * c * 3 + 2) * sizeof(float), st) != hipSuccess) return CINEMA_ERR_BAD_ARG;
+  int gx = (vox + 255) / 256;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(gx, b), dim3(256), 0, st, logits, labels, vox, c, acc, acc + (size_t)b * c * 3);
+  hipLaunchKernelGGL(seg_loss_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)acc, (const float*)(acc + (size_t)b * c * 3), b, c, 1e-5f, 1e-5f, out4, coef);
+  return launch_status();
+}
+
+CINEMA_API int cinema_seg_loss_bwd(const float* logits, const int* labels, int b, int vox, int c, const float* coef, const float* out4, const float* upstream,
+                                   float* dlogits, void* stream) {
+  if (!logits || !labels || !coef || !out4 || !dlogits || b <= 0 || vox <= 0 || c < 2) return CINEMA_ERR_BAD_ARG;
+  if (c > SEG_MAXC) return CINEMA_ERR_UNSUPPORTED;
+  int gx = (vox + 255) / 256;
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, logits, labels, vox, c, coef, out4, upstream, dlogits);
+  return launch_status();
+}

@@ -89,6 +89,8 @@ _PROTOS = {
     "cinema_patch_gather": [_vp, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_patch_scatter": [_vp, _i, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_row_copy": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "cinema_seg_loss_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "cinema_seg_loss_bwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_segment_mean_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp],
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
@@ -237,6 +239,29 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ev1.record()
     GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k)))
     return out
+
+
+def seg_loss_fwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int):  # noqa: ANN201
+    """-> (out4 = [loss, cross entropy, mean dice loss, 1/count], coef) for fp32 rows [batch*vox, c] and int32 labels [batch*vox]."""
+    _dev(logits_rows, labels)
+    if logits_rows.dtype != torch.float32 or labels.dtype != torch.int32 or not logits_rows.is_contiguous() or not labels.is_contiguous():
+        raise HipLibraryError("seg_loss: logits fp32 rows and int32 labels, both contiguous")
+    rows, c = logits_rows.shape
+    acc = torch.empty(batch * c * 3 + 2, dtype=torch.float32, device=logits_rows.device)
+    out4 = torch.empty(4, dtype=torch.float32, device=logits_rows.device)
+    coef = torch.empty(batch * c * 2, dtype=torch.float32, device=logits_rows.device)
+    _check(load().cinema_seg_loss_fwd(logits_rows.data_ptr(), labels.data_ptr(), batch, rows // batch, c, acc.data_ptr(), out4.data_ptr(), coef.data_ptr(),
+                                      _stream()), "seg_loss_fwd")
+    return out4, coef
+
+
+def seg_loss_bwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int, coef: torch.Tensor, out4: torch.Tensor, upstream: torch.Tensor | None):  # noqa: ANN201
+    _dev(logits_rows, labels, coef, out4, upstream)
+    rows, c = logits_rows.shape
+    d = torch.empty_like(logits_rows)
+    _check(load().cinema_seg_loss_bwd(logits_rows.data_ptr(), labels.data_ptr(), batch, rows // batch, c, coef.data_ptr(), out4.data_ptr(), _p(upstream),
+                                      d.data_ptr(), _stream()), "seg_loss_bwd")
+    return d
 
 
 def segment_mean(x: torch.Tensor, n_seg: int, scale: float | None = None) -> torch.Tensor:

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from collections import deque
 from typing import Callable
 
@@ -104,10 +105,14 @@ class WeightCache:
         key = (tuple(id(p) for p in params), kind)
         stamp = (self.epoch, tuple((p._version, p.data_ptr()) for p in params))  # noqa: SLF001
         hit = self._store.get(key)
-        if hit is not None and hit[0] == stamp:
+        # the weak references pin the entry to the parameter OBJECTS: a dead parameter's id(), storage address and version can all be
+        # handed to a new one (seen as a rare stale-shadow error when many models are built in one process, e.g. the test suite)
+        if hit is not None and hit[0] == stamp and all(r() is p for r, p in zip(hit[2], params)):
             return hit[1]
         val = build()
-        self._store[key] = (stamp, val)
+        if len(self._store) > 4096:  # entries of dead models
+            self._store = {k: v for k, v in self._store.items() if all(r() is not None for r in v[2])}
+        self._store[key] = (stamp, val, tuple(weakref.ref(p) for p in params))
         return val
 
 

@@ -174,6 +174,15 @@ int cinema_row_copy(void* dst, int dst_dtype, int ld_dst, const int* dst_idx, co
                     const int* src_idx, const void* add, int add_dtype, int ld_add, const int* add_idx, int n_rows, int c,
                     int accumulate, void* stream);
 
+/* Segmentation loss of one view (reference _segmentation_loss, cinema/segmentation/train.py:77-103): cross_entropy(ignore_index = -1) +
+ * monai DiceLoss(include_background=False, softmax=True) against one_hot(max(labels, 0)); smooth_nr = smooth_dr = 1e-5, mean over samples x foreground classes.
+ * logits fp32 channels-last rows [b*vox][c] (2 <= c <= 16), labels int32 [b*vox].
+ * fwd: acc = scratch of (b*c*3 + 2) floats; out4 = {loss, cross entropy, mean dice loss, 1/count}; coef [b][c][2] is consumed by bwd.
+ * bwd: dlogits [b*vox][c] = upstream[0] * d loss / d logits (upstream NULL = 1). */
+int cinema_seg_loss_fwd(const float* logits, const int* labels, int b, int vox, int c, float* acc, float* out4, float* coef, void* stream);
+int cinema_seg_loss_bwd(const float* logits, const int* labels, int b, int vox, int c, const float* coef, const float* out4, const float* upstream,
+                        float* dlogits, void* stream);
+
 /* Token pooling of the ConvViT heads (reference cinema/convvit.py:523-547, `x.mean(dim=1, keepdim=True)` and the mean over head outputs):
  * out[s][:] = scale * sum of the seg_rows consecutive rows of segment s of x (fp32 [n_seg*seg_rows][c]); bwd broadcasts scale * dy[s] back. */
 int cinema_segment_mean_fwd(const float* x, int ldx, int n_seg, int seg_rows, int c, float scale, float* out, void* stream);

@@ -627,3 +627,25 @@ class Trainer:
             norm = torch.linalg.vector_norm(torch.stack([t.grad.norm() for t in tensors if t.grad is not None]))
         self.opt.step()
         return loss.detach(), norm.detach(), preds, metrics
+
+
+def segmentation_loss_one_view(logits: Tensor, labels: Tensor):  # noqa: ANN201
+    """``_segmentation_loss`` (``cinema/segmentation/train.py:77-103``) with monai's ``one_hot`` / ``DiceLoss(include_background=False,
+    softmax=True)`` (monai 1.5.2, absent here) restated: smooth_nr = smooth_dr = 1e-5, sums over the spatial axes per (sample, class),
+    mean over samples x foreground classes.  Returns (loss, metrics).
+
+    PARITY UNPINNED for the Dice term: monai==1.5.2 (reference pyproject.toml:20) is not installed here and the reference holds no test or
+    golden value for this function; the restatement follows monai's published ``DiceLoss.forward`` (softmax, drop channel 0, per-item spatial
+    sums, ``1 - (2 I + smooth_nr) / (G + P + smooth_dr)``, mean) and is checked against a hand-computed known answer in the tests."""
+    labels = labels.long()
+    c = logits.shape[1]
+    target = F.one_hot(labels.clamp(min=0).squeeze(1), c).movedim(-1, 1).to(logits.dtype)
+    ce = F.cross_entropy(logits, labels.squeeze(1), ignore_index=-1)
+    prob = torch.softmax(logits, dim=1)[:, 1:]
+    tgt = target[:, 1:]
+    axes = tuple(range(2, logits.ndim))
+    inter = (prob * tgt).sum(axes)
+    den = tgt.sum(axes) + prob.sum(axes)
+    dice = (1.0 - (2.0 * inter + 1e-5) / (den + 1e-5)).mean()
+    loss = dice + ce
+    return loss, {"cross_entropy": ce, "mean_dice_loss": dice, "loss": loss}

@@ -435,3 +435,23 @@ def test_adamw_and_clip() -> None:
     close(norm, ref_norm.reshape(1), 1e-5, 0, "grad norm")
     close(p, pr.detach(), 1e-5, 1e-6, "adamw params")
     assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize(("shape", "c"), [((2, 24, 20, 6), 4), ((3, 40, 33), 3), ((1, 7, 5, 3), 2)])
+def test_segmentation_loss_vs_oracle(shape: tuple, c: int) -> None:
+    """CE(ignore -1) + soft Dice (reference cinema/segmentation/train.py:77-103) and its gradient against the fp32 oracle (autograd)."""
+    from cinema_amd.segmentation.train import _segmentation_loss
+
+    b, *sp = shape
+    g = torch.Generator(device="cpu").manual_seed(17)
+    logits = (torch.randn(b, c, *sp, generator=g) * 2.0)
+    labels = torch.randint(-1, c, (b, 1, *sp), generator=g)
+    ref_in = logits.clone().requires_grad_(True)
+    ref_loss, ref_m = O.segmentation_loss_one_view(ref_in, labels)
+    (ref_loss * 1.7).backward()
+    x = logits.to(DEV).requires_grad_(True)
+    loss, m = _segmentation_loss(x, labels.to(DEV))
+    (loss * 1.7).backward()
+    for k in ("cross_entropy", "mean_dice_loss", "loss"):
+        assert float(m[k]) == pytest.approx(float(ref_m[k]), rel=2e-5, abs=1e-6), k  # fp32 both sides, different summation order
+    close(x.grad, ref_in.grad.to(DEV), 1e-3, 1e-7, "seg loss grad")

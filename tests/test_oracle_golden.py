@@ -6,6 +6,7 @@ Pins the oracle.  CPU only.
 from __future__ import annotations
 
 import json
+import math
 
 import pytest
 import torch
@@ -248,3 +249,17 @@ def test_convunetr_logits_gradients_and_layer_kats() -> None:
     up = {f"d.{k}": v for k, v in split(g, "updec/param/").items()}
     y = O.upsample_decoder([g["updec/e0"], None, g["updec/e2"]], up, "d", 2)
     assert torch.allclose(y, g["updec/y"], rtol=1e-4, atol=2e-5)
+
+
+def test_segmentation_loss_known_answer() -> None:
+    """Hand-computed value (monai is absent: the Dice restatement is unpinned against the reference, see the oracle docstring).
+    2 classes, 1 sample, 4 voxels, zero logits -> p = 0.5 everywhere; labels [1, 1, 0, -1]:
+      CE over the 3 labelled voxels = ln 2;  foreground class: I = 1.0, P = 2.0, G = 2  ->  dice = 1 - (2 + 1e-5) / (4 + 1e-5)."""
+    logits = torch.zeros(1, 2, 4, requires_grad=True)
+    labels = torch.tensor([[[1, 1, 0, -1]]])
+    loss, m = O.segmentation_loss_one_view(logits, labels)
+    ce, dice = math.log(2.0), 1.0 - (2.0 + 1e-5) / (4.0 + 1e-5)
+    assert float(m["cross_entropy"]) == pytest.approx(ce, rel=1e-6) and float(m["mean_dice_loss"]) == pytest.approx(dice, rel=1e-6)
+    assert float(loss) == pytest.approx(ce + dice, rel=1e-6)
+    loss.backward()
+    assert torch.isfinite(logits.grad).all() and float(logits.grad[0, :, 3].abs().sum()) > 0  # the ignored voxel still feeds the Dice sums
