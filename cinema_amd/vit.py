@@ -225,8 +225,11 @@ class Block(nn.Module, _CkptFlag):
                  act_layer: type, mlp_layer: type, qk_norm: bool = False, proj_drop: float = 0.0, attn_drop: float = 0.0,
                  init_values: float | None = None) -> None:
         super().__init__()
-        if drop_path > 0.0 or init_values:
-            raise NotImplementedError("drop_path / LayerScale are fine-tuning options outside the MAE pre-training path.")
+        if init_values:
+            raise NotImplementedError("LayerScale is a fine-tuning option outside the HIP path.")
+        # stochastic depth (fine-tuning configs use 0.1): identity in eval mode like timm's DropPath; the training-mode sampling has no
+        # HIP path yet, so a training-mode forward with drop_path > 0 raises instead of silently training a different model
+        self.drop_path_rate = float(drop_path)
         if mlp_layer is not Mlp and getattr(mlp_layer, "__name__", "") != "Mlp":
             raise NotImplementedError("only the GELU Mlp has a HIP path (SwiGLU is unused by the reference configs).")
         self.norm1 = norm_layer(dim, eps=norm_eps)
@@ -247,6 +250,8 @@ class Block(nn.Module, _CkptFlag):
 
     def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int) -> T.Var:
         """xq: fp32 residual stream [b*tq, c]; xk: bf16 un-normed keys [b*tk, c] or None (``vit.py:589``)."""
+        if self.training and self.drop_path_rate > 0.0:
+            raise NotImplementedError("drop_path > 0 in training mode has no HIP path yet (evaluation, or drop_path = 0).")
         T.mark_params(tp, self._param_list())  # gradient all-reduce of this block may start once its backward ops are launched
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = self.attn.tape_forward(tp, qn, xk, batch)
