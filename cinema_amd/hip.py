@@ -43,7 +43,9 @@ class GemmArgs(C.Structure):
 
 
 GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel", 1: "gemm_mfma_kernel<true, true, true>", 2: "gemm_mfma_kernel<true, false, true>",
-                     3: "gemm_mfma_kernel<false, false, true>", 4: "gemm_mfma_ws_kernel<false, false>"}  # as rocprofv3 prints them
+                     3: "gemm_mfma_kernel<false, false, true>", 4: "gemm_mfma_ws_kernel<false, false>",
+                     5: "gemm_mfma_persist_kernel<true, true>", 6: "gemm_mfma_persist_kernel<true, false>",
+                     7: "gemm_mfma_persist_kernel<false, false>"}  # as rocprofv3 prints them
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (kernel_used, algorithmic_flops, start_event, end_event)
 GEMM_PROFILE: list | None = None
