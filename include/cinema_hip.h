@@ -60,7 +60,7 @@ typedef struct {
   long long workspace_bytes;
   float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
   int kernel_used;            /* OUT: 0 generic FMA; 1/2/3 one-shot 128x128 MFMA kernel for the fwd / dgrad / wgrad operand layouts, 5/6/7 its persistent
-                                 form (default), 4 the 256x128 wave-specialised weight-gradient kernel */
+                                 form (CINEMA_GEMM_PERSIST=1), 4 the 256x128 wave-specialised weight-gradient kernel */
 } cinema_gemm_args;
 int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
 

@@ -21,7 +21,7 @@ for m, n, k in ((10960, 3072, 768), (10960, 768, 3072), (32848, 2048, 512), (328
     y16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
     res = {}
     for mode in ("1", "0", "1", "0"):
-        os.environ["CINEMA_GEMM_ONESHOT"] = mode
+        os.environ["CINEMA_GEMM_PERSIST"] = "0" if mode == "1" else "1"
         res.setdefault(mode, []).append(timeit(lambda: K.gemm(x, w, out=y16, bias=bias)) * 1e6)
     print(f"{m}x{n}x{k}: one-shot {min(res['1']):.1f} us, persistent {min(res['0']):.1f} us")
 
@@ -40,7 +40,7 @@ def run(n):
 
 run(25)
 for mode in ("1", "0", "1", "0", "1", "0"):
-    os.environ["CINEMA_GEMM_ONESHOT"] = mode
+    os.environ["CINEMA_GEMM_PERSIST"] = "0" if mode == "1" else "1"
     run(4)
     t0 = time.perf_counter()
     run(30)
