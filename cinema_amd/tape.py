@@ -545,8 +545,8 @@ def op_sparse_dwconv(tape: Tape, x: Var, geom, weight: torch.nn.Parameter, bias:
         if y.grad is None:
             return
         c = x.data.shape[1]
-        K.sparse_dwconv_bwd_weight(x.data, y.grad, tuple(weight.shape), wv.grad_buffer(tuple(weight.shape)), None if bias is None else bv.grad_buffer((c,)),
-                                   geom)
+        dw, db, dy = wv.grad_buffer(tuple(weight.shape)), None if bias is None else bv.grad_buffer((c,)), y.grad
+        _wgrad_launch(lambda: K.sparse_dwconv_bwd_weight(x.data, dy, tuple(weight.shape), dw, db, geom), x.data, dy)  # off the critical path
         if x.needs_grad:
             x.add_grad(K.sparse_dwconv(y.grad, weight.detach(), None, geom, flip=True))
 
