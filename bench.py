@@ -97,6 +97,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (reference batch_size_per_device, mae/config.yaml:45)")
     ap.add_argument("--size", default="base")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 disables)")
+    ap.add_argument("--prewarm", type=int, default=20, help="untimed steps run in total before the timed region (>= --warmup); 0 for profiling runs")
     ap.add_argument("--force-sync", action="store_true", help="N=1 only: still issue the gradient collectives (RCCL path check)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the per-kernel roofline")
     args = ap.parse_args()
@@ -144,7 +145,7 @@ def main() -> None:
     loss = None
     # steady state needs ~20 steps (caching-allocator growth, clock ramp: 38.7 -> 36.0 ms/step measured between steps 10 and 50); when the
     # caller asks for fewer warm-up steps the difference is run here, untimed, before the W warm-up steps of the contract
-    for i in range(max(0, 20 - args.warmup)):
+    for i in range(max(0, args.prewarm - args.warmup)):
         step(batches[i % 2], 0.75)
     for i in range(args.warmup):
         loss, gnorm, _ = step(batches[i % 2], 0.75)
