@@ -178,17 +178,19 @@ def main() -> None:
 
     # ---- per-kernel roofline: time every GEMM launch with HIP events on the launch stream (extra steps, same workload)
     roofline = None
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:  # EVERY rank steps (the steps contain the gradient collectives); only rank 0 records and reports
         from cinema_amd import tape as T_
 
         side, T_.SIDE_WGRAD = T_.SIDE_WGRAD, False  # one stream while timing single launches: a kernel sharing the chip with the
         step(batches[0], 0.75)                      # side-stream weight gradients would be charged for the overlap
-        K.GEMM_PROFILE = []
+        if rank == 0:
+            K.GEMM_PROFILE = []
         for i in range(args.profile_steps):
             step(batches[i % 2], 0.75)
-        torch.cuda.synchronize()
+        barrier()
         prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
         T_.SIDE_WGRAD = side
+    if rank == 0 and args.profile_steps > 0:
         agg: dict = {}
         for kind, flops, e0, e1, _shape in prof:
             a = agg.setdefault(kind, [0.0, 0.0, 0])
