@@ -156,8 +156,17 @@ def mark_params(tape: "Tape", params: list) -> None:
     hook = PARAMS_DONE_HOOK
     if hook is not None and tape.train:
         def fire() -> None:
-            join_side_stream()  # the block's weight gradients may still be running beside the main stream
-            hook(tape, params)
+            # the block's weight gradients may still be running on the side stream: issue the collective FROM the side stream (after
+            # everything queued on the main stream so far), so that RCCL orders itself behind both without stalling the main stream
+            if SIDE_WGRAD and torch.cuda.is_available():
+                main, side = torch.cuda.current_stream(), side_stream()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    hook(tape, params)
+            else:
+                hook(tape, params)
 
         tape.record(fire)
 
