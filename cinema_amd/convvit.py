@@ -294,7 +294,7 @@ class MultiScaleFusion(nn.Module, _CkptFlag):
         for vol, conv in zip(skips, self.down_convs):
             if isinstance(vol, CompactVolume):  # visible-voxel stem: one row per kept token already, voxels in hierarchical order
                 x = T.op_linear(tp, vol.token_rows(tp), conv.weight, conv.bias, residual=x, w16=T.w_patch_perm(conv.weight, vol.inv_pos),
-                                to_param_layout=T.patch_grad_to_param_perm(conv.weight, vol.pos))
+                                to_param_layout=T.patch_grad_to_param_perm(conv.weight, vol.pos, vol.inv_pos))
                 continue
             geom = K.patch_geom(vol.batch, vol.chans, grid, tuple(conv.kernel_size), vol.strides(), token_idx=None if sel.all_tokens else sel.keep)
             rows = T.op_patch_gather(tp, vol.var, geom)

@@ -135,6 +135,31 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(const float* x, float al
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * alpha;
 }
 
+// Conv weight (out, c, *k) fp32 <-> GEMM operand rows [out][ld] in the patch feature order (*k, c):
+//   direction 0: rows_bf16[o][jj * c + i] = w[(o * c + i) * kvol + jm]   (tail of the row up to ld zero-filled)
+//   direction 1: w_grad[(o * c + i) * kvol + jm] += rows_f32[o][jj * c + i]
+// with jm = jmap ? jmap[jj] : jj (voxel permutation of the visible-voxel stem).  One launch replaces permute + contiguous + cast
+// (forward, every step for every k == s conv) and permute + contiguous + accumulate (end of the backward pass).
+__global__ __launch_bounds__(256) void patch_weight_relayout_kernel(float* w, void* rows, int rows_bf16, int outer, int c, int kvol, int ld, const int* jmap,
+                                                                   int direction) {
+  const long long total = (long long)outer * ld;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int o = (int)(idx / ld), f = (int)(idx - (long long)o * ld);
+    if (f >= kvol * c) {
+      if (direction == 0) { if (rows_bf16) reinterpret_cast<bf16_t*>(rows)[idx] = 0; else reinterpret_cast<float*>(rows)[idx] = 0.f; }
+      continue;
+    }
+    const int jj = f / c, i = f - jj * c;
+    const int jm = jmap ? jmap[jj] : jj;
+    const size_t wi = ((size_t)o * c + i) * kvol + jm;
+    if (direction == 0) {
+      if (rows_bf16) reinterpret_cast<bf16_t*>(rows)[idx] = f2bf(w[wi]); else reinterpret_cast<float*>(rows)[idx] = w[wi];
+    } else {
+      w[wi] += reinterpret_cast<const float*>(rows)[idx];
+    }
+  }
+}
+
 }  // namespace
 
 CINEMA_API int cinema_hip_info(int* out) {
@@ -202,5 +227,14 @@ CINEMA_API int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows,
 CINEMA_API int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream) {
   if (!x || !y || n <= 0) return CINEMA_ERR_BAD_ARG;
   hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, n);
+  return launch_status();
+}
+
+CINEMA_API int cinema_patch_weight_relayout(float* w, void* rows, int rows_is_bf16, int outer, int c, int kvol, int ld, const int* jmap, int direction,
+                                            void* stream) {
+  if (!w || !rows || outer <= 0 || c <= 0 || kvol <= 0 || ld < c * kvol || (direction != 0 && direction != 1)) return CINEMA_ERR_BAD_ARG;
+  if (direction == 1 && rows_is_bf16) return CINEMA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(patch_weight_relayout_kernel, dim3(grid_for((long long)outer * ld, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, rows_is_bf16, outer, c,
+                     kvol, ld, jmap, direction);
   return launch_status();
 }

@@ -96,6 +96,7 @@ _PROTOS = {
     "cinema_segment_mean_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp],
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
+    "cinema_patch_weight_relayout": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "cinema_cast": [_vp, _i, _vp, _i, _ll, _vp],
     "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
     "cinema_gelu_fwd": [_vp, _vp, _ll, _vp],
@@ -295,6 +296,31 @@ def scale(x: torch.Tensor, alpha: float) -> torch.Tensor:
     y = torch.empty_like(x)
     _check(load().cinema_scale_f32(x.data_ptr(), alpha, y.data_ptr(), x.numel(), _stream()), "scale")
     return y
+
+
+def patch_weight_rows(w: torch.Tensor, jmap: torch.Tensor | None = None, pad_to: int = 1) -> torch.Tensor:
+    """Conv weight (out, c, *k) fp32 -> bf16 GEMM operand [out, ld], features ordered (*k, c); ld = kvol*c rounded up to ``pad_to``."""
+    _dev(w, jmap)
+    if w.dtype != torch.float32 or not w.is_contiguous() or (jmap is not None and (jmap.dtype != torch.int32 or jmap.numel() != w[0, 0].numel())):
+        raise HipLibraryError("patch_weight_rows: contiguous fp32 weight, int32 jmap with one entry per kernel voxel")
+    out, c = w.shape[0], w.shape[1]
+    kvol = w[0, 0].numel()
+    ld = (kvol * c + pad_to - 1) // pad_to * pad_to
+    rows = torch.empty((out, ld), dtype=torch.bfloat16, device=w.device)
+    _check(load().cinema_patch_weight_relayout(w.data_ptr(), rows.data_ptr(), 1, out, c, kvol, ld, _p(jmap), 0, _stream()), "patch_weight_relayout")
+    return rows
+
+
+def patch_weight_grad_accumulate(g_rows: torch.Tensor, w_grad: torch.Tensor, jmap: torch.Tensor | None = None) -> None:
+    """w_grad (out, c, *k) fp32 += g_rows fp32 [out, ld] (features (*k, c), padding ignored)."""
+    _dev(g_rows, w_grad, jmap)
+    if (g_rows.dtype != torch.float32 or w_grad.dtype != torch.float32 or not w_grad.is_contiguous() or g_rows.shape[0] != w_grad.shape[0]
+            or (jmap is not None and (jmap.dtype != torch.int32 or jmap.numel() != w_grad[0, 0].numel()))):
+        raise HipLibraryError("patch_weight_grad_accumulate: fp32 tensors, contiguous destination")
+    out, c = w_grad.shape[0], w_grad.shape[1]
+    kvol = w_grad[0, 0].numel()
+    _check(load().cinema_patch_weight_relayout(w_grad.data_ptr(), g_rows.data_ptr(), 0, out, c, kvol, _rowmajor(g_rows, "g_rows"), _p(jmap), 1, _stream()),
+           "patch_weight_relayout")
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, row_idx: torch.Tensor | None = None) -> torch.Tensor:

@@ -228,15 +228,15 @@ def w_plain(weight: torch.nn.Parameter) -> torch.Tensor:
     return WEIGHTS.get((weight,), "plain", lambda: K.cast(weight.detach().reshape(weight.shape[0], -1), BF16))
 
 
+def _hip_layout(fn: Callable, jmap: torch.Tensor | None) -> Callable:
+    """Tag a to-parameter-layout function with what the HIP re-layout kernel needs to add the gradient straight into the flat buffer."""
+    fn.hip_relayout = (jmap,)
+    return fn
+
+
 def w_patch(weight: torch.nn.Parameter) -> torch.Tensor:
-    """k==s conv weight (out, c, *k) -> bf16 [out, (*k, c)] matching the patch-gather feature order."""
-
-    def build() -> torch.Tensor:
-        w = weight.detach()
-        perm = (0, *range(2, w.dim()), 1)
-        return K.cast(w.permute(perm).reshape(w.shape[0], -1).contiguous(), BF16)
-
-    return WEIGHTS.get((weight,), "patch", build)
+    """k==s conv weight (out, c, *k) -> bf16 [out, (*k, c)] matching the patch-gather feature order (one re-layout kernel)."""
+    return WEIGHTS.get((weight,), "patch", lambda: K.patch_weight_rows(weight.detach()))
 
 
 def patch_grad_to_param(weight: torch.nn.Parameter) -> Callable:
@@ -247,23 +247,16 @@ def patch_grad_to_param(weight: torch.nn.Parameter) -> Callable:
         g = g.reshape(shape[0], *shape[2:], shape[1])
         return g.permute(0, nd + 1, *range(1, nd + 1)).contiguous()
 
-    return conv
+    return _hip_layout(conv, None)
 
 
 def w_patch_perm(weight: torch.nn.Parameter, inv_pos: torch.Tensor) -> torch.Tensor:
     """Like :func:`w_patch` for rows whose patch voxels are stored in a permuted order: feature block q of a row holds
     the voxel with raster index ``inv_pos[q]`` (the visible-voxel stem keeps coarser-stage children contiguous)."""
-
-    def build() -> torch.Tensor:
-        w = weight.detach()
-        perm = (0, *range(2, w.dim()), 1)
-        w3 = w.permute(perm).reshape(w.shape[0], -1, w.shape[1])
-        return K.cast(w3[:, inv_pos.long(), :].reshape(w.shape[0], -1).contiguous(), BF16)
-
-    return WEIGHTS.get((weight,), "patch_perm", build)
+    return WEIGHTS.get((weight,), "patch_perm", lambda: K.patch_weight_rows(weight.detach(), jmap=inv_pos))
 
 
-def patch_grad_to_param_perm(weight: torch.nn.Parameter, pos: torch.Tensor) -> Callable:
+def patch_grad_to_param_perm(weight: torch.nn.Parameter, pos: torch.Tensor, inv_pos: torch.Tensor) -> Callable:
     shape = weight.shape
     base = patch_grad_to_param(weight)
 
@@ -271,22 +264,12 @@ def patch_grad_to_param_perm(weight: torch.nn.Parameter, pos: torch.Tensor) -> C
         g3 = g.reshape(shape[0], -1, shape[1])
         return base(g3[:, pos.long(), :].contiguous())  # raster voxel u sits at row block pos[u]
 
-    return conv
+    return _hip_layout(conv, inv_pos)
 
 
 def w_conv_same(weight: torch.nn.Parameter) -> torch.Tensor:
     """Dense conv weight (out, c, *k) -> bf16 [out, ld] in the im2col feature order (*k, c), zero-padded to ld = ceil(taps*c / 8) * 8."""
-
-    def build() -> torch.Tensor:
-        w = weight.detach()
-        perm = (0, *range(2, w.dim()), 1)
-        flat = w.permute(perm).reshape(w.shape[0], -1)
-        ld = (flat.shape[1] + 7) // 8 * 8
-        if ld != flat.shape[1]:
-            flat = torch.nn.functional.pad(flat, (0, ld - flat.shape[1]))
-        return K.cast(flat.contiguous(), BF16)
-
-    return WEIGHTS.get((weight,), "conv_same", build)
+    return WEIGHTS.get((weight,), "conv_same", lambda: K.patch_weight_rows(weight.detach(), pad_to=8))
 
 
 def conv_same_grad_to_param(weight: torch.nn.Parameter) -> Callable:
@@ -297,7 +280,7 @@ def conv_same_grad_to_param(weight: torch.nn.Parameter) -> Callable:
         f = math.prod(shape[1:])
         return base(g[:, :f].contiguous())
 
-    return conv
+    return _hip_layout(conv, None)
 
 
 def w_cat(weights: tuple) -> torch.Tensor:
@@ -843,8 +826,14 @@ class _TapedCall(torch.autograd.Function):
         p_grads = []
         for p in ctx.params:
             pv = ctx.tape.pvars.get(id(p))
-            g = pv.final_grad() if (pv is not None and p.requires_grad) else None
             flat = getattr(p, "_cinema_flat_grad", None)
+            in_flat = flat is not None and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)()
+            tagged = getattr(pv.to_param_layout, "hip_relayout", None) if pv is not None else None
+            if tagged is not None and in_flat and pv.grad is not None and not pv.direct and p.requires_grad:
+                K.patch_weight_grad_accumulate(pv.grad.view(p.shape[0], -1), flat.view(p.shape), tagged[0])  # re-layout + add, one kernel
+                p_grads.append(None)
+                continue
+            g = pv.final_grad() if (pv is not None and p.requires_grad) else None
             if g is not None and flat is not None and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)():
                 # the optimiser's flat buffer: add here, on the current stream, instead of through autograd's AccumulateGrad node (which
                 # runs on the parameter's creation stream - a cross-stream launch that breaks HIP-graph capture of the step)

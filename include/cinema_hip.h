@@ -191,6 +191,12 @@ int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, flo
 /* y = alpha * x (fp32) */
 int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream);
 
+/* k == s / dense conv weights (out, c, *k) fp32 <-> GEMM operand rows [out][ld] in the patch feature order (*k, c)  (the re-layout the
+ * reference gets for free from cuDNN/MIOpen's own filter layouts; here it feeds cinema_gemm_bf16):
+ *   direction 0: rows (bf16 or fp32) <- w, columns beyond kvol*c zero-filled;   direction 1: w += rows (fp32), the gradient way back.
+ *   jmap[kvol] (optional): row feature block jj holds kernel voxel jmap[jj] (visible-voxel stem ordering). */
+int cinema_patch_weight_relayout(float* w, void* rows, int rows_is_bf16, int outer, int c, int kvol, int ld, const int* jmap, int direction, void* stream);
+
 /* elementwise: dtype codes as above */
 int cinema_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
 /* dst[c][r] = src[r][c] (bf16 out); src fp32 or bf16 */

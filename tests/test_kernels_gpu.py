@@ -349,6 +349,32 @@ def test_patch_gather_channels_last_with_token_subset() -> None:
     assert torch.equal(dst, O.unpatchify(ref_dst.reshape(b, -1, 4 * c).cpu(), patch, grid).movedim(1, -1).to(DEV))
 
 
+@pytest.mark.parametrize(("shape", "pad_to", "permuted"), [((32, 5, 4, 4, 1), 1, True), ((16, 1, 3, 3, 3), 8, False), ((24, 8, 2, 2), 1, False)])
+def test_patch_weight_relayout(shape: tuple, pad_to: int, permuted: bool) -> None:
+    """Conv weight (out, c, *k) <-> GEMM operand rows in (*k, c) feature order: bf16 rounding only one way, exact fp32 adds the other way."""
+    w = rnd(*shape, dtype=torch.float32, seed=70)
+    kvol = math.prod(shape[2:])
+    jmap = torch.randperm(kvol, generator=torch.Generator().manual_seed(3)).to(torch.int32).to(DEV) if permuted else None
+    rows = K.patch_weight_rows(w, jmap=jmap, pad_to=pad_to)
+    ref = w.reshape(shape[0], shape[1], kvol).permute(0, 2, 1)  # [out, kvol, c]
+    if permuted:
+        ref = ref[:, jmap.long(), :]
+    ref = ref.reshape(shape[0], -1)
+    f = ref.shape[1]
+    assert rows.shape[1] == (f + pad_to - 1) // pad_to * pad_to
+    assert torch.equal(rows[:, :f], ref.to(torch.bfloat16)) and not rows[:, f:].any()
+    g_rows = rnd(shape[0], rows.shape[1], dtype=torch.float32, seed=71)
+    acc = rnd(*shape, dtype=torch.float32, seed=72)
+    expect = g_rows[:, :f].reshape(shape[0], kvol, shape[1])
+    if permuted:
+        inv = torch.empty_like(jmap)
+        inv[jmap.long()] = torch.arange(kvol, dtype=torch.int32, device=DEV)
+        expect = expect[:, inv.long(), :]
+    expect = acc + expect.permute(0, 2, 1).reshape(shape)
+    K.patch_weight_grad_accumulate(g_rows, acc, jmap)
+    assert torch.equal(acc, expect)
+
+
 def test_row_copy_cast_transpose_gelu() -> None:
     src = rnd(10, 32, dtype=torch.float32, seed=60)
     add = rnd(7, 32, dtype=torch.float32, seed=61)
