@@ -431,7 +431,7 @@ class ConvViT(nn.Module):
             cls, feats, _ = self._features(tp, views, images, mask_dict)
             return [cls] + [feats[v] for v in views], []
 
-        res = T.taped_call(run, [], [p for p in self.parameters() if p.requires_grad])
+        res = T.taped_call(run, [], T.trainable_params(self))
         return {k: r.reshape(batch, -1, r.shape[-1]) for k, r in zip(["cls", *views], res)}
 
     def forward(self, image_dict: dict, mask_dict: dict | None = None, reduce: str = "all") -> torch.Tensor:
@@ -461,7 +461,7 @@ class ConvViT(nn.Module):
                 k += 1
             return [T.op_scale(tp, acc, 1.0 / k)], []
 
-        (logits,) = T.taped_call(run, [], [p for p in self.parameters() if p.requires_grad])
+        (logits,) = T.taped_call(run, [], T.trainable_params(self))
         return logits.reshape(batch, -1)
 
     @classmethod

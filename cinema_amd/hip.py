@@ -96,6 +96,9 @@ _PROTOS = {
     "cinema_segment_mean_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp],
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
+    "cinema_stream_fork": [_vp, _vp],
+    "cinema_marker_record": [_vp],
+    "cinema_marker_done": [_ll],
     "cinema_patch_weight_relayout": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "cinema_cast": [_vp, _i, _vp, _i, _ll, _vp],
     "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
@@ -131,7 +134,7 @@ def load():  # noqa: ANN201
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints")) else C.c_int
+        fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints", "_marker_record")) else C.c_int
     _lib = lib
     return lib
 
@@ -142,8 +145,49 @@ def _check(rc: int, what: str) -> None:
         raise HipLibraryError(f"{what} failed: {kind}")
 
 
+_raw_current_stream = torch._C._cuda_getCurrentRawStream  # (device index) -> hipStream_t as int; ~0.2 us, torch.cuda.current_stream() costs ~8 us
+_current_device = torch._C._cuda_getDevice
+_STREAM_OVERRIDE: int | None = None
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The stream every launch goes to: torch's current stream of the current device, or the override set by :func:`on_stream`."""
+    return _STREAM_OVERRIDE if _STREAM_OVERRIDE is not None else _raw_current_stream(_current_device())
+
+
+class on_stream:  # noqa: N801
+    """``with on_stream(raw_handle):`` sends the launches of this module to another stream without touching torch's current stream
+    (used for the side-stream weight-gradient launches; their scratch comes from :func:`_workspace`, which is per stream, and their
+    outputs are caller-owned, so nothing is allocated under the wrong stream).  One launching thread at a time."""
+
+    def __init__(self, raw: int) -> None:
+        self.raw = raw
+
+    def __enter__(self) -> None:
+        global _STREAM_OVERRIDE  # noqa: PLW0603
+        self.prev, _STREAM_OVERRIDE = _STREAM_OVERRIDE, self.raw
+
+    def __exit__(self, *exc) -> None:  # noqa: ANN002
+        global _STREAM_OVERRIDE  # noqa: PLW0603
+        _STREAM_OVERRIDE = self.prev
+
+
+def stream_fork(from_stream: int, to_stream: int) -> None:
+    _check(load().cinema_stream_fork(from_stream, to_stream), "stream_fork")
+
+
+def marker_record(stream: int) -> int:
+    ticket = load().cinema_marker_record(stream)
+    if ticket < 0:
+        raise HipLibraryError(f"marker_record failed: {ticket}")
+    return ticket
+
+
+def marker_done(ticket: int) -> bool:
+    rc = load().cinema_marker_done(ticket)
+    if rc < 0:
+        raise HipLibraryError(f"marker_done({ticket}) failed: {rc}")
+    return rc == 1
 
 
 def _p(t: torch.Tensor | None) -> int | None:
@@ -164,17 +208,27 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
     return t.stride(0)
 
 
-_TAIL_WS: dict = {}
+_WORKSPACES: dict = {}
+_RETIRED_WORKSPACES: list = []
+
+
+def _workspace(tag: str, n_floats: int, device: torch.device) -> torch.Tensor:
+    """fp32 scratch per (tag, device, stream), grown on demand and kept: every use is one stream-ordered kernel sequence (producer ->
+    reduce / fix-up), so a single buffer per stream serves all launches on it, and a launch redirected by :func:`on_stream` never
+    borrows memory the allocator believes to belong to torch's current stream.  Outgrown buffers are parked, not freed (a kernel on the
+    other stream may still be reading them; there are only a handful of growth steps per process)."""
+    key = (tag, device.index, _stream())
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < n_floats:
+        if ws is not None:
+            _RETIRED_WORKSPACES.append(ws)
+        ws = _WORKSPACES[key] = torch.empty(n_floats, dtype=torch.float32, device=device)
+    return ws
 
 
 def _tail_workspace(device: torch.device) -> torch.Tensor:
-    """32 MiB of fp32 scratch per (device, stream): 512 workgroup slots x one 128x128 partial tile.  Use is stream-ordered
-    (GEMM kernel -> fix-up kernel), so one buffer per stream serves every GEMM launched on it."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _TAIL_WS.get(key)
-    if ws is None:
-        ws = _TAIL_WS[key] = torch.empty(512 * 128 * 128, dtype=torch.float32, device=device)
-    return ws
+    """32 MiB: 512 workgroup slots x one 128x128 fp32 partial tile (split-tail GEMM -> fix-up kernel)."""
+    return _workspace("tail", 512 * 128 * 128, device)
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -228,8 +282,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         g.a_rowsum = a_rowsum.data_ptr()
     ws = None
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
-        ws = torch.empty(split_k * m * n, dtype=torch.float32, device=a.device)
-        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        ws = _workspace("splitk", split_k * m * n, a.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), split_k * m * n * 4
     elif split_k == 1 and k >= 1536:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
         ws = _tail_workspace(a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -355,7 +409,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: 
     dx16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
         raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
-    ws = torch.empty(2048 * 2 * c, dtype=torch.float32, device=x.device) if (dgamma is not None or dbeta is not None) else None
+    ws = _workspace("ln_bwd", 2048 * 2 * c, x.device) if (dgamma is not None or dbeta is not None) else None
     _check(load().cinema_layernorm_bwd(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
                                        int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
                                        rstd.data_ptr(), rows, c, act, _p(dx_residual), _p(dx32), _p(dx16), c, _p(dgamma), _p(dbeta),
@@ -429,7 +483,7 @@ def dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dbias
     """dw (fp32, torch layout (c,1,*k)) and dbias (fp32 [c]) are accumulated in place."""
     _dev(x, dy, dw, dbias)
     b, X, Y, Z, c, kx, ky, kz = _dw_dims(x, tuple(dw.shape[2:]))  # noqa: N806
-    ws = torch.empty(1024 * c * (kx * ky * kz + 1), dtype=torch.float32, device=x.device)  # per-block partial slabs (deterministic two-pass)
+    ws = _workspace("dwconv_wgrad", 1024 * c * (kx * ky * kz + 1), x.device)  # per-block partial slabs (deterministic two-pass)
     _check(load().cinema_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), ws.numel() * 4, b, X, Y, Z, c, kx, ky,
                                            kz, _stream()), "dwconv_bwd_weight")
 
@@ -515,7 +569,7 @@ def sparse_dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, w_shape: tuple, 
     ks = tuple(w_shape[2:])
     kx, ky, kz = (1,) * (3 - len(ks)) + ks
     need = load().cinema_sparse_dwconv_wgrad_workspace_bytes(geom.n_tok, c, kx, ky, kz)
-    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    ws = _workspace("sparse_wgrad", (need + 3) // 4, x.device)
     _check(load().cinema_sparse_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), need, C.byref(geom), c, kx, ky, kz,
                                                   _stream()), "sparse_dwconv_bwd_weight")
 

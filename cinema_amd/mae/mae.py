@@ -244,7 +244,7 @@ class CineMA(nn.Module):
             out["views"], out["metric_keys"] = list(preds), list(metrics)
             return [loss], [p.data for p in preds.values()] + list(metrics.values())
 
-        res = T.taped_call(run, [], [p for p in self.parameters() if p.requires_grad])
+        res = T.taped_call(run, [], T.trainable_params(self))
         loss = res[0].reshape(())
         n_v = len(out["views"])
         pred_dict = {}
@@ -271,7 +271,7 @@ class CineMA(nn.Module):
                 outs.append(self.enc_fusion_dict[v].tape_forward(tp, skips_all[v], parts[i + 1], sels[v], grids[v], out_f32=True))
             return outs, []
 
-        res = T.taped_call(run, [], [p for p in self.parameters() if p.requires_grad])
+        res = T.taped_call(run, [], T.trainable_params(self))
         return {k: r.reshape(batch, -1, r.shape[-1]) for k, r in zip(["cls", *views], res)}
 
     @classmethod

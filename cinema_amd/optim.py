@@ -159,7 +159,7 @@ class TrainStep:
     (``cinema/mae/pretrain.py:242-269``) without its per-step host synchronisations."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, clip_grad: float | None = 5.0,
-                 synchronizer=None) -> None:  # noqa: ANN001
+                 synchronizer=None, hip_graph: bool = False) -> None:  # noqa: ANN001
         self.model = model
         self.flat = FlatModel(model, weight_decay)
         self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas)
@@ -167,8 +167,17 @@ class TrainStep:
         self.sync = synchronizer
         if self.sync is not None:
             self.sync.attach(self.flat)
+        # hip_graph: forward + backward (~2000 launches on two streams) are captured once per input signature and replayed as one HIP
+        # graph, which takes the host out of the step; clip + AdamW stay eager (their scalars change every step).  Single process only:
+        # the overlapped RCCL collectives are issued from Python hooks in the backward pass.
+        self.hip_graph = hip_graph
+        self._graphs: dict = {}
+        if hip_graph and synchronizer is not None:
+            raise ValueError("hip_graph=True captures the single-process step; the data-parallel step runs eagerly")
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
+        if self.hip_graph and enc_mask_dict is None and n_accum_steps == 1 and update_grad:
+            return self._graph_step(image_dict, enc_mask_ratio)
         loss, _, _, metrics = self.model(image_dict, enc_mask_ratio, enc_mask_dict=enc_mask_dict)
         if self.sync is not None:
             self.sync.arm(update_grad)  # on the micro-step that ends with the optimiser update, blocks all-reduce as their gradients complete
@@ -180,3 +189,35 @@ class TrainStep:
             grad_norm = self.optimizer.step(self.clip_grad)
             self.optimizer.zero_grad()
         return loss.detach(), grad_norm, metrics
+
+    # ------------------------------------------------------------------------------------------------ HIP-graph step
+    def _capture(self, image_dict: dict, enc_mask_ratio: float) -> tuple:
+        static = {k: v.clone() for k, v in image_dict.items()}
+        self.optimizer.zero_grad()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on a non-default stream: per-stream workspaces, allocator pools, neighbour lists
+            for _ in range(2):
+                loss, _, _, _ = self.model(static, enc_mask_ratio)
+                loss.backward()
+            self.optimizer.zero_grad()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            loss, _, _, metrics = self.model(static, enc_mask_ratio)
+            loss.backward()
+        return graph, static, loss.detach(), {k: v.detach() for k, v in metrics.items()}
+
+    def _graph_step(self, image_dict: dict, enc_mask_ratio: float):  # noqa: ANN202
+        key = (float(enc_mask_ratio), tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(image_dict.items())))
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._graphs[key] = self._capture(image_dict, enc_mask_ratio)
+        graph, static, loss, metrics = entry
+        for k, v in image_dict.items():
+            if v.data_ptr() != static[k].data_ptr():
+                static[k].copy_(v, non_blocking=True)
+        graph.replay()  # random masks are drawn inside the graph (torch's graph-safe Philox offsets advance per replay)
+        grad_norm = self.optimizer.step(self.clip_grad)
+        self.optimizer.zero_grad()
+        return loss, grad_norm, metrics  # static output buffers: overwritten by the next replay

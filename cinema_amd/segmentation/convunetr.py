@@ -216,7 +216,7 @@ class ConvUNetR(nn.Module):
                 outs.append(T.op_linear(tp, T.op_cast_bf16(tp, y.var), head.weight, head.bias, out_f32=True))
             return outs, []
 
-        res = T.taped_call(run, [], [p for p in self.parameters() if p.requires_grad])
+        res = T.taped_call(run, [], T.trainable_params(self))
         return {v: r.reshape(batch, *images[v].shape[2:], -1).movedim(-1, 1).contiguous() for v, r in zip(views, res)}
 
     @classmethod

@@ -131,7 +131,7 @@ _SIDE_STREAMS: dict = {}
 
 
 def side_stream() -> "torch.cuda.Stream":
-    dev = torch.cuda.current_device()
+    dev = torch._C._cuda_getDevice()
     st = _SIDE_STREAMS.get(dev)
     if st is None:
         st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
@@ -299,6 +299,14 @@ def b_cat(biases: tuple) -> torch.Tensor:
     return WEIGHTS.get(tuple(biases), "bcat", lambda: torch.cat(ds, dim=0))
 
 
+def trainable_params(module: torch.nn.Module) -> list:
+    """The module's trainable parameters without walking the module tree on every step (the tree is static; requires_grad is not)."""
+    pl = module.__dict__.get("_cinema_param_list")
+    if pl is None:
+        pl = module.__dict__["_cinema_param_list"] = list(module.parameters())
+    return [p for p in pl if p.requires_grad]
+
+
 def _split_k(m_red: int, n_out: int, k_out: int) -> int:
     tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
     want = max(1, 512 // tiles)
@@ -310,17 +318,18 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
     are the activation / gradient tensors the launch reads: they were allocated on the main stream, so they are kept alive until the
     backward pass joins the side stream (a closure may drop its last reference right away and the allocator would reuse the memory)."""
     if SIDE_WGRAD and operands[0].is_cuda:
-        main, side = torch.cuda.current_stream(), side_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        with torch.cuda.stream(side):  # the split-K workspace is allocated under the side stream too
-            side.wait_event(ev)
+        side = side_stream().cuda_stream
+        K.stream_fork(K._stream(), side)
+        with K.on_stream(side):  # raw redirection: no torch stream context, no event objects (this runs ~200x per step)
             fn()
-            done = torch.cuda.Event()
-            done.record(side)
-        _SIDE_KEEP.append((done, operands))  # cheaper than record_stream (allocator events on every free of these blocks)
-        while _SIDE_KEEP and _SIDE_KEEP[0][0].query():  # finished launches give their operands back (holding everything to the end of
-            _SIDE_KEEP.popleft()                        # the backward pass kept ~4 GB more live and cost 2 ms/step of cache locality)
+        if torch._C._cuda_isCurrentStreamCapturing():  # HIP-graph capture: events cannot be queried; hold the operands until the join
+            _SIDE_KEEP.append((None, operands))
+            return
+        _SIDE_KEEP.append((K.marker_record(side), operands))  # cheaper than record_stream (allocator events on every free of these blocks)
+        while _SIDE_KEEP and (len(_SIDE_KEEP) > 2048 or _SIDE_KEEP[0][0] is None or K.marker_done(_SIDE_KEEP[0][0])):
+            if len(_SIDE_KEEP) > 2048:                # finished launches give their operands back (holding everything to the end of the
+                side_stream().synchronize()           # backward pass kept ~4 GB more live and cost 2 ms/step of cache locality); the
+            _SIDE_KEEP.popleft()                      # marker ring holds 4096 tickets
         return
     fn()
 

@@ -191,6 +191,16 @@ int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, flo
 /* y = alpha * x (fp32) */
 int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream);
 
+/* Stream ordering (no reference counterpart: torch hides its streams; the reference runs one).  The host launches the weight-gradient
+ * GEMMs of the backward pass on a second stream; these three calls are the fork / completion bookkeeping, on per-device event rings.
+ *   cinema_stream_fork:   to_stream waits for everything queued on from_stream so far.
+ *   cinema_marker_record: returns a ticket (>= 0) that completes when everything queued on `stream` so far has run; at most 4096
+ *                         tickets may be outstanding per device.
+ *   cinema_marker_done:   1 = complete, 0 = still running, < 0 = error. */
+int cinema_stream_fork(void* from_stream, void* to_stream);
+long long cinema_marker_record(void* stream);
+int cinema_marker_done(long long ticket);
+
 /* k == s / dense conv weights (out, c, *k) fp32 <-> GEMM operand rows [out][ld] in the patch feature order (*k, c)  (the re-layout the
  * reference gets for free from cuDNN/MIOpen's own filter layouts; here it feeds cinema_gemm_bf16):
  *   direction 0: rows (bf16 or fp32) <- w, columns beyond kvol*c zero-filled;   direction 1: w += rows (fp32), the gradient way back.
