@@ -85,6 +85,12 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
 // a LOAD half and an APPLY half: the staged tile epilogue issues the loads of all its sub-blocks up front, so the residual / GELU-input
 // reads are in flight while the accumulators go through LDS (as one function the loads sat in the dependency chain of every 32x32
 // sub-block: +20 us for a bias, +130 us for bias + fp32 residual on the 32848x2048 decoder GEMM).
+#ifdef CINEMA_GEMM_TIMING  // dev build only (tools/gemm_phase_timing.py): per-workgroup phase timestamps of the one-shot kernel
+__device__ long long* g_gemm_timing = nullptr;
+#define GEMM_STAMP(i) do { if (g_gemm_timing && threadIdx.x == 0) g_gemm_timing[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define GEMM_STAMP(i) do { } while (0)
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int W>
 struct EpiPre {   // plain vector members (arrays inside the struct were left in scratch memory by the compiler)
@@ -178,105 +184,89 @@ __device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, floa
   epi_apply<W>(p, m, n0, v, bv, e);
 }
 
-// General fused epilogue of one wave tile through the LDS staging block: W = 4 columns per lane (fp32 output, 4 row passes per 32x32
-// sub-block) or 8 (bf16 output, 2 passes).  Operand loads of ALL sub-blocks first, then stage / apply / store sub-block by sub-block.
-template <int MI, int W>
-__device__ __forceinline__ void staged_general_epilogue(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, bool add_bias, float* stg) {
-  constexpr int PASSES = W == 4 ? 4 : 2, RPP = 32 / PASSES, LPR = 32 / W;  // rows per pass, lanes per row
+// Epilogue classes of the 128x128 kernel, fixed at compile time.  With every flag tested at run time the kernel was 69.5 KB of code - more
+// than the 64 KiB instruction cache its CU pair shares - and a workgroup spent 4.3 us (plain bf16) to 7.4 us (GELU + pre-activation) in an
+// epilogue whose arithmetic takes a few hundred cycles (per-phase timestamps, tools/gemm_phase_timing.py); with the flags folded the same
+// code is a fraction of that size.  The host (cinema_gemm_bf16) maps the argument combination to a class; GENERAL keeps all of them.
+enum { EPI_GENERAL = 0, EPI_BF16 = 1, EPI_BF16_GELU = 2, EPI_BF16_GELU_GRAD = 3, EPI_F32 = 4 };
+template <int EPI>
+__device__ __forceinline__ GemmP epi_fold(GemmP p) {  // a by-value copy with the fields the class fixes set to constants (the compiler folds the tests)
+  if (EPI == EPI_GENERAL) return p;
+  p.row_mask = nullptr; p.res_bf16 = nullptr; p.accumulate = 0;
+  if (EPI == EPI_BF16) { p.out_f32 = 0; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; p.res_f32 = nullptr; }
+  if (EPI == EPI_BF16_GELU) { p.out_f32 = 0; p.act = 1; p.gelu_in = nullptr; p.res_f32 = nullptr; }                     // bias + GELU, optional pre-activation out
+  if (EPI == EPI_BF16_GELU_GRAD) { p.out_f32 = 0; p.act = 0; p.aux_out = nullptr; p.res_f32 = nullptr; p.bias = nullptr; }  // dY * GELU'(pre-activation)
+  if (EPI == EPI_F32) { p.out_f32 = 1; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; }                           // optional bias and fp32 residual
+  return p;
+}
+
+// Fused epilogue of one 64x64 wave tile of the 128x128 kernel through LDS.  All four 32x32 accumulator blocks are staged at once (16 KiB
+// per wave: the two operand stages are free after the loop's last barrier), so there is ONE LDS write -> read turn-around per tile instead
+// of one per 32x32 block (measured: 0.6-0.9 us each under the other workgroup's loop traffic), and a lane then owns W = 8 (bf16 out) or
+// 4 (fp32 out) consecutive columns of one row: every store instruction writes whole 128- / 256-byte row segments.  Staging layout:
+// [64 rows][16 chunks of 16 B], chunk index XORed with (row & 15): the 16 lanes of a ds_write_b128 group (16 rows, one chunk column) and
+// of a ds_read_b128 group (1-2 rows, 16 chunks) both touch 16 distinct chunks.  Operand loads (bias, residual, GELU input) of all row
+// passes are issued before the staging so that they are in flight during it.  ws_base != nullptr: plain fp32 partial tile (split-K slab
+// or split-tail slice) instead of the fused epilogue.
+template <int W>
+__device__ __forceinline__ void tile_epilogue_rows(const GemmP& p, const float16v (&acc)[2][2], int mw, int nw, int lane, bool add_bias, float* stg,
+                                                   float* ws_base, long long ws_ld) {
+  constexpr int LPR = 64 / W, RPP = 64 / LPR, PASSES = 64 / RPP;  // lanes per row, rows per pass, passes
   const int ml = lane & 31, hi = lane >> 5;
-  const int rl = lane / LPR, cl = (lane % LPR) * W;  // this lane's row within a pass and first column within the sub-block
-  float bv[2][W];
-  EpiPre<W> pre[MI][2][PASSES];
+  const int rl = lane / LPR, cl = (lane % LPR) * W;
+  const int n = nw + cl;
+  float bv[W];
+  EpiPre<W> pre[PASSES];
+  if (!ws_base) {
+    epi_load_bias<W>(p, n, add_bias, bv);
 #pragma unroll
-  for (int j = 0; j < 2; j++) epi_load_bias<W>(p, nw + j * 32 + cl, add_bias, bv[j]);
+    for (int pss = 0; pss < PASSES; pss++) {
+      const int m = mw + pss * RPP + rl;
+      if (m < p.m && n < p.n) epi_load<W>(p, m, n, pre[pss]);
+    }
+  }
 #pragma unroll
-  for (int i = 0; i < MI; i++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int pss = 0; pss < PASSES; pss++) {
-        const int m = mw + i * 32 + pss * RPP + rl, n = nw + j * 32 + cl;
-        if (m < p.m && n < p.n) epi_load<W>(p, m, n, pre[i][j][pss]);
-      }
-#pragma unroll
-  for (int i = 0; i < MI; i++) {
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      if (nw + j * 32 >= p.n) continue;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int col4 = 2 * q + hi;
-        *reinterpret_cast<float4*>(stg + ml * 32 + ((col4 ^ (ml & 7)) << 2)) =
+      for (int q = 0; q < 4; q++)
+        *reinterpret_cast<float4*>(stg + (i * 32 + ml) * 64 + (((j * 8 + 2 * q + hi) ^ (ml & 15)) << 2)) =
             make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-      }
 #pragma unroll
-      for (int pss = 0; pss < PASSES; pss++) {
-        const int r = pss * RPP + rl;
-        const int m = mw + i * 32 + r, n = nw + j * 32 + cl;
-        float v[W];
+  for (int pss = 0; pss < PASSES; pss++) {
+    const int r = pss * RPP + rl;
+    const int m = mw + r;
+    float v[W];
 #pragma unroll
-        for (int c = 0; c < W / 4; c++) {
-          const float4 t = *reinterpret_cast<const float4*>(stg + r * 32 + ((((cl >> 2) + c) ^ (r & 7)) << 2));
-          v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
-        }
-        if (m < p.m && n < p.n) epi_apply<W>(p, m, n, v, bv[j], pre[i][j][pss]);
+    for (int c = 0; c < W / 4; c++) {
+      const float4 t = *reinterpret_cast<const float4*>(stg + r * 64 + ((((cl >> 2) + c) ^ (r & 15)) << 2));
+      v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+    }
+    if (m < p.m && n < p.n) {
+      if (ws_base) {
+#pragma unroll
+        for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+      } else {
+        epi_apply<W>(p, m, n, v, bv, pre[pss]);
       }
     }
   }
 }
 
-// Coalesced epilogue of one wave tile (MI x 2 accumulator tiles of 32x32): every 32x32 fp32 block goes through a private
-// 4 KiB LDS staging area (XOR-swizzled float4 columns, no padding) so that a lane ends up with 4 (fp32 out) or 8 (bf16 out)
-// CONSECUTIVE columns of one row and the wave writes whole 64/128-byte row segments.  The direct register epilogue wrote
-// 8 bytes into 64 different cache lines per store instruction and dominated short-K GEMMs (K-sweep intercept 34-48 us).
-// SIMPLE: fp32 output with at most alpha and an fp32 residual (the weight-gradient kernel): keeps the fully unrolled epilogue small - with the
-// general one the compiler left the (i, j) loop rolled, indexed the accumulators dynamically and moved all 128 of them through scratch.
-template <int MI, bool SIMPLE = false>
-__device__ __forceinline__ void store_wave_tile_staged(const GemmP& p, const float16v (&acc)[MI][2], int mw, int nw, int lane, int z, float* stg,
-                                                       float* ws_base = nullptr, long long ws_ld = 0) {
-  // fp32 partial destination: an explicit one (split-tail slice), else the split-K slab of slice z
-  if (!ws_base && p.ws) { ws_base = p.ws + (size_t)z * p.m * p.n; ws_ld = p.n; }
-  const bool to_ws = ws_base != nullptr;
-  const bool add_bias = z == 0;
-  if (!SIMPLE && !to_ws) {
-    if (p.out_f32) staged_general_epilogue<MI, 4>(p, acc, mw, nw, lane, add_bias, stg);
-    else staged_general_epilogue<MI, 8>(p, acc, mw, nw, lane, add_bias, stg);
-    return;
-  }
-  const int ml = lane & 31, hi = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < MI; i++) {
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      if (nw + j * 32 >= p.n) continue;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int col4 = 2 * q + hi;
-        *reinterpret_cast<float4*>(stg + ml * 32 + ((col4 ^ (ml & 7)) << 2)) =
-            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-      }
-      const int mb = mw + i * 32, nb = nw + j * 32;
-      {
-#pragma unroll
-        for (int pss = 0; pss < 4; pss++) {
-          const int r = pss * 8 + (lane >> 3), col4 = lane & 7;
-          const float4 t = *reinterpret_cast<const float4*>(stg + r * 32 + ((col4 ^ (r & 7)) << 2));
-          const int m = mb + r, n = nb + col4 * 4;
-          if (m < p.m && n < p.n) {
-            if (to_ws) {
-              *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n) = t;
-            } else if (SIMPLE) {
-              float4 o = make_float4(t.x * p.alpha, t.y * p.alpha, t.z * p.alpha, t.w * p.alpha);
-              if (p.res_f32) {
-                const float4 r = *reinterpret_cast<const float4*>(p.res_f32 + (size_t)m * p.ld_res + n);
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-              }
-              *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.d) + (size_t)m * p.ldd + n) = o;
-            }
-          }
-        }
-      }
-    }
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, const float16v (&acc)[2][2], int mw, int nw, int lane, int z, float* stg, float* ws_base = nullptr,
+                                              long long ws_ld = 0) {
+  if (!ws_base && p.ws) { ws_base = p.ws + (size_t)z * p.m * p.n; ws_ld = p.n; }  // split-K slab of slice z
+  if (ws_base) { tile_epilogue_rows<4>(p, acc, mw, nw, lane, false, stg, ws_base, ws_ld); return; }
+  const GemmP q = epi_fold<EPI>(p);
+  if (EPI == EPI_GENERAL) {
+    if (q.out_f32) tile_epilogue_rows<4>(q, acc, mw, nw, lane, z == 0, stg, nullptr, 0);
+    else tile_epilogue_rows<8>(q, acc, mw, nw, lane, z == 0, stg, nullptr, 0);
+  } else if (EPI == EPI_F32) {
+    tile_epilogue_rows<4>(q, acc, mw, nw, lane, z == 0, stg, nullptr, 0);
+  } else {
+    tile_epilogue_rows<8>(q, acc, mw, nw, lane, z == 0, stg, nullptr, 0);
   }
 }
 
@@ -446,6 +436,7 @@ struct TileIO {
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
 
+
 // XCD-aware work order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private 4 MiB L2, so
 // neighbouring ids never share a cache: with the plain row-major map the 6 column tiles of one A row block were fetched
 // by 6 different L2s (PMC: fabric reads 3-4x the operand bytes).  xcd_remap() hands XCD x the CONTIGUOUS logical range
@@ -461,8 +452,9 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
   tm = first_m + in_g - tn * gsz;
 }
 
-template <bool A_KMAJ, bool B_KMAJ, bool GLDS>
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
+  constexpr bool GLDS = true;  // operands always arrive by LDS-DMA (the register-staged variant lost every A/B and was removed)
   using AIO = TileIO<A_KMAJ>;
   using BIO = TileIO<B_KMAJ>;
   constexpr int STAGE = AIO::BYTES + BIO::BYTES;
@@ -496,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
   tile_of(tile, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   if (kt_begin >= kt_end) return;
+  GEMM_STAMP(0);
 
   float16v acc[2][2];
 #pragma unroll
@@ -507,20 +500,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
 
   float rs[2] = {0.f, 0.f};
   const bool do_rowsum = p.a_rowsum != nullptr && wn == 0 && n0 == 0;  // one wave column of the first n-tile covers every A row once
-  uint4 ra[4], rb[4];
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
-  if (GLDS) {
-    AIO::glds(smem, p.a, p.lda, m0, p.m, kt_begin * BK, p.k, lane, wave_u, zero_page);
-    BIO::glds(smem + AIO::BYTES, p.b, p.ldb, n0, p.n, kt_begin * BK, p.k, lane, wave_u, zero_page);
-  } else {
-    AIO::load(ra, p.a, p.lda, m0, p.m, kt_begin * BK, p.k, tid);
-    BIO::load(rb, p.b, p.ldb, n0, p.n, kt_begin * BK, p.k, tid);
-    AIO::store(ra, smem, tid);
-    BIO::store(rb, smem + AIO::BYTES, tid);
-  }
+  AIO::glds(smem, p.a, p.lda, m0, p.m, kt_begin * BK, p.k, lane, wave_u, zero_page);
+  BIO::glds(smem + AIO::BYTES, p.b, p.ldb, n0, p.n, kt_begin * BK, p.k, lane, wave_u, zero_page);
   if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  GEMM_STAMP(1);
 
   for (int kt = kt_begin; kt < kt_end; kt++) {
     const int cur = (kt - kt_begin) & 1;
@@ -528,14 +514,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
     const char* sb = sa + AIO::BYTES;
     const bool more = kt + 1 < kt_end;
     if (more) {
-      if (GLDS) {
-        char* na = smem + (cur ^ 1) * STAGE;
-        AIO::glds(na, p.a, p.lda, m0, p.m, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
-        BIO::glds(na + AIO::BYTES, p.b, p.ldb, n0, p.n, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
-      } else {
-        AIO::load(ra, p.a, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid);
-        BIO::load(rb, p.b, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid);
-      }
+      char* na = smem + (cur ^ 1) * STAGE;
+      AIO::glds(na, p.a, p.lda, m0, p.m, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
+      BIO::glds(na + AIO::BYTES, p.b, p.ldb, n0, p.n, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
@@ -550,15 +531,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
       if (!A_KMAJ && do_rowsum) { rs[0] += frag_sum8(fa[0]); rs[1] += frag_sum8(fa[1]); }  // VALU work in the shadow of the MFMAs
     }
-    if (more && !GLDS) {
-      char* na = smem + (cur ^ 1) * STAGE;
-      AIO::store(ra, na, tid);
-      BIO::store(rb, na + AIO::BYTES, tid);
-    }
     if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA must have landed before anyone reads it
     __syncthreads();
   }
 
+  GEMM_STAMP(2);
   if (!A_KMAJ && do_rowsum) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -567,8 +544,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
       if (lane < 32 && m < p.m) unsafeAtomicAdd(p.a_rowsum + m, t);
     }
   }
-  // epilogue: the stage buffers are free after the last barrier -> 4 KiB of them per wave stage the coalesced stores
-  if (p.accumulate && !p.ws) {  // atomic fallback (no workspace given): register epilogue
+  // epilogue: both operand stages (64 KiB) are free after the last barrier -> 16 KiB of staging per wave
+  float* stg = reinterpret_cast<float*>(smem + wave * 16384);
+  if (EPI == EPI_GENERAL && p.accumulate && !p.ws) {  // atomic fallback (split-K without a workspace): register epilogue
     const bool add_bias = zsplit == 0;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -584,127 +562,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
     }
     return;
   }
-  if (tail_dst) {  // fp32 partial of this k-slice, plain [128][128] rows (address = base + m * 128 + n with the tile origin folded into base)
-    store_wave_tile_staged<2>(p, acc, m0 + wm, n0 + wn, lane, 0, reinterpret_cast<float*>(smem + wave * 4096),
-                              tail_dst - ((long long)m0 * BN + n0), BN);
-    return;
-  }
-  store_wave_tile_staged<2>(p, acc, m0 + wm, n0 + wn, lane, zsplit, reinterpret_cast<float*>(smem + wave * 4096));
-}
-
-// PERSISTENT form of the kernel above (LDS-DMA operands only; opt-in, see no_persist()): 2 workgroups per CU walk the item list with stride gridDim.x.  Per round
-// of tiles the one-shot kernel paid a workgroup dispatch plus the exposed latency of the first k-tile (K sweep: ~4.6 us per round on top
-// of ~1 us per k-tile); here the first k-tile of the NEXT item is issued before the epilogue of the current one, so it lands while the
-// accumulators go through the LDS staging.  Stage use: a tile's first k-tile always sits in stage 1 (the epilogue stages through the first
-// 16 KiB of stage 0).  Items: [0, n_main * gz) = (tile, split) pairs, split-major, XCD-remapped inside each round of gridDim.x items;
-// [n_main * gz, n_items) = k-slices of the split-tail tiles (gz == 1 only).
-template <bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_persist_kernel(GemmP p, int n_main, int gz, int n_items) {
-  using AIO = TileIO<A_KMAJ>;
-  using BIO = TileIO<B_KMAJ>;
-  constexpr int STAGE = AIO::BYTES + BIO::BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
-  const int nkt = (p.k + BK - 1) / BK;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
-  const int n_pairs = n_main * gz, G = (int)gridDim.x;
-
-  struct Item { int m0, n0, kt_begin, kt_end, zsplit; float* tail_dst; };
-  auto decode = [&](int item) {
-    Item it;
-    int tile;
-    it.tail_dst = nullptr;
-    if (item >= n_pairs) {
-      const int j = item - n_pairs;
-      tile = p.tail_begin + j / p.tail_split;
-      const int slice = j - (tile - p.tail_begin) * p.tail_split;
-      it.kt_begin = slice * p.tail_ktiles;
-      it.kt_end = min(nkt, it.kt_begin + p.tail_ktiles);
-      it.tail_dst = p.tail_ws + (size_t)j * (BM * BN);
-      it.zsplit = slice;
-    } else {
-      const int round0 = (item / G) * G;
-      const int logical = round0 + xcd_remap(item - round0, min(G, n_pairs - round0));
-      it.zsplit = logical / n_main;
-      tile = logical - it.zsplit * n_main;
-      it.kt_begin = it.zsplit * p.ktiles_per_split;
-      it.kt_end = min(nkt, it.kt_begin + p.ktiles_per_split);
-    }
-    int tm, tn;
-    tile_of(tile, tiles_m, tiles_n, tm, tn);
-    it.m0 = tm * BM; it.n0 = tn * BN;
-    return it;
-  };
-  auto first_ktile = [&](const Item& it) {  // -> stage 1
-    AIO::glds(smem + STAGE, p.a, p.lda, it.m0, p.m, it.kt_begin * BK, p.k, lane, wave_u, zero_page);
-    BIO::glds(smem + STAGE + AIO::BYTES, p.b, p.ldb, it.n0, p.n, it.kt_begin * BK, p.k, lane, wave_u, zero_page);
-  };
-
-  int item = blockIdx.x;
-  if (item >= n_items) return;
-  Item it = decode(item);
-  first_ktile(it);
-  while (true) {
-    float16v acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    float rs[2] = {0.f, 0.f};
-    const bool do_rowsum = p.a_rowsum != nullptr && wn == 0 && it.n0 == 0;
-    for (int kt = it.kt_begin; kt < it.kt_end; kt++) {
-      const int cur = (kt - it.kt_begin + 1) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this k-tile's DMA has landed (and the previous item's stores are acknowledged)
-      __syncthreads();                                   // ... for every wave; nobody still reads the other stage / the staging area
-      const char* sa = smem + cur * STAGE;
-      const char* sb = sa + AIO::BYTES;
-      if (kt + 1 < it.kt_end) {
-        char* na = smem + (cur ^ 1) * STAGE;
-        AIO::glds(na, p.a, p.lda, it.m0, p.m, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
-        BIO::glds(na + AIO::BYTES, p.b, p.ldb, it.n0, p.n, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
-      }
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ks++) {
-        short8v fa[2], fb[2];
-        fa[0] = AIO::frag(sa, wm, ks, lane);
-        fa[1] = AIO::frag(sa, wm + 32, ks, lane);
-        fb[0] = BIO::frag(sb, wn, ks, lane);
-        fb[1] = BIO::frag(sb, wn + 32, ks, lane);
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        if (!A_KMAJ && do_rowsum) { rs[0] += frag_sum8(fa[0]); rs[1] += frag_sum8(fa[1]); }
-      }
-    }
-    __syncthreads();  // every wave is done with both stages: stage 0 may become the epilogue staging area, stage 1 the next item's first k-tile
-    const int next = item + G;
-    const bool has_next = next < n_items;
-    const Item cur_it = it;
-    if (has_next) {
-      it = decode(next);
-      first_ktile(it);
-    }
-    if (!A_KMAJ && do_rowsum) {
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const float t = rs[i] + __shfl_xor(rs[i], 32, 64);
-        const int m = cur_it.m0 + wm + i * 32 + lane;
-        if (lane < 32 && m < p.m) unsafeAtomicAdd(p.a_rowsum + m, t);
-      }
-    }
-    float* stg = reinterpret_cast<float*>(smem + wave * 4096);
-    if (cur_it.tail_dst) store_wave_tile_staged<2>(p, acc, cur_it.m0 + wm, cur_it.n0 + wn, lane, 0, stg, cur_it.tail_dst - ((long long)cur_it.m0 * BN + cur_it.n0), BN);
-    else store_wave_tile_staged<2>(p, acc, cur_it.m0 + wm, cur_it.n0 + wn, lane, cur_it.zsplit, stg);
-    if (!has_next) break;
-    item = next;
-  }
+  // fp32 partial of a split-tail k-slice: plain [128][128] rows (address = base + m * 128 + n with the tile origin folded into base)
+  if (tail_dst) tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, 0, stg, tail_dst - ((long long)m0 * BN + n0), BN);
+  else tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, zsplit, stg);
+#ifdef CINEMA_GEMM_TIMING
+  GEMM_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GEMM_STAMP(4);
+#endif
 }
 
 // Sums the k-slices of the split-tail tiles and applies the fused epilogue: thread = 8 consecutive columns of one row.
@@ -1099,12 +964,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* x, i
 
 }  // namespace
 
-static bool no_persist() {  // CINEMA_GEMM_PERSIST=1 selects the persistent form (read at every call so that one process can A/B the two).
-  // Measured on the step (rocprofv3, one stream): persistent fwd 8.13 / dgrad 7.68 ms vs one-shot 7.94 / 7.17 ms - the two resident workgroups
-  // per CU already hide each other's prologue and epilogue, so the one-shot form stays the default.
-  const char* e = getenv("CINEMA_GEMM_PERSIST");
-  return !(e && e[0] == '1');
+#ifdef CINEMA_GEMM_TIMING
+CINEMA_API int cinema_debug_gemm_timing(long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_timing), &buf, sizeof(buf));
 }
+#endif
 
 CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
@@ -1184,27 +1048,30 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, true>), pgrid, dim3(768), 0, st, p, n_items, tiles_n, gz);
       else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_ws_kernel<true, false>), pgrid, dim3(768), 0, st, p, n_items, tiles_n, gz);
       else hipLaunchKernelGGL((gemm_mfma_ws_kernel<false, false>), pgrid, dim3(768), 0, st, p, n_items, tiles_n, gz);
-    } else if (a->force_generic == 2) {  // register-staged variant (kept for A/B measurements)
-      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, false>), grid, dim3(256), 0, st, p);
-      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, false>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_mfma_kernel<false, false, false>), grid, dim3(256), 0, st, p);
-    } else if (a->force_generic == 3 || (p.accumulate && !p.ws) || no_persist()) {  // one-shot form (A/B measurements, atomic fallback)
-      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, true>), grid, dim3(256), 0, st, p);
-      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_mfma_kernel<false, false, true>), grid, dim3(256), 0, st, p);
     } else {
-      const int n_main = tail ? p.tail_begin : (int)grid.x;
-      const int n_items = n_main * gz + (tail ? (int)grid.x - p.tail_begin : 0);
-      static int slots2 = 0;
-      if (slots2 == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        slots2 = 2 * ((hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256);
+      // epilogue class (compile-time specialisation, see EPI_*): what the argument combination needs, GENERAL for the rest
+      int epi = EPI_GENERAL;
+      const bool common = !p.row_mask && !p.res_bf16 && !(p.accumulate && !p.ws);
+      if (p.ws) epi = EPI_F32;  // split-K slabs: only the plain partial-tile path of the epilogue runs
+      else if (common && !p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) epi = EPI_BF16;
+      else if (common && !p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 1) epi = EPI_BF16_GELU;
+      else if (common && !p.out_f32 && !p.res_f32 && p.gelu_in && p.act == 0 && !p.aux_out && !p.bias) epi = EPI_BF16_GELU_GRAD;
+      else if (common && p.out_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) epi = EPI_F32;
+      a->kernel_used += 8 * epi;  // 1..3 = operand layout, + 8 x epilogue class
+#define LAUNCH_LAYOUT(E)                                                                                                    \
+  do {                                                                                                                      \
+    if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, E>), grid, dim3(256), 0, st, p);        \
+    else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, E>), grid, dim3(256), 0, st, p); \
+    else hipLaunchKernelGGL((gemm_mfma_kernel<false, false, E>), grid, dim3(256), 0, st, p);                                 \
+  } while (0)
+      switch (epi) {
+        case EPI_BF16: LAUNCH_LAYOUT(EPI_BF16); break;
+        case EPI_BF16_GELU: LAUNCH_LAYOUT(EPI_BF16_GELU); break;
+        case EPI_BF16_GELU_GRAD: LAUNCH_LAYOUT(EPI_BF16_GELU_GRAD); break;
+        case EPI_F32: LAUNCH_LAYOUT(EPI_F32); break;
+        default: LAUNCH_LAYOUT(EPI_GENERAL); break;
       }
-      dim3 pg(n_items < slots2 ? n_items : slots2);
-      a->kernel_used += 4;  // 5..7: the persistent form of kernels 1..3
-      if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_persist_kernel<true, true>), pg, dim3(256), 0, st, p, n_main, gz, n_items);
-      else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_persist_kernel<true, false>), pg, dim3(256), 0, st, p, n_main, gz, n_items);
-      else hipLaunchKernelGGL((gemm_mfma_persist_kernel<false, false>), pg, dim3(256), 0, st, p, n_main, gz, n_items);
+#undef LAUNCH_LAYOUT
     }
     if (tail) {
       const int rem = ((int)grid.x - p.tail_begin) / p.tail_split;
