@@ -100,6 +100,7 @@ def main() -> None:
     ap.add_argument("--prewarm", type=int, default=20, help="untimed steps run in total before the timed region (>= --warmup); 0 for profiling runs")
     ap.add_argument("--force-sync", action="store_true", help="N=1 only: still issue the gradient collectives (RCCL path check)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the per-kernel roofline")
+    ap.add_argument("--eager", action="store_true", help="issue every launch from the module code instead of the recorded launch list (A/B)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +134,7 @@ def main() -> None:
     model = CineMA(**kw)
     cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model.to(device)
-    step = TrainStep(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0, synchronizer=sync)
+    step = TrainStep(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0, synchronizer=sync, replay=not args.eager)
     torch.manual_seed(1234 + rank)  # per-rank mask / data streams (pretrain.py:309-310)
     batches = [synthetic_batch(kw, args.batch, 1234 + rank * 100 + i, device) for i in range(2)]
 
@@ -160,6 +161,8 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     final_loss = float(loss)
+    n_launches = next(iter(step._recorded.values())).n_launches if step._recorded else None  # noqa: SLF001
+    step.replay = False  # the information-only runs below (dense stem, per-launch events) go through the module code
 
     # the same steps with the stem evaluated on every voxel like the reference (information only; single process)
     from cinema_amd import convvit
@@ -219,6 +222,8 @@ def main() -> None:
                        "stem": "dense (every voxel, as the reference)" if dense_stem else
                                "visible voxels only - exact: masked voxels never reach a kept token (DESIGN.md 3a); CINEMA_DENSE_STEM=1 runs every voxel",
                        "dense_stem_ms_per_step": dense_ms,
+                       "host": ("module code issues every launch (--eager)" if args.eager else
+                                f"forward+backward re-issued from a recorded list of {n_launches} HIP launches (cinema_amd/replay.py); clip+AdamW eager"),
                        # the REFERENCE's dense FLOP count per sample x samples/s: a reference-equivalent rate, not executed FLOPs
                        "reference_equiv_tflops_per_gpu": round(samples_per_s / world * STEP_GFLOP_PER_SAMPLE / 1e3, 1)},
             "roofline": roofline,

@@ -73,23 +73,24 @@ class TokenSelection:
 
     def __init__(self, mask: torch.Tensor | None, batch: int, n_patches: int, device: torch.device, n_masked: int | None = None) -> None:
         self.mask, self.batch, self.n_patches = mask, batch, n_patches
-        base = torch.arange(batch, dtype=torch.int32, device=device)[:, None] * n_patches
         if mask is None:
-            pos = torch.arange(n_patches, dtype=torch.int32, device=device)[None].expand(batch, -1)
             self.n_keep, self.n_drop = n_patches, 0
-            self.keep_pos = pos.reshape(-1).contiguous()
-            self.keep = (base + pos).reshape(-1).contiguous()
-            self.drop = self.drop_pos = torch.empty(0, dtype=torch.int32, device=device)
+            self.keep_pos = T.const(("sel_pos", batch, n_patches, str(device)), lambda: torch.arange(n_patches, dtype=torch.int32, device=device).repeat(batch))
+            self.keep = T.const(("sel_all", batch, n_patches, str(device)), lambda: torch.arange(batch * n_patches, dtype=torch.int32, device=device))
+            self.drop = self.drop_pos = T.const(("sel_none", str(device)), lambda: torch.empty(0, dtype=torch.int32, device=device))
             self.all_tokens = True
             return
-        order = torch.argsort(mask.to(torch.uint8), dim=1, stable=True).to(torch.int32)  # kept (0) first, raster order preserved
         # every row of a mask from get_batch_random_patch_mask has the same count; unknown (injected) masks are read back once
         self.n_drop = int(n_masked) if n_masked is not None else int(mask[0].sum())
-        self.n_keep = n_patches - self.n_drop
-        self.keep_pos = order[:, :self.n_keep].reshape(-1).contiguous()
-        self.drop_pos = order[:, self.n_keep:].reshape(-1).contiguous()
-        self.keep = (base + order[:, :self.n_keep]).reshape(-1).contiguous()
-        self.drop = (base + order[:, self.n_keep:]).reshape(-1).contiguous()
+        self.n_keep = n_keep = n_patches - self.n_drop
+
+        def select() -> tuple:  # torch ops on this step's mask: a host entry of a recorded step (tape.host)
+            base = torch.arange(batch, dtype=torch.int32, device=device)[:, None] * n_patches
+            order = torch.argsort(mask.to(torch.uint8), dim=1, stable=True).to(torch.int32)  # kept (0) first, raster order preserved
+            return (order[:, :n_keep].reshape(-1).contiguous(), order[:, n_keep:].reshape(-1).contiguous(),
+                    (base + order[:, :n_keep]).reshape(-1).contiguous(), (base + order[:, n_keep:]).reshape(-1).contiguous())
+
+        self.keep_pos, self.drop_pos, self.keep, self.drop = T.host(select)
         self.all_tokens = False
 
 
@@ -196,28 +197,32 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
         n_tok_all = math.prod(grid)
         n_tok = sel.keep.numel()
         tables = self._stage_tables(dev)
-        rank = torch.full((batch * n_tok_all,), -1, dtype=torch.int32, device=dev)
-        rank[sel.keep.long()] = torch.arange(n_tok, dtype=torch.int32, device=dev)
-        # stage-1 voxels of the kept tokens, in compact row order, as flat ids of the (batch, *grid1) stage-1 volume
         block1, pos1, inv1 = tables[0]
         grid1 = tuple(g * b for g, b in zip(grid, block1))
-        t = sel.keep.long() % n_tok_all
-        bb = sel.keep.long() // n_tok_all
-        tcoord = []
-        for g in reversed(grid):
-            tcoord.append(t % g)
-            t = t // g
-        tcoord.reverse()
-        u = inv1.long()  # raster voxel index stored at row offset q
-        ucoord = []
-        for bdim in reversed(block1):
-            ucoord.append(u % bdim)
-            u = u // bdim
-        ucoord.reverse()
-        vid = bb[:, None]
-        for d in range(n_dims):
-            vid = vid * grid1[d] + (tcoord[d][:, None] * block1[d] + ucoord[d][None, :])
-        idx1 = vid.reshape(-1).to(torch.int32).contiguous()
+
+        def visible_index() -> tuple:  # torch ops on this step's selection: a host entry of a recorded step (tape.host)
+            rank = torch.full((batch * n_tok_all,), -1, dtype=torch.int32, device=dev)
+            rank[sel.keep.long()] = torch.arange(n_tok, dtype=torch.int32, device=dev)
+            # stage-1 voxels of the kept tokens, in compact row order, as flat ids of the (batch, *grid1) stage-1 volume
+            t = sel.keep.long() % n_tok_all
+            bb = sel.keep.long() // n_tok_all
+            tcoord = []
+            for g in reversed(grid):
+                tcoord.append(t % g)
+                t = t // g
+            tcoord.reverse()
+            u = inv1.long()  # raster voxel index stored at row offset q
+            ucoord = []
+            for bdim in reversed(block1):
+                ucoord.append(u % bdim)
+                u = u // bdim
+            ucoord.reverse()
+            vid = bb[:, None]
+            for d in range(n_dims):
+                vid = vid * grid1[d] + (tcoord[d][:, None] * block1[d] + ucoord[d][None, :])
+            return rank, vid.reshape(-1).to(torch.int32).contiguous()
+
+        rank, idx1 = T.host(visible_index)
 
         skips = []
         vol = None
@@ -311,15 +316,19 @@ def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids
     e = model.encoder.cls_token.shape[-1]
     n_keep = [sels[v].n_keep for v in views]
     t_e = 1 + sum(n_keep)
-    b_ar = torch.arange(batch, dtype=torch.int32, device=dev)
-    cls_rows = b_ar * t_e
+
+    def rows_of(off: int, n: int) -> torch.Tensor:  # row b * t_e + off + i for i < n: shape-only, cached
+        return T.const(("rows_of", batch, t_e, off, n, str(dev)), lambda: (
+            torch.arange(batch, dtype=torch.int32, device=dev)[:, None] * t_e + off + torch.arange(n, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous())
+
+    cls_rows = rows_of(0, 1)
     segs, skips_all, view_rows = [T.Segment(cls_rows, src=model.encoder.cls_token)], {}, {}
     off = 1
     for v, nk in zip(views, n_keep):
         enc = model.enc_down_dict[v]
         skips, tok = enc.tape_forward(tp, images[v], sels[v], grids[v])
         skips_all[v] = skips
-        rows = (b_ar[:, None] * t_e + off + torch.arange(nk, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous()
+        rows = rows_of(off, nk)
         view_rows[v] = rows
         pe = enc.interpolate_pos_encoding(grids[v]).detach().reshape(-1, e)
         segs.append(T.Segment(rows, src=tok, add=pe, add_idx=sels[v].keep_pos))

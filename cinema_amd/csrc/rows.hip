@@ -160,6 +160,15 @@ __global__ __launch_bounds__(256) void patch_weight_relayout_kernel(float* w, vo
   }
 }
 
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* dst, uint32_t word, long long n_words) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (long long)gridDim.x * 256) dst[i] = word;
+}
+
+__global__ __launch_bounds__(256) void mul_scalar_kernel(const float* x, const float* s, float* y, long long n) {
+  const float f = s[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * f;
+}
+
 }  // namespace
 
 CINEMA_API int cinema_hip_info(int* out) {
@@ -236,5 +245,21 @@ CINEMA_API int cinema_patch_weight_relayout(float* w, void* rows, int rows_is_bf
   if (direction == 1 && rows_is_bf16) return CINEMA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(patch_weight_relayout_kernel, dim3(grid_for((long long)outer * ld, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, rows_is_bf16, outer, c,
                      kvol, ld, jmap, direction);
+  return launch_status();
+}
+
+// dst[0 .. n_words) = word (32-bit pattern: 0 for any zero tensor, the bits of a float for fp32 fills).  A kernel rather than hipMemsetAsync so
+// that it is an ordinary launch of the replayable call list (cinema_amd/replay.py) like everything else on the path.
+CINEMA_API int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream) {
+  if (!dst || n_words < 0 || (((uintptr_t)dst) & 3)) return CINEMA_ERR_BAD_ARG;
+  if (n_words == 0) return 0;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)dst, (uint32_t)word, n_words);
+  return launch_status();
+}
+
+// y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
+CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
+  if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(mul_scalar_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, s, y, n);
   return launch_status();
 }

@@ -70,3 +70,13 @@ CINEMA_API int cinema_marker_done(long long ticket) {
   if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
   return CINEMA_ERR_BAD_ARG;
 }
+
+// Host-side cost of a kernel launch on this machine: n back-to-back launches of an empty kernel from one C loop (tools/launch_rate.py).
+namespace {
+__global__ void empty_kernel(int) {}
+}  // namespace
+
+CINEMA_API int cinema_launch_probe(int n, void* stream) {
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, i);
+  return launch_status();
+}

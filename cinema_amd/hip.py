@@ -9,6 +9,7 @@ call raises.
 from __future__ import annotations
 
 import ctypes as C
+import struct
 import os
 from pathlib import Path
 
@@ -98,9 +99,12 @@ _PROTOS = {
     "cinema_segment_mean_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp],
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
+    "cinema_fill_u32": [_vp, C.c_uint, _ll, _vp],
+    "cinema_mul_scalar_f32": [_vp, _vp, _vp, _ll, _vp],
     "cinema_stream_fork": [_vp, _vp],
     "cinema_marker_record": [_vp],
     "cinema_marker_done": [_ll],
+    "cinema_launch_probe": [_i, _vp],
     "cinema_patch_weight_relayout": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "cinema_cast": [_vp, _i, _vp, _i, _ll, _vp],
     "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
@@ -122,6 +126,36 @@ def library_path() -> Path:
     return _LIB_PATH
 
 
+# Call recording (cinema_amd/replay.py): while RECORD is a list every launch through this module is appended to it as (cfunc, args) right
+# after it ran.  The arguments are plain ints / floats / ctypes structs, so the same launch can be issued again verbatim; host-only queries
+# (workspace sizes) and the completion markers are not part of a step's launch list.
+RECORD: list | None = None
+_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe")
+
+
+class _Entry:
+    """One exported function of the C-ABI: call-through, plus the append to RECORD when a recording is active."""
+
+    __slots__ = ("fn", "replayed")
+
+    def __init__(self, fn, replayed: bool) -> None:  # noqa: ANN001
+        self.fn, self.replayed = fn, replayed
+
+    def __call__(self, *args):  # noqa: ANN002, ANN204
+        rc = self.fn(*args)
+        if RECORD is not None and self.replayed:
+            RECORD.append((self.fn, args))
+        return rc
+
+
+class _Library:
+    def __init__(self, cdll) -> None:  # noqa: ANN001
+        self.cdll = cdll
+
+    def __getattr__(self, name: str):  # noqa: ANN204
+        return getattr(self.cdll, name)  # symbols outside _PROTOS (dev builds)
+
+
 def load():  # noqa: ANN201
     """Load the shared library (once). Raises :class:`HipLibraryError` if it was not built."""
     global _lib  # noqa: PLW0603
@@ -132,11 +166,12 @@ def load():  # noqa: ANN201
             f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). cinema_amd has no CPU/ATen fallback."
         )
-    lib = C.CDLL(str(_LIB_PATH))
+    lib = _Library(C.CDLL(str(_LIB_PATH)))
     for name, argtypes in _PROTOS.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib.cdll, name)
         fn.argtypes = argtypes
         fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints", "_marker_record")) else C.c_int
+        setattr(lib, name, _Entry(fn, not name.endswith(_NOT_REPLAYED)))
     _lib = lib
     return lib
 
@@ -352,6 +387,38 @@ def scale(x: torch.Tensor, alpha: float) -> torch.Tensor:
     y = torch.empty_like(x)
     _check(load().cinema_scale_f32(x.data_ptr(), alpha, y.data_ptr(), x.numel(), _stream()), "scale")
     return y
+
+
+def mul_scalar(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """x * s[0] for contiguous fp32 x and a one-element fp32 device tensor s."""
+    _dev(x, s)
+    if x.dtype != torch.float32 or s.dtype != torch.float32 or not x.is_contiguous() or s.numel() != 1:
+        raise HipLibraryError("mul_scalar: contiguous fp32 x, one-element fp32 s")
+    y = torch.empty_like(x)
+    _check(load().cinema_mul_scalar_f32(x.data_ptr(), s.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mul_scalar")
+    return y
+
+
+def full(shape, value: float, dtype: torch.dtype = torch.float32, device=None) -> torch.Tensor:  # noqa: ANN001
+    """torch.full / torch.zeros as a launch of this library (so that it is part of a recorded step, see cinema_amd/replay.py): fp32 with
+    any value, other dtypes with zero only; the tensor must span whole 32-bit words."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    _dev(t)
+    nbytes = t.numel() * t.element_size()
+    if value == 0:
+        word = 0
+    elif dtype == torch.float32:
+        word = struct.unpack("<I", struct.pack("<f", value))[0]
+    else:
+        raise HipLibraryError("full: non-zero fills are fp32 only")
+    if nbytes % 4:
+        raise HipLibraryError("full: the tensor must span whole 32-bit words")
+    _check(load().cinema_fill_u32(t.data_ptr(), word, nbytes // 4, _stream()), "fill")
+    return t
+
+
+def zeros(shape, dtype: torch.dtype = torch.float32, device=None) -> torch.Tensor:  # noqa: ANN001
+    return full(shape, 0.0, dtype, device)
 
 
 def patch_weight_rows(w: torch.Tensor, jmap: torch.Tensor | None = None, pad_to: int = 1) -> torch.Tensor:

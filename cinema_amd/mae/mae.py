@@ -156,14 +156,13 @@ class CineMA(nn.Module):
         # decoder sequences (mae.py:569-585)
         n_keep = [sels[v].n_keep for v in views]
         n_drop = [sels[v].n_drop for v in views]
-        b_ar = torch.arange(batch, dtype=torch.int32, device=dev)
-
-        def rows_of(total: int, off: int, n: int) -> torch.Tensor:
-            return (b_ar[:, None] * total + off + torch.arange(n, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous()
+        def rows_of(total: int, off: int, n: int) -> torch.Tensor:  # row b * total + off + i for i < n: shape-only, cached
+            return T.const(("rows_of", batch, total, off, n, str(dev)), lambda: (
+                torch.arange(batch, dtype=torch.int32, device=dev)[:, None] * total + off + torch.arange(n, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous())
 
         if self.cross_attn:
             t_q, t_k = 1 + sum(n_drop), sum(n_keep)
-            q_segs, k_segs, mask_rows = [T.Segment(b_ar * t_q, src=z_cls)], [], {}
+            q_segs, k_segs, mask_rows = [T.Segment(rows_of(t_q, 0, 1), src=z_cls)], [], {}
             offq, offk = 1, 0
             for v, nk, nd in zip(views, n_keep, n_drop):
                 emb = self.dec_embed_dict[v]
@@ -177,7 +176,7 @@ class CineMA(nn.Module):
             x_k = T.op_cast_bf16(tp, T.op_assemble(tp, batch * t_k, d, k_segs, dev))
         else:
             t_q = 1 + sum(n_keep) + sum(n_drop)
-            q_segs, mask_rows = [T.Segment(b_ar * t_q, src=z_cls)], {}
+            q_segs, mask_rows = [T.Segment(rows_of(t_q, 0, 1), src=z_cls)], {}
             off = 1
             for v, nk in zip(views, n_keep):
                 pe = self.dec_embed_dict[v].pos_embed.detach().reshape(-1, d)
@@ -200,12 +199,12 @@ class CineMA(nn.Module):
             img = images[v]
             chans = img.shape[1]
             patch = self.dec_patch_size_dict[v]
-            stats = torch.zeros(2, dtype=torch.float32, device=dev)
+            stats = T.zeros(2, torch.float32, dev)
             K.patch_stats(img, K.patch_geom(batch, chans, grids[v], patch, tuple(img.stride())), stats)
             metrics[f"{v}_target_mean"], metrics[f"{v}_target_std"] = stats[0], stats[1]
             if v not in dec_parts:
                 preds[v] = T.Var(torch.empty((0, math.prod(patch) * chans), dtype=torch.float32, device=dev), needs_grad=False)
-                nan = T.Var(torch.full((1,), float("nan"), dtype=torch.float32, device=dev), needs_grad=False)
+                nan = T.Var(K.full((1,), float("nan"), torch.float32, dev), needs_grad=False)
                 losses.append(nan)
                 metrics[f"{v}_mse_loss"] = nan.data[0]
                 continue
@@ -221,21 +220,32 @@ class CineMA(nn.Module):
         loss = T.op_mean_finite(tp, losses)
         return loss, preds, metrics
 
-    def forward(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None):  # noqa: ANN201
+    def draw_masks(self, image_dict: dict, enc_mask_ratio: float) -> tuple:
+        """One random mask per view, drawn exactly as ``forward`` does (same recipe, same RNG consumption, view order of ``image_dict``):
+        -> ({view: bool (batch, n_patches)}, {view: masked patches per sample}).  Used by recorded steps (``cinema_amd/replay.py``)."""
+        views = self._check_views(image_dict)
+        batch = image_dict[views[0]].shape[0]
+        dev = image_dict[views[0]].device
+        masks, n_masked = {}, {}
+        for v in views:
+            n = math.prod(self.enc_down_dict[v].grid_for(tuple(image_dict[v].shape[2:])))
+            masks[v] = get_batch_random_patch_mask(batch, n, enc_mask_ratio, dev)
+            n_masked[v] = 0 if enc_mask_ratio == 0 else n - int(n * (1 - enc_mask_ratio))
+        return masks, n_masked
+
+    def forward(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_masked: dict | None = None):  # noqa: ANN201
         """Reference contract (``mae.py:504-520``).  ``enc_mask_dict`` (additive, optional) injects fixed masks -- used by the
-        parity tests so that CPU oracle and GPU path see identical masks."""
+        parity tests so that CPU oracle and GPU path see identical masks; ``n_masked`` (with it) gives the masked count per view
+        so that it is not read back from the device."""
         views = self._check_views(image_dict)
         batch = image_dict[views[0]].shape[0]
         dev = image_dict[views[0]].device
         images = {v: image_dict[v].float().contiguous() for v in views}
-        masks, n_masked = {}, {}
-        for v in views:
-            n = math.prod(self.enc_down_dict[v].grid_for(tuple(images[v].shape[2:])))
-            if enc_mask_dict is not None:
-                masks[v], n_masked[v] = enc_mask_dict[v].to(device=dev, dtype=torch.bool), None  # count read back once
-            else:
-                masks[v] = get_batch_random_patch_mask(batch, n, enc_mask_ratio, dev)
-                n_masked[v] = 0 if enc_mask_ratio == 0 else n - int(n * (1 - enc_mask_ratio))
+        if enc_mask_dict is not None:
+            masks = {v: enc_mask_dict[v].to(device=dev, dtype=torch.bool) for v in views}
+            n_masked = {v: (None if n_masked is None else n_masked[v]) for v in views}  # None: count read back once
+        else:
+            masks, n_masked = self.draw_masks(images, enc_mask_ratio)
 
         out: dict = {}
 

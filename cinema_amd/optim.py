@@ -159,7 +159,7 @@ class TrainStep:
     (``cinema/mae/pretrain.py:242-269``) without its per-step host synchronisations."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, clip_grad: float | None = 5.0,
-                 synchronizer=None, hip_graph: bool = False) -> None:  # noqa: ANN001
+                 synchronizer=None, hip_graph: bool = False, replay: bool = False, audit: bool = False) -> None:  # noqa: ANN001
         self.model = model
         self.flat = FlatModel(model, weight_decay)
         self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas)
@@ -171,11 +171,17 @@ class TrainStep:
         # graph, which takes the host out of the step; clip + AdamW stay eager (their scalars change every step).  Single process only:
         # the overlapped RCCL collectives are issued from Python hooks in the backward pass.
         self.hip_graph = hip_graph
+        # replay: forward + backward are recorded once per input signature as the flat list of this library's launches and re-issued
+        # from that list (cinema_amd/replay.py) - the host cost of a step drops from ~33 ms of module code to ~3 us per launch
+        self.replay, self.audit = replay, audit
+        self._recorded: dict = {}
         self._graphs: dict = {}
         if hip_graph and synchronizer is not None:
             raise ValueError("hip_graph=True captures the single-process step; the data-parallel step runs eagerly")
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
+        if self.replay and enc_mask_dict is None and n_accum_steps == 1:
+            return self._replay_step(image_dict, enc_mask_ratio, update_grad)
         if self.hip_graph and enc_mask_dict is None and n_accum_steps == 1 and update_grad:
             return self._graph_step(image_dict, enc_mask_ratio)
         loss, _, _, metrics = self.model(image_dict, enc_mask_ratio, enc_mask_dict=enc_mask_dict)
@@ -189,6 +195,27 @@ class TrainStep:
             grad_norm = self.optimizer.step(self.clip_grad)
             self.optimizer.zero_grad()
         return loss.detach(), grad_norm, metrics
+
+    # ------------------------------------------------------------------------------------------------ recorded step
+    def _replay_step(self, image_dict: dict, enc_mask_ratio: float, update_grad: bool):  # noqa: ANN202
+        from cinema_amd.replay import RecordedStep
+
+        if self.sync is not None:
+            self.sync.arm(update_grad)
+        key = (float(enc_mask_ratio), tuple((k, tuple(v.shape), v.dtype) for k, v in image_dict.items()))
+        rec = self._recorded.get(key)
+        if rec is None:  # the recording IS this step (an eager forward + backward under hip.RECORD)
+            rec = self._recorded[key] = RecordedStep(self.model, image_dict, enc_mask_ratio, audit=self.audit)
+            loss, metrics = rec.loss, rec.metrics
+        else:
+            loss, metrics = rec.run(image_dict)
+        grad_norm = None
+        if update_grad:
+            if self.sync is not None:
+                self.sync.all_reduce()
+            grad_norm = self.optimizer.step(self.clip_grad)
+            self.optimizer.zero_grad()
+        return loss, grad_norm, metrics  # static tensors: overwritten by the next step
 
     # ------------------------------------------------------------------------------------------------ HIP-graph step
     def _capture(self, image_dict: dict, enc_mask_ratio: float) -> tuple:

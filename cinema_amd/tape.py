@@ -58,6 +58,66 @@ class Var:
         return self.grad16
 
 
+def zeros(shape, dtype: torch.dtype = F32, device=None) -> torch.Tensor:  # noqa: ANN001
+    """Zero tensor whose fill is a launch of the HIP library on GPU (part of a recorded step); torch.zeros elsewhere (host-logic tests)."""
+    if torch.device(device).type == "cuda":
+        return K.zeros(shape, dtype, device)
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+# ---- recorded steps (cinema_amd/replay.py) ---------------------------------------------------------------------
+# A recorded step re-issues the HIP launches of one eager step verbatim.  Device work done by torch (ATen) between them is not in that
+# list, so the model code marks it: host() for index tensors that depend on this step's random masks (re-run on every replay, results
+# copied into the tensors the recorded launches point at) and const() for tensors that depend on shapes only (computed once, cached).
+_CONST: dict = {}
+REC_CALL = None    # while recording: the (tape, vars, params) of the step's top-level call, whose backward the recorder runs itself
+
+
+class _Allowed:
+    """Marks torch ops as accounted for while a recording is audited (see cinema_amd.replay)."""
+
+    def __enter__(self) -> None:
+        if K.RECORD is not None:
+            from cinema_amd import replay
+            self.ctx = replay.allowed_aten()
+            self.ctx.__enter__()
+        else:
+            self.ctx = None
+
+    def __exit__(self, *exc) -> None:  # noqa: ANN002
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
+def const(key: tuple, fn: Callable) -> torch.Tensor:
+    """Shape-only device tensor (index tables): computed once per key and kept for the life of the process."""
+    t = _CONST.get(key)
+    if t is None:
+        with _Allowed():
+            t = _CONST[key] = fn()
+    return t
+
+
+def host(fn: Callable) -> tuple:
+    """``fn() -> tuple of tensors`` computed with torch ops from this step's masks.  Eager: just call it.  While recording: the results
+    become static tensors and the call is appended to the recording as a host entry that recomputes them in place on every replay."""
+    if K.RECORD is None:
+        return fn()
+    with _Allowed():
+        static = tuple(o.clone() for o in fn())
+
+    def again() -> None:
+        for dst, src in zip(static, fn()):
+            dst.copy_(src)
+
+    K.RECORD.append((None, again))
+    return static
+
+
+def recording() -> bool:
+    return K.RECORD is not None
+
+
 class PVar:
     """A parameter on the tape.  ``grad`` (fp32, in the *kernel* layout) is created zeroed on first use."""
 
@@ -76,7 +136,7 @@ class PVar:
                 # the optimiser owns a flat gradient buffer (cinema_amd.optim.FlatModel): accumulate straight into it
                 self.grad, self.direct = flat.view(shape), True
             else:
-                self.grad = torch.zeros(shape, dtype=F32, device=self.param.device)
+                self.grad = zeros(shape, F32, self.param.device)
             self.to_param_layout = to_param_layout
         return self.grad
 
@@ -145,7 +205,7 @@ def join_side_stream(release: bool = False) -> None:
     """Make the current stream wait for the side stream.  ``release`` (end of the backward pass): the operands kept alive for the side
     stream may go back to the allocator - their next user is ordered after this wait."""
     if SIDE_WGRAD and _SIDE_STREAMS:
-        torch.cuda.current_stream().wait_stream(side_stream())
+        K.stream_fork(side_stream().cuda_stream, K._stream())
     if release:
         _SIDE_KEEP.clear()
 
@@ -155,7 +215,7 @@ def mark_params(tape: "Tape", params: list) -> None:
     marker runs after all of their gradient kernels, which is where their gradient all-reduce may start."""
     hook = PARAMS_DONE_HOOK
     if hook is not None and tape.train:
-        def fire() -> None:
+        def run_hook() -> None:
             # the block's weight gradients may still be running on the side stream: issue the collective FROM the side stream (after
             # everything queued on the main stream so far), so that RCCL orders itself behind both without stalling the main stream
             if SIDE_WGRAD and torch.cuda.is_available():
@@ -167,6 +227,11 @@ def mark_params(tape: "Tape", params: list) -> None:
                     hook(tape, params)
             else:
                 hook(tape, params)
+
+        def fire() -> None:
+            if K.RECORD is not None:  # recorded step: the collective is a torch call, so it enters the launch list as a host entry
+                K.RECORD.append((None, run_hook))
+            run_hook()
 
         tape.record(fire)
 
@@ -322,7 +387,8 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
         K.stream_fork(K._stream(), side)
         with K.on_stream(side):  # raw redirection: no torch stream context, no event objects (this runs ~200x per step)
             fn()
-        if torch._C._cuda_isCurrentStreamCapturing():  # HIP-graph capture: events cannot be queried; hold the operands until the join
+        if K.RECORD is not None or torch._C._cuda_isCurrentStreamCapturing():  # recorded / captured step: no completion queries at replay time, so the
+            # allocator must not reuse an operand before the join (which is itself part of the recording)
             _SIDE_KEEP.append((None, operands))
             return
         _SIDE_KEEP.append((K.marker_record(side), operands))  # cheaper than record_stream (allocator events on every free of these blocks)
@@ -701,7 +767,7 @@ def op_patch_gather(tape: Tape, x: Var, geom, dst_shape: tuple | None = None) ->
         if y.grad is None or not x.needs_grad:
             return
         subset = geom.token_idx is not None
-        dx = (torch.zeros if subset else torch.empty)(x.data.shape, dtype=F32, device=x.data.device)
+        dx = zeros(x.data.shape, F32, x.data.device) if subset else torch.empty(x.data.shape, dtype=F32, device=x.data.device)
         K.patch_scatter(y.grad, dx, geom)
         x.add_grad(dx)
 
@@ -720,7 +786,7 @@ def op_split_rows(tape: Tape, x: Var, idx_list: list) -> list:
     def bwd() -> None:
         if not x.needs_grad or all(y.grad is None for y in ys):
             return
-        dx = torch.zeros(x.data.shape, dtype=x.data.dtype, device=x.data.device)
+        dx = zeros(x.data.shape, x.data.dtype, x.data.device)
         for y, idx in zip(ys, idx_list):
             if y.grad is not None:
                 K.row_copy(dx, y.grad, dst_idx=idx)
@@ -745,13 +811,12 @@ def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.d
     """Build a token matrix [n_rows, c] (fp32) from row segments (replaces torch.cat / bool-mask selects / pos-embed adds:
     cinema/vit.py:672-674, cinema/mae/mae.py:98-104,580-585, cinema/convvit.py:205)."""
     out = torch.empty((n_rows, c), dtype=F32, device=device)
-    zero_idx = {}
     for s in segments:
         n = s.dst_idx.numel()
         if isinstance(s.src, Var):
             K.row_copy(out, s.src.data, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx)
         elif s.src is not None:  # broadcast token parameter
-            z = zero_idx.setdefault(n, torch.zeros(n, dtype=torch.int32, device=device))
+            z = const(("zero_idx", n, str(device)), lambda: torch.zeros(n, dtype=torch.int32, device=device))
             K.row_copy(out, s.src.detach().view(1, c), dst_idx=s.dst_idx, src_idx=z, add=s.add, add_idx=s.add_idx)
         else:
             K.row_copy(out, None, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx)
@@ -774,8 +839,8 @@ def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.d
 
 def op_mse(tape: Tape, pred: Var, image: torch.Tensor, geom_masked, norm_target: bool, eps: float = 1e-6) -> Var:  # noqa: ANN001
     """Scalar masked-patch MSE (cinema/mae/mae.py:140-143); the target patches are gathered from ``image`` on the fly."""
-    loss = torch.zeros(1, dtype=F32, device=pred.data.device)
-    maxes = torch.full((2,), float("-inf"), dtype=F32, device=pred.data.device) if norm_target else None
+    loss = zeros(1, F32, pred.data.device)
+    maxes = K.full((2,), float("-inf"), F32, pred.data.device) if norm_target else None
     K.mse_fwd(image, geom_masked, pred.data, norm_target, eps, loss, maxes)
     y = Var(loss)
 
@@ -803,7 +868,7 @@ def op_mean_finite(tape: Tape, losses: list) -> Var:
         if y.grad is None:
             return
         for i, lv in enumerate(losses):
-            lv.add_grad(coef[i:i + 1] * y.grad.reshape(1))  # one-element scalar product: d loss / d loss_i = coef[i] * upstream
+            lv.add_grad(K.mul_scalar(coef[i:i + 1], y.grad.reshape(1)))  # d loss / d loss_i = coef[i] * upstream
 
     tape.record(bwd)
     return y
@@ -827,6 +892,10 @@ class _TapedCall(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):  # noqa: ANN001, ANN205
+        return _TapedCall._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, *grads):  # noqa: ANN001, ANN205
         for v, g in zip(ctx.out_vars, grads):
             if g is not None:
                 v.grad = g.contiguous().to(v.data.dtype).reshape(v.data.shape)
@@ -854,10 +923,32 @@ class _TapedCall(torch.autograd.Function):
         return (None, None, None, None, *in_grads, *p_grads)
 
 
+class _DirectCall:
+    """The context of a top-level call run WITHOUT autograd (recorded steps): same fields as the autograd context of _TapedCall."""
+
+    def __init__(self, runner: Callable, inputs: list, params: list) -> None:
+        self.tape = Tape(train=True)
+        self.in_vars = [Var(t, needs_grad=False) if isinstance(t, torch.Tensor) else t for t in inputs]
+        self.out_vars, extras = runner(self.tape, *self.in_vars)
+        self.params, self.n_extras = params, len(extras)
+        self.outputs = tuple(v.data for v in self.out_vars) + tuple(extras)
+
+    def backward(self, *grads: torch.Tensor) -> None:
+        left = [g for g in _TapedCall._backward(self, *grads)[4:] if g is not None]  # noqa: SLF001
+        if left:  # a gradient that did not go into the optimiser's flat buffer would need autograd's accumulation
+            raise RuntimeError("recorded steps need every trainable parameter in a FlatModel gradient buffer")
+
+
 def taped_call(runner: Callable, inputs: list, params: list) -> tuple:
     """Run ``runner(tape, *input_vars) -> (out_vars, extra_tensors)`` as a single autograd node.
 
-    Returns the output tensors (differentiable) followed by the extras (non-differentiable).
+    Returns the output tensors (differentiable) followed by the extras (non-differentiable).  While a step is being recorded
+    (cinema_amd/replay.py) the call runs without autograd - the engine would run the backward pass on its own thread, outside the
+    recording's memory pool - and the recorder calls ``REC_CALL.backward`` itself.
     """
+    global REC_CALL  # noqa: PLW0603
     params = [p for p in params if p is not None]
+    if K.RECORD is not None:
+        REC_CALL = _DirectCall(runner, inputs, params)
+        return REC_CALL.outputs
     return _TapedCall.apply(runner, len(inputs), params, torch.is_grad_enabled(), *inputs, *params)

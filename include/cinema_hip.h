@@ -190,6 +190,10 @@ int cinema_segment_mean_fwd(const float* x, int ldx, int n_seg, int seg_rows, in
 int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, float scale, float* dx, int lddx, int accumulate, void* stream);
 /* y = alpha * x (fp32) */
 int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream);
+/* y[i] = x[i] * s[0], the scalar s read from device memory (chain rule through the scalar loss mean, cinema/mae/mae.py:604-608). */
+int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream);
+/* dst[0 .. n_words) = word (32-bit pattern; torch.zeros / torch.full of the reference's host code as a launch of this library). */
+int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream);
 
 /* Stream ordering (no reference counterpart: torch hides its streams; the reference runs one).  The host launches the weight-gradient
  * GEMMs of the backward pass on a second stream; these three calls are the fork / completion bookkeeping, on per-device event rings.
@@ -200,6 +204,8 @@ int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* s
 int cinema_stream_fork(void* from_stream, void* to_stream);
 long long cinema_marker_record(void* stream);
 int cinema_marker_done(long long ticket);
+/* n back-to-back launches of an empty kernel (measures the host cost of one launch; used by tools/launch_rate.py and DESIGN.md section 5). */
+int cinema_launch_probe(int n, void* stream);
 
 /* k == s / dense conv weights (out, c, *k) fp32 <-> GEMM operand rows [out][ld] in the patch feature order (*k, c)  (the re-layout the
  * reference gets for free from cuDNN/MIOpen's own filter layouts; here it feeds cinema_gemm_bf16):

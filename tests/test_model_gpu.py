@@ -186,6 +186,38 @@ def test_random_masks_and_api_contract() -> None:
     assert math.isnan(float(loss0)) and all(p.shape[1] == 0 for p in pred0.values())
 
 
+@pytest.mark.parametrize("kw", [{}, {"cross_attn": False, "norm_target": True}])
+def test_recorded_step_replays_the_eager_step(kw: dict) -> None:
+    """TrainStep(replay=True): forward + backward re-issued from the recorded launch list (cinema_amd/replay.py) must walk the same
+    optimisation trajectory as the module code from the same seed (same random masks: identical RNG consumption), with no torch (ATen)
+    device work left unaccounted inside the recorded region.  Tolerance: a few fp32 atomics (bias-gradient row sums) reorder between runs."""
+    from cinema_amd.optim import TrainStep
+
+    traj = {}
+    for mode in ("eager", "replay"):
+        torch.manual_seed(7)
+        model = CineMA(**mini_kwargs(**kw)).to(DEV)
+        step = TrainStep(model, lr=1e-3, replay=(mode == "replay"), audit=True)
+        torch.manual_seed(11)
+        batches = [{v: torch.rand(2, 1, *s, device=DEV) for v, s in model_sizes(model).items()} for _ in range(2)]
+        out = []
+        for i in range(6):
+            loss, gn, metrics = step(batches[i % 2], 0.75)
+            out.append((float(loss), float(gn), float(metrics["sax_mse_loss"])))
+        traj[mode] = out
+        if mode == "replay":
+            rec = next(iter(step._recorded.values()))  # noqa: SLF001
+            assert rec.unaccounted == [], rec.unaccounted[:5]
+            assert rec.n_launches > 100 and len(step._recorded) == 1  # noqa: SLF001
+            # a different input signature gets its own recording; update_grad=False (accumulation micro-step) leaves the weights alone
+            before = step.flat.flat_param.clone()
+            step({"sax": batches[0]["sax"]}, 0.5, update_grad=False)
+            assert len(step._recorded) == 2 and torch.equal(before, step.flat.flat_param)  # noqa: SLF001
+    for a, b in zip(traj["eager"], traj["replay"]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-4 * abs(x) + 1e-6, (traj["eager"], traj["replay"])
+
+
 def model_sizes(model: CineMA) -> dict:
     out = {}
     for v in model.views:
