@@ -1,0 +1,54 @@
+"""Phase timeline of the last step in a rocprofv3 kernel trace (rocpd sqlite): where the wall time of one step goes, and how busy the GPU is
+inside each phase.  Usage: phase_timeline.py mae_results.db"""
+import sqlite3
+import sys
+
+con = sqlite3.connect(sys.argv[1])
+tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+kd = next(t for t in tabs if t.startswith("kernels") or t == "kernels")
+cols = [r[1] for r in con.execute(f"pragma table_info({kd})")]
+rows = con.execute(f"select name, start, end from {kd} order by start").fetchall()
+rows = [(n.replace("(anonymous namespace)::", "").replace("void ", ""), s, e) for n, s, e in rows]
+adam = [i for i, r in enumerate(rows) if r[0].startswith("adamw_kernel")]
+ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] - i > 8]  # last AdamW launch of every step (one per param group)
+lo, hi = ends[-2] + 1, ends[-1] + 1  # the last full step
+step = rows[lo:hi]
+t0 = step[0][1]
+
+
+def first(pred, begin=0):
+    return next(i for i in range(begin, len(step)) if pred(step[i][0]))
+
+
+def last(pred):
+    return max(i for i in range(len(step)) if pred(step[i][0]))
+
+
+marks = [("stems fwd (4 views) + token assembly", 0)]
+i_enc = first(lambda n: n.startswith("attn_fwd_mfma<64>"))
+marks.append(("encoder fwd", i_enc - 3))
+i_dec = first(lambda n: n.startswith("attn_fwd_mfma<32>"))
+marks.append(("fusion + decoder fwd + loss", last(lambda n: n.startswith("attn_fwd_mfma<64>")) + 8))
+i_bwd = first(lambda n: n.startswith("attn_bwd") or n.startswith("attn_delta"))
+marks.append(("decoder bwd", i_bwd - 12))
+marks.append(("fusion bwd + encoder bwd", last(lambda n: n.startswith("attn_bwd_dkv_mfma<32>") or n.startswith("attn_bwd_dq_mfma<32>")) + 12))
+marks.append(("stems bwd", last(lambda n: n.startswith("attn_bwd_dkv_mfma<64>") or n.startswith("attn_bwd_dq_mfma<64>")) + 12))
+marks.append(("clip + AdamW", first(lambda n: n.startswith("sqnorm_kernel"))))
+marks.append(("end", len(step)))
+print(f"step: {len(step)} kernels, {(step[-1][2] - t0) / 1e6:.2f} ms wall")
+for (name, a), (_, b) in zip(marks, marks[1:]):
+    seg = step[a:b]
+    if not seg:
+        continue
+    wall = (seg[-1][2] - seg[0][1]) / 1e6
+    # union of busy intervals (two streams overlap)
+    busy, cur_s, cur_e = 0, None, None
+    for _, s, e in sorted(seg, key=lambda r: r[1]):
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += cur_e - cur_s
+    print(f"  {name:40s} {len(seg):5d} kernels  wall {wall:6.2f} ms  GPU busy {busy / 1e6:6.2f} ms ({100 * busy / 1e6 / wall:3.0f}%)  avg kernel {sum(e - s for _, s, e in seg) / len(seg) / 1e3:6.1f} us")
