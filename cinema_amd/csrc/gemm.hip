@@ -997,10 +997,11 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     const int sp = split > nkt ? nkt : split;
     p.ktiles_per_split = (nkt + sp - 1) / sp;
     const int gz = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    // measured (tools/bench_gemm.py): the wave-specialised persistent kernel wins for the long-reduction weight-gradient GEMMs, the
-    // 128x128 two-stage kernel (2 blocks/CU) for the short-K forward / data-gradient GEMMs
+    // the 256x128 wave-specialised kernel used to win on the long-reduction weight-gradient GEMMs; since the 128x128 kernel got its small
+    // epilogue it is 8-12 % faster on every weight-gradient shape of the step (tools/wgrad_ab.py: dW[768x3072] over 10960 rows 75.6 vs 84.7 us,
+    // dW[512x2048] over 32848 rows 84.6 vs 93.0 us) and shares a CU with the main stream's workgroups, so the big kernel is opt-in (force_generic 4)
     const bool plain_f32 = a->out_f32 && !a->bias && !a->act && !a->aux_out && !a->gelu_in && !a->row_mask && !a->residual_bf16;  // its epilogue is the simple one
-    const bool big = plain_f32 && (a->force_generic == 4 || (a->force_generic == 0 && !a->a_kmajor && a->m >= 256 && a->n >= 128));
+    const bool big = plain_f32 && a->force_generic == 4;
     dim3 grid(big ? ((a->m + 255) / 256) * ((a->n + 127) / 128) : ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, gz);
     p.a_rowsum = (!a->a_kmajor) ? a->a_rowsum : nullptr;
     if (a->a_rowsum && a->a_kmajor) return CINEMA_ERR_UNSUPPORTED;
