@@ -84,13 +84,13 @@ class TokenSelection:
         self.n_drop = int(n_masked) if n_masked is not None else int(mask[0].sum())
         self.n_keep = n_keep = n_patches - self.n_drop
 
-        def select() -> tuple:  # torch ops on this step's mask: a host entry of a recorded step (tape.host)
+        if mask.is_cuda:  # one launch: raster-ordered kept / dropped lists (a recorded launch of a recorded step)
+            self.keep_pos, self.drop_pos, self.keep, self.drop = K.mask_select(mask.contiguous(), n_keep)
+        else:  # host-logic tests
             base = torch.arange(batch, dtype=torch.int32, device=device)[:, None] * n_patches
             order = torch.argsort(mask.to(torch.uint8), dim=1, stable=True).to(torch.int32)  # kept (0) first, raster order preserved
-            return (order[:, :n_keep].reshape(-1).contiguous(), order[:, n_keep:].reshape(-1).contiguous(),
-                    (base + order[:, :n_keep]).reshape(-1).contiguous(), (base + order[:, n_keep:]).reshape(-1).contiguous())
-
-        self.keep_pos, self.drop_pos, self.keep, self.drop = T.host(select)
+            self.keep_pos, self.drop_pos = order[:, :n_keep].reshape(-1).contiguous(), order[:, n_keep:].reshape(-1).contiguous()
+            self.keep, self.drop = (base + order[:, :n_keep]).reshape(-1).contiguous(), (base + order[:, n_keep:]).reshape(-1).contiguous()
         self.all_tokens = False
 
 
@@ -200,29 +200,9 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
         block1, pos1, inv1 = tables[0]
         grid1 = tuple(g * b for g, b in zip(grid, block1))
 
-        def visible_index() -> tuple:  # torch ops on this step's selection: a host entry of a recorded step (tape.host)
-            rank = torch.full((batch * n_tok_all,), -1, dtype=torch.int32, device=dev)
-            rank[sel.keep.long()] = torch.arange(n_tok, dtype=torch.int32, device=dev)
-            # stage-1 voxels of the kept tokens, in compact row order, as flat ids of the (batch, *grid1) stage-1 volume
-            t = sel.keep.long() % n_tok_all
-            bb = sel.keep.long() // n_tok_all
-            tcoord = []
-            for g in reversed(grid):
-                tcoord.append(t % g)
-                t = t // g
-            tcoord.reverse()
-            u = inv1.long()  # raster voxel index stored at row offset q
-            ucoord = []
-            for bdim in reversed(block1):
-                ucoord.append(u % bdim)
-                u = u // bdim
-            ucoord.reverse()
-            vid = bb[:, None]
-            for d in range(n_dims):
-                vid = vid * grid1[d] + (tcoord[d][:, None] * block1[d] + ucoord[d][None, :])
-            return rank, vid.reshape(-1).to(torch.int32).contiguous()
-
-        rank, idx1 = T.host(visible_index)
+        # compact rank of every token (-1: masked) and the stage-1 voxels of the kept tokens, in compact row order, as flat ids of the
+        # (batch, *grid1) stage-1 volume: one launch
+        rank, idx1 = K.visible_index(sel.keep, batch, grid, block1, inv1)
 
         skips = []
         vol = None

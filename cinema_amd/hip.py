@@ -101,6 +101,8 @@ _PROTOS = {
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
     "cinema_fill_u32": [_vp, C.c_uint, _ll, _vp],
     "cinema_mul_scalar_f32": [_vp, _vp, _vp, _ll, _vp],
+    "cinema_mask_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "cinema_visible_index": [_vp, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp, _vp, _vp],
     "cinema_stream_fork": [_vp, _vp],
     "cinema_marker_record": [_vp],
     "cinema_marker_done": [_ll],
@@ -584,6 +586,50 @@ def col2im(dcols: torch.Tensor, shape: tuple, ks: tuple) -> torch.Tensor:
     dx = torch.empty(shape, dtype=torch.bfloat16, device=dcols.device)
     _check(load().cinema_col2im(dcols.data_ptr(), _rowmajor(dcols, "dcols"), dx.data_ptr(), b, X, Y, Z, c, kx, ky, kz, _stream()), "col2im")
     return dx
+
+
+def random_mask(noise: torch.Tensor, n_keep: int) -> torch.Tensor:
+    """bool [b, n], True = removed: the n - n_keep largest of each row of ``noise`` (ties by index), i.e. ``argsort(argsort(noise)) >= n_keep``."""
+    _dev(noise)
+    if noise.dtype != torch.float32 or noise.dim() != 2 or not noise.is_contiguous():
+        raise HipLibraryError("random_mask: contiguous fp32 [batch, n] noise")
+    b, n = noise.shape
+    mask = torch.empty((b, n), dtype=torch.bool, device=noise.device)
+    _check(load().cinema_mask_select(noise.data_ptr(), mask.data_ptr(), b, n, n_keep, None, None, None, None, _stream()), "mask_select")
+    return mask
+
+
+def mask_select(mask: torch.Tensor, n_keep: int) -> tuple:
+    """bool [b, n] with n_keep False per row -> (keep_pos, drop_pos, keep, drop): int32 raster-ordered positions / flat ids b*n + i."""
+    _dev(mask)
+    if mask.dtype != torch.bool or mask.dim() != 2 or not mask.is_contiguous():
+        raise HipLibraryError("mask_select: contiguous bool [batch, n] mask")
+    b, n = mask.shape
+    outs = [torch.empty(b * k, dtype=torch.int32, device=mask.device) for k in (n_keep, n - n_keep, n_keep, n - n_keep)]
+    _check(load().cinema_mask_select(None, mask.data_ptr(), b, n, n_keep, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
+                                     _stream()), "mask_select")
+    return tuple(outs)
+
+
+def visible_index(keep: torch.Tensor, batch: int, grid: tuple, block: tuple, inv1: torch.Tensor) -> tuple:
+    """-> (rank int32 [batch * prod(grid)]: compact index of a kept token or -1, idx1 int32 [n_kept * prod(block)]: stage-1 voxel ids in row order)."""
+    _dev(keep, inv1)
+    if keep.dtype != torch.int32 or inv1.dtype != torch.int32 or not keep.is_contiguous() or not inv1.is_contiguous():
+        raise HipLibraryError("visible_index: contiguous int32 index tensors")
+    nd = len(grid)
+    n_all, vol = batch, 1
+    for g_ in grid:
+        n_all *= int(g_)
+    for b_ in block:
+        vol *= int(b_)
+    if inv1.numel() != vol:
+        raise HipLibraryError("visible_index: inv1 must have one entry per voxel of a token block")
+    rank = torch.empty(n_all, dtype=torch.int32, device=keep.device)
+    _check(load().cinema_fill_u32(rank.data_ptr(), 0xFFFFFFFF, n_all, _stream()), "fill")  # -1
+    idx1 = torch.empty(keep.numel() * vol, dtype=torch.int32, device=keep.device)
+    garr, barr = (C.c_int * nd)(*[int(v) for v in grid]), (C.c_int * nd)(*[int(v) for v in block])
+    _check(load().cinema_visible_index(keep.data_ptr(), keep.numel(), nd, garr, barr, inv1.data_ptr(), rank.data_ptr(), idx1.data_ptr(), _stream()), "visible_index")
+    return rank, idx1
 
 
 def sparse_geom(batch: int, tok_grid: tuple, block: tuple, keep: torch.Tensor, rank: torch.Tensor, pos: torch.Tensor) -> SparseGeom:

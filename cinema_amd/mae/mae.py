@@ -40,8 +40,11 @@ def get_batch_random_patch_mask(batch_size: int, n_patches: int, mask_ratio: flo
     if mask_ratio == 0:
         return torch.zeros((batch_size, n_patches), dtype=torch.bool, device=device)
     noise = torch.rand(batch_size, n_patches, device=device)
-    rank = torch.argsort(torch.argsort(noise, dim=1), dim=1)
-    return rank >= int(n_patches * (1 - mask_ratio))
+    n_keep = int(n_patches * (1 - mask_ratio))
+    if noise.is_cuda:  # one launch: rank of every element in its row (ties by index) >= n_keep
+        return K.random_mask(noise, n_keep)
+    rank = torch.argsort(torch.argsort(noise, dim=1, stable=True), dim=1, stable=True)
+    return rank >= n_keep
 
 
 def get_decoder_patch_size(image_size: tuple, n_conv_layers: int, enc_patch_size: tuple, enc_scale_factor: tuple) -> tuple:

@@ -207,6 +207,17 @@ int cinema_marker_done(long long ticket);
 /* n back-to-back launches of an empty kernel (measures the host cost of one launch; used by tools/launch_rate.py and DESIGN.md section 5). */
 int cinema_launch_probe(int n, void* stream);
 
+/* Random-mask bookkeeping (cinema/mae/mae.py:30-65 get_batch_random_patch_mask, :550 boolean-mask indexing; cinema/convvit.py:153-170).
+ *   cinema_mask_select: noise != NULL: mask[b][i] = rank of noise[b][i] in its row >= n_keep (True = removed; ties by index, as
+ *       argsort(argsort(noise)) with a stable sort); noise == NULL: mask is an input.  Then, for the lists that are not NULL, the kept /
+ *       dropped tokens of every row in raster order: positions i (keep_pos / drop_pos) and flat ids b*n + i (keep / drop).  Every row of
+ *       `mask` must hold the same number of kept tokens when lists are requested.
+ *   cinema_visible_index: rank[keep[r]] = r (rank pre-filled with -1) and idx1[r*block_vol + q] = flat id of the stage-1 voxel stored at row
+ *       offset q of kept token r (inv1[q] = raster index inside the token's block); grid / block: n_dims host ints (tokens per sample, voxels per token). */
+int cinema_mask_select(const float* noise, uint8_t* mask, int batch, int n, int n_keep, int* keep_pos, int* drop_pos, int* keep, int* drop, void* stream);
+int cinema_visible_index(const int* keep, int n_rows, int n_dims, const int* grid_host, const int* block_host, const int* inv1, int* rank, int* idx1,
+                         void* stream);
+
 /* k == s / dense conv weights (out, c, *k) fp32 <-> GEMM operand rows [out][ld] in the patch feature order (*k, c)  (the re-layout the
  * reference gets for free from cuDNN/MIOpen's own filter layouts; here it feeds cinema_gemm_bf16):
  *   direction 0: rows (bf16 or fp32) <- w, columns beyond kvol*c zero-filled;   direction 1: w += rows (fp32), the gradient way back.

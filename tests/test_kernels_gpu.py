@@ -375,6 +375,54 @@ def test_patch_weight_relayout(shape: tuple, pad_to: int, permuted: bool) -> Non
     assert torch.equal(acc, expect)
 
 
+@pytest.mark.parametrize(("b", "n", "ratio"), [(3, 144, 0.75), (2, 2304, 0.75), (4, 37, 0.5), (1, 5000, 0.9)])
+def test_random_mask_and_selection_lists(b: int, n: int, ratio: float) -> None:
+    """One-launch mask recipe == the reference recipe argsort(argsort(noise)) >= n_keep (cinema/mae/mae.py:30-65), incl. tied noise values;
+    one-launch raster-ordered kept/dropped lists == boolean-mask indexing order (mae.py:550).  Integer work: bit-exact."""
+    n_keep = int(n * (1 - ratio))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    noise = torch.rand(b, n, generator=g)
+    noise[:, n // 3] = noise[:, n // 2]  # a tie in every row: resolved by index, like a stable sort
+    noise = noise.to(DEV)
+    mask = K.random_mask(noise, n_keep)
+    ref = torch.argsort(torch.argsort(noise, dim=1, stable=True), dim=1, stable=True) >= n_keep
+    assert mask.dtype == torch.bool and torch.equal(mask, ref)
+    keep_pos, drop_pos, keep, drop = K.mask_select(mask, n_keep)
+    ar = torch.arange(n, device=DEV, dtype=torch.int32)[None].expand(b, -1)
+    base = torch.arange(b, device=DEV, dtype=torch.int32)[:, None] * n
+    assert torch.equal(keep_pos, ar[~ref]) and torch.equal(drop_pos, ar[ref])
+    assert torch.equal(keep, (base + ar)[~ref]) and torch.equal(drop, (base + ar)[ref])
+
+
+@pytest.mark.parametrize(("grid", "block"), [((3, 4, 2), (4, 4, 1)), ((5, 6), (2, 2))])
+def test_visible_index(grid: tuple, block: tuple) -> None:
+    """rank table and stage-1 voxel ids of the kept tokens vs the torch integer ops they replace (bit-exact)."""
+    batch, n_tok_all, vol = 2, math.prod(grid), math.prod(block)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    keep = torch.sort(torch.randperm(batch * n_tok_all, generator=g)[: batch * n_tok_all // 3]).values.to(torch.int32).to(DEV)
+    inv1 = torch.randperm(vol, generator=g).to(torch.int32).to(DEV)
+    rank, idx1 = K.visible_index(keep, batch, grid, block, inv1)
+    ref_rank = torch.full((batch * n_tok_all,), -1, dtype=torch.int32, device=DEV)
+    ref_rank[keep.long()] = torch.arange(keep.numel(), dtype=torch.int32, device=DEV)
+    assert torch.equal(rank, ref_rank)
+    grid1 = tuple(a * b_ for a, b_ in zip(grid, block))
+    t, bb = keep.long() % n_tok_all, keep.long() // n_tok_all
+    tc = []
+    for gd in reversed(grid):
+        tc.append(t % gd)
+        t = t // gd
+    tc.reverse()
+    u, uc = inv1.long(), []
+    for bd in reversed(block):
+        uc.append(u % bd)
+        u = u // bd
+    uc.reverse()
+    vid = bb[:, None]
+    for d in range(len(grid)):
+        vid = vid * grid1[d] + (tc[d][:, None] * block[d] + uc[d][None, :])
+    assert torch.equal(idx1, vid.reshape(-1).to(torch.int32))
+
+
 def test_row_copy_cast_transpose_gelu() -> None:
     src = rnd(10, 32, dtype=torch.float32, seed=60)
     add = rnd(7, 32, dtype=torch.float32, seed=61)
