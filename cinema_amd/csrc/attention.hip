@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
   const int b = bc.b, h = bc.h;
   const int qrow = bc.t * 128 + wave * 32 + (lane & 31);
   const int qc = qrow < p.tq ? qrow : p.tq - 1;
+  const bool active = bc.t * 128 + wave * 32 < p.tq;  // wave-uniform: a wave past the last query only helps with the loads
   const bf16_t* kbase = p.k + (size_t)b * p.tk * p.ldk + h * HD;
   const bf16_t* vbase = p.v + (size_t)b * p.tk * p.ldv + h * HD;
   short8v qf[HD / 16], dof[HD / 16];
@@ -275,8 +276,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
       Stage::glds(nk + TB, vbase, p.ldv, (kt + 1) * 64, p.tk, lane, wave_u);
     }
     const int key0 = kt * 64 + 4 * g;
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
+    // idle wave / empty 32-key half of the last tile: wave-uniform trip count (kept rolled: unrolled with the guards inside, the hd=64
+    // kernel went from 130 to 168 registers and spilled)
+    const int nu = !active ? 0 : (kt * 64 + 32 < p.tk ? 2 : 1);
+#pragma unroll 1
+    for (int u = 0; u < nu; u++) {
       float16v s, dp;
       zero16(s); zero16(dp);
 #pragma unroll
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
   const int b = bc.b, h = bc.h;
   const int krow = bc.t * 128 + wave * 32 + (lane & 31);
   const int kc = krow < p.tk ? krow : p.tk - 1;
+  const bool active = bc.t * 128 + wave * 32 < p.tk;  // wave-uniform: a wave past the last key only helps with the loads
   const bf16_t* qbase = p.q + (size_t)b * p.tq * p.ldq + h * HD;
   const bf16_t* dobase = p.d_o + (size_t)b * p.tq * p.lddo + h * HD;
   const float* lsebase = p.lse + ((size_t)b * p.h + h) * p.tq;
@@ -370,8 +375,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
       Stage::glds(nb + TB, dobase, p.lddo, (qt + 1) * 64, p.tq, lane, wave_u);
       load_stats((qt + 1) * 64);
     }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
+    const int nu = !active ? 0 : (qt * 64 + 32 < p.tq ? 2 : 1);  // idle wave / empty 32-query half of the last tile (wave-uniform)
+#pragma unroll 1
+    for (int u = 0; u < nu; u++) {
       float16v s, dp;
       zero16(s); zero16(dp);
 #pragma unroll
