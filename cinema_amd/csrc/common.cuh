@@ -131,6 +131,20 @@ __device__ __forceinline__ void glds16(uint32_t lds_addr, const void* gsrc) {
                : "v"(gsrc), "s"(lds_addr)
                : "memory");
 }
+// four LDS-DMA pieces in one statement: M0 is saved / restored once and the loads are issued back to back
+__device__ __forceinline__ void glds16x4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, const void* g0, const void* g1, const void* g2, const void* g3) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(a0), "s"(a1), "s"(a2), "s"(a3)
+      : "memory");
+}
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }  // low 32 bits of a flat LDS pointer = LDS byte address
 
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private 4 MiB L2.  xcd_remap() is a bijection

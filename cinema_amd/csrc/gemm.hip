@@ -431,6 +431,36 @@ struct TileIO {
       glds16(__builtin_amdgcn_readfirstlane(lds_address(lds) + blk * 1024), src);
     }
   }
+  // The same with the per-lane source pointers of k-tile 0 computed once (src4) and advanced by a k offset per tile (glds_at): the
+  // per-tile address arithmetic with its range tests was ~100 instructions per wave in front of every tile's first MFMA.  Only for
+  // k-tiles that lie entirely inside the reduction range (the caller uses glds() for a ragged last tile).
+  struct Src4 { const bf16_t* p[4]; };
+  static __device__ __forceinline__ Src4 src4(const bf16_t* base, int ld, int row0, int nrows, int lane, int wave) {
+    Src4 r;
+#pragma unroll
+    for (int pss = 0; pss < 4; pss++) {
+      const int blk = pss * 4 + wave;
+      if (KMAJ) {
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int rg = row0 + row;
+        rg = rg < nrows ? rg : nrows - 1;
+        r.p[pss] = base + (size_t)rg * ld + c * 8;
+      } else {
+        const int kr = blk * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);
+        int col = row0 + c * 8;
+        col = col < nrows ? col : 0;
+        r.p[pss] = base + (size_t)kr * ld + col;
+      }
+    }
+    return r;
+  }
+  static __device__ __forceinline__ size_t k_step(int ld) { return KMAJ ? (size_t)BK : (size_t)BK * ld; }  // elements per k-tile
+  static __device__ __forceinline__ void glds_at(uint32_t lds_addr, const Src4& s, size_t koff, int wave) {
+    const uint32_t a = lds_addr + wave * 1024;
+    glds16x4(a, a + 4096, a + 8192, a + 12288, s.p[0] + koff, s.p[1] + koff, s.p[2] + koff, s.p[3] + koff);
+  }
   static constexpr int BYTES = KMAJ ? KMAJ_BYTES : MNMAJ_BYTES;
 };
 
@@ -502,9 +532,21 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
   const bool do_rowsum = p.a_rowsum != nullptr && wn == 0 && n0 == 0;  // one wave column of the first n-tile covers every A row once
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
-  AIO::glds(smem, p.a, p.lda, m0, p.m, kt_begin * BK, p.k, lane, wave_u, zero_page);
-  BIO::glds(smem + AIO::BYTES, p.b, p.ldb, n0, p.n, kt_begin * BK, p.k, lane, wave_u, zero_page);
-  if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const typename AIO::Src4 asrc = AIO::src4(p.a, p.lda, m0, p.m, lane, wave_u);
+  const typename BIO::Src4 bsrc = BIO::src4(p.b, p.ldb, n0, p.n, lane, wave_u);
+  const size_t astep = AIO::k_step(p.lda), bstep = BIO::k_step(p.ldb);
+  const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  auto load_tile = [&](int stage, int kt) {  // operands of k-tile kt -> stage
+    if ((kt + 1) * BK <= p.k) {
+      AIO::glds_at(smem_addr + stage * STAGE, asrc, (size_t)kt * astep, wave_u);
+      BIO::glds_at(smem_addr + stage * STAGE + AIO::BYTES, bsrc, (size_t)kt * bstep, wave_u);
+    } else {  // ragged last k-tile: per-element range tests, zero page
+      AIO::glds(smem + stage * STAGE, p.a, p.lda, m0, p.m, kt * BK, p.k, lane, wave_u, zero_page);
+      BIO::glds(smem + stage * STAGE + AIO::BYTES, p.b, p.ldb, n0, p.n, kt * BK, p.k, lane, wave_u, zero_page);
+    }
+  };
+  load_tile(0, kt_begin);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   GEMM_STAMP(1);
 
@@ -513,11 +555,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + AIO::BYTES;
     const bool more = kt + 1 < kt_end;
-    if (more) {
-      char* na = smem + (cur ^ 1) * STAGE;
-      AIO::glds(na, p.a, p.lda, m0, p.m, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
-      BIO::glds(na + AIO::BYTES, p.b, p.ldb, n0, p.n, (kt + 1) * BK, p.k, lane, wave_u, zero_page);
-    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       short8v fa[2], fb[2];
@@ -530,8 +567,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
       if (!A_KMAJ && do_rowsum) { rs[0] += frag_sum8(fa[0]); rs[1] += frag_sum8(fa[1]); }  // VALU work in the shadow of the MFMAs
+      // the next tile's DMA is issued behind the first MFMA group, so its address arithmetic runs while the matrix pipe is busy (the other
+      // stage was last read before the barrier that ended the previous iteration)
+      if (ks == 0 && more) load_tile(cur ^ 1, kt + 1);
     }
-    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA must have landed before anyone reads it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA must have landed before anyone reads it
     __syncthreads();
   }
 
