@@ -11,6 +11,7 @@ ATen compute on this path except index bookkeeping on tiny integer tensors.
 from __future__ import annotations
 
 import math
+import contextlib
 import os
 import weakref
 from collections import deque
@@ -105,10 +106,11 @@ def host(fn: Callable) -> tuple:
         return fn()
     with _Allowed():
         static = tuple(o.clone() for o in fn())
-    st = torch.cuda.current_stream()  # a view stream, possibly: the replayed torch ops must be queued where the recorded consumers wait
+    # a view stream, possibly: the replayed torch ops must be queued where the recorded consumers wait
+    st = torch.cuda.current_stream() if static and static[0].is_cuda else None
 
     def again() -> None:
-        with torch.cuda.stream(st):
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
             for dst, src in zip(static, fn()):
                 dst.copy_(src)
 

@@ -392,3 +392,36 @@ def test_convunetr_state_dict_seeded_init_and_compat_checks_match_the_reference(
         check_conv_unetr_enc_dec_compatiblity((6, 6, 1), (2, 2, 1), 2, 5, (2, 2, 1), (2, 2, 1))
     with pytest.raises(ValueError):
         model({"bogus": torch.zeros(1, 1, 64, 64)})
+
+
+def test_tape_host_and_const_entries_of_a_recording() -> None:
+    """Host logic of recorded steps (cinema_amd/replay.py) without a GPU: tape.const caches by key; tape.host is a plain call outside a
+    recording and, inside one, returns static tensors plus a host entry that recomputes them IN PLACE from the current inputs."""
+    from cinema_amd import hip as K
+    from cinema_amd import tape as T
+
+    calls = []
+
+    def table() -> torch.Tensor:
+        calls.append(1)
+        return torch.arange(5, dtype=torch.int32)
+
+    a, b = T.const(("test_table", 5), table), T.const(("test_table", 5), table)
+    assert a is b and len(calls) == 1
+    mask = torch.tensor([[True, False, True, False]])
+
+    def select() -> tuple:
+        return ((~mask).nonzero()[:, 1].to(torch.int32), mask.nonzero()[:, 1].to(torch.int32))
+
+    keep, drop = T.host(select)  # eager: no recording
+    assert keep.tolist() == [1, 3] and drop.tolist() == [0, 2] and not T.recording()
+    K.RECORD = rec = []
+    try:
+        keep, drop = T.host(select)
+        assert T.recording() and len(rec) == 1 and rec[0][0] is None
+        ptrs = (keep.data_ptr(), drop.data_ptr())
+        mask.copy_(torch.tensor([[False, False, True, True]]))  # "next step": new mask in the same static tensor
+        rec[0][1]()
+        assert keep.tolist() == [0, 1] and drop.tolist() == [2, 3] and (keep.data_ptr(), drop.data_ptr()) == ptrs
+    finally:
+        K.RECORD = None
