@@ -80,3 +80,32 @@ CINEMA_API int cinema_launch_probe(int n, void* stream) {
   for (int i = 0; i < n; ++i) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, i);
   return launch_status();
 }
+
+// Sustained rate of the matrix pipe alone on this device (tools/mfma_peak.py): every wave issues `iters` x 16 independent
+// v_mfma_f32_32x32x16_bf16 from registers (no memory traffic in the loop).  FLOPs per launch = grid * 4 waves * iters * 16 * 32768.
+namespace {
+typedef short mp_short8 __attribute__((ext_vector_type(8)));
+typedef float mp_float16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(int iters, float* out) {
+  mp_short8 a, b;
+  for (int i = 0; i < 8; i++) { a[i] = (short)(0x3c00 + threadIdx.x + i); b[i] = (short)(0x3c00 + 2 * threadIdx.x + i); }
+  mp_float16 acc[4];
+  for (int j = 0; j < 4; j++)
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; j++)
+    for (int r = 0; r < 16; r++) s += acc[j][r];
+  if (s == 123.456f) out[0] = s;  // keep the accumulators alive
+}
+}  // namespace
+
+CINEMA_API int cinema_mfma_probe(int grid, int iters, float* out, void* stream) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, iters, out);
+  return launch_status();
+}

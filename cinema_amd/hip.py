@@ -107,6 +107,7 @@ _PROTOS = {
     "cinema_marker_record": [_vp],
     "cinema_marker_done": [_ll],
     "cinema_launch_probe": [_i, _vp],
+    "cinema_mfma_probe": [_i, _i, _vp, _vp],
     "cinema_patch_weight_relayout": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "cinema_cast": [_vp, _i, _vp, _i, _ll, _vp],
     "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
@@ -132,7 +133,7 @@ def library_path() -> Path:
 # after it ran.  The arguments are plain ints / floats / ctypes structs, so the same launch can be issued again verbatim; host-only queries
 # (workspace sizes) and the completion markers are not part of a step's launch list.
 RECORD: list | None = None
-_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe")
+_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe")
 
 
 class _Entry:

@@ -206,6 +206,9 @@ long long cinema_marker_record(void* stream);
 int cinema_marker_done(long long ticket);
 /* n back-to-back launches of an empty kernel (measures the host cost of one launch; used by tools/launch_rate.py and DESIGN.md section 5). */
 int cinema_launch_probe(int n, void* stream);
+/* grid x 4 waves x iters x 16 independent v_mfma_f32_32x32x16_bf16 from registers: the sustained rate of the matrix pipe alone
+ * (clock / power limits included), the practical ceiling the GEMM kernels are priced against in DESIGN.md (tools/mfma_peak.py). */
+int cinema_mfma_probe(int grid, int iters, float* out, void* stream);
 
 /* Random-mask bookkeeping (cinema/mae/mae.py:30-65 get_batch_random_patch_mask, :550 boolean-mask indexing; cinema/convvit.py:153-170).
  *   cinema_mask_select: noise != NULL: mask[b][i] = rank of noise[b][i] in its row >= n_keep (True = removed; ties by index, as
