@@ -43,11 +43,11 @@ class GemmArgs(C.Structure):
     ]
 
 
-# cinema_gemm_args.kernel_used -> kernel name as rocprofv3 prints it: 0 generic, 4 wave-specialised 256x128 weight-gradient kernel, otherwise
+# cinema_gemm_args.kernel_used -> kernel name as rocprofv3 prints it: 0 generic, otherwise
 # operand layout (1: A,B k-major = forward; 2: B n-major = data gradient; 3: both strided = small weight gradients) + 8 x epilogue class
 # (0 general, 1 bf16, 2 bf16 + GELU, 3 bf16 x GELU', 4 fp32 (+ residual)), see csrc/gemm.hip
 _LAYOUTS = {1: "true, true", 2: "true, false", 3: "false, false"}
-GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel", 4: "gemm_mfma_ws_kernel<false, false>"}
+GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel"}
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (kernel_used, algorithmic_flops, start_event, end_event)

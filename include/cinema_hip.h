@@ -59,8 +59,8 @@ typedef struct {
                                  into k-slices (partial tiles here, a fix-up launch applies the epilogue); contents are scratch, use is stream-ordered */
   long long workspace_bytes;
   float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
-  int kernel_used;            /* OUT: 0 generic FMA; 1/2/3 one-shot 128x128 MFMA kernel for the fwd / dgrad / wgrad operand layouts, 5/6/7 its persistent
-                                 form (CINEMA_GEMM_PERSIST=1), 4 the 256x128 wave-specialised weight-gradient kernel */
+  int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
+                                 + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32) */
 } cinema_gemm_args;
 int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
 
