@@ -96,6 +96,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (reference batch_size_per_device, mae/config.yaml:45)")
     ap.add_argument("--size", default="base")
+    ap.add_argument("--sax", default="192,192,16", help="SAX volume size (BASELINE config 5: 256,256,24 with --size large --lax 256,256)")
+    ap.add_argument("--lax", default="192,192", help="long-axis view size")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 disables)")
     ap.add_argument("--prewarm", type=int, default=20, help="untimed steps run in total before the timed region (>= --warmup); 0 for profiling runs")
     ap.add_argument("--force-sync", action="store_true", help="N=1 only: still issue the gradient collectives (RCCL path check)")
@@ -129,7 +131,7 @@ def main() -> None:
         ddp_setup(0, 1, backend="nccl")
         sync = GradientSynchronizer(1, force_collectives=True)
 
-    kw = base_kwargs(args.size)
+    kw = base_kwargs(args.size, tuple(int(v) for v in args.sax.split(",")), tuple(int(v) for v in args.lax.split(",")))
     torch.manual_seed(0)  # identical weights on every rank (config.seed, mae/config.yaml:1)
     model = CineMA(**kw)
     cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
@@ -162,6 +164,8 @@ def main() -> None:
         dt = float(t)
     final_loss = float(loss)
     n_launches = next(iter(step._recorded.values())).n_launches if step._recorded else None  # noqa: SLF001
+    # forward GFLOP of the reference graph x 3 (SURVEY appendix A probes): config 2 and config 5 shapes only
+    ref_gflop = {("base", "192,192,16", "192,192"): STEP_GFLOP_PER_SAMPLE, ("large", "256,256,24", "256,256"): 3 * 1806.7}.get((args.size, args.sax, args.lax))
     step.replay = False  # the information-only runs below (dense stem, per-launch events) go through the module code
 
     # the same steps with the stem evaluated on every voxel like the reference (information only; single process)
@@ -216,7 +220,7 @@ def main() -> None:
             "metric": "MAE-pretrain samples/sec (4-view cine, 75% mask)", "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX 192x192x16 + LAX 2C/3C/4C 192x192), mask 0.75, "
+            "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX {args.sax.replace(',', 'x')} + LAX 2C/3C/4C {args.lax.replace(',', 'x')}), mask 0.75, "
                                    f"per-GPU batch {args.batch}, fwd+bwd+clip(5.0)+AdamW, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
                        "stem": "dense (every voxel, as the reference)" if dense_stem else
@@ -225,7 +229,7 @@ def main() -> None:
                        "host": ("module code issues every launch (--eager)" if args.eager else
                                 f"forward+backward re-issued from a recorded list of {n_launches} HIP launches (cinema_amd/replay.py); clip+AdamW eager"),
                        # the REFERENCE's dense FLOP count per sample x samples/s: a reference-equivalent rate, not executed FLOPs
-                       "reference_equiv_tflops_per_gpu": round(samples_per_s / world * STEP_GFLOP_PER_SAMPLE / 1e3, 1)},
+                       "reference_equiv_tflops_per_gpu": (None if ref_gflop is None else round(samples_per_s / world * ref_gflop / 1e3, 1))},
             "roofline": roofline,
         }
         if world == 1 and args.cpu_budget > 0:
