@@ -776,10 +776,10 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     }
     a->kernel_used = (a->a_kmajor && a->b_kmajor) ? 1 : (a->a_kmajor ? 2 : 3);
     // split tail (measured: 516 tiles on 512 slots cost 1.64 rounds, the 4 left-over tiles run alone at the end): worth a second
-    // launch only for long reductions and when the left-over tiles can be cut at least in two
+    // launch only when the reduction has >= 12 k-tiles and the left-over tiles can be cut at least in two
     p.tail_split = 0; p.tail_begin = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
     bool tail = false;
-    if (gz == 1 && a->force_generic == 0 && !p.accumulate && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= 24) {
+    if (gz == 1 && a->force_generic == 0 && !p.accumulate && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= 12) {  // K >= 768 (tools/tail_ab.py: 10960x768x768 38 -> 34 us, x1024 42 -> 35 us; at K = 512 the fix-up launch costs what it saves)
       static int slots = 0;
       if (slots == 0) {
         int dev = 0; hipDeviceProp_t prop;

@@ -324,7 +324,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
         ws = _workspace("splitk", split_k * m * n, a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), split_k * m * n * 4
-    elif split_k == 1 and k >= 1536:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
+    elif split_k == 1 and k >= 768:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
         ws = _tail_workspace(a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     if GEMM_PROFILE is None:
