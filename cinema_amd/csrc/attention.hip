@@ -288,11 +288,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(ks_, 32 * u, ks, lane), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(vs_, 32 * u, ks, lane), dof[ks], dp, 0, 0, 0);
       }
+      if (kt == nkt - 1 && (p.tk & 63)) {  // only the ragged last tile needs the key-range test (wave-uniform branch)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = key0 + 32 * u + (r & 3) + 8 * (r >> 2);
-        const float pr = key < p.tk ? fast_exp2(fmaf(s[r], p.c2, -lse)) : 0.f;
-        s[r] = pr * (dp[r] - dl);  // dS^T
+        for (int r = 0; r < 16; r++) {
+          const int key = key0 + 32 * u + (r & 3) + 8 * (r >> 2);
+          const float pr = key < p.tk ? fast_exp2(fmaf(s[r], p.c2, -lse)) : 0.f;
+          s[r] = pr * (dp[r] - dl);  // dS^T
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = fast_exp2(fmaf(s[r], p.c2, -lse)) * (dp[r] - dl);
       }
 #pragma unroll
       for (int st = 0; st < 2; st++) {
