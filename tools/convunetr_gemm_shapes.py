@@ -1,17 +1,18 @@
-"""First timing of the ConvUNetR segmentation step at BASELINE config 4 shape (ACDC-like SAX 256x256x12, 4 classes, ViT-Base): dev tooling."""
+"""Per-shape GEMM table of one ConvUNetR segmentation step (which launches fall to the generic kernel, and why): dev tooling."""
 import sys
-import time
 from pathlib import Path
 
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from cinema_amd import hip as K  # noqa: E402
+from cinema_amd import tape as T  # noqa: E402
 from cinema_amd.optim import FlatModel, FusedAdamW  # noqa: E402
 from cinema_amd.segmentation.convunetr import ConvUNetR  # noqa: E402
 from cinema_amd.segmentation.train import _segmentation_loss  # noqa: E402
 from cinema_amd.vit import get_vit_config  # noqa: E402
 
-b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+b = 2
 vit = get_vit_config("base")
 torch.manual_seed(0)
 model = ConvUNetR(image_size_dict={"sax": (256, 256, 12)}, in_chans_dict={"sax": 1}, out_chans=4, enc_patch_size_dict={"sax": (4, 4, 1)},
@@ -31,20 +32,21 @@ def step():
     loss.backward()
     opt.step(1.0)
     opt.zero_grad()
-    return loss
 
 
-for _ in range(3):
-    loss = step()
+T.SIDE_WGRAD = False
+for _ in range(2):
+    step()
+K.GEMM_PROFILE = []
+step()
 torch.cuda.synchronize()
-import os
-c0, t0 = os.times(), time.perf_counter()
-n = 5
-for _ in range(n):
-    loss = step()
-t1, c1 = time.perf_counter(), os.times()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-print(f"host: enqueue returns after {1e3 * (t1 - t0) / n:.1f} ms/step, process CPU {1e3 * (c1.user - c0.user + c1.system - c0.system) / n:.1f} ms/step")
-print(f"ConvUNetR base, SAX 256x256x12, batch {b}: {dt * 1e3:.1f} ms/step ({b / dt:.2f} samples/s), loss {float(loss):.4f}, "
-      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+agg = {}
+for kind, flops, e0, e1, shape in prof:
+    a = agg.setdefault((kind, shape), [0.0, 0.0, 0])
+    a[0] += flops
+    a[1] += e0.elapsed_time(e1) * 1e-3
+    a[2] += 1
+print(f"all GEMM launches: {sum(v[1] for v in agg.values()) * 1e3:.1f} ms/step")
+for (kind, (m, n, k, ak, bk, sk)), (fl, secs, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+    print(f"{K.GEMM_KERNEL_NAMES[kind]:36s} m{m:8d} n{n:5d} k{k:8d} aK{ak} bK{bk} sk{sk:3d} x{cnt:3d} {secs / cnt * 1e6:9.1f} us {fl / secs / 1e12:6.1f} TF {secs * 1e3:7.2f} ms")
