@@ -329,6 +329,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     if GEMM_PROFILE is None:
         _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
+        if g.kernel_used == 0 and not g.force_generic and 2.0 * m * n * k > 1e9:
+            _warn_generic(m, n, k, a, b, out)
         return out
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -336,6 +338,21 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ev1.record()
     GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k)))
     return out
+
+
+_WARNED_GENERIC: set = set()
+
+
+def _warn_generic(m: int, n: int, k: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
+    """A large GEMM on the generic FMA kernel is ~20x slower than the MFMA kernel and almost always an alignment accident (16-byte
+    pointers, leading dimensions / n / k multiples of 8): say so once per shape instead of being silently slow."""
+    key = (m, n, k)
+    if key not in _WARNED_GENERIC:
+        _WARNED_GENERIC.add(key)
+        import warnings
+
+        warnings.warn(f"cinema_gemm_bf16 {m}x{n}x{k} ran on the generic (non-MFMA) kernel: operand pointers a/b/out % 16 = "
+                      f"{a.data_ptr() % 16}/{b.data_ptr() % 16}/{out.data_ptr() % 16}, strides {a.stride()}/{b.stride()}/{out.stride()}", stacklevel=3)
 
 
 def seg_loss_fwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int):  # noqa: ANN201
