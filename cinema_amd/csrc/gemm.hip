@@ -440,38 +440,15 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
   tm = first_m + in_g - tn * gsz;
 }
 
+// One 128x128 output tile (or k-slice of one) of problem p: everything after the work-item decoding of the kernels below.
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
-  constexpr bool GLDS = true;  // operands always arrive by LDS-DMA (the register-staged variant lost every A/B and was removed)
+__device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, int kt_begin, int kt_end, float* tail_dst, char* smem) {
   using AIO = TileIO<A_KMAJ>;
   using BIO = TileIO<B_KMAJ>;
   constexpr int STAGE = AIO::BYTES + BIO::BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
-  // linear dispatch id (x fastest, then z) -> logical work item, split-major so that one XCD sees one k-range
-  const int nkt = (p.k + BK - 1) / BK;
-  int zsplit = 0, tile, kt_begin, kt_end;
-  float* tail_dst = nullptr;
-  if (p.tail_split > 0 && (int)blockIdx.x >= p.tail_begin) {
-    // split tail: dispatched last (highest ids), dealt round-robin over the XCDs as they drain
-    const int j = (int)blockIdx.x - p.tail_begin;
-    tile = p.tail_begin + j / p.tail_split;
-    const int slice = j - (tile - p.tail_begin) * p.tail_split;
-    kt_begin = slice * p.tail_ktiles;
-    kt_end = min(nkt, kt_begin + p.tail_ktiles);
-    tail_dst = p.tail_ws + (size_t)j * (BM * BN);
-    zsplit = slice;  // bias-gradient row sums / nothing else depends on it in this mode
-  } else {
-    const int n_main = p.tail_split > 0 ? p.tail_begin : (int)gridDim.x;
-    const int logical = xcd_remap(blockIdx.z * n_main + blockIdx.x, n_main * gridDim.z);
-    zsplit = logical / n_main;
-    tile = logical - zsplit * n_main;
-    kt_begin = zsplit * p.ktiles_per_split;
-    kt_end = min(nkt, kt_begin + p.ktiles_per_split);
-  }
   int tm, tn;
   tile_of(tile, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -568,6 +545,62 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GEMM_STAMP(4);
 #endif
+}
+
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
+  using AIO = TileIO<A_KMAJ>;
+  using BIO = TileIO<B_KMAJ>;
+  constexpr int STAGE = AIO::BYTES + BIO::BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
+  // linear dispatch id (x fastest, then z) -> logical work item, split-major so that one XCD sees one k-range
+  const int nkt = (p.k + BK - 1) / BK;
+  int zsplit = 0, tile, kt_begin, kt_end;
+  float* tail_dst = nullptr;
+  if (p.tail_split > 0 && (int)blockIdx.x >= p.tail_begin) {
+    // split tail: dispatched last (highest ids), dealt round-robin over the XCDs as they drain
+    const int j = (int)blockIdx.x - p.tail_begin;
+    tile = p.tail_begin + j / p.tail_split;
+    const int slice = j - (tile - p.tail_begin) * p.tail_split;
+    kt_begin = slice * p.tail_ktiles;
+    kt_end = min(nkt, kt_begin + p.tail_ktiles);
+    tail_dst = p.tail_ws + (size_t)j * (BM * BN);
+    zsplit = slice;  // bias-gradient row sums / nothing else depends on it in this mode
+  } else {
+    const int n_main = p.tail_split > 0 ? p.tail_begin : (int)gridDim.x;
+    const int logical = xcd_remap(blockIdx.z * n_main + blockIdx.x, n_main * gridDim.z);
+    zsplit = logical / n_main;
+    tile = logical - zsplit * n_main;
+    kt_begin = zsplit * p.ktiles_per_split;
+    kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+  }
+  gemm_tile<A_KMAJ, B_KMAJ, EPI>(p, tile, zsplit, kt_begin, kt_end, tail_dst, smem);
+}
+
+// GROUPED launch: the tiles of up to 8 independent problems in one grid (no split-K).  The four weight gradients of a transformer block
+// have 36-144 tiles each - far fewer than the 512 workgroup slots - so each used to be cut into 3-14 k-slices with fp32 slabs and a reduce
+// launch; together they are 432 tiles, which fill the slots with whole-K tiles: no slabs, no reduce, one launch instead of eight.
+struct GroupP {
+  GemmP p[8];
+  int tile_begin[9];  // prefix sums of the tile counts
+  int count;
+};
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_grouped_kernel(GroupP g) {
+  using AIO = TileIO<A_KMAJ>;
+  using BIO = TileIO<B_KMAJ>;
+  constexpr int STAGE = AIO::BYTES + BIO::BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);  // one XCD works on a contiguous tile range, i.e. mostly on one problem
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < 8; j++) i += (j < g.count && logical >= g.tile_begin[j]) ? 1 : 0;
+  const GemmP& p = g.p[i];
+  gemm_tile<A_KMAJ, B_KMAJ, EPI>(p, logical - g.tile_begin[i], 0, 0, (p.k + BK - 1) / BK, nullptr, smem);
 }
 
 // Sums the k-slices of the split-tail tiles and applies the fused epilogue: thread = 8 consecutive columns of one row.
@@ -859,6 +892,39 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   const int b_rs = a->b_kmajor ? 1 : a->ldb, b_cs = a->b_kmajor ? a->ldb : 1;   // element (k,n) = b[k*b_rs + n*b_cs]
   a->kernel_used = 0;
   hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, st, p, a_rs, a_cs, b_rs, b_cs);
+  return launch_status();
+}
+
+CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void* stream) {
+  if (!args || count < 1 || count > 8) return CINEMA_ERR_BAD_ARG;
+  auto al8 = [](int v) { return (v & 7) == 0; };
+  auto ptr16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  GroupP g;
+  g.count = count;
+  g.tile_begin[0] = 0;
+  for (int i = 0; i < count; i++) {
+    const cinema_gemm_args* a = &args[i];
+    if (!a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
+    // weight-gradient form only: both operands reduction-strided, fp32 output (optionally accumulated), no fused epilogue terms
+    if (a->a_kmajor || a->b_kmajor || !a->out_f32 || a->bias || a->residual_f32 || a->residual_bf16 || a->gelu_in || a->row_mask || a->aux_out || a->act)
+      return CINEMA_ERR_UNSUPPORTED;
+    if (!(al8(a->lda) && al8(a->ldb) && al8(a->ldd) && al8(a->n) && al8(a->m) && ptr16(a->a) && ptr16(a->b) && ptr16(a->d))) return CINEMA_ERR_UNSUPPORTED;
+    GemmP& p = g.p[i];
+    p.a = (const bf16_t*)a->a; p.b = (const bf16_t*)a->b; p.d = a->d;
+    p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldb = a->ldb; p.ldd = a->ldd;
+    p.alpha = a->alpha;
+    p.bias = nullptr; p.res_bf16 = nullptr; p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
+    p.act = 0; p.out_f32 = 1; p.accumulate = 0;
+    p.res_f32 = a->accumulate ? (const float*)a->d : nullptr;  // one owner per element: plain read-modify-write
+    p.ld_res = a->ldd;
+    p.ktiles_per_split = (a->k + BK - 1) / BK;
+    p.ws = nullptr; p.a_rowsum = a->a_rowsum;
+    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+    g.tile_begin[i + 1] = g.tile_begin[i] + ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN);
+    args[i].kernel_used = 64;  // the grouped kernel
+  }
+  for (int i = count + 1; i < 9; i++) g.tile_begin[i] = g.tile_begin[count];
+  hipLaunchKernelGGL((gemm_mfma_grouped_kernel<false, false, EPI_F32>), dim3(g.tile_begin[count]), dim3(256), 0, (hipStream_t)stream, g);
   return launch_status();
 }
 

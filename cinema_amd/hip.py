@@ -48,6 +48,7 @@ class GemmArgs(C.Structure):
 # (0 general, 1 bf16, 2 bf16 + GELU, 3 bf16 x GELU', 4 fp32 (+ residual)), see csrc/gemm.hip
 _LAYOUTS = {1: "true, true", 2: "true, false", 3: "false, false"}
 GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel"}
+GEMM_KERNEL_NAMES[64] = "gemm_mfma_grouped_kernel<false, false, 4>"
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (kernel_used, algorithmic_flops, start_event, end_event)
@@ -76,6 +77,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 _PROTOS = {
     "cinema_hip_info": [C.POINTER(C.c_int)],
     "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "cinema_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i, _vp],
     "cinema_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _vp],
@@ -341,6 +343,31 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
 
 
 _WARNED_GENERIC: set = set()
+
+
+def gemm_wgrad_grouped(problems: list) -> None:
+    """One launch for up to 8 weight gradients: each problem is (dy [rows, n_out] bf16, x [rows, k_out] bf16, dst fp32 [n_out, k_out] view,
+    a_rowsum fp32 [n_out] | None); dst += dy^T x, a_rowsum += column sums of dy.  Whole-K tiles, no split-K slabs (see the header)."""
+    arr = (GemmArgs * len(problems))()
+    for g, (dy, x, dst, rowsum) in zip(arr, problems):
+        _dev(dy, x, dst, rowsum)
+        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dst.dtype != torch.float32 or dy.shape[0] != x.shape[0]:
+            raise HipLibraryError("gemm_wgrad_grouped: bf16 operands with a common row count, fp32 destination")
+        g.a, g.b, g.d = dy.data_ptr(), x.data_ptr(), dst.data_ptr()
+        g.m, g.n, g.k = dy.shape[1], x.shape[1], dy.shape[0]
+        g.lda, g.ldb, g.ldd = _rowmajor(dy, "dy"), _rowmajor(x, "x"), _rowmajor(dst, "dst")
+        g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, 1
+        if rowsum is not None:
+            g.a_rowsum = rowsum.data_ptr()
+    if GEMM_PROFILE is None:
+        _check(load().cinema_gemm_bf16_grouped(arr, len(problems), _stream()), "gemm_grouped")
+        return
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    _check(load().cinema_gemm_bf16_grouped(arr, len(problems), _stream()), "gemm_grouped")
+    ev1.record()
+    flops = sum(2.0 * g.m * g.n * g.k for g in arr)
+    GEMM_PROFILE.append((64, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems))))
 
 
 def _warn_generic(m: int, n: int, k: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:

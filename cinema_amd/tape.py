@@ -291,6 +291,8 @@ class Tape:
         self.ops: list = []   # (backward closure, stream the forward op ran on: None = the caller's stream, else a view stream)
         self.stream = None
         self.view_streams_used: list = []
+        self.pending_wgrads: list = []  # (dy, x, dst, bias_grad) deferred to the enclosing weight-gradient group
+        self.grouping = False
         self.pvars: dict = {}
         self.train = train
 
@@ -329,6 +331,7 @@ class Tape:
         finally:
             if cur is not None:
                 torch.cuda.set_stream(main)
+        flush_wgrads(self)
         for st in used:
             K.stream_fork(st.cuda_stream, main.cuda_stream)
         join_side_stream(release=True)
@@ -468,6 +471,64 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
     fn()
 
 
+# The weight gradients of one transformer block in ONE launch (cinema_gemm_bf16_grouped): alone, each has 36-144 output tiles for 512
+# workgroup slots and is cut into k-slices with fp32 slabs and a reduce launch; together the encoder block's four have 432 whole-K tiles.
+# Measured (tools/wgrad_group_ab.py): in isolation 223 us instead of 308 us for the four launches - but the STEP gets slower (32.85 vs
+# 32.39 ms): the group can only be issued at the end of the block's backward and its 432 workgroups each run for 160 us, so the side
+# stream no longer fills the main stream's idle slots early and the main stream's kernels wait for slots behind long tiles.  Opt-in.
+# Groups that would leave the slots mostly empty (decoder blocks: 192 tiles) keep the per-GEMM split-K path either way.
+GROUP_WGRAD = bool(int(os.environ.get("CINEMA_GROUP_WGRAD", "0")))
+_GROUP_MIN_TILES = 384
+
+
+def wgrad_group(tape: Tape) -> None:
+    """Bracket the forward ops of a module whose weight gradients should be launched together: call at the START of its forward ops (the
+    flush runs at the end of its backward) ... and :func:`wgrad_group_end` at the end of them (grouping switches on when the backward enters)."""
+    def flush() -> None:
+        flush_wgrads(tape)
+        tape.grouping = False
+
+    tape.record(flush)
+
+
+def wgrad_group_end(tape: Tape) -> None:
+    def begin() -> None:
+        tape.grouping = GROUP_WGRAD and not K.FORCE_GENERIC
+
+    tape.record(begin)
+
+
+def _wgrad_single(dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias_grad: torch.Tensor | None) -> None:
+    n, k = dy16.shape[1], x16.shape[1]
+    _wgrad_launch(lambda: K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k),
+                                 a_rowsum=bias_grad), dy16, x16)
+
+
+def flush_wgrads(tape: Tape) -> None:
+    probs, tape.pending_wgrads = tape.pending_wgrads, []
+    if not probs:
+        return
+    tiles = sum(((dy.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128) for dy, x, _, _ in probs)
+    if len(probs) < 2 or tiles < _GROUP_MIN_TILES:
+        for pr in probs:
+            _wgrad_single(*pr)
+        return
+    for i in range(0, len(probs), 8):
+        chunk = probs[i:i + 8]
+        _wgrad_launch(lambda c=chunk: K.gemm_wgrad_grouped(c), *[t for dy, x, _, _ in chunk for t in (dy, x)])
+
+
+def wgrad_problem(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias_grad: torch.Tensor | None) -> None:
+    """dst[n,k] += dy^T x ; bias_grad[n] += colsum(dy): launched now (split-K) or deferred to the enclosing weight-gradient group."""
+    n, k = dy16.shape[1], x16.shape[1]
+    ok = (n % 8 == 0 and k % 8 == 0 and dy16.stride(1) == 1 and x16.stride(1) == 1 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0
+          and dst.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0 and x16.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0)
+    if getattr(tape, "grouping", False) and ok:
+        tape.pending_wgrads.append((dy16, x16, dst, bias_grad))
+    else:
+        _wgrad_single(dy16, x16, dst, bias_grad)
+
+
 def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar | None, wshape: tuple, to_param_layout: Callable | None = None,
           row_offset: int = 0, total_rows: int | None = None) -> None:
     """dW[n,k] += dy^T x ; db[n] += colsum(dy).  ``row_offset`` targets a row block of a fused (cat) weight."""
@@ -475,8 +536,7 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
     full = wv.grad_buffer(wshape if total_rows is None else (total_rows, k), to_param_layout)
     dst = full.view(-1, k)[row_offset:row_offset + n]
     bias_grad = None if bv is None else bv.grad_buffer((n,) if total_rows is None else (total_rows,))[row_offset:row_offset + n]
-    _wgrad_launch(lambda: K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k),
-                                 a_rowsum=bias_grad), dy16, x16)
+    wgrad_problem(tape, dy16, x16, dst, bias_grad)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -582,8 +642,7 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
             bq, bkv = pv[1].grad_buffer((c,)), pv[3].grad_buffer((2 * c,))
             if pv[1].direct and pv[3].direct and _adjacent(bq, bkv):  # one [3c, c] weight-gradient GEMM + one column sum
                 g3, b3 = gq.as_strided((3 * c, c), (c, 1)), bq.as_strided((3 * c,), (1,))
-                _wgrad_launch(lambda: K.gemm(dqkv, x.data, a_kmajor=False, b_kmajor=False, out=g3, accumulate=True,
-                                             split_k=_split_k(dqkv.shape[0], 3 * c, c), a_rowsum=b3), dqkv, x.data)
+                wgrad_problem(tape, dqkv, x.data, g3, b3)
                 gq = None
         if gq is not None:
             wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))

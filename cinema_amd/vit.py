@@ -253,11 +253,14 @@ class Block(nn.Module, _CkptFlag):
         if self.training and self.drop_path_rate > 0.0:
             raise NotImplementedError("drop_path > 0 in training mode has no HIP path yet (evaluation, or drop_path = 0).")
         T.mark_params(tp, self._param_list())  # gradient all-reduce of this block may start once its backward ops are launched
+        T.wgrad_group(tp)                      # ... which includes the grouped weight-gradient launch: its flush runs before that marker fires
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = self.attn.tape_forward(tp, qn, xk, batch)
         x1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, residual=xq)
         xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1)
+        y = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1)
+        T.wgrad_group_end(tp)
+        return y
 
     def forward(self, q: torch.Tensor, k: torch.Tensor | None = None) -> torch.Tensor:
         b, tq, c = q.shape

@@ -60,9 +60,13 @@ typedef struct {
   long long workspace_bytes;
   float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
-                                 + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32) */
+                                 + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped */
 } cinema_gemm_args;
 int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
+/* The tiles of up to 8 independent weight-gradient GEMMs (a_kmajor = b_kmajor = 0, fp32 D, optional accumulate and a_rowsum, no other
+ * epilogue term, split_k ignored) in ONE launch with whole-K tiles: the four dW of a transformer block (cinema/vit.py:525-609) have
+ * 36-144 output tiles each and would otherwise be cut into k-slices with fp32 slabs and a reduce launch each. */
+int cinema_gemm_bf16_grouped(cinema_gemm_args* args_host_array, int count, void* stream);
 
 /* column sums: out[n] += sum_{i<m} x[row(i), n] with row(i) = row_idx ? row_idx[i] : i  (bias / token-parameter gradients).
  * x bf16 (x_dtype 0) or fp32 (1), row-major [.][ldx]; out fp32 [n], accumulated atomically */

@@ -122,6 +122,32 @@ def test_gemm_split_tail_full_size(m: int, n: int, k: int) -> None:
     close(out2, ref - bias, 2e-4, 2e-3, "tail dgrad layout")
 
 
+def test_gemm_wgrad_grouped_matches_single_launches() -> None:
+    """cinema_gemm_bf16_grouped: several weight gradients in one launch (whole-K tiles, no split-K slabs) == the per-GEMM launches
+    (deterministic split-K) and the fp32 reference; fp32 accumulation order differs, tolerance 1e-3 relative to the largest element."""
+    rows = 1000
+    shapes = [(256, 384), (128, 128), (384, 256), (64, 512)]
+    probs, single, ref = [], [], []
+    for i, (n, k) in enumerate(shapes):
+        dy = rnd(rows, n, scale=0.5, seed=80 + i)
+        x = rnd(rows, k, scale=0.5, seed=90 + i)
+        base = rnd(n, k, dtype=torch.float32, seed=100 + i)
+        bsum = rnd(n, dtype=torch.float32, seed=110 + i)
+        dst, b1 = base.clone(), bsum.clone()
+        probs.append((dy, x, dst, b1))
+        d2, b2 = base.clone(), bsum.clone()
+        K.gemm(dy, x, a_kmajor=False, b_kmajor=False, out=d2, accumulate=True, split_k=3, a_rowsum=b2)
+        single.append((d2, b2))
+        ref.append((base + dy.float().t() @ x.float(), bsum + dy.float().sum(0)))
+    K.gemm_wgrad_grouped(probs)
+    for (dy, x, dst, b1), (d2, b2), (rd, rb) in zip(probs, single, ref):
+        close(dst, rd, 0.0, 1e-3 * float(rd.abs().max()), "grouped dW vs fp32")
+        close(dst, d2, 0.0, 1e-3 * float(rd.abs().max()), "grouped dW vs single launch")
+        close(b1, rb, 0.0, 1e-3 * float(rb.abs().max()), "grouped bias gradient")
+    with pytest.raises(K.HipLibraryError):  # forward-layout problems are not groupable
+        K.gemm_wgrad_grouped([(rnd(64, 8), rnd(32, 8), torch.zeros(8, 8, device=DEV), None)])
+
+
 def test_gemm_strided_views_and_colsum() -> None:
     big = rnd(300, 3 * 256, seed=13)
     a = big[:, 256:512]  # column slice of a fused buffer
