@@ -164,6 +164,7 @@ def main() -> None:
         dt = float(t)
     final_loss = float(loss)
     n_launches = next(iter(step._recorded.values())).n_launches if step._recorded else None  # noqa: SLF001
+    peak_gib = round(torch.cuda.max_memory_reserved() / 2**30, 1)  # of 288: parameters + optimiser state + the recorded step's private pool
     # forward GFLOP of the reference graph x 3 (SURVEY appendix A probes): config 2 and config 5 shapes only
     ref_gflop = {("base", "192,192,16", "192,192"): STEP_GFLOP_PER_SAMPLE, ("large", "256,256,24", "256,256"): 3 * 1806.7}.get((args.size, args.sax, args.lax))
     step.replay = False  # the information-only runs below (dense stem, per-launch events) go through the module code
@@ -225,7 +226,7 @@ def main() -> None:
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
                        "stem": "dense (every voxel, as the reference)" if dense_stem else
                                "visible voxels only - exact: masked voxels never reach a kept token (DESIGN.md 3a); CINEMA_DENSE_STEM=1 runs every voxel",
-                       "dense_stem_ms_per_step": dense_ms,
+                       "dense_stem_ms_per_step": dense_ms, "peak_mem_gib": peak_gib,
                        "host": ("module code issues every launch (--eager)" if args.eager else
                                 f"forward+backward re-issued from a recorded list of {n_launches} HIP launches (cinema_amd/replay.py); clip+AdamW eager"),
                        # the REFERENCE's dense FLOP count per sample x samples/s: a reference-equivalent rate, not executed FLOPs
