@@ -199,6 +199,13 @@ class TrainStep:
         return loss.detach(), grad_norm, metrics
 
     # ------------------------------------------------------------------------------------------------ recorded step
+    def reset_recordings(self) -> None:
+        """Drop the recorded steps (and their memory pools).  A recording is the launch list of the model AS IT WAS when recorded: call this
+        after changing ``requires_grad`` flags, swapping sub-modules, switching train / eval behaviour or resizing parameters; input
+        shapes and the mask ratio are part of the key and need no reset."""
+        self._recorded.clear()
+        self._graphs.clear()
+
     def _replay_step(self, image_dict: dict, enc_mask_ratio: float, update_grad: bool):  # noqa: ANN202
         from cinema_amd.replay import RecordedStep
 

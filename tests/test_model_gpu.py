@@ -213,6 +213,10 @@ def test_recorded_step_replays_the_eager_step(kw: dict) -> None:
             before = step.flat.flat_param.clone()
             step({"sax": batches[0]["sax"]}, 0.5, update_grad=False)
             assert len(step._recorded) == 2 and torch.equal(before, step.flat.flat_param)  # noqa: SLF001
+            step.reset_recordings()
+            assert len(step._recorded) == 0  # noqa: SLF001
+            loss, _, _ = step(batches[0], 0.75)  # records again
+            assert len(step._recorded) == 1 and math.isfinite(float(loss))  # noqa: SLF001
     for a, b in zip(traj["eager"], traj["replay"]):
         for x, y in zip(a, b):
             assert abs(x - y) <= 2e-4 * abs(x) + 1e-6, (traj["eager"], traj["replay"])
