@@ -304,14 +304,9 @@ def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids
     cls_rows = rows_of(0, 1)
     segs, skips_all, view_rows = [T.Segment(cls_rows, src=model.encoder.cls_token)], {}, {}
     off = 1
-    toks = {}
-    for i, v in enumerate(views):  # the stems are independent: the first view stays on this stream, the others run beside it
-        with T.on_view_stream(tp, i):
-            skips_all[v], toks[v] = model.enc_down_dict[v].tape_forward(tp, images[v], sels[v], grids[v])
-    T.join_view_streams(tp)
     for v, nk in zip(views, n_keep):
         enc = model.enc_down_dict[v]
-        tok = toks[v]
+        skips_all[v], tok = enc.tape_forward(tp, images[v], sels[v], grids[v])
         rows = rows_of(off, nk)
         view_rows[v] = rows
         pe = enc.interpolate_pos_encoding(grids[v]).detach().reshape(-1, e)

@@ -194,50 +194,6 @@ SIDE_WGRAD = bool(int(os.environ.get("CINEMA_SIDE_WGRAD", "1")))
 _SIDE_STREAMS: dict = {}
 
 
-# The conv stems of the views are independent until the encoder concatenates their tokens, and the 2-D long-axis views are chains of ~100
-# tiny launches each (5-10 us kernels, latency-bound): they run on their own streams beside the short-axis stem (forward and backward).
-VIEW_STREAMS = bool(int(os.environ.get("CINEMA_VIEW_STREAMS", "0")))  # measured neutral on the step (33.95 vs 33.83 ms): opt-in
-_VIEW_STREAMS: dict = {}
-
-
-def view_stream(i: int) -> "torch.cuda.Stream":
-    key = (torch._C._cuda_getDevice(), i)  # noqa: SLF001
-    st = _VIEW_STREAMS.get(key)
-    if st is None:
-        st = _VIEW_STREAMS[key] = torch.cuda.Stream(device=key[0])
-    return st
-
-
-class on_view_stream:  # noqa: N801
-    """Forward ops inside run on view stream ``i`` (i == 0 or VIEW_STREAMS off: the caller's stream): the stream first waits for the
-    caller's queue; torch's current stream is switched too, so tensors allocated inside belong to that stream's allocator pool.  The
-    caller joins with :func:`join_view_streams` before consuming the results."""
-
-    def __init__(self, tape: "Tape", i: int) -> None:
-        self.tape = tape
-        self.st = view_stream(i) if (VIEW_STREAMS and i > 0 and torch.cuda.is_available()) else None
-
-    def __enter__(self) -> None:
-        if self.st is not None:
-            self.main = torch.cuda.current_stream()
-            K.stream_fork(self.main.cuda_stream, self.st.cuda_stream)
-            torch.cuda.set_stream(self.st)
-            self.tape.stream = self.st
-            self.tape.view_streams_used.append(self.st)
-
-    def __exit__(self, *exc) -> None:  # noqa: ANN002
-        if self.st is not None:
-            torch.cuda.set_stream(self.main)
-            self.tape.stream = None
-
-
-def join_view_streams(tape: "Tape") -> None:
-    main = K._stream()  # noqa: SLF001
-    for st in tape.view_streams_used:
-        K.stream_fork(st.cuda_stream, main)
-    tape.view_streams_used = []
-
-
 def side_stream() -> "torch.cuda.Stream":
     dev = torch._C._cuda_getDevice()
     st = _SIDE_STREAMS.get(dev)
@@ -288,9 +244,7 @@ class Tape:
     """Backward closures in forward order + the parameter registry of one top-level call."""
 
     def __init__(self, params: dict | None = None, train: bool = True) -> None:
-        self.ops: list = []   # (backward closure, stream the forward op ran on: None = the caller's stream, else a view stream)
-        self.stream = None
-        self.view_streams_used: list = []
+        self.ops: list = []
         self.pending_wgrads: list = []  # (dy, x, dst, bias_grad) deferred to the enclosing weight-gradient group
         self.grouping = False
         self.pvars: dict = {}
@@ -298,7 +252,7 @@ class Tape:
 
     def record(self, fn: Callable) -> None:
         if self.train:
-            self.ops.append((fn, self.stream))
+            self.ops.append(fn)
 
     def pvar(self, param: torch.nn.Parameter | None) -> PVar | None:
         if param is None:
@@ -309,31 +263,13 @@ class Tape:
         return pv
 
     def backward(self) -> None:
-        """Run the closures in reverse.  An op recorded on a view stream (see view_streams) runs its backward there as well: the stream first
-        waits for everything queued on the caller's stream (the gradients coming down from the later ops), and all of them are joined at
-        the end, before anyone reads the parameter gradients."""
         debug = os.environ.get("CINEMA_TAPE_DEBUG") == "1"
-        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
-        cur, used = None, []
-        try:
-            for i, (fn, st) in enumerate(reversed(self.ops)):
-                if st is not cur:
-                    if st is not None:
-                        K.stream_fork(main.cuda_stream, st.cuda_stream)
-                        if st not in used:
-                            used.append(st)
-                    torch.cuda.set_stream(st if st is not None else main)
-                    cur = st
-                fn()
-                if debug:  # localise an asynchronous kernel fault to one backward closure
-                    torch.cuda.synchronize()
-                    print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
-        finally:
-            if cur is not None:
-                torch.cuda.set_stream(main)
+        for i, fn in enumerate(reversed(self.ops)):
+            fn()
+            if debug:  # localise an asynchronous kernel fault to one backward closure
+                torch.cuda.synchronize()
+                print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
         flush_wgrads(self)
-        for st in used:
-            K.stream_fork(st.cuda_stream, main.cuda_stream)
         join_side_stream(release=True)
         self.ops = []
 
