@@ -52,7 +52,7 @@ def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float) -> dic
     import cinema_oracle as O  # noqa: N812
 
     # intra-op threads actually used: torch's CPU kernels on this graph peak at ~16 threads on the 256-core GPU-box host
-    # (tools/cpu_threads_probe.py: 16 threads 3.6 s/step, 32 -> 4.2 s, 64 -> 7.6 s, 256 -> 640 s at batch 2)
+    # (probe run once with this function at different thread counts: 16 threads 3.6 s/step, 32 -> 4.2 s, 64 -> 7.6 s, 256 -> 640 s at batch 2)
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     cfg = O.MAEConfig(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
