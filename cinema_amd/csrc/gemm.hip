@@ -440,6 +440,181 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
   tm = first_m + in_g - tn * gsz;
 }
 
+// ---- BK = 32 variant of the operand tiles (8 KiB each): for the short-reduction GEMMs, where a 32 KiB workgroup (2 stages) lets THREE
+// workgroups share a CU: finer rounds over the tile count (768 slots) and one more workgroup to cover a neighbour's prologue / epilogue.
+constexpr int BK32 = 32;
+template <bool KMAJ>
+struct TileIO32 {
+  static constexpr int BYTES = 8192;  // k-major: [128 rows][64 B]; mn-major: [32 k rows][256 B]
+  static __device__ __forceinline__ short8v frag(const char* lds, int base, int ks, int lane) {
+    if (KMAJ) {
+      const int row = base + (lane & 31);
+      return *reinterpret_cast<const short8v*>(lds + swz_off<64>(row, ks * 2 + (lane >> 5)));
+    } else {
+      const int q4 = lane >> 4, t = lane & 15;
+      const int col = base + 16 * (q4 & 1) + 4 * (t & 3);
+      const int kr = ks * 16 + 8 * (q4 >> 1) + (t >> 2);
+      const short4v lo = lds_tr16_b64(lds + mn_off(kr, col >> 3) + (col & 7) * 2);
+      const short4v hi = lds_tr16_b64(lds + mn_off(kr + 4, col >> 3) + (col & 7) * 2);
+      short8v out;
+      out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+      out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+      return out;
+    }
+  }
+  struct Src2 { const bf16_t* p[2]; };  // per-lane DMA sources of k-tile 0: two 1 KiB pieces per wave and tile
+  static __device__ __forceinline__ Src2 src2(const bf16_t* base, int ld, int row0, int nrows, int lane, int wave) {
+    Src2 r;
+#pragma unroll
+    for (int pss = 0; pss < 2; pss++) {
+      const int blk = pss * 4 + wave;
+      if (KMAJ) {
+        const int row = blk * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        int rg = row0 + row;
+        rg = rg < nrows ? rg : nrows - 1;
+        r.p[pss] = base + (size_t)rg * ld + c * 8;
+      } else {
+        const int kr = blk * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);
+        int col = row0 + c * 8;
+        col = col < nrows ? col : 0;
+        r.p[pss] = base + (size_t)kr * ld + col;
+      }
+    }
+    return r;
+  }
+  static __device__ __forceinline__ size_t k_step(int ld) { return KMAJ ? (size_t)BK32 : (size_t)BK32 * ld; }
+};
+
+// fused epilogue of a 32x64 half of a wave tile through 8 KiB of LDS (the BK = 32 kernel has 32 KiB in all): same row-contiguous scheme
+// as tile_epilogue_rows, 32 rows at a time
+template <int W>
+__device__ __forceinline__ void half_epilogue_rows(const GemmP& p, const float16v (&acc)[2], int mw, int nw, int lane, bool add_bias, float* stg,
+                                                   float* ws_base, long long ws_ld) {
+  constexpr int LPR = 64 / W, RPP = 64 / LPR, PASSES = 32 / RPP;
+  const int ml = lane & 31, hi = lane >> 5;
+  const int rl = lane / LPR, cl = (lane % LPR) * W;
+  const int n = nw + cl;
+  float bv[W];
+  EpiPre<W> pre[PASSES];
+  if (!ws_base) {
+    epi_load_bias<W>(p, n, add_bias, bv);
+#pragma unroll
+    for (int pss = 0; pss < PASSES; pss++) {
+      const int m = mw + pss * RPP + rl;
+      if (m < p.m && n < p.n) epi_load<W>(p, m, n, pre[pss]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      *reinterpret_cast<float4*>(stg + ml * 64 + (((j * 8 + 2 * q + hi) ^ (ml & 15)) << 2)) =
+          make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+#pragma unroll
+  for (int pss = 0; pss < PASSES; pss++) {
+    const int r = pss * RPP + rl;
+    const int m = mw + r;
+    float v[W];
+#pragma unroll
+    for (int c = 0; c < W / 4; c++) {
+      const float4 t = *reinterpret_cast<const float4*>(stg + r * 64 + ((((cl >> 2) + c) ^ (r & 15)) << 2));
+      v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+    }
+    if (m < p.m && n < p.n) {
+      if (ws_base) {
+#pragma unroll
+        for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+      } else {
+        epi_apply<W>(p, m, n, v, bv, pre[pss]);
+      }
+    }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void half_epilogue(const GemmP& p, const float16v (&acc)[2], int mw, int nw, int lane, int z, float* stg) {
+  static_assert(EPI != EPI_GENERAL, "the BK = 32 kernel is instantiated for the specialised epilogue classes only");
+  float* ws_base = nullptr;
+  long long ws_ld = 0;
+  if (p.ws) { ws_base = p.ws + (size_t)z * p.m * p.n; ws_ld = p.n; }
+  if (ws_base) { half_epilogue_rows<4>(p, acc, mw, nw, lane, false, stg, ws_base, ws_ld); return; }
+  const GemmP q = epi_fold<EPI>(p);
+  if (EPI == EPI_F32) {
+    half_epilogue_rows<4>(q, acc, mw, nw, lane, z == 0, stg, nullptr, 0);
+  } else {
+    half_epilogue_rows<8>(q, acc, mw, nw, lane, z == 0, stg, nullptr, 0);
+  }
+}
+
+// 128x128x32 kernel, 2 stages of 16 KiB, three workgroups per CU (see TileIO32).  gridDim.z = split-K slices as in the BK = 64 kernel;
+// no split tail, no bias-gradient row sums; K % 32 == 0.
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_mfma_k32_kernel(GemmP p) {
+  using AIO = TileIO32<A_KMAJ>;
+  using BIO = TileIO32<B_KMAJ>;
+  constexpr int STAGE = AIO::BYTES + BIO::BYTES;  // 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
+  const int nkt = p.k / BK32;
+  const int n_main = (int)gridDim.x;
+  const int logical = xcd_remap(blockIdx.z * n_main + blockIdx.x, n_main * gridDim.z);
+  const int zsplit = logical / n_main, tile = logical - zsplit * n_main;
+  const int kt_begin = zsplit * p.ktiles_per_split * 2, kt_end = min(nkt, kt_begin + p.ktiles_per_split * 2);  // ktiles_per_split counts 64-wide tiles
+  int tm, tn;
+  tile_of(tile, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (kt_begin >= kt_end) return;
+
+  float16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const typename AIO::Src2 asrc = AIO::src2(p.a, p.lda, m0, p.m, lane, wave_u);
+  const typename BIO::Src2 bsrc = BIO::src2(p.b, p.ldb, n0, p.n, lane, wave_u);
+  const size_t astep = AIO::k_step(p.lda), bstep = BIO::k_step(p.ldb);
+  const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  auto load_tile = [&](int stage, int kt) {  // 4 DMA pieces per wave: A blocks wave, wave+4; B blocks wave, wave+4
+    const uint32_t sa = smem_addr + stage * STAGE + wave_u * 1024, sb = sa + AIO::BYTES;
+    const size_t ka = (size_t)kt * astep, kb = (size_t)kt * bstep;
+    glds16x4(sa, sa + 4096, sb, sb + 4096, asrc.p[0] + ka, asrc.p[1] + ka, bsrc.p[0] + kb, bsrc.p[1] + kb);
+  };
+  load_tile(0, kt_begin);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; kt++) {
+    const int cur = (kt - kt_begin) & 1;
+    const char* sa = smem + cur * STAGE;
+    const char* sb = sa + AIO::BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK32 / 16; ks++) {
+      short8v fa[2], fb[2];
+      fa[0] = AIO::frag(sa, wm, ks, lane);
+      fa[1] = AIO::frag(sa, wm + 32, ks, lane);
+      fb[0] = BIO::frag(sb, wn, ks, lane);
+      fb[1] = BIO::frag(sb, wn + 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if (ks == 0 && kt + 1 < kt_end) load_tile(cur ^ 1, kt + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  float* stg = reinterpret_cast<float*>(smem + wave * 8192);  // 8 KiB per wave: one 32x64 half at a time
+  half_epilogue<EPI>(p, acc[0], m0 + wm, n0 + wn, lane, zsplit, stg);
+  half_epilogue<EPI>(p, acc[1], m0 + wm + 32, n0 + wn, lane, zsplit, stg);
+}
+
 // One 128x128 output tile (or k-slice of one) of problem p: everything after the work-item decoding of the kernels below.
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, int kt_begin, int kt_end, float* tail_dst, char* smem) {
@@ -842,6 +1017,26 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       else if (common && !p.out_f32 && !p.res_f32 && p.gelu_in && p.act == 0 && !p.aux_out && !p.bias) epi = EPI_BF16_GELU_GRAD;
       else if (common && p.out_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) epi = EPI_F32;
       a->kernel_used += 8 * epi;  // 1..3 = operand layout, + 8 x epilogue class
+      // short reductions go to the BK = 32 kernel (3-4 workgroups per CU): in the step 32.47 vs 32.79 ms with the threshold at 512, 32.52 at 768
+      // (above that the BK = 64 loop and its split tail win); CINEMA_GEMM_K32 overrides the threshold (0 = never)
+      static const int k32_env = getenv("CINEMA_GEMM_K32") ? atoi(getenv("CINEMA_GEMM_K32")) : 512;
+      const bool k32 = k32_env > 0 && epi != EPI_GENERAL && !tail && !p.a_rowsum && !(p.accumulate && !p.ws) && (a->k % 32) == 0 && a->k <= k32_env && a->force_generic == 0;
+      if (k32) {
+        a->kernel_used += 128;  // the BK = 32 instance of the same layout / epilogue class
+#define LAUNCH_K32(E)                                                                                                          \
+  do {                                                                                                                         \
+    if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_k32_kernel<true, true, E>), grid, dim3(256), 0, st, p);        \
+    else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_k32_kernel<true, false, E>), grid, dim3(256), 0, st, p); \
+    else hipLaunchKernelGGL((gemm_mfma_k32_kernel<false, false, E>), grid, dim3(256), 0, st, p);                                 \
+  } while (0)
+        switch (epi) {
+          case EPI_BF16: LAUNCH_K32(EPI_BF16); break;
+          case EPI_BF16_GELU: LAUNCH_K32(EPI_BF16_GELU); break;
+          case EPI_BF16_GELU_GRAD: LAUNCH_K32(EPI_BF16_GELU_GRAD); break;
+          default: LAUNCH_K32(EPI_F32); break;
+        }
+#undef LAUNCH_K32
+      } else {
 #define LAUNCH_LAYOUT(E)                                                                                                    \
   do {                                                                                                                      \
     if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, E>), grid, dim3(256), 0, st, p);        \
@@ -856,6 +1051,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
         default: LAUNCH_LAYOUT(EPI_GENERAL); break;
       }
 #undef LAUNCH_LAYOUT
+      }
     }
     if (tail) {
       const int rem = ((int)grid.x - p.tail_begin) / p.tail_split;

@@ -49,6 +49,7 @@ class GemmArgs(C.Structure):
 _LAYOUTS = {1: "true, true", 2: "true, false", 3: "false, false"}
 GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel"}
 GEMM_KERNEL_NAMES[64] = "gemm_mfma_grouped_kernel<false, false, 4>"
+GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (kernel_used, algorithmic_flops, start_event, end_event)
