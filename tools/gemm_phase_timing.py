@@ -1,6 +1,8 @@
 """Where a workgroup of the one-shot 128x128 GEMM spends its time: prologue (first k-tile lands) / MFMA loop / epilogue issue / store drain.
 
-Needs the dev build with -DCINEMA_GEMM_TIMING (see the hipcc line in DESIGN.md section 5): cinema_amd/csrc/build/libcinema_hip_timing.so.
+Needs the dev build of the library with -DCINEMA_GEMM_TIMING as cinema_amd/csrc/build/libcinema_hip_timing.so:
+  cd cinema_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DCINEMA_GEMM_TIMING -c gemm.hip -o build/gemm_timing.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcinema_hip_timing.so build/gemm_timing.o $(ls build/*.o | grep -v gemm)
 wall_clock64() ticks at 100 MHz (10 ns)."""
 import ctypes as C
 import sys
