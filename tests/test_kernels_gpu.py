@@ -103,6 +103,27 @@ def test_gemm_epilogues(generic: bool) -> None:
     close(out, (a.float() @ w.float().t()) * hx.grad, 5e-4, 5e-3, "gelu' epilogue")
 
 
+@pytest.mark.parametrize("k", [128, 1024])  # BK = 32 kernel (K <= 512) and BK = 64 kernel
+def test_gemm_bf16_epilogue_classes_on_both_tile_depths(k: int) -> None:
+    """The compile-time epilogue classes with a bf16 output (plain, GELU + pre-activation, dY x GELU'(pre-activation) on the data-gradient
+    layout) on both kernels; tolerance = one bf16 rounding of the output."""
+    m, n = 1300, 384
+    a, w = rnd(m, k, seed=21), rnd(n, k, seed=22, scale=0.1)
+    bias = rnd(n, dtype=torch.float32, seed=23)
+    pre = a.float() @ w.float().t() + bias
+    aux = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    out = K.gemm(a, w, bias=bias, act=1, aux_out=aux)
+    close(aux, pre, 1e-2, 2e-2, "pre-activation")
+    close(out, F.gelu(pre), 1e-2, 2e-2, "gelu")
+    close(K.gemm(a, w, bias=bias), pre, 1e-2, 2e-2, "plain bf16")
+    dy, w2 = rnd(m, k, seed=24), rnd(k, n, seed=25, scale=0.1)  # dh[m, n] = (dy[m, k] @ W2[k, n]) * gelu'(pre[m, n])
+    hx = aux.float().requires_grad_(True)
+    F.gelu(hx).backward(torch.ones_like(hx))
+    dh = K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=aux)
+    assert dh.dtype == torch.bfloat16
+    close(dh, (dy.float() @ w2.float()) * hx.grad, 1e-2, 2e-2, "gelu' on the data-gradient layout")
+
+
 @pytest.mark.parametrize(("m", "n", "k"), [(10960, 768, 3072), (8300, 512, 2048), (10960, 768, 2304)])
 def test_gemm_split_tail_full_size(m: int, n: int, k: int) -> None:
     """BASELINE config-2 shapes whose tile count just exceeds the 512 workgroup slots (516 / 260 tiles): the left-over tiles
