@@ -92,6 +92,10 @@ __device__ long long* g_gemm_timing = nullptr;
 #define GEMM_STAMP(i) do { } while (0)
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+// The outputs stream out (67-270 MB per GEMM against 4 MiB of L2 per XCD): non-temporal stores keep them from evicting the operand panels the
+// resident tiles share - 31.23 -> 30.99 ms/step in a same-box A/B.
+constexpr bool NT_STORES = true;
 template <int W>
 struct EpiPre {   // plain vector members (arrays inside the struct were left in scratch memory by the compiler)
   u32x4 ra, rb;   // fp32 residual words 0-3 / 4-7, or packed bf16 residual in ra (W/2 words)
@@ -136,8 +140,9 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
   for (int i = 0; i < W; i++) v[i] = fmaf(v[i], p.alpha, bv[i]);
   auto store_bf16 = [&](bf16_t* dst) {
     if (W == 8) {
-      uint4 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]); pk.z = pack_bf2(v[W - 4], v[W - 3]); pk.w = pack_bf2(v[W - 2], v[W - 1]);
-      *reinterpret_cast<uint4*>(dst) = pk;
+      u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[W - 4], v[W - 3]), pack_bf2(v[W - 2], v[W - 1])};
+      if (NT_STORES) __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(dst));
+      else *reinterpret_cast<u32x4*>(dst) = pk;
     } else {
       uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
       *reinterpret_cast<uint2*>(dst) = pk;
@@ -170,7 +175,11 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
   if (p.out_f32) {
     float* dp = reinterpret_cast<float*>(p.d) + (size_t)m * p.ldd + n0;
 #pragma unroll
-    for (int i = 0; i < W; i += 4) *reinterpret_cast<float4*>(dp + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    for (int i = 0; i < W; i += 4) {
+      f32x4e o = {v[i], v[i + 1], v[i + 2], v[i + 3]};
+      if (NT_STORES) __builtin_nontemporal_store(o, reinterpret_cast<f32x4e*>(dp + i));
+      else *reinterpret_cast<f32x4e*>(dp + i) = o;
+    }
   } else {
     store_bf16(reinterpret_cast<bf16_t*>(p.d) + (size_t)m * p.ldd + n0);
   }
