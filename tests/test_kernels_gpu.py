@@ -177,6 +177,13 @@ def test_gemm_strided_views_and_colsum() -> None:
     out = torch.zeros(768, dtype=torch.float32, device=DEV)
     K.colsum(big, out)
     close(out, big.float().sum(0), 1e-4, 1e-3, "colsum")
+    # fp32 rows gathered through an index list (token-parameter gradients): vectorised kernel (n % 4 == 0) and scalar kernel (n = 6)
+    for n in (512, 6):
+        x32 = rnd(5000, n, dtype=torch.float32, seed=15)
+        idx = torch.randperm(5000, generator=torch.Generator().manual_seed(4))[:3333].to(torch.int32).to(DEV)
+        acc = torch.full((n,), 2.0, dtype=torch.float32, device=DEV)
+        K.colsum(x32, acc, row_idx=idx)
+        close(acc, x32[idx.long()].sum(0) + 2.0, 1e-4, 2e-3, f"gathered fp32 colsum n={n}")
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
