@@ -395,3 +395,18 @@ def test_convunetr_logits_and_gradients_vs_reference_golden() -> None:
         got = named[k].grad.float().cpu()
         rel = float((got - t).norm() / (t.norm() + 1e-12))
         assert rel <= 8e-2, (k, rel)  # relative L2 per tensor (a deeper chain than the MAE checks: 6e-2 there)
+    # the step-level API of the reference (cinema/segmentation/train.py:106-146): batch keys {view}_image / {view}_label, metric keys as it builds them
+    from cinema_amd.segmentation.train import segmentation_loss
+
+    model.zero_grad(set_to_none=True)
+    views = list(images)
+    batch = {f"{v}_image": images[v] for v in views}
+    gen = torch.Generator().manual_seed(2)
+    batch.update({f"{v}_label": torch.randint(0, logits[v].shape[1], (logits[v].shape[0], 1, *logits[v].shape[2:]), generator=gen) for v in views})
+    loss, metrics = segmentation_loss(model, batch, views, torch.device(DEV))
+    assert loss.dim() == 0 and torch.isfinite(loss) and abs(metrics["loss"] - float(loss)) < 1e-6
+    expected = {"loss", "cross_entropy", "mean_dice_loss"} | {f"{v}_{k}" for v in views for k in ("cross_entropy", "mean_dice_loss", "loss", f"{v}_loss")}
+    assert set(metrics) == expected, set(metrics) ^ expected
+    assert abs(metrics["cross_entropy"] + metrics["mean_dice_loss"] - metrics["loss"]) < 1e-4
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
