@@ -254,7 +254,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
   load_row_frags<HD>(qf, p.q + ((size_t)b * p.tq + qc) * p.ldq + h * HD, lane);
   load_row_frags<HD>(dof, p.d_o + ((size_t)b * p.tq + qc) * p.lddo + h * HD, lane);
   const size_t sidx = ((size_t)b * p.h + h) * p.tq + qc;
-  const float lse = p.lse[sidx], dl = p.delta[sidx];
+  const float lse = p.lse[sidx];
+  // delta = rowsum(dO * O), computed here from the row fragments (the lane pair l, l^32 holds the whole row) and stored for the dK/dV kernel
+  // that runs next: this used to be a launch of its own that read O and dO once more
+  float dl = 0.f;
+  {
+    short8v of[HD / 16];
+    load_row_frags<HD>(of, p.o + ((size_t)b * p.tq + qc) * p.ldo + h * HD, lane);
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ks++)
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        dl = fmaf(__uint_as_float((uint32_t)(uint16_t)of[ks][e] << 16), __uint_as_float((uint32_t)(uint16_t)dof[ks][e] << 16), dl);
+    dl += __shfl_xor(dl, 32, 64);
+    if (g == 0 && qrow < p.tq) p.delta[sidx] = dl;
+  }
 
   float16v dq[HD / 32];
 #pragma unroll
@@ -618,13 +632,16 @@ CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* 
   hipStream_t st = (hipStream_t)stream;
   const long long nq = (long long)b * h * tq;
   const bool pow2 = (hd & (hd - 1)) == 0 && hd >= 8;
-  if (pow2 && !(ldo & 7) && !(lddo & 7) && !(((uintptr_t)o) & 15) && !(((uintptr_t)d_o) & 15)) {
+  const bool mfma = mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv}) && !(((uintptr_t)o) & 15);
+  if (mfma) {
+    // delta is produced by the dQ kernel (from its O / dO row fragments) and consumed by the dK/dV kernel behind it
+  } else if (pow2 && !(ldo & 7) && !(lddo & 7) && !(((uintptr_t)o) & 15) && !(((uintptr_t)d_o) & 15)) {
     const long long rows = (long long)b * tq;
     hipLaunchKernelGGL(attn_delta_vec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   } else {
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, p);
   }
-  if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv})) {
+  if (mfma && mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv})) {
     dim3 gq((tq + 127) / 128, h, b), gk((tk + 127) / 128, h, b);
     if (hd == 64) {
       hipLaunchKernelGGL(attn_bwd_dq_mfma<64>, gq, dim3(256), 0, st, p);
