@@ -345,10 +345,11 @@ CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const
   });
 }
 
-CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
-                                    const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
-                                    const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
-                                    float* workspace, long long workspace_bytes, void* stream) {
+static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
+                              const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
+                              float* workspace, long long workspace_bytes, int* deferred_partials, void* stream) {
+  if (deferred_partials) *deferred_partials = 0;
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
   if (act == 1 && !beta) return CINEMA_ERR_BAD_ARG;
   LnBwdP p{dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
@@ -370,7 +371,71 @@ CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, co
     const bool two_pass = (dgamma || dbeta) && workspace && workspace_bytes >= (long long)grid * 2 * c * 4 && grid >= 64;
     if (two_pass) p.ws = workspace;
     hipLaunchKernelGGL((ln_bwd_kernel<CPL, RG>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
-    if (two_pass) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, grid, c, dgamma, dbeta);
+    if (two_pass && deferred_partials) *deferred_partials = grid;  // the caller reduces `grid` partial rows later (cinema_ln_param_reduce_batched)
+    else if (two_pass) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, grid, c, dgamma, dbeta);
     return launch_status();
   });
+}
+
+CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
+                                    const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
+                                    const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
+                                    float* workspace, long long workspace_bytes, void* stream) {
+  return layernorm_bwd_impl(dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
+                            workspace, workspace_bytes, nullptr, stream);
+}
+
+CINEMA_API int cinema_layernorm_bwd_deferred(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
+                                             const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
+                                             const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
+                                             float* workspace, long long workspace_bytes, int* n_partials_out, void* stream) {
+  if (!n_partials_out) return CINEMA_ERR_BAD_ARG;
+  return layernorm_bwd_impl(dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
+                            workspace, workspace_bytes, n_partials_out, stream);
+}
+
+namespace {
+struct LnReduceBatch { cinema_ln_reduce_item it[48]; };
+// the per-block partial sums of up to 48 LayerNorm backward launches in one grid: blockIdx.z = item, same tiling as ln_param_reduce_kernel
+__global__ __launch_bounds__(256) void ln_param_reduce_batched_kernel(LnReduceBatch b) {
+  __shared__ float red[4][64];
+  const cinema_ln_reduce_item& e = b.it[blockIdx.z];
+  const int c = e.c, nblocks = e.n_partials;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= 2 * c) return;
+  const int slices = gridDim.y * 4;
+  const int per = (nblocks + slices - 1) / slices;
+  const int b0 = (blockIdx.y * 4 + sub) * per, b1 = min(nblocks, b0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < 2 * c) {
+    const float* src = e.partials + col;
+    const size_t ld = (size_t)2 * c;
+    int r = b0;
+    for (; r + 3 < b1; r += 4) { s0 += src[r * ld]; s1 += src[(r + 1) * ld]; s2 += src[(r + 2) * ld]; s3 += src[(r + 3) * ld]; }
+    for (; r < b1; r++) s0 += src[r * ld];
+  }
+  red[sub][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0 && col < 2 * c) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float* dst = col < c ? e.dgamma : e.dbeta;
+    if (dst) unsafeAtomicAdd(dst + (col < c ? col : col - c), t);
+  }
+}
+}  // namespace
+
+CINEMA_API int cinema_ln_param_reduce_batched(const cinema_ln_reduce_item* items_host, int count, void* stream) {
+  if (!items_host || count <= 0) return CINEMA_ERR_BAD_ARG;
+  for (int i0 = 0; i0 < count; i0 += 48) {
+    LnReduceBatch b;
+    const int n = count - i0 < 48 ? count - i0 : 48;
+    int cmax = 0;
+    for (int i = 0; i < n; i++) {
+      b.it[i] = items_host[i0 + i];
+      if (!b.it[i].partials || b.it[i].n_partials <= 0 || b.it[i].c <= 0) return CINEMA_ERR_BAD_ARG;
+      if (b.it[i].c > cmax) cmax = b.it[i].c;
+    }
+    hipLaunchKernelGGL(ln_param_reduce_batched_kernel, dim3((2 * cmax + 63) / 64, 16, n), dim3(256), 0, (hipStream_t)stream, b);
+  }
+  return launch_status();
 }

@@ -65,6 +65,12 @@ class PatchGeom(C.Structure):
     ]
 
 
+class LnReduceItem(C.Structure):
+    """Mirror of ``cinema_ln_reduce_item``."""
+
+    _fields_ = [("partials", C.c_void_p), ("n_partials", C.c_int), ("c", C.c_int), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
 class SparseGeom(C.Structure):
     """Mirror of ``cinema_sparse_geom``: visible-voxel (token-major compact row) geometry of one stem stage."""
 
@@ -82,6 +88,8 @@ _PROTOS = {
     "cinema_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _vp],
+    "cinema_layernorm_bwd_deferred": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, C.POINTER(C.c_int), _vp],
+    "cinema_ln_param_reduce_batched": [_vp, _i, _vp],
     "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -518,20 +526,43 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor | None, mean: torch.Tensor, rstd: torch.Tensor, *,
                   act: int = 0, dx_residual: torch.Tensor | None = None, want_f32: bool = True, want_bf16: bool = False,
-                  dgamma: torch.Tensor | None = None, dbeta: torch.Tensor | None = None, dx_f32_out: torch.Tensor | None = None):  # noqa: ANN201
-    """-> (dx_f32 | None, dx_bf16 | None); dgamma/dbeta (fp32 [c]) are accumulated in place when given."""
+                  dgamma: torch.Tensor | None = None, dbeta: torch.Tensor | None = None, dx_f32_out: torch.Tensor | None = None,
+                  deferred: list | None = None):  # noqa: ANN201
+    """-> (dx_f32 | None, dx_bf16 | None); dgamma/dbeta (fp32 [c]) are accumulated in place when given - at once, or (``deferred`` list)
+    by a later :func:`ln_param_reduce_batched` over the entries appended to that list."""
     _dev(dy, x, gamma, mean, rstd, dx_residual, dgamma, dbeta)
     rows, c = x.shape
     dx32 = dx_f32_out if dx_f32_out is not None else (torch.empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
     dx16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
         raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
+    if deferred is not None and (dgamma is not None or dbeta is not None):
+        # the per-block partial sums stay in a buffer of their own until ln_param_reduce_batched adds them up (end of the backward pass)
+        ws = torch.empty(2048 * 2 * c, dtype=torch.float32, device=x.device)
+        n_part = C.c_int(0)
+        _check(load().cinema_layernorm_bwd_deferred(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
+                                                    int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
+                                                    rstd.data_ptr(), rows, c, act, _p(dx_residual), _p(dx32), _p(dx16), c, _p(dgamma), _p(dbeta),
+                                                    ws.data_ptr(), ws.numel() * 4, C.byref(n_part), _stream()), "layernorm_bwd")
+        if n_part.value > 0:
+            deferred.append((ws, n_part.value, c, dgamma, dbeta))
+        return dx32, dx16
     ws = _workspace("ln_bwd", 2048 * 2 * c, x.device) if (dgamma is not None or dbeta is not None) else None
     _check(load().cinema_layernorm_bwd(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
                                        int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
                                        rstd.data_ptr(), rows, c, act, _p(dx_residual), _p(dx32), _p(dx16), c, _p(dgamma), _p(dbeta),
                                        ws.data_ptr() if ws is not None else None, 0 if ws is None else ws.numel() * 4, _stream()), "layernorm_bwd")
     return dx32, dx16
+
+
+def ln_param_reduce_batched(items: list) -> None:
+    """items: (partials, n_partials, c, dgamma | None, dbeta | None) from layernorm_bwd(..., deferred=list): one launch per 48 LayerNorms."""
+    if not items:
+        return
+    arr = (LnReduceItem * len(items))()
+    for e, (ws, n_part, c, dg, db) in zip(arr, items):
+        e.partials, e.n_partials, e.c, e.dgamma, e.dbeta = ws.data_ptr(), n_part, c, _p(dg), _p(db)
+    _check(load().cinema_ln_param_reduce_batched(arr, len(items), _stream()), "ln_param_reduce_batched")
 
 
 def _attn_view(t: torch.Tensor, heads: int, hd: int, name: str):  # noqa: ANN202

@@ -246,6 +246,7 @@ class Tape:
     def __init__(self, params: dict | None = None, train: bool = True) -> None:
         self.ops: list = []
         self.pending_wgrads: list = []  # (dy, x, dst, bias_grad) deferred to the enclosing weight-gradient group
+        self.pending_ln: list = []      # LayerNorm parameter-gradient partials: one batched reduce at the end of the backward pass
         self.grouping = False
         self.pvars: dict = {}
         self.train = train
@@ -270,6 +271,8 @@ class Tape:
                 torch.cuda.synchronize()
                 print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
         flush_wgrads(self)
+        K.ln_param_reduce_batched(self.pending_ln)  # 86 LayerNorms per step: one launch per 48 instead of one each
+        self.pending_ln = []
         join_side_stream(release=True)
         self.ops = []
 
@@ -414,6 +417,8 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
 # stream no longer fills the main stream's idle slots early and the main stream's kernels wait for slots behind long tiles.  Opt-in.
 # Groups that would leave the slots mostly empty (decoder blocks: 192 tiles) keep the per-GEMM split-K path either way.
 GROUP_WGRAD = bool(int(os.environ.get("CINEMA_GROUP_WGRAD", "0")))
+# LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
+DEFER_LN_REDUCE = bool(int(os.environ.get("CINEMA_LN_DEFER", "1")))
 _GROUP_MIN_TILES = 384
 
 
@@ -492,7 +497,7 @@ def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.P
         res = x.grad if (x.grad is not None and x.grad.dtype == F32) else None
         dx32, dx16 = K.layernorm_bwd(y.grad, x.data, gamma.detach(), beta.detach(), mean, rstd, act=act, dx_residual=res,
                                      want_f32=x.data.dtype == F32, want_bf16=want16 or x.data.dtype == BF16,
-                                     dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)))
+                                     dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln if DEFER_LN_REDUCE else None)
         if x.data.dtype == F32:
             x.grad, x.grad16 = dx32, dx16  # includes the previously accumulated residual gradient
         else:

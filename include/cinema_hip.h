@@ -88,6 +88,21 @@ int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x
                          const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
                          float* workspace, long long workspace_bytes, void* stream);
 
+/* The same with the parameter-gradient reduction left to the caller: the per-block partial sums stay in `workspace` ([n_partials][2*c] fp32,
+ * n_partials returned; 0 = the gradients were added directly) and cinema_ln_param_reduce_batched adds the partials of many LayerNorms to their
+ * dgamma / dbeta in one launch (a training step has 86 LayerNorm backward passes: 86 tiny reduce launches otherwise). */
+typedef struct {
+  const float* partials;  /* the workspace of one cinema_layernorm_bwd_deferred call */
+  int n_partials, c;
+  float* dgamma;          /* accumulated; either may be NULL */
+  float* dbeta;
+} cinema_ln_reduce_item;
+int cinema_layernorm_bwd_deferred(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
+                                  const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
+                                  const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
+                                  float* workspace, long long workspace_bytes, int* n_partials_out, void* stream);
+int cinema_ln_param_reduce_batched(const cinema_ln_reduce_item* items_host, int count, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Attention (reference: F.scaled_dot_product_attention / matmul-softmax-matmul cinema/vit.py:505-517, no mask, no
  * dropout).  q:[b,tq,h,hd] k,v:[b,tk,h,hd] addressed as base + (b*t + t_i)*ld + h*hd + d (bf16) so that the fused

@@ -225,6 +225,26 @@ def attn_ref(q, k, v, heads):  # noqa: ANN001, ANN201
     return (w @ vh).transpose(1, 2).reshape(b, tq, c)
 
 
+def test_layernorm_deferred_param_gradients() -> None:
+    """cinema_layernorm_bwd_deferred + cinema_ln_param_reduce_batched (one reduce for many LayerNorms) == the per-launch reduction."""
+    items, direct = [], []
+    for i, (rows, c) in enumerate([(5000, 512), (3000, 768), (9000, 64), (40, 128)]):  # the last one is too small for partials: added directly
+        x, dy = rnd(rows, c, dtype=torch.float32, seed=120 + i), rnd(rows, c, dtype=torch.float32, seed=130 + i)
+        g, b = rnd(c, dtype=torch.float32, seed=140 + i), rnd(c, dtype=torch.float32, seed=150 + i)
+        _, _, mean, rstd = K.layernorm_fwd(x, g, b, 1e-6, want_bf16=False, want_f32=True)
+        dg1, db1 = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+        dx1, _ = K.layernorm_bwd(dy, x, g, b, mean, rstd, dgamma=dg1, dbeta=db1)
+        dg2, db2 = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+        dx2, _ = K.layernorm_bwd(dy, x, g, b, mean, rstd, dgamma=dg2, dbeta=db2, deferred=items)
+        assert torch.equal(dx1, dx2)
+        direct.append((dg1, db1, dg2, db2))
+    assert len(items) == 3
+    K.ln_param_reduce_batched(items)
+    for dg1, db1, dg2, db2 in direct:
+        close(dg2, dg1, 1e-5, 1e-4 * float(dg1.abs().max()), "deferred dgamma")
+        close(db2, db1, 1e-5, 1e-4 * float(db1.abs().max()), "deferred dbeta")
+
+
 @pytest.mark.parametrize(("hd", "heads", "tq", "tk", "generic"), [
     (64, 3, 685, 685, False), (32, 4, 300, 77, False), (64, 2, 64, 64, False), (32, 2, 129, 200, False), (64, 2, 200, 130, True),
     (8, 2, 129, 129, True), (8, 2, 385, 128, True), (16, 4, 50, 33, False), (32, 16, 2053, 684, False)])
