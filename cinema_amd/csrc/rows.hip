@@ -56,6 +56,34 @@ __global__ void row_copy_kernel(RowP p) {
   }
 }
 
+// several independent row copies in one grid (blockIdx.y = segment): the token assembly / split ops of a step are 4-9 small copies each
+struct RowMultiP { RowP seg[12]; };
+__global__ __launch_bounds__(256) void row_copy_multi_kernel(RowMultiP m) {
+  const RowP& p = m.seg[blockIdx.y];
+  const bool vec = !(p.c & 3) && !(p.ld_dst & 3) && (!p.src || !(p.ld_src & 3)) && (!p.add || !(p.ld_add & 3)) && !(((uintptr_t)p.dst) & 15) &&
+                   (!p.src || !(((uintptr_t)p.src) & 15)) && (!p.add || !(((uintptr_t)p.add) & 15));
+  const int vw = vec ? 4 : 1;
+  const int per_row = p.c / vw;
+  const long long total = (long long)p.n_rows * per_row;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int row = (int)(i / per_row), col = (int)(i % per_row) * vw;
+    const int dr = p.dst_idx ? p.dst_idx[row] : row;
+    const int sr = p.src_idx ? p.src_idx[row] : row;
+    const int ar = p.add_idx ? p.add_idx[row] : row;
+    if (vec) {
+      float4 v = p.src ? ld4(p.src, p.src_dtype, (size_t)sr * p.ld_src + col) : make_float4(0, 0, 0, 0);
+      if (p.add) { const float4 a = ld4(p.add, p.add_dtype, (size_t)ar * p.ld_add + col); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+      if (p.accumulate) { const float4 a = ld4(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+      st4(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col, v);
+    } else {
+      float v = p.src ? ld1(p.src, p.src_dtype, (size_t)sr * p.ld_src + col) : 0.f;
+      if (p.add) v += ld1(p.add, p.add_dtype, (size_t)ar * p.ld_add + col);
+      if (p.accumulate) v += ld1(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col);
+      st1(p.dst, p.dst_dtype, (size_t)dr * p.ld_dst + col, v);
+    }
+  }
+}
+
 __global__ void cast_kernel(const void* src, int sd, void* dst, int dd, long long n) {
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
@@ -192,6 +220,25 @@ CINEMA_API int cinema_row_copy(void* dst, int dst_dtype, int ld_dst, const int* 
   const bool vec = !(c & 3) && !(ld_dst & 3) && (!src || !(ld_src & 3)) && (!add || !(ld_add & 3)) && a16(dst) && (!src || a16(src)) && (!add || a16(add));
   if (vec) hipLaunchKernelGGL(row_copy_kernel<4>, dim3(grid_for((long long)n_rows * c / 4, 256)), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(row_copy_kernel<1>, dim3(grid_for((long long)n_rows * c, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+CINEMA_API int cinema_row_copy_multi(const cinema_row_copy_args* segs, int count, void* stream) {
+  if (!segs || count <= 0) return CINEMA_ERR_BAD_ARG;
+  for (int i0 = 0; i0 < count; i0 += 12) {
+    RowMultiP m;
+    const int n = count - i0 < 12 ? count - i0 : 12;
+    long long most = 1;
+    for (int i = 0; i < n; i++) {
+      const cinema_row_copy_args& a = segs[i0 + i];
+      if (!a.dst || a.n_rows <= 0 || a.c <= 0 || (!a.src && !a.add)) return CINEMA_ERR_BAD_ARG;
+      m.seg[i] = RowP{a.dst, a.dst_dtype, a.ld_dst, a.dst_idx, a.src, a.src_dtype, a.ld_src, a.src_idx, a.add, a.add_dtype, a.ld_add, a.add_idx, a.n_rows, a.c,
+                      a.accumulate};
+      const long long work = (long long)a.n_rows * a.c / 4 + 1;
+      if (work > most) most = work;
+    }
+    hipLaunchKernelGGL(row_copy_multi_kernel, dim3(grid_for(most, 256), n), dim3(256), 0, (hipStream_t)stream, m);
+  }
   return launch_status();
 }
 

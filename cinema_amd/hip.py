@@ -65,6 +65,15 @@ class PatchGeom(C.Structure):
     ]
 
 
+class RowCopyArgs(C.Structure):
+    """Mirror of ``cinema_row_copy_args``."""
+
+    _fields_ = [("dst", C.c_void_p), ("dst_dtype", C.c_int), ("ld_dst", C.c_int), ("dst_idx", C.c_void_p),
+                ("src", C.c_void_p), ("src_dtype", C.c_int), ("ld_src", C.c_int), ("src_idx", C.c_void_p),
+                ("add", C.c_void_p), ("add_dtype", C.c_int), ("ld_add", C.c_int), ("add_idx", C.c_void_p),
+                ("n_rows", C.c_int), ("c", C.c_int), ("accumulate", C.c_int)]
+
+
 class LnReduceItem(C.Structure):
     """Mirror of ``cinema_ln_reduce_item``."""
 
@@ -90,6 +99,7 @@ _PROTOS = {
     "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _vp],
     "cinema_layernorm_bwd_deferred": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, C.POINTER(C.c_int), _vp],
     "cinema_ln_param_reduce_batched": [_vp, _i, _vp],
+    "cinema_row_copy_multi": [_vp, _i, _vp],
     "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -818,6 +828,35 @@ def row_copy(dst: torch.Tensor, src: torch.Tensor | None = None, *, dst_idx: tor
                                   _rowmajor(src, "src") if src is not None else 0, _p(src_idx), _p(add), _DT[add.dtype] if add is not None else 0,
                                   _rowmajor(add, "add") if add is not None else 0, _p(add_idx), n_rows, c, int(accumulate), _stream()), "row_copy")
     return dst
+
+
+ROW_COPY_MULTI = bool(int(os.environ.get("CINEMA_ROW_MULTI", "1")))  # 0: one launch per copy (A/B)
+
+
+def row_copy_multi(copies: list) -> None:
+    """Several independent :func:`row_copy` calls in one launch: ``copies`` = list of dicts with row_copy's arguments (dst, src, dst_idx, ...)."""
+    if not copies:
+        return
+    if len(copies) == 1 or not ROW_COPY_MULTI:
+        for kw in copies:
+            row_copy(**kw)
+        return
+    arr = (RowCopyArgs * len(copies))()
+    for a, kw in zip(arr, copies):
+        dst, src, add = kw["dst"], kw.get("src"), kw.get("add")
+        dst_idx, src_idx, add_idx = kw.get("dst_idx"), kw.get("src_idx"), kw.get("add_idx")
+        _dev(dst, src, add, dst_idx, src_idx, add_idx)
+        for idx in (dst_idx, src_idx, add_idx):
+            if idx is not None and idx.dtype != torch.int32:
+                raise HipLibraryError("row_copy indices must be int32")
+        n_rows = kw.get("n_rows")
+        if n_rows is None:
+            n_rows = next((i.numel() for i in (dst_idx, src_idx, add_idx) if i is not None), dst.shape[0])
+        a.dst, a.dst_dtype, a.ld_dst, a.dst_idx = dst.data_ptr(), _DT[dst.dtype], _rowmajor(dst, "dst"), _p(dst_idx)
+        a.src, a.src_dtype, a.ld_src, a.src_idx = _p(src), _DT[src.dtype] if src is not None else 0, _rowmajor(src, "src") if src is not None else 0, _p(src_idx)
+        a.add, a.add_dtype, a.ld_add, a.add_idx = _p(add), _DT[add.dtype] if add is not None else 0, _rowmajor(add, "add") if add is not None else 0, _p(add_idx)
+        a.n_rows, a.c, a.accumulate = n_rows, dst.shape[1], int(bool(kw.get("accumulate", False)))
+    _check(load().cinema_row_copy_multi(arr, len(copies), _stream()), "row_copy_multi")
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:

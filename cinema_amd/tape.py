@@ -844,20 +844,18 @@ def op_patch_gather(tape: Tape, x: Var, geom, dst_shape: tuple | None = None) ->
 
 
 def op_split_rows(tape: Tape, x: Var, idx_list: list) -> list:
-    """ys[i] = x[idx_list[i]] (int32 row indices, disjoint across the list).  One zeroed gradient buffer is shared."""
+    """ys[i] = x[idx_list[i]] (int32 row indices, disjoint across the list).  One zeroed gradient buffer is shared; all the gathers (and,
+    backward, all the scatters) go out as one multi-segment launch."""
     c = x.data.shape[1]
-    ys = []
-    for idx in idx_list:
-        out = torch.empty((idx.numel(), c), dtype=x.data.dtype, device=x.data.device)
-        ys.append(Var(K.row_copy(out, x.data, src_idx=idx)))
+    outs = [torch.empty((idx.numel(), c), dtype=x.data.dtype, device=x.data.device) for idx in idx_list]
+    K.row_copy_multi([dict(dst=out, src=x.data, src_idx=idx) for out, idx in zip(outs, idx_list)])
+    ys = [Var(out) for out in outs]
 
     def bwd() -> None:
         if not x.needs_grad or all(y.grad is None for y in ys):
             return
         dx = zeros(x.data.shape, x.data.dtype, x.data.device)
-        for y, idx in zip(ys, idx_list):
-            if y.grad is not None:
-                K.row_copy(dx, y.grad, dst_idx=idx)
+        K.row_copy_multi([dict(dst=dx, src=y.grad, dst_idx=idx) for y, idx in zip(ys, idx_list) if y.grad is not None])
         x.add_grad(dx)
 
     tape.record(bwd)
@@ -879,27 +877,34 @@ def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.d
     """Build a token matrix [n_rows, c] (fp32) from row segments (replaces torch.cat / bool-mask selects / pos-embed adds:
     cinema/vit.py:672-674, cinema/mae/mae.py:98-104,580-585, cinema/convvit.py:205)."""
     out = torch.empty((n_rows, c), dtype=F32, device=device)
-    for s in segments:
+    copies = []
+    for s in segments:  # disjoint destination rows: one multi-segment launch
         n = s.dst_idx.numel()
         if isinstance(s.src, Var):
-            K.row_copy(out, s.src.data, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx)
+            copies.append(dict(dst=out, src=s.src.data, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx))
         elif s.src is not None:  # broadcast token parameter
             z = const(("zero_idx", n, str(device)), lambda: torch.zeros(n, dtype=torch.int32, device=device))
-            K.row_copy(out, s.src.detach().view(1, c), dst_idx=s.dst_idx, src_idx=z, add=s.add, add_idx=s.add_idx)
+            copies.append(dict(dst=out, src=s.src.detach().view(1, c), dst_idx=s.dst_idx, src_idx=z, add=s.add, add_idx=s.add_idx))
         else:
-            K.row_copy(out, None, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx)
+            copies.append(dict(dst=out, src=None, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx))
+    K.row_copy_multi(copies)
     y = Var(out)
 
     def bwd() -> None:
         if y.grad is None:
             return
+        gathers, targets = [], []
         for s in segments:
             if isinstance(s.src, Var):
                 if s.src.needs_grad:
                     g = torch.empty((s.dst_idx.numel(), c), dtype=F32, device=device)
-                    s.src.add_grad(K.row_copy(g, y.grad, src_idx=s.dst_idx))
+                    gathers.append(dict(dst=g, src=y.grad, src_idx=s.dst_idx))
+                    targets.append((s.src, g))
             elif s.src is not None and s.src.requires_grad:
                 K.colsum(y.grad, tape.pvar(s.src).grad_buffer((c,)), row_idx=s.dst_idx)
+        K.row_copy_multi(gathers)
+        for var, g in targets:
+            var.add_grad(g)
 
     tape.record(bwd)
     return y
@@ -926,8 +931,7 @@ def op_mean_finite(tape: Tape, losses: list) -> Var:
     """Mean over the finite per-view losses (cinema/mae/mae.py:604-608) without a host round trip."""
     dev = losses[0].data.device
     vals = torch.empty(len(losses), dtype=F32, device=dev)
-    for i, lv in enumerate(losses):
-        K.row_copy(vals[i:i + 1].view(1, 1), lv.data.view(1, 1))
+    K.row_copy_multi([dict(dst=vals[i:i + 1].view(1, 1), src=lv.data.view(1, 1)) for i, lv in enumerate(losses)])
     mean, coef = torch.empty(1, dtype=F32, device=dev), torch.empty(len(losses), dtype=F32, device=dev)
     K.mean_finite(vals, mean, coef)
     y = Var(mean)

@@ -193,6 +193,15 @@ int cinema_patch_scatter(const void* rows, int rows_dtype, int ld_rows, void* ds
 int cinema_row_copy(void* dst, int dst_dtype, int ld_dst, const int* dst_idx, const void* src, int src_dtype, int ld_src,
                     const int* src_idx, const void* add, int add_dtype, int ld_add, const int* add_idx, int n_rows, int c,
                     int accumulate, void* stream);
+/* The arguments of one cinema_row_copy as a struct, and up to any number of them (12 per launch) in ONE grid: the token assembly / split /
+ * concatenation ops of a step (cinema/vit.py:672-674, cinema/mae/mae.py:98-104,580-585) are 4-9 independent small copies each. */
+typedef struct {
+  void* dst; int dst_dtype, ld_dst; const int* dst_idx;
+  const void* src; int src_dtype, ld_src; const int* src_idx;
+  const void* add; int add_dtype, ld_add; const int* add_idx;
+  int n_rows, c, accumulate;
+} cinema_row_copy_args;
+int cinema_row_copy_multi(const cinema_row_copy_args* segs_host, int count, void* stream);
 
 /* Segmentation loss of one view (reference _segmentation_loss, cinema/segmentation/train.py:77-103): cross_entropy(ignore_index = -1) +
  * monai DiceLoss(include_background=False, softmax=True) against one_hot(max(labels, 0)); smooth_nr = smooth_dr = 1e-5, mean over samples x foreground classes.
