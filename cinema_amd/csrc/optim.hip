@@ -21,18 +21,23 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n
   if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
-// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
-__global__ void clip_coef_kernel(const float* sq, float max_norm, float* coef, float* norm_out) {
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)).
+// Non-finite guard (cinema/mae/pretrain.py:255-257 skips a NaN loss, torch's GradScaler.step skips inf/NaN gradients): a non-finite norm
+// gives coef = 0, which adamw_kernel reads as "leave parameters, moments and shadows alone"; state[0] counts the updates applied (the Adam
+// step used for the bias corrections), state[1] the updates skipped.  The decision stays on the device - no host round trip.
+__global__ void clip_coef_kernel(const float* sq, float max_norm, float* coef, float* norm_out, int* state) {
   if (threadIdx.x || blockIdx.x) return;
   const float nrm = sqrtf(sq[0]);
+  const bool ok = isfinite(nrm);
   if (norm_out) norm_out[0] = nrm;
-  if (coef) coef[0] = max_norm > 0.f ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
+  if (coef) coef[0] = !ok ? 0.f : (max_norm > 0.f ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f);
+  if (state) state[ok ? 0 : 1] += 1;
 }
 
 struct AdamP {
   float* p; const float* g; float* m; float* v; long long n;
   float lr, b1, b2, eps, wd, bc1, bc2;
-  const float* clip; bf16_t* shadow;
+  const float* clip; bf16_t* shadow; const int* state;
 };
 
 __device__ __forceinline__ float adam1(float& p, float g, float& m, float& v, const AdamP& a, float cc) {
@@ -47,6 +52,12 @@ __device__ __forceinline__ float adam1(float& p, float g, float& m, float& v, co
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
   const float cc = a.clip ? a.clip[0] : 1.f;
+  if (a.state) {  // guarded update: coef == 0 marks a non-finite gradient norm (skip); the step count lives on the device
+    if (!(cc > 0.f)) return;
+    const double step = (double)a.state[0];
+    a.bc1 = (float)(1.0 - pow((double)a.b1, step));
+    a.bc2 = (float)(1.0 - pow((double)a.b2, step));
+  }
   const long long n4 = a.n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 p = reinterpret_cast<float4*>(a.p)[i];
@@ -82,18 +93,20 @@ CINEMA_API int cinema_sqnorm_f32(const float* g, long long n, float* out, void* 
   return launch_status();
 }
 
-CINEMA_API int cinema_clip_coef(const float* sqnorm, float max_norm, float* coef_out, float* norm_out, void* stream) {
+CINEMA_API int cinema_clip_coef(const float* sqnorm, float max_norm, float* coef_out, float* norm_out, int* step_state, void* stream) {
   if (!sqnorm) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sqnorm, max_norm, coef_out, norm_out);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sqnorm, max_norm, coef_out, norm_out, step_state);
   return launch_status();
 }
 
 CINEMA_API int cinema_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float bias_corr1, float bias_corr2, const float* clip_coef, uint16_t* p_bf16, void* stream) {
+                            float weight_decay, float bias_corr1, float bias_corr2, const float* clip_coef, uint16_t* p_bf16, const int* step_state,
+                            void* stream) {
   if (!p || !g || !m || !v || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if (step_state && !clip_coef) return CINEMA_ERR_BAD_ARG;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CINEMA_ERR_UNSUPPORTED;
   if (p_bf16 && (((uintptr_t)p_bf16) & 7)) return CINEMA_ERR_UNSUPPORTED;
-  AdamP a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, clip_coef, p_bf16};
+  AdamP a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, clip_coef, p_bf16, step_state};
   long long grid = (n / 4 + 255) / 256;
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;

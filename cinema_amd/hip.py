@@ -139,8 +139,8 @@ _PROTOS = {
     "cinema_patch_stats": [_vp, C.POINTER(PatchGeom), _vp, _vp],
     "cinema_mean_finite": [_vp, _i, _vp, _vp, _vp],
     "cinema_sqnorm_f32": [_vp, _ll, _vp, _vp],
-    "cinema_clip_coef": [_vp, _f, _vp, _vp, _vp],
-    "cinema_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp],
+    "cinema_clip_coef": [_vp, _f, _vp, _vp, _vp, _vp],
+    "cinema_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 FORCE_GENERIC = bool(int(os.environ.get("CINEMA_HIP_FORCE_GENERIC", "0")))
@@ -925,16 +925,23 @@ def sqnorm(g: torch.Tensor, out: torch.Tensor) -> None:
     _check(load().cinema_sqnorm_f32(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "sqnorm")
 
 
-def clip_coef(sq: torch.Tensor, max_norm: float, coef_out: torch.Tensor | None, norm_out: torch.Tensor | None) -> None:
-    _dev(sq, coef_out, norm_out)
-    _check(load().cinema_clip_coef(sq.data_ptr(), max_norm, _p(coef_out), _p(norm_out), _stream()), "clip_coef")
+def clip_coef(sq: torch.Tensor, max_norm: float, coef_out: torch.Tensor | None, norm_out: torch.Tensor | None, step_state: torch.Tensor | None = None) -> None:
+    """coef = min(1, max_norm / (sqrt(sq) + 1e-6)); a non-finite norm gives coef = 0 (= skip, see :func:`adamw`).  ``step_state`` int32 [2]:
+    [0] counts applied updates, [1] skipped ones."""
+    _dev(sq, coef_out, norm_out, step_state)
+    if step_state is not None and (step_state.dtype != torch.int32 or step_state.numel() < 2):
+        raise HipLibraryError("clip_coef: step_state must be int32 [2]")
+    _check(load().cinema_clip_coef(sq.data_ptr(), max_norm, _p(coef_out), _p(norm_out), _p(step_state), _stream()), "clip_coef")
 
 
 def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
-          step: int, clip: torch.Tensor | None = None, shadow: torch.Tensor | None = None) -> None:
-    _dev(p, g, m, v, clip, shadow)
+          step: int, clip: torch.Tensor | None = None, shadow: torch.Tensor | None = None, step_state: torch.Tensor | None = None) -> None:
+    """``step_state`` (int32 [2] written by :func:`clip_coef`): the update is skipped on the device when ``clip[0]`` is not > 0 and the Adam
+    step of the bias corrections is ``step_state[0]`` (``step`` is then ignored)."""
+    _dev(p, g, m, v, clip, shadow, step_state)
+    step = max(int(step), 1)
     _check(load().cinema_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, weight_decay,
-                               1.0 - beta1**step, 1.0 - beta2**step, _p(clip), _p(shadow), _stream()), "adamw")
+                               1.0 - beta1**step, 1.0 - beta2**step, _p(clip), _p(shadow), _p(step_state), _stream()), "adamw")
 
 
 def info() -> dict:

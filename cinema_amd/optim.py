@@ -125,31 +125,48 @@ class FusedAdamW:
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.coef = torch.ones(1, dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.step_count = 0
+        # [updates applied, updates skipped]: lives on the device because the non-finite-gradient decision does (no host sync in a step)
+        self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    @property
+    def step_count(self) -> int:
+        """Updates applied so far = the Adam step of the bias corrections (a device read-back; not used inside a step)."""
+        return int(self.step_state[0])
+
+    @property
+    def n_skipped(self) -> int:
+        """Updates skipped because the (all-reduced) gradient norm was not finite."""
+        return int(self.step_state[1])
 
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002
         self.flat.zero_grad()
 
     def step(self, clip_grad: float | None = None) -> torch.Tensor:
-        """One update; returns the pre-clip global gradient norm as a device scalar (``cinema/optim.py:208-210``)."""
+        """One update; returns the pre-clip global gradient norm as a device scalar (``cinema/optim.py:208-210``).
+
+        Non-finite guard, decided on the device: the reference skips the step on a NaN loss (``cinema/mae/pretrain.py:255-257``) and its
+        ``GradScaler.step`` skips the optimiser when a gradient is inf / NaN.  Here a NaN loss back-propagates NaN into the flat gradient
+        buffer, the squared norm is NaN, ``clip_coef`` writes coef = 0 and the AdamW kernels return without touching parameters, moments or
+        bf16 shadows; the Adam step count does not advance.  Under data parallelism the norm is taken AFTER the mean all-reduce, so every
+        rank sees the same NaN and skips together (no rank-local ``continue`` that would dead-lock the collectives)."""
         f = self.flat
-        self.step_count += 1
         self.sq.zero_()
         K.sqnorm(f.flat_grad, self.sq)
-        K.clip_coef(self.sq, float(clip_grad) if clip_grad else 0.0, self.coef, self.grad_norm)
+        K.clip_coef(self.sq, float(clip_grad) if clip_grad else 0.0, self.coef, self.grad_norm, self.step_state)
         for group, (a, b) in zip(self.param_groups, f.ranges):
             if b > a:
                 K.adamw(f.flat_param[a:b], f.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], group["lr"], self.betas[0], self.betas[1],
-                        self.eps, group["weight_decay"], self.step_count, clip=self.coef,
-                        shadow=None if f.flat_shadow is None else f.flat_shadow[a:b])
+                        self.eps, group["weight_decay"], 1, clip=self.coef,
+                        shadow=None if f.flat_shadow is None else f.flat_shadow[a:b], step_state=self.step_state)
         T.WEIGHTS.invalidate()  # parameters were written through raw pointers: re-laid-out shadows (patch convs) are rebuilt next forward
         return self.grad_norm
 
     def state_dict(self) -> dict:
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lrs": [g["lr"] for g in self.param_groups]}
+        return {"step": self.step_count, "skipped": self.n_skipped, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lrs": [g["lr"] for g in self.param_groups]}
 
     def load_state_dict(self, state: dict) -> None:
-        self.step_count = int(state["step"])
+        self.step_state[0] = int(state["step"])
+        self.step_state[1] = int(state.get("skipped", 0))
         self.exp_avg.copy_(state["exp_avg"])
         self.exp_avg_sq.copy_(state["exp_avg_sq"])
         for g, lr in zip(self.param_groups, state["lrs"]):
