@@ -46,15 +46,25 @@ def synthetic_batch(kw: dict, batch: int, seed: int, device: str) -> dict:
     return {v: torch.rand(batch, 1, *s, generator=gen).to(device) for v, s in kw["image_size_dict"].items()}
 
 
-def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float) -> dict:
-    """The CPU oracle (fp32, torch CPU ops on all host cores) on a bounded sample of the same workload."""
+def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float, device: str) -> tuple:
+    """The CPU oracle (fp32, torch CPU ops on the host cores) on a bounded sample of the same workload -> (cpu_baseline, parity).
+    ``parity``: the first step of the HIP path against the oracle on identical weights, inputs and masks (oracle/parity.py, checker only)."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import cinema_oracle as O  # noqa: N812
+    from parity import mae_step_parity
 
     # intra-op threads actually used: torch's CPU kernels on this graph peak at ~16 threads on the 256-core GPU-box host
     # (probe run once with this function at different thread counts: 16 threads 3.6 s/step, 32 -> 4.2 s, 64 -> 7.6 s, 256 -> 640 s at batch 2)
-    cores = min(os.cpu_count() or 1, 16)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
     torch.set_num_threads(cores)
+    par = mae_step_parity(kw, state_dict, batch=batch, seed=7, device=device)
+    parity = {"loss_rel": round(par["loss_rel"], 6), "grad_rel": round(par["grad_rel"], 5), "grad_norm_rel": round(par["grad_norm_rel"], 6),
+              "worst_grad_rel_l2": {"name": par["worst_grad_rel_l2"]["name"], "value": round(par["worst_grad_rel_l2"]["value"], 5)},
+              "view_loss_rel": {k: round(v, 6) for k, v in par["view_loss_rel"].items()}, "pred_max_abs": round(par["pred_max_abs"], 5),
+              "loss": round(par["loss"], 6), "oracle_loss": round(par["oracle_loss"], 6),
+              "what": f"first forward+backward of the HIP path vs the fp32 CPU oracle on identical weights, inputs and masks at batch {batch} of this workload; "
+                      "grad_rel = worst relative L2 error over 10 named gradients (oracle/parity.py), worst_grad_rel_l2 over ALL parameters"}
     cfg = O.MAEConfig(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
     trainer = O.Trainer({k: v.detach().float().cpu() for k, v in state_dict.items()}, cfg, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0)
     gen = torch.Generator().manual_seed(99)
@@ -72,21 +82,35 @@ def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float) -> dic
         loss, _, _, _ = trainer.step(images, masks())
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(batch * n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": round(batch * n / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"{n} optimisation steps (fwd+bwd+clip+AdamW) of the same Base 4-view config at batch {batch}, fp32 torch-CPU oracle, "
-                      f"after 1 warm-up step ({warm:.1f} s); final loss {float(loss):.4f}"}
+                      f"after 1 warm-up step ({warm:.1f} s); final loss {float(loss):.4f} (different data and step count than the GPU run: not comparable; "
+                      f"see `parity` for the like-for-like comparison); {cores} intra-op threads of the host's {host_cores} cores (more threads are slower on this graph)"}, parity
+
+
+PMC_TRAFFIC_FILE = "profiles/pmc_hbm_traffic.json"
+PMC_MFMA_FILE = "profiles/r02_mfma_util.json"
+
+
+def _committed(rel: str, kernel: str):  # noqa: ANN202
+    try:
+        return json.loads((ROOT / rel).read_text())["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def pmc_traffic(kernel: str):  # noqa: ANN201
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command (tools/gpu_pmc_bench.sh ->
-    profiles/pmc_hbm_traffic.json; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); None when no capture is committed."""
-    path = Path(__file__).resolve().parent / "profiles" / "pmc_hbm_traffic.json"
-    try:
-        k = json.loads(path.read_text())["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    hit = k.get(kernel)
+    """HBM bytes per launch of ``kernel`` from the COMMITTED rocprofv3 PMC passes of this same command (tools/gpu_pmc_bench.sh ->
+    profiles/pmc_hbm_traffic.json; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); None when no capture is committed.
+    Not a live measurement: counter collection needs rocprofv3 around the process."""
+    hit = _committed(PMC_TRAFFIC_FILE, kernel)
     return None if hit is None else hit["hbm_bytes_per_launch"]
+
+
+def pmc_mfma_util(kernel: str):  # noqa: ANN201
+    """SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of ``kernel`` from the committed PMC passes (tools/gpu_pmc_mfma.sh)."""
+    hit = _committed(PMC_MFMA_FILE, kernel)
+    return None if hit is None else hit.get("mfma_util")
 
 
 def main() -> None:
@@ -148,7 +172,8 @@ def main() -> None:
     loss = None
     # steady state needs ~20 steps (caching-allocator growth, clock ramp: 38.7 -> 36.0 ms/step measured between steps 10 and 50); when the
     # caller asks for fewer warm-up steps the difference is run here, untimed, before the W warm-up steps of the contract
-    for i in range(max(0, args.prewarm - args.warmup)):
+    extra_untimed = max(0, args.prewarm - args.warmup)
+    for i in range(extra_untimed):
         step(batches[i % 2], 0.75)
     for i in range(args.warmup):
         loss, gnorm, _ = step(batches[i % 2], 0.75)
@@ -210,6 +235,10 @@ def main() -> None:
         achieved = flops / secs / 1e12
         roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(K.GEMM_KERNEL_NAMES[kind]),
+                    "traffic_source": f"committed {PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc_bench.sh); not collected live",
+                    "mfma_util": pmc_mfma_util(K.GEMM_KERNEL_NAMES[kind]),
+                    "mfma_util_source": f"committed {PMC_MFMA_FILE} (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes, tools/gpu_pmc_mfma.sh); not collected live",
+                    "timing": "HIP events on the launch stream around every launch of this kernel, live in this process (the events also cover the split-K reduce that follows each launch)",
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(secs / n * 1e6, 2),
                     "gflop_per_launch": round(flops / n / 1e9, 3),
                     "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
@@ -219,7 +248,7 @@ def main() -> None:
         samples_per_s = world * args.batch * args.steps / dt
         out = {
             "metric": "MAE-pretrain samples/sec (4-view cine, 75% mask)", "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "steps": args.steps, "warmup": args.warmup, "untimed_steps": extra_untimed + args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX {args.sax.replace(',', 'x')} + LAX 2C/3C/4C {args.lax.replace(',', 'x')}), mask 0.75, "
                                    f"per-GPU batch {args.batch}, fwd+bwd+clip(5.0)+AdamW, random-init weights",
@@ -234,7 +263,7 @@ def main() -> None:
             "roofline": roofline,
         }
         if world == 1 and args.cpu_budget > 0:
-            out["cpu_baseline"] = cpu_baseline(kw, cpu_state, 2, args.cpu_budget)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(kw, cpu_state, 2, args.cpu_budget, device)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_sync:
         dist.destroy_process_group()

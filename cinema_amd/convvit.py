@@ -81,7 +81,13 @@ class TokenSelection:
             self.all_tokens = True
             return
         # every row of a mask from get_batch_random_patch_mask has the same count; unknown (injected) masks are read back once
-        self.n_drop = int(n_masked) if n_masked is not None else int(mask[0].sum())
+        if n_masked is not None:
+            self.n_drop = int(n_masked)
+        else:  # injected mask: one read-back, which also checks that every sample masks the same number of patches (the reference fails in
+            counts = mask.sum(dim=1)  # its reshape at mae.py:550 when they differ; unequal rows would give index lists of the wrong length here)
+            self.n_drop = int(counts[0])
+            if bool((counts != counts[0]).any()):
+                raise ValueError(f"every sample must mask the same number of patches, got per-sample counts {counts.tolist()}")
         self.n_keep = n_keep = n_patches - self.n_drop
 
         if mask.is_cuda:  # one launch: raster-ordered kept / dropped lists (a recorded launch of a recorded step)

@@ -385,6 +385,20 @@ CINEMA_API int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, co
                             workspace, workspace_bytes, nullptr, stream);
 }
 
+// Number of per-block partial rows ([2][c] fp32 each) a backward launch over (rows, c) writes: sizes the workspace of the deferred form exactly
+// (the same grid computation as layernorm_bwd_impl; 0 = the small-channel kernel, which takes no workspace).
+CINEMA_API long long cinema_layernorm_bwd_workspace_bytes(int rows, int c) {
+  if (rows <= 0 || c <= 0 || (c & 3)) return 0;
+  const int lpr = pick_lpr(c);
+  const int cpl = ((c >> 2) + lpr - 1) / lpr;
+  const int rg = cpl <= 1 ? 4 : 1;
+  const int rows_per_block = 4 * (64 / lpr) * rg;
+  int grid = (rows + rows_per_block - 1) / rows_per_block;
+  const int cap = cpl <= 1 ? 2048 : 1024;
+  if (grid > cap) grid = cap;
+  return (long long)grid * 2 * c * 4;
+}
+
 CINEMA_API int cinema_layernorm_bwd_deferred(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
                                              const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                                              const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,

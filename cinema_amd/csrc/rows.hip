@@ -304,6 +304,63 @@ CINEMA_API int cinema_fill_u32(void* dst, unsigned int word, long long n_words, 
   return launch_status();
 }
 
+// Rotary embedding as the reference calls it (cinema/vit.py:496-499 -> cinema/rotary.py:30-60): q and k arrive as (batch, heads, tokens,
+// head_dim) and RotaryEmbedding indexes its table with dim 1, so the angle depends on the HEAD index h (table row h), the same for every
+// token: x1' = x1 cos - x2 sin, x2' = x2 cos + x1 sin over the two halves of the rotated part (rotate_half, rotary.py:12-24).  In place on bf16
+// rows [rows, ld] holding n_slots consecutive head slots of hd columns from column 0 (slot s uses table row s % heads: the fused q|k
+// projection is 2*heads slots).  inverse = 1 applies the transposed rotation (the gradient of the forward one).  half = rotated pairs per head.
+template <int VEC>
+__global__ __launch_bounds__(256) void rope_heads_kernel(bf16_t* x, int ld, long long rows, int n_slots, int heads, int hd, int half, const float* cos_t,
+                                                         const float* sin_t, int inverse) {
+  const int chunks = half / VEC;                       // per head slot
+  const long long total = rows * n_slots * chunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks);
+    const long long t = i / chunks;
+    const int slot = (int)(t % n_slots);
+    const long long r = t / n_slots;
+    const int h = slot % heads;
+    bf16_t* p1 = x + r * ld + (long long)slot * hd + ch * VEC;
+    bf16_t* p2 = p1 + half;
+    const float* cs = cos_t + (long long)h * half + ch * VEC;
+    const float* sn = sin_t + (long long)h * half + ch * VEC;
+    if constexpr (VEC == 8) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(p1), b = *reinterpret_cast<const bf16x8*>(p2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = cs[j], s_ = inverse ? -sn[j] : sn[j];
+        const float x1 = bf2f(a.v[j]), x2 = bf2f(b.v[j]);
+        a.v[j] = f2bf(x1 * c - x2 * s_);
+        b.v[j] = f2bf(x2 * c + x1 * s_);
+      }
+      *reinterpret_cast<bf16x8*>(p1) = a;
+      *reinterpret_cast<bf16x8*>(p2) = b;
+    } else {
+      const float c = cs[0], s_ = inverse ? -sn[0] : sn[0];
+      const float x1 = bf2f(p1[0]), x2 = bf2f(p2[0]);
+      p1[0] = f2bf(x1 * c - x2 * s_);
+      p2[0] = f2bf(x2 * c + x1 * s_);
+    }
+  }
+}
+
+CINEMA_API int cinema_rope_heads(uint16_t* x, int ld, long long rows, int n_slots, int heads, int head_dim, int rotary_dim, const float* cos_table,
+                                 const float* sin_table, int inverse, void* stream) {
+  if (!x || !cos_table || !sin_table || rows <= 0 || n_slots <= 0 || heads <= 0 || head_dim <= 0 || rotary_dim <= 0 || (rotary_dim & 1) ||
+      rotary_dim > head_dim || ld < n_slots * head_dim)
+    return CINEMA_ERR_BAD_ARG;
+  const int half = rotary_dim / 2;
+  const bool vec = (half % 8 == 0) && (head_dim % 8 == 0) && (ld % 8 == 0) && ((((uintptr_t)x) & 15) == 0);
+  const long long total = rows * n_slots * (vec ? half / 8 : half);
+  if (vec)
+    hipLaunchKernelGGL(rope_heads_kernel<8>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, n_slots, heads, head_dim, half,
+                       cos_table, sin_table, inverse);
+  else
+    hipLaunchKernelGGL(rope_heads_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, n_slots, heads, head_dim, half,
+                       cos_table, sin_table, inverse);
+  return launch_status();
+}
+
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;

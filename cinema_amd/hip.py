@@ -98,6 +98,7 @@ _PROTOS = {
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _vp],
     "cinema_layernorm_bwd_deferred": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, C.POINTER(C.c_int), _vp],
+    "cinema_layernorm_bwd_workspace_bytes": [_i, _i],
     "cinema_ln_param_reduce_batched": [_vp, _i, _vp],
     "cinema_row_copy_multi": [_vp, _i, _vp],
     "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -121,6 +122,7 @@ _PROTOS = {
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
     "cinema_fill_u32": [_vp, C.c_uint, _ll, _vp],
+    "cinema_rope_heads": [_vp, _i, _ll, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "cinema_mul_scalar_f32": [_vp, _vp, _vp, _ll, _vp],
     "cinema_mask_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_visible_index": [_vp, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp, _vp, _vp],
@@ -465,6 +467,18 @@ def mul_scalar(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def rope_heads(x: torch.Tensor, n_slots: int, heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """In-place head-indexed rotary embedding on bf16 rows x [rows, >= n_slots*head_dim] (see ``cinema_rope_heads``); cos/sin fp32 [heads, rotary_dim/2]."""
+    _dev(x, cos, sin)
+    if x.dtype != torch.bfloat16 or cos.dtype != torch.float32 or sin.dtype != torch.float32 or not cos.is_contiguous() or not sin.is_contiguous():
+        raise HipLibraryError("rope_heads: bf16 rows, contiguous fp32 tables")
+    if cos.shape != sin.shape or cos.shape[0] != heads:
+        raise HipLibraryError(f"rope_heads: tables must be [heads={heads}, rotary_dim/2], got {tuple(cos.shape)}")
+    _check(load().cinema_rope_heads(x.data_ptr(), _rowmajor(x, "x"), x.shape[0], n_slots, heads, head_dim, 2 * cos.shape[1], cos.data_ptr(), sin.data_ptr(),
+                                    int(inverse), _stream()), "rope_heads")
+    return x
+
+
 def full(shape, value: float, dtype: torch.dtype = torch.float32, device=None) -> torch.Tensor:  # noqa: ANN001
     """torch.full / torch.zeros as a launch of this library (so that it is part of a recorded step, see cinema_amd/replay.py): fp32 with
     any value, other dtypes with zero only; the tensor must span whole 32-bit words."""
@@ -548,7 +562,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: 
         raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
     if deferred is not None and (dgamma is not None or dbeta is not None):
         # the per-block partial sums stay in a buffer of their own until ln_param_reduce_batched adds them up (end of the backward pass)
-        ws = torch.empty(2048 * 2 * c, dtype=torch.float32, device=x.device)
+        # sized from the launch's actual grid (a fixed 2048-block buffer was 12.6 MB per LayerNorm at c = 768: ~1 GB held across a step)
+        ws = torch.empty(max(load().cinema_layernorm_bwd_workspace_bytes(rows, c) // 4, 4), dtype=torch.float32, device=x.device)
         n_part = C.c_int(0)
         _check(load().cinema_layernorm_bwd_deferred(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
                                                     int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),

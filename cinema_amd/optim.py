@@ -58,9 +58,12 @@ def param_groups_weight_decay(model: nn.Module, weight_decay: float = 1e-5, no_w
 class FlatModel:
     """Flat fp32 parameter / gradient storage for a model's trainable parameters, grouped by weight decay."""
 
-    def __init__(self, model: nn.Module, weight_decay: float) -> None:
+    def __init__(self, model: nn.Module, weight_decay: float, param_groups: list | None = None) -> None:
+        """``param_groups`` (optional): torch-style list of dicts with ``params`` and per-group ``weight_decay`` / ``lr_scale`` (e.g.
+        ``cinema_amd.convvit.param_groups_lr_decay``); default: timm's two-group weight-decay split used by the reference pre-training."""
         self.model = model
-        self.groups = param_groups_weight_decay(model, weight_decay)
+        self.groups = [dict(g) for g in param_groups] if param_groups is not None else param_groups_weight_decay(model, weight_decay)
+        self.groups = [g for g in self.groups if len(g["params"]) > 0] or self.groups
         params = [p for g in self.groups for p in g["params"]]
         if not params:
             raise ValueError("model has no trainable parameters")
@@ -115,9 +118,14 @@ class FusedAdamW:
     ``param_groups`` mimics the torch optimiser attribute so that :func:`adjust_learning_rate` works unchanged.
     """
 
-    def __init__(self, flat: FlatModel, lr: float = 1e-3, betas: tuple = (0.9, 0.95), eps: float = 1e-8) -> None:
+    def __init__(self, flat: FlatModel, lr: float = 1e-3, betas: tuple = (0.9, 0.95), eps: float = 1e-8, synchronizer=None) -> None:  # noqa: ANN001
         self.flat = flat
-        self.param_groups = [{"params": g["params"], "weight_decay": g["weight_decay"], "lr": lr} for g in flat.groups]
+        # data-parallel gradient exchange of the flat buffer (cinema_amd.ddp.GradientSynchronizer); defaults to the one setup_ddp_model left on the model
+        self.synchronizer = synchronizer if synchronizer is not None else getattr(flat.model, "grad_synchronizer", None)
+        if self.synchronizer is not None and self.synchronizer.flat is not flat:
+            self.synchronizer.attach(flat)
+        self.param_groups = [{**{k: v for k, v in g.items() if k != "params"}, "params": g["params"], "weight_decay": g.get("weight_decay", 0.0),
+                              "lr": lr * g["lr_scale"] if "lr_scale" in g else lr} for g in flat.groups]
         self.betas, self.eps = tuple(betas), eps
         self.exp_avg = torch.zeros_like(flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(flat.flat_param)
@@ -178,14 +186,12 @@ class TrainStep:
     (``cinema/mae/pretrain.py:242-269``) without its per-step host synchronisations."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, clip_grad: float | None = 5.0,
-                 synchronizer=None, hip_graph: bool = False, replay: bool = False, audit: bool = False) -> None:  # noqa: ANN001
+                 synchronizer=None, hip_graph: bool = False, replay: bool = False, audit: bool = False, param_groups: list | None = None) -> None:  # noqa: ANN001
         self.model = model
-        self.flat = FlatModel(model, weight_decay)
-        self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas)
+        self.flat = FlatModel(model, weight_decay, param_groups=param_groups)
+        self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas, synchronizer=synchronizer)
         self.clip_grad = clip_grad
-        self.sync = synchronizer
-        if self.sync is not None:
-            self.sync.attach(self.flat)
+        self.sync = self.optimizer.synchronizer
         # hip_graph: forward + backward (~2000 launches on two streams) are captured once per input signature and replayed as one HIP
         # graph, which takes the host out of the step; clip + AdamW stay eager (their scalars change every step).  Single process only:
         # the overlapped RCCL collectives are issued from Python hooks in the backward pass.
@@ -195,7 +201,7 @@ class TrainStep:
         self.replay, self.audit = replay, audit
         self._recorded: dict = {}
         self._graphs: dict = {}
-        if hip_graph and synchronizer is not None:
+        if hip_graph and self.sync is not None:
             raise ValueError("hip_graph=True captures the single-process step; the data-parallel step runs eagerly")
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
@@ -274,3 +280,137 @@ class TrainStep:
         grad_norm = self.optimizer.step(self.clip_grad)
         self.optimizer.zero_grad()
         return loss, grad_norm, metrics  # static output buffers: overwritten by the next replay
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Harness pieces of the reference's ``cinema/optim.py`` that callers of the path import: same names, arguments and
+# return values, so ``pretrain_one_epoch`` / ``train_one_epoch`` style loops (``cinema/mae/pretrain.py:242-269``, ``cinema/train.py:85-168``)
+# run unchanged on either a ``torch.optim`` optimiser or the fused flat-buffer optimiser above.
+# ---------------------------------------------------------------------------------------------------------------------
+def get_grad_norm(parameters, norm_type: float = 2.0) -> torch.Tensor:  # noqa: ANN001
+    """Global gradient norm without clipping (reference ``cinema/optim.py:146-170``)."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    parameters = [p for p in parameters if p.grad is not None]
+    norm_type = float(norm_type)
+    if len(parameters) == 0:
+        return torch.tensor(0.0)
+    device = parameters[0].grad.device
+    if norm_type == math.inf:
+        return max(p.grad.detach().abs().max().to(device) for p in parameters)
+    return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(device) for p in parameters]), norm_type)
+
+
+class GradScaler:
+    """``loss_scaler(loss, optimizer, clip_grad, parameters, update_grad=...) -> grad_norm`` (reference ``cinema/optim.py:173-226``).
+
+    * ``optimizer`` is a :class:`FusedAdamW`: ``loss.backward()`` accumulates straight into the flat gradient buffer (the model's single
+      autograd node), then - on ``update_grad`` - the data-parallel mean all-reduce of that buffer (when the model carries a
+      ``GradientSynchronizer``, see ``cinema_amd.ddp.setup_ddp_model``), squared norm, clip coefficient and fused AdamW kernels.  bf16 has
+      fp32's exponent range, so there is no loss scale to maintain; the inf/NaN skip of ``torch.GradScaler.step`` is the device-side
+      non-finite guard of :meth:`FusedAdamW.step`.
+    * any other ``torch.optim`` optimiser: the reference's own sequence on ``torch.GradScaler`` (scale -> backward -> unscale_ ->
+      ``clip_grad_norm_`` / ``get_grad_norm`` -> step -> update), with the gradient mean all-reduce of DDP done here when a process group
+      of more than one rank is up (the models are not wrapped in ``DistributedDataParallel``).
+    """
+
+    state_dict_key = "amp_scaler"
+
+    def __init__(self) -> None:
+        self._scaler = torch.GradScaler("cuda", enabled=torch.cuda.is_available())
+
+    def __call__(self, loss: torch.Tensor, optimizer, clip_grad: float | None = None, parameters=None, create_graph: bool = False,  # noqa: ANN001
+                 update_grad: bool = True):  # noqa: ANN204
+        fused = isinstance(optimizer, FusedAdamW)
+        sync = getattr(optimizer, "synchronizer", None) if fused else None
+        if sync is not None:
+            sync.arm(update_grad)
+        if fused:
+            loss.backward(create_graph=create_graph)
+        else:
+            self._scaler.scale(loss).backward(create_graph=create_graph)
+        if not update_grad:
+            return None
+        if parameters is None:
+            raise ValueError("parameters must not be None.")
+        if fused:
+            if sync is not None:
+                sync.all_reduce()
+            return optimizer.step(clip_grad)
+        parameters = list(parameters) if not isinstance(parameters, torch.Tensor) else [parameters]
+        _all_reduce_param_grads(parameters)
+        self._scaler.unscale_(optimizer)
+        norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad) if clip_grad is not None else get_grad_norm(parameters)
+        self._scaler.step(optimizer)
+        self._scaler.update()
+        return norm
+
+    def state_dict(self) -> dict:
+        return self._scaler.state_dict()
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        self._scaler.load_state_dict(state_dict)
+
+
+def _all_reduce_param_grads(parameters: list) -> None:
+    """DDP's gradient averaging for the torch-optimiser path (one flattened bucket; the fused path all-reduces its flat buffer instead)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def save_checkpoint(ckpt_dir, epoch: int, model_wo_ddp: nn.Module, optimizer, loss_scaler: GradScaler, n_samples: int):  # noqa: ANN001, ANN201
+    """``ckpt_dir / f"ckpt_{epoch}.pt"`` with the reference's keys (``cinema/optim.py:229-261``): model, optimizer, epoch, scaler, n_samples."""
+    from pathlib import Path
+
+    ckpt_dir = Path(ckpt_dir)
+    ckpt_dir.mkdir(parents=True, exist_ok=True)
+    ckpt_path = ckpt_dir / f"ckpt_{epoch}.pt"
+    torch.save({"model": model_wo_ddp.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch, "scaler": loss_scaler.state_dict(),
+                "n_samples": n_samples}, ckpt_path)
+    return ckpt_path
+
+
+def load_checkpoint_and_optimizer(ckpt_path, model_wo_ddp: nn.Module, optimizer, loss_scaler: GradScaler) -> tuple:  # noqa: ANN001
+    """-> (model, optimizer, loss_scaler, epoch, n_samples) (reference ``cinema/optim.py:264-294``).  For a :class:`FusedAdamW` the masters
+    are loaded in place into the flat buffer and the bf16 weight shadows are re-derived."""
+    ckpt = torch.load(ckpt_path, map_location="cpu")
+    model_wo_ddp.load_state_dict(ckpt["model"])
+    optimizer.load_state_dict(ckpt["optimizer"])
+    if isinstance(optimizer, FusedAdamW):
+        optimizer.flat.refresh_shadows()
+        T.WEIGHTS.invalidate()
+    loss_scaler.load_state_dict(ckpt["scaler"])
+    return model_wo_ddp, optimizer, loss_scaler, ckpt["epoch"], ckpt.get("n_samples", 0)
+
+
+class EarlyStopping:
+    """Patience counter on a metric that should decrease (reference ``cinema/optim.py:297-330``)."""
+
+    def __init__(self, min_delta: float, patience: int) -> None:
+        self.min_delta = min_delta
+        self.best_metric = float("inf")
+        self.patience = patience
+        self.patience_count = 0
+        self.should_stop = False
+        self.has_improved = False
+
+    def update(self, metric: float) -> None:
+        self.has_improved = self.best_metric > metric  # not necessarily improved enough
+        if self.has_improved and self.best_metric >= metric + self.min_delta:
+            self.best_metric = metric
+            self.patience_count = 0
+        else:
+            self.patience_count += 1
+            self.should_stop = self.patience_count >= self.patience

@@ -74,7 +74,10 @@ class RecordedStep:
 
     def __init__(self, model: torch.nn.Module, image_dict: dict, enc_mask_ratio: float, audit: bool = False) -> None:
         self.model, self.ratio = model, enc_mask_ratio
-        self.images = {k: v.clone() for k, v in image_dict.items()}
+        # static inputs in the layout the recorded launches read: CineMA.forward converts with .float().contiguous() (mae.py), which is a
+        # no-op on these and an ATen copy OUTSIDE the launch list on anything else (the replays would train on the first batch for ever);
+        # run() copies every new batch into these tensors, converting dtype / strides on the way
+        self.images = {k: v.detach().float().contiguous().clone() for k, v in image_dict.items()}
         masks, self.n_masked = model.draw_masks(self.images, enc_mask_ratio)
         self.masks = {k: m.clone() for k, m in masks.items()}
         self.pool = torch.cuda.MemPool()

@@ -233,6 +233,9 @@ def mark_params(tape: "Tape", params: list) -> None:
                 hook(tape, params)
 
         def fire() -> None:
+            # deferred LayerNorm parameter gradients of the ops launched so far (this block's included) must be in the flat buffer before any
+            # of its ranges is handed to a collective: reduce the pending partials now (one extra launch per block, data-parallel runs only)
+            flush_ln(tape)
             if K.RECORD is not None:  # recorded step: the collective is a torch call, so it enters the launch list as a host entry
                 K.RECORD.append((None, run_hook))
             run_hook()
@@ -271,10 +274,15 @@ class Tape:
                 torch.cuda.synchronize()
                 print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
         flush_wgrads(self)
-        K.ln_param_reduce_batched(self.pending_ln)  # 86 LayerNorms per step: one launch per 48 instead of one each
-        self.pending_ln = []
+        flush_ln(self)  # 86 LayerNorms per step: one launch per 48 instead of one each
         join_side_stream(release=True)
         self.ops = []
+
+
+def flush_ln(tape: "Tape") -> None:
+    """Add the LayerNorm parameter-gradient partials collected so far into dgamma / dbeta (one batched launch)."""
+    items, tape.pending_ln = tape.pending_ln, []
+    K.ln_param_reduce_batched(items)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -558,12 +566,16 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     return y
 
 
-def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b) -> Var:  # noqa: ANN001
-    """Fused q|k|v projection (one N=3C GEMM on concatenated shadow weights) + flash attention.  x bf16 [b*t, c]."""
+def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, rope: tuple | None = None) -> Var:  # noqa: ANN001
+    """Fused q|k|v projection (one N=3C GEMM on concatenated shadow weights) + flash attention.  x bf16 [b*t, c].
+    ``rope`` = (cos, sin) fp32 [heads, hd/2]: the reference's head-indexed rotary embedding (``cinema/vit.py:496-499``), applied in place to the
+    q|k columns of the projection; the backward pass rotates dq|dk back before the weight / data gradients."""
     c = x.data.shape[1]
     w = w_cat((q_w, kv_w))
     bias = b_cat((q_b, kv_b)) if q_b is not None else None
     qkv = K.gemm(x.data, w, bias=bias)
+    if rope is not None:
+        K.rope_heads(qkv, 2 * heads, heads, c // heads, rope[0], rope[1])
     t = qkv.shape[0] // batch
     q3 = qkv.view(batch, t, 3 * c)
     scale = (c // heads) ** -0.5
@@ -578,6 +590,8 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
         d3 = dqkv.view(batch, t, 3 * c)
         K.attention_bwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], o, y.grad.view(batch, t, c), lse, heads, scale, d3[..., :c],
                         d3[..., c:2 * c], d3[..., 2 * c:])
+        if rope is not None:
+            K.rope_heads(dqkv, 2 * heads, heads, c // heads, rope[0], rope[1], inverse=True)
         gq, gkv = pv[0].grad_buffer((c, c)), pv[2].grad_buffer((2 * c, c))
         if q_b is not None and pv[0].direct and pv[2].direct and _adjacent(gq, gkv):
             bq, bkv = pv[1].grad_buffer((c,)), pv[3].grad_buffer((2 * c,))

@@ -17,6 +17,7 @@ from torch import nn
 
 from cinema_amd import tape as T
 from cinema_amd.conv import Linear, _CkptFlag
+from cinema_amd.rotary import RotaryEmbedding
 
 
 def init_weights(m: nn.Module) -> None:
@@ -174,16 +175,22 @@ class Attention(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
-        # The reference applies its rotary table along the HEAD axis, identically to q and k, so the rotation cancels in
-        # q.k^T (golden "rotary/out" == "rotary/out_plain").  Reproducing it exactly means: no-op.
-        self.rotary = rotary
+        # The reference hands RotaryEmbedding q, k as (batch, heads, tokens, head_dim) (vit.py:496-499), so its table is indexed by the HEAD
+        # and q, k of one head get the same rotation, which cancels in q.k^T up to rounding (golden "rotary/out" ==
+        # "rotary/out_plain" to 6e-8).  The HIP path applies that same head-indexed rotation (cinema_rope_heads) to the fused q|k rows.
+        self.rotary = RotaryEmbedding(self.head_dim) if rotary else None
 
     def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int) -> T.Var:
         """xq: bf16 [b*tq, c] (normed queries); xk: bf16 [b*tk, c] or None for self-attention.  Returns bf16 [b*tq, c]."""
         if xk is not None and self.rotary:
             raise ValueError("Rotary positional embedding is not supported with different query and key.")
         if xk is None:
-            return T.op_self_attention(tp, xq, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias)
+            rope = None
+            if self.rotary is not None:
+                dev = xq.data.device
+                rope = T.const(("rope_tables", self.n_heads, self.head_dim, self.rotary.base, self.rotary.scaling_factor, str(dev)),
+                               lambda: self.rotary.head_tables(self.n_heads, dev))
+            return T.op_self_attention(tp, xq, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, rope=rope)
         return T.op_cross_attention(tp, xq, xk, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor | None = None) -> torch.Tensor:

@@ -97,6 +97,8 @@ typedef struct {
   float* dgamma;          /* accumulated; either may be NULL */
   float* dbeta;
 } cinema_ln_reduce_item;
+/* bytes of per-block partial sums the deferred backward of a (rows, c) LayerNorm writes (host-only query; 0: no workspace needed) */
+long long cinema_layernorm_bwd_workspace_bytes(int rows, int c);
 int cinema_layernorm_bwd_deferred(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
                                   const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                                   const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
@@ -220,6 +222,13 @@ int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, flo
 int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream);
 /* y[i] = x[i] * s[0], the scalar s read from device memory (chain rule through the scalar loss mean, cinema/mae/mae.py:604-608). */
 int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream);
+/* Rotary embedding of q / k as the reference calls it (cinema/vit.py:496-499 -> cinema/rotary.py:30-60, 109-128): the table row is the HEAD index
+ * (q, k are (batch, heads, tokens, head_dim) and the module indexes dim 1), the rotation acts on the two halves of the first rotary_dim columns of
+ * every head (rotate_half, cinema/rotary.py:12-24).  In place on bf16 rows [rows][ld]: n_slots consecutive head slots of head_dim columns from
+ * column 0, slot s uses table row s % heads (fused q|k rows: n_slots = 2*heads).  cos/sin fp32 [heads][rotary_dim/2].  inverse=1: transposed
+ * rotation (backward pass). */
+int cinema_rope_heads(uint16_t* x, int ld, long long rows, int n_slots, int heads, int head_dim, int rotary_dim, const float* cos_table,
+                      const float* sin_table, int inverse, void* stream);
 /* dst[0 .. n_words) = word (32-bit pattern; torch.zeros / torch.full of the reference's host code as a launch of this library). */
 int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream);
 

@@ -1,0 +1,262 @@
+"""GPU checks of the boundary pieces added around the MAE step: the head-indexed rotary kernel and ``Attention(rotary=True)``, the
+device-side non-finite guard of the fused optimiser, checkpoint save / resume of the flat-buffer optimiser through the reference-shaped
+``save_checkpoint`` / ``load_checkpoint_and_optimizer``, the ``GradScaler``-shaped call on the fused optimiser, recorded steps fed with
+non-fp32 / non-contiguous inputs, and layer-decay parameter groups on the fused optimiser."""
+
+from __future__ import annotations
+
+import math
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cinema_oracle as O  # noqa: E402
+from cinema_amd import CineMA  # noqa: E402
+from cinema_amd import hip as K  # noqa: E402
+from conftest import load_golden  # noqa: E402
+from test_model_gpu import mini_kwargs, model_sizes, split  # noqa: E402
+
+DEV = "cuda"
+
+
+# ---------------------------------------------------------------------------------------------------- rotary (a10)
+@pytest.mark.parametrize(("heads", "hd", "ro"), [(4, 8, 8), (12, 64, 64), (16, 32, 32), (4, 16, 8)])
+def test_rope_heads_kernel_vs_reference_formula(heads: int, hd: int, ro: int) -> None:
+    """cinema_rope_heads on fused q|k rows == apply_rotary_emb as the reference calls it (q, k as (batch, heads, tokens, head_dim), table rows =
+    heads; cinema/vit.py:496-499, cinema/rotary.py:27-60), incl. a partial rotary dim; inverse=1 undoes it (orthogonal rotation)."""
+    from cinema_amd.rotary import apply_rotary_emb
+
+    torch.manual_seed(0)
+    b, t = 2, 37
+    c = heads * hd
+    x = torch.randn(b * t, 3 * c).bfloat16()
+    ang = torch.rand(heads, ro // 2)
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    xf = x.float()
+    want = xf.clone()
+    for part in range(2):  # q and k thirds of the fused projection
+        blk = xf[:, part * c:(part + 1) * c].reshape(b, t, heads, hd).permute(0, 2, 1, 3)  # (b, heads, t, hd)
+        rot = apply_rotary_emb(blk, cos, sin).permute(0, 2, 1, 3).reshape(b * t, c)
+        want[:, part * c:(part + 1) * c] = rot
+    xg = x.to(DEV)
+    K.rope_heads(xg, 2 * heads, heads, hd, cos.to(DEV), sin.to(DEV))
+    got = xg.float().cpu()
+    assert torch.equal(got[:, 2 * c:], xf[:, 2 * c:])  # v untouched
+    assert (got - want).abs().max() <= 2.0 ** -7 * want.abs().max()  # one bf16 rounding of the result
+    K.rope_heads(xg, 2 * heads, heads, hd, cos.to(DEV), sin.to(DEV), inverse=True)
+    assert (xg.float().cpu() - xf).abs().max() <= 2.0 ** -6 * xf.abs().max()
+
+
+def test_attention_with_rotary_vs_reference_golden() -> None:
+    """Attention(rotary=True) on the HIP path against the reference layer output (tests/golden/layers.safetensors: rotary/out), forward and
+    input gradient against autograd through the oracle's attention on the same weights."""
+    from cinema_amd.vit import Attention
+
+    g = load_golden("layers.safetensors")
+    attn = Attention(32, n_heads=4, qkv_bias=True, rotary=True)
+    attn.load_state_dict(split(g, "rotary/param/"))
+    attn.to(DEV)
+    x = g["rotary/x"].to(DEV).requires_grad_(True)
+    y = attn(x)
+    err = (y.float().cpu() - g["rotary/out"]).abs().max()
+    assert err <= 2e-2 * g["rotary/out"].abs().max() + 2e-3, float(err)
+    y.square().sum().backward()
+    p = {f"a.{k}": v.clone().requires_grad_(True) for k, v in split(g, "rotary/param/").items()}
+    xr = g["rotary/x"].clone().requires_grad_(True)
+    O.attention(xr, xr, p, "a", 4).square().sum().backward()
+    assert (x.grad.cpu() - xr.grad).norm() <= 5e-2 * xr.grad.norm()
+    got_w = attn.kv.weight.grad.cpu()
+    assert (got_w - p["a.kv.weight"].grad).norm() <= 5e-2 * p["a.kv.weight"].grad.norm()
+
+
+def test_cinema_model_with_rotary_matches_plain_model() -> None:
+    """rotary=True through the whole MAE step: the head-indexed rotation cancels in q.k^T, so loss and gradients equal the rotary=False model's
+    up to the extra bf16 rounding of q and k (the reference: 'rotary/out' == 'rotary/out_plain' to 6e-8 in fp32)."""
+    torch.manual_seed(0)
+    plain = CineMA(**mini_kwargs())
+    rot = CineMA(**mini_kwargs(rotary=True))
+    rot.load_state_dict(plain.state_dict())
+    assert rot.encoder.blocks[0].attn.rotary is not None and plain.encoder.blocks[0].attn.rotary is None
+    plain.to(DEV)
+    rot.to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    images = {v: torch.rand(2, 1, *s, generator=gen).to(DEV) for v, s in model_sizes(plain).items()}
+    masks = {v: O.random_patch_mask(2, math.prod(plain.enc_down_dict[v].patch_embed.grid_size), 0.75, gen).to(DEV) for v in images}
+    out = {}
+    for name, m in (("plain", plain), ("rot", rot)):
+        loss, _, _, _ = m(images, 0.75, enc_mask_dict=masks)
+        loss.backward()
+        out[name] = (float(loss), m.encoder.blocks[0].attn.kv.weight.grad.float().cpu())
+    assert abs(out["plain"][0] - out["rot"][0]) <= 5e-3 * abs(out["plain"][0])
+    assert (out["plain"][1] - out["rot"][1]).norm() <= 5e-2 * out["plain"][1].norm()
+
+
+# ---------------------------------------------------------------------------------------------------- non-finite guard (a27)
+def test_clip_coef_and_adamw_skip_on_a_non_finite_norm() -> None:
+    """cinema_clip_coef writes coef = 0 and counts a skipped update when the squared norm is NaN / inf; cinema_adamw then leaves parameters,
+    moments and the bf16 shadow untouched; a finite norm advances the device step count that feeds the bias corrections."""
+    n = 1000
+    torch.manual_seed(0)
+    p, g = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = p.bfloat16()
+    coef, norm = torch.ones(1, device=DEV), torch.zeros(1, device=DEV)
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for bad in (float("nan"), float("inf")):
+        sq = torch.tensor([bad], device=DEV)
+        K.clip_coef(sq, 5.0, coef, norm, state)
+        p0, s0 = p.clone(), shadow.clone()
+        K.adamw(p, g, m, v, 1e-3, 0.9, 0.95, 1e-8, 0.05, 1, clip=coef, shadow=shadow, step_state=state)
+        assert float(coef) == 0.0 and torch.equal(p, p0) and torch.equal(shadow, s0) and float(m.abs().sum()) == 0.0 and float(v.abs().sum()) == 0.0
+    assert state.tolist() == [0, 2]
+    ref_p = p.detach().cpu().clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    for _ in range(3):
+        sq = (g * g).sum().reshape(1)
+        K.clip_coef(sq, 5.0, coef, norm, state)
+        K.adamw(p, g, m, v, 1e-3, 0.9, 0.95, 1e-8, 0.05, 12345, clip=coef, shadow=shadow, step_state=state)  # the host step argument is ignored
+        ref_p.grad = g.cpu().clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 5.0)
+        opt.step()
+    assert state.tolist() == [3, 2]
+    assert torch.allclose(p.cpu(), ref_p.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(shadow, p.bfloat16())
+
+
+def test_train_step_skips_a_nan_batch_and_recovers() -> None:
+    """A NaN input gives a NaN loss (a value, not an exception: cinema/mae/mae.py:604-608 keeps finite views only, all views NaN here); the
+    optimisation step must not touch the model (reference: pretrain.py:255-257 `continue`, GradScaler.step inf/NaN skip) and the next clean
+    batch must train normally."""
+    from cinema_amd.optim import TrainStep
+
+    torch.manual_seed(0)
+    model = CineMA(**mini_kwargs()).to(DEV)
+    step = TrainStep(model, lr=1e-3)
+    gen = torch.Generator().manual_seed(1)
+    good = {v: torch.rand(2, 1, *s, generator=gen).to(DEV) for v, s in model_sizes(model).items()}
+    l0, g0, _ = step(good, 0.75)
+    assert math.isfinite(float(l0)) and step.optimizer.step_count == 1
+    before = (step.flat.flat_param.clone(), step.optimizer.exp_avg.clone(), step.optimizer.exp_avg_sq.clone(), step.flat.flat_shadow.clone())
+    bad = {k: v.clone() for k, v in good.items()}
+    for v in bad.values():
+        v.view(-1)[::7] = float("nan")
+    l1, g1, _ = step(bad, 0.75)
+    assert math.isnan(float(l1)) and not math.isfinite(float(g1))
+    after = (step.flat.flat_param, step.optimizer.exp_avg, step.optimizer.exp_avg_sq, step.flat.flat_shadow)
+    assert all(torch.equal(a, b) for a, b in zip(before, after))
+    assert step.optimizer.step_count == 1 and step.optimizer.n_skipped == 1 and float(step.flat.flat_grad.abs().sum()) == 0.0
+    l2, g2, _ = step(good, 0.75)
+    assert math.isfinite(float(l2)) and math.isfinite(float(g2)) and float(l2) < float(l0) and step.optimizer.step_count == 2
+    assert not torch.equal(before[0], step.flat.flat_param)
+
+
+# ---------------------------------------------------------------------------------------------------- checkpoint / GradScaler call (f1, b)
+def test_fused_optimizer_checkpoint_round_trip_and_grad_scaler_call(tmp_path: Path) -> None:
+    """save_checkpoint / load_checkpoint_and_optimizer (cinema/optim.py:229-294) with the flat-buffer optimiser: masters, both Adam moments,
+    the step count and the learning rates come back bit-identical in a FRESH model + optimiser, the bf16 shadows are re-derived, and the
+    resumed run continues the original trajectory.  The steps are driven through the reference-shaped GradScaler call."""
+    from cinema_amd.optim import FlatModel, FusedAdamW, GradScaler, adjust_learning_rate, load_checkpoint_and_optimizer, save_checkpoint
+
+    def make():  # noqa: ANN202
+        torch.manual_seed(0)
+        model = CineMA(**mini_kwargs()).to(DEV)
+        return model, FusedAdamW(FlatModel(model, 0.05), lr=1e-3)
+
+    gen = torch.Generator().manual_seed(5)
+    sizes = model_sizes(CineMA(**mini_kwargs()))
+    batches = [{v: torch.rand(2, 1, *s, generator=gen).to(DEV) for v, s in sizes.items()} for _ in range(4)]
+    masks = [{v: O.random_patch_mask(2, math.prod(tuple(a // b for a, b in zip(s, (8, 8, 1)[:len(s)]))), 0.75, gen).to(DEV) for v, s in sizes.items()}
+             for _ in range(4)]
+
+    def run(model, opt, scaler, i):  # noqa: ANN001, ANN202
+        adjust_learning_rate(opt, i / 4, 1, 5, 1e-3, 1e-6)
+        loss, _, _, _ = model(batches[i], 0.75, enc_mask_dict=masks[i])
+        norm = scaler(loss=loss, optimizer=opt, clip_grad=5.0, parameters=model.parameters(), update_grad=True)
+        opt.zero_grad()
+        return float(loss), float(norm)
+
+    model, opt = make()
+    scaler = GradScaler()
+    for i in range(2):
+        run(model, opt, scaler, i)
+    path = save_checkpoint(tmp_path, epoch=1, model_wo_ddp=model, optimizer=opt, loss_scaler=scaler, n_samples=4)
+    tail = [run(model, opt, scaler, i) for i in (2, 3)]
+
+    model2, opt2 = make()
+    run(model2, opt2, GradScaler(), 3)  # dirty the fresh state first: everything must come from the file
+    _, _, _, epoch, n_samples = load_checkpoint_and_optimizer(path, model2, opt2, GradScaler())
+    assert (epoch, n_samples) == (1, 4) and opt2.step_count == 2
+    ck = torch.load(path, map_location="cpu")
+    assert torch.equal(opt2.exp_avg.cpu(), ck["optimizer"]["exp_avg"].cpu()) and torch.equal(opt2.exp_avg_sq.cpu(), ck["optimizer"]["exp_avg_sq"].cpu())
+    for k, v in model2.state_dict().items():
+        assert torch.equal(v.cpu(), ck["model"][k].cpu()), k
+    assert torch.equal(opt2.flat.flat_shadow, opt2.flat.flat_param.bfloat16())
+    tail2 = [run(model2, opt2, GradScaler(), i) for i in (2, 3)]
+    for (la, na), (lb, nb) in zip(tail, tail2):
+        assert abs(la - lb) <= 2e-4 * abs(la) and abs(na - nb) <= 2e-3 * abs(na), (tail, tail2)
+
+
+def test_recorded_step_with_bf16_and_non_contiguous_inputs() -> None:
+    """The static input tensors of a recording are fp32 contiguous whatever the caller passes (the forward's .float().contiguous() would
+    otherwise be an ATen copy outside the launch list and every replay would train on the first batch): replays on bf16 / permuted
+    batches must give the eager loss of those batches."""
+    from cinema_amd.optim import TrainStep
+
+    sizes = {"sax": (32, 32, 4)}
+    kw = mini_kwargs()
+    for key in ("image_size_dict", "in_chans_dict", "enc_patch_size_dict", "enc_scale_factor_dict"):
+        kw[key] = {"sax": kw[key]["sax"]}
+    gen = torch.Generator().manual_seed(9)
+    raw = [torch.rand(2, 1, 4, 32, 32, generator=gen) for _ in range(3)]
+    feeds = [[r.permute(0, 1, 3, 4, 2).to(DEV) for r in raw],                      # non-contiguous fp32 views
+             [r.permute(0, 1, 3, 4, 2).contiguous().bfloat16().to(DEV) for r in raw]]  # bf16
+    for batches in feeds:
+        losses = {}
+        for mode in ("eager", "replay"):
+            torch.manual_seed(7)
+            model = CineMA(**kw).to(DEV)
+            step = TrainStep(model, lr=0.0, replay=(mode == "replay"))  # lr 0: the loss of a step depends on its batch only
+            torch.manual_seed(21)
+            losses[mode] = [float(step({"sax": b}, 0.75)[0]) for b in batches]
+        assert len(set(round(x, 6) for x in losses["eager"])) == 3, losses  # three different batches
+        for a, b in zip(losses["eager"], losses["replay"]):
+            assert abs(a - b) <= 2e-4 * abs(a), losses
+    assert sizes["sax"] == tuple(feeds[0][0].shape[2:])
+
+
+def test_train_step_with_layer_decay_groups_matches_per_group_adamw() -> None:
+    """TrainStep(param_groups=...) (ConvViT fine-tuning, convvit.py:741-810 groups with lr_scale): one fused AdamW launch per group range with
+    the group's lr and weight decay == torch.optim.AdamW over the same groups on the same gradients."""
+    from cinema_amd.optim import FlatModel, FusedAdamW, adjust_learning_rate
+
+    torch.manual_seed(0)
+    model = CineMA(**mini_kwargs()).to(DEV)
+    named = dict(model.named_parameters())
+    enc = [p for n, p in named.items() if n.startswith("encoder.") and p.requires_grad]
+    rest = [p for n, p in named.items() if not n.startswith("encoder.") and p.requires_grad]
+    groups = [{"params": enc, "weight_decay": 0.05, "lr_scale": 0.25}, {"params": rest, "weight_decay": 0.0, "lr_scale": 1.0}]
+    ref = {n: p.detach().cpu().clone().requires_grad_(p.requires_grad) for n, p in named.items()}
+    ref_groups = [{"params": [ref[n] for n, p in named.items() if n.startswith("encoder.") and p.requires_grad], "weight_decay": 0.05, "lr_scale": 0.25},
+                  {"params": [ref[n] for n, p in named.items() if not n.startswith("encoder.") and p.requires_grad], "weight_decay": 0.0, "lr_scale": 1.0}]
+    opt = FusedAdamW(FlatModel(model, 0.05, param_groups=groups), lr=1e-3)
+    ropt = torch.optim.AdamW(ref_groups, lr=1e-3, betas=(0.9, 0.95))
+    gen = torch.Generator().manual_seed(2)
+    for i in range(3):
+        adjust_learning_rate(opt, i + 1, 2, 10, 1e-3, 1e-5)
+        adjust_learning_rate(ropt, i + 1, 2, 10, 1e-3, 1e-5)
+        assert [g["lr"] for g in opt.param_groups] == [g["lr"] for g in ropt.param_groups]
+        for n, p in named.items():
+            if p.requires_grad:
+                gval = torch.randn(p.shape, generator=gen) * 0.01
+                p.grad.copy_(gval.to(DEV))
+                ref[n].grad = gval.clone()
+        norm = opt.step(clip_grad=None)
+        ropt.step()
+        want = torch.sqrt(sum(r.grad.pow(2).sum() for r in ref.values() if r.grad is not None))
+        assert abs(float(norm) - float(want)) <= 1e-4 * float(want)
+    for n, p in named.items():
+        if p.requires_grad:
+            assert torch.allclose(p.detach().cpu(), ref[n].detach(), rtol=2e-5, atol=2e-7), n

@@ -24,6 +24,8 @@ from conftest import load_golden  # noqa: E402
 
 DEV = "cuda"
 LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-2, 5e-2, 6e-2, 12e-2
+# config-2 real-shape first-step parity (test_base_4view_192_first_step_vs_oracle): provisional, replaced by 3 x measured
+CFG2_LOSS_RTOL, CFG2_VIEW_LOSS_RTOL, CFG2_GRAD_NORM_RTOL, CFG2_NAMED_GRAD_L2, CFG2_WORST_GRAD_L2 = 2e-2, 2e-2, 6e-2, 6e-2, 2e-1
 
 
 def split(t: dict, prefix: str) -> dict:
@@ -58,7 +60,7 @@ def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tens
         assert abs(float(metrics[k]) - float(t)) <= tol * abs(float(t)) + 1e-6, (k, float(metrics[k]), float(t))
     loss.backward()
     named = dict(model.named_parameters())
-    worst = {}
+    worst, worst_max = {}, {}
     for k, t in ref_grads.items():
         g = named[k].grad
         assert g is not None, k
@@ -67,9 +69,11 @@ def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tens
         err = float(diff.abs().max())
         l2 = float(diff.norm() / t.norm().clamp_min(1e-12))
         worst[k] = l2
+        worst_max[k] = err / max(scale, 1e-30)
         assert l2 <= GRAD_L2, (k, l2)
         assert err <= GRAD_MAX * scale + 1e-7, (k, err, scale)
-    print("worst grad rel err:", max(worst.items(), key=lambda kv: kv[1]))
+    print("measured: loss rel", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "worst grad rel-L2:", max(worst.items(), key=lambda kv: kv[1]),
+          "worst max-abs/max:", max(worst_max.items(), key=lambda kv: kv[1]))
 
 
 def test_tiny_cfg1_vs_reference_golden() -> None:
@@ -220,6 +224,35 @@ def test_recorded_step_replays_the_eager_step(kw: dict) -> None:
     for a, b in zip(traj["eager"], traj["replay"]):
         for x, y in zip(a, b):
             assert abs(x - y) <= 2e-4 * abs(x) + 1e-6, (traj["eager"], traj["replay"])
+
+
+def test_base_4view_192_first_step_vs_oracle() -> None:
+    """BASELINE config 2 at its REAL shape (ViT-Base, SAX 192x192x16 + 3 LAX 192x192, 685-token encoder, 2053 x 684 cross-attention, the ragged
+    80-row GEMM strips, split-tail and BK = 32 / 64 dispatch that bench.py times) at batch 2: first forward + backward of the HIP path against
+    the live fp32 CPU oracle on identical weights, inputs and masks (oracle/parity.py; the same object bench.py prints as `parity`).
+    Tolerances = 3 x the errors measured on an MI355X (printed by this test), see the constants."""
+    import os
+
+    from parity import NAMED_GRADS, mae_step_parity
+
+    views = ["sax", "lax_2c", "lax_3c", "lax_4c"]
+    kw = dict(image_size_dict={v: (192, 192, 16) if v == "sax" else (192, 192) for v in views}, in_chans_dict=dict.fromkeys(views, 1),
+              enc_patch_size_dict={v: (4, 4, 1) if v == "sax" else (4, 4) for v in views},
+              enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2,
+              **get_vit_config("base"))
+    torch.manual_seed(0)
+    sd = CineMA(**kw).state_dict()
+    par = mae_step_parity(kw, sd, batch=2, seed=7, device=DEV, threads=min(os.cpu_count() or 1, 16))
+    print("config-2 parity:", {k: v for k, v in par.items() if k != "named_grads"})
+    for k, v in par["named_grads"].items():
+        print(f"  {k}: rel_l2 {v['rel_l2']:.4f} max {v['max_abs_over_max']:.4f}")
+    assert set(par["named_grads"]) == set(NAMED_GRADS)
+    assert par["loss_rel"] <= CFG2_LOSS_RTOL, par["loss_rel"]
+    assert max(par["view_loss_rel"].values()) <= CFG2_VIEW_LOSS_RTOL, par["view_loss_rel"]
+    assert par["grad_norm_rel"] <= CFG2_GRAD_NORM_RTOL, par["grad_norm_rel"]
+    assert par["pred_max_abs"] <= PRED_ATOL, par["pred_max_abs"]
+    assert par["grad_rel"] <= CFG2_NAMED_GRAD_L2, par["named_grads"]
+    assert par["worst_grad_rel_l2"]["value"] <= CFG2_WORST_GRAD_L2, par["worst_grad_rel_l2"]
 
 
 def test_large_config_256_step_properties() -> None:
