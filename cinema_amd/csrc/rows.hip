@@ -361,6 +361,101 @@ CINEMA_API int cinema_rope_heads(uint16_t* x, int ld, long long rows, int n_slot
   return launch_status();
 }
 
+// ---- stochastic regularisers of the fine-tuning recipes (nn.Dropout in ConvResBlock, cinema/conv.py:329,343; timm DropPath in Block,
+// cinema/vit.py:561-577, 606-609; both 0.1 in cinema/segmentation/acdc/config.yaml:64-65).  Counter-based RNG (Philox4x32-10, the generator
+// family torch's CUDA dropout uses): the keep decision of element i of call site `salt` in step `state[0]` is a pure function of
+// (seed, step, salt, i), so the backward pass regenerates the mask instead of storing it, and a recorded step (cinema_amd/replay.py) gets new
+// masks on every replay because the step counter lives in device memory (cinema_rng_advance is one more launch of the list).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x, hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0; key.y += W1;
+  }
+  return ctr;
+}
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }  // [0, 1), 24 bits
+
+// state[0] = step counter (advanced once per optimisation step), state[1] = seed
+__global__ void rng_advance_kernel(unsigned long long* state) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1;
+}
+
+// y = x * keep_mask / (1 - p) on bf16, 8 elements per thread (two Philox draws); forward and backward are the same map
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16_t* x, bf16_t* y, long long n, float p, const unsigned long long* state, uint32_t salt) {
+  const unsigned long long step = state[0], seed = state[1];
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  const float inv_keep = 1.0f / (1.0f - p);
+  const long long n8 = (n + 7) >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const uint4 r0 = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), salt, (uint32_t)step), key);
+    const uint4 r1 = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32) | 0x80000000u, salt, (uint32_t)step), key);
+    const uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    if (i * 8 + 8 <= n) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v.v[j] = u01(r[j]) >= p ? f2bf(bf2f(v.v[j]) * inv_keep) : (bf16_t)0;
+      *reinterpret_cast<bf16x8*>(y + i * 8) = v;
+    } else {
+      for (int j = 0; i * 8 + j < n; ++j) y[i * 8 + j] = u01(r[j]) >= p ? f2bf(bf2f(x[i * 8 + j]) * inv_keep) : (bf16_t)0;
+    }
+  }
+}
+
+// DropPath factors: scale[b] = (u >= p) / (1 - p) per sample (timm DropPath, scale_by_keep=True)
+__global__ void droppath_scale_kernel(float* scale, int batch, float p, const unsigned long long* state, uint32_t salt) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const unsigned long long step = state[0], seed = state[1];
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)b, 0x40000000u, salt, (uint32_t)step), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  scale[b] = u01(r.x) >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+// out[r, :] = (res ? res[r, :] : 0) + scale[r / rows_per_sample] * h[r, :]   (fp32 rows; the residual add behind a DropPath; backward: res = nullptr)
+__global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* h, const float* res, const float* scale, float* out, long long rows, int c,
+                                                             int rows_per_sample) {
+  const int c4 = c >> 2;
+  const long long total = rows * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c4;
+    const float s = scale[r / rows_per_sample];
+    float4 v = reinterpret_cast<const float4*>(h)[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    if (res) { const float4 q = reinterpret_cast<const float4*>(res)[i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+CINEMA_API int cinema_rng_advance(unsigned long long* state, void* stream) {
+  if (!state) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+  return launch_status();
+}
+
+CINEMA_API int cinema_dropout_bf16(const uint16_t* x, uint16_t* y, long long n, float p, const unsigned long long* state, unsigned int salt, void* stream) {
+  if (!x || !y || !state || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return CINEMA_ERR_BAD_ARG;
+  if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return CINEMA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, state, salt);
+  return launch_status();
+}
+
+CINEMA_API int cinema_droppath_scale(float* scale, int batch, float p, const unsigned long long* state, unsigned int salt, void* stream) {
+  if (!scale || !state || batch <= 0 || !(p >= 0.f) || !(p < 1.f)) return CINEMA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(droppath_scale_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, scale, batch, p, state, salt);
+  return launch_status();
+}
+
+CINEMA_API int cinema_scale_rows_add(const float* h, const float* residual, const float* scale, float* out, long long rows, int c, int rows_per_sample,
+                                     void* stream) {
+  if (!h || !scale || !out || rows <= 0 || c <= 0 || rows_per_sample <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((c & 3) || ((((uintptr_t)h) | ((uintptr_t)out) | ((uintptr_t)residual)) & 15)) return CINEMA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(scale_rows_add_kernel, dim3(grid_for(rows * (c >> 2), 256)), dim3(256), 0, (hipStream_t)stream, h, residual, scale, out, rows, c,
+                     rows_per_sample);
+  return launch_status();
+}
+
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;

@@ -122,6 +122,10 @@ _PROTOS = {
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
     "cinema_fill_u32": [_vp, C.c_uint, _ll, _vp],
+    "cinema_rng_advance": [_vp, _vp],
+    "cinema_dropout_bf16": [_vp, _vp, _ll, _f, _vp, C.c_uint, _vp],
+    "cinema_droppath_scale": [_vp, _i, _f, _vp, C.c_uint, _vp],
+    "cinema_scale_rows_add": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_rope_heads": [_vp, _i, _ll, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "cinema_mul_scalar_f32": [_vp, _vp, _vp, _ll, _vp],
     "cinema_mask_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -477,6 +481,60 @@ def rope_heads(x: torch.Tensor, n_slots: int, heads: int, head_dim: int, cos: to
     _check(load().cinema_rope_heads(x.data_ptr(), _rowmajor(x, "x"), x.shape[0], n_slots, heads, head_dim, 2 * cos.shape[1], cos.data_ptr(), sin.data_ptr(),
                                     int(inverse), _stream()), "rope_heads")
     return x
+
+
+# ---- stochastic regularisers (dropout / drop-path): device RNG state = [step counter, seed] as 2 x int64
+_RNG_STATE: dict = {}
+
+
+def rng_state(device: torch.device) -> torch.Tensor:
+    """The per-device Philox state tensor (int64 [2]: step counter, seed); the seed is drawn from torch's generator on first use, so
+    ``torch.manual_seed`` makes the dropout / drop-path masks reproducible."""
+    key = torch.device(device).index or 0
+    st = _RNG_STATE.get(key)
+    if st is None:
+        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        st = _RNG_STATE[key] = torch.tensor([0, seed], dtype=torch.int64, device=device)
+    return st
+
+
+def rng_seed(device: torch.device, seed: int) -> None:
+    st = rng_state(device)
+    st.copy_(torch.tensor([0, int(seed)], dtype=torch.int64))
+
+
+def rng_advance(device: torch.device) -> None:
+    """New masks from here on (one launch; part of a recorded step's list)."""
+    _check(load().cinema_rng_advance(rng_state(device).data_ptr(), _stream()), "rng_advance")
+
+
+def dropout(x: torch.Tensor, p: float, salt: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """y = x * keep / (1 - p) on contiguous bf16 (``nn.Dropout`` in training mode); the same call on a gradient is the backward pass."""
+    _dev(x, out)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        raise HipLibraryError("dropout: contiguous bf16 only")
+    y = torch.empty_like(x) if out is None else out
+    _check(load().cinema_dropout_bf16(x.data_ptr(), y.data_ptr(), x.numel(), float(p), rng_state(x.device).data_ptr(), salt & 0xFFFFFFFF, _stream()), "dropout")
+    return y
+
+
+def droppath_scale(batch: int, p: float, salt: int, device: torch.device) -> torch.Tensor:
+    """fp32 [batch]: 0 or 1 / (1 - p) per sample (timm ``DropPath``, ``scale_by_keep=True``)."""
+    s = torch.empty(batch, dtype=torch.float32, device=device)
+    _dev(s)
+    _check(load().cinema_droppath_scale(s.data_ptr(), batch, float(p), rng_state(device).data_ptr(), salt & 0xFFFFFFFF, _stream()), "droppath_scale")
+    return s
+
+
+def scale_rows_add(h: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, residual: torch.Tensor | None = None) -> torch.Tensor:
+    """residual + scale[row // rows_per_sample] * h over fp32 rows [n, c]."""
+    _dev(h, scale, residual)
+    if h.dtype != torch.float32 or not h.is_contiguous() or (residual is not None and (residual.dtype != torch.float32 or not residual.is_contiguous())):
+        raise HipLibraryError("scale_rows_add: contiguous fp32 rows")
+    out = torch.empty_like(h)
+    _check(load().cinema_scale_rows_add(h.data_ptr(), _p(residual), scale.data_ptr(), out.data_ptr(), h.shape[0], h.shape[1], rows_per_sample, _stream()),
+           "scale_rows_add")
+    return out
 
 
 def full(shape, value: float, dtype: torch.dtype = torch.float32, device=None) -> torch.Tensor:  # noqa: ANN001

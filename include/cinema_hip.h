@@ -229,6 +229,17 @@ int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n,
  * rotation (backward pass). */
 int cinema_rope_heads(uint16_t* x, int ld, long long rows, int n_slots, int heads, int head_dim, int rotary_dim, const float* cos_table,
                       const float* sin_table, int inverse, void* stream);
+/* Stochastic regularisers of the fine-tuning recipes: nn.Dropout inside ConvResBlock (cinema/conv.py:329,343) and timm DropPath around both paths of
+ * a transformer Block (cinema/vit.py:561-577,606-609); cinema/segmentation/acdc/config.yaml:64-65 sets both to 0.1.  Counter-based Philox4x32-10:
+ * the draw for element i of call site `salt` is a function of (state[1] = seed, state[0] = step, salt, i) - the backward pass regenerates the mask
+ * (call the same function on the gradient), nothing is stored; state is 2 x uint64 in device memory, cinema_rng_advance bumps the step.
+ *   dropout_bf16  : y[i] = keep(i) ? x[i] / (1 - p) : 0                       (x may equal y)
+ *   droppath_scale: scale[b] = keep(b) ? 1 / (1 - p) : 0 per sample           (timm DropPath, scale_by_keep=True)
+ *   scale_rows_add: out[r,:] = residual[r,:] + scale[r / rows_per_sample] * h[r,:]  (fp32 rows; residual may be NULL: the backward of the same op) */
+int cinema_rng_advance(unsigned long long* state, void* stream);
+int cinema_dropout_bf16(const uint16_t* x, uint16_t* y, long long n, float p, const unsigned long long* state, unsigned int salt, void* stream);
+int cinema_droppath_scale(float* scale, int batch, float p, const unsigned long long* state, unsigned int salt, void* stream);
+int cinema_scale_rows_add(const float* h, const float* residual, const float* scale, float* out, long long rows, int c, int rows_per_sample, void* stream);
 /* dst[0 .. n_words) = word (32-bit pattern; torch.zeros / torch.full of the reference's host code as a launch of this library). */
 int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream);
 

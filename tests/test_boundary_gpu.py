@@ -76,8 +76,11 @@ def test_cinema_model_with_rotary_matches_plain_model() -> None:
     """rotary=True through the whole MAE step: the head-indexed rotation cancels in q.k^T, so loss and gradients equal the rotary=False model's
     up to the extra bf16 rounding of q and k (the reference: 'rotary/out' == 'rotary/out_plain' to 6e-8 in fp32)."""
     torch.manual_seed(0)
-    plain = CineMA(**mini_kwargs())
-    rot = CineMA(**mini_kwargs(rotary=True))
+    plain = CineMA(**mini_kwargs(cross_attn=False))  # the reference refuses rotary with separate keys (cinema/vit.py:494-495): self-attention decoder
+    rot = CineMA(**mini_kwargs(cross_attn=False, rotary=True))
+    with pytest.raises(ValueError, match="not supported with different query and key"):
+        bad = CineMA(**mini_kwargs(rotary=True)).to(DEV)
+        bad({v: torch.rand(1, 1, *s, device=DEV) for v, s in model_sizes(bad).items()}, 0.75)
     rot.load_state_dict(plain.state_dict())
     assert rot.encoder.blocks[0].attn.rotary is not None and plain.encoder.blocks[0].attn.rotary is None
     plain.to(DEV)
@@ -166,10 +169,11 @@ def test_fused_optimizer_checkpoint_round_trip_and_grad_scaler_call(tmp_path: Pa
         return model, FusedAdamW(FlatModel(model, 0.05), lr=1e-3)
 
     gen = torch.Generator().manual_seed(5)
-    sizes = model_sizes(CineMA(**mini_kwargs()))
+    probe = CineMA(**mini_kwargs())
+    sizes = model_sizes(probe)
+    n_patches = {v: probe.enc_down_dict[v].patch_embed.n_patches for v in sizes}
     batches = [{v: torch.rand(2, 1, *s, generator=gen).to(DEV) for v, s in sizes.items()} for _ in range(4)]
-    masks = [{v: O.random_patch_mask(2, math.prod(tuple(a // b for a, b in zip(s, (8, 8, 1)[:len(s)]))), 0.75, gen).to(DEV) for v, s in sizes.items()}
-             for _ in range(4)]
+    masks = [{v: O.random_patch_mask(2, n_patches[v], 0.75, gen).to(DEV) for v in sizes} for _ in range(4)]
 
     def run(model, opt, scaler, i):  # noqa: ANN001, ANN202
         adjust_learning_rate(opt, i / 4, 1, 5, 1e-3, 1e-6)

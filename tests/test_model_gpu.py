@@ -2,10 +2,17 @@
  (1) golden vectors captured from the upstream reference (tests/golden, fp32 CPU), and
  (2) the CPU oracle run live on the same seeded inputs.
 
-Stated tolerances (bf16 MFMA compute, fp32 accumulation/residual stream):
-  loss: relative 2e-2;  predictions: max-abs 5e-2 on O(1) values;  metrics (fp32 reductions): relative 1e-4;
-  gradients (bf16 operands in dgrad/wgrad): relative L2 error of every parameter gradient <= 6 %, and no single element off by
-  more than 12 % of the tensor's max-abs gradient.
+Tolerances (bf16 MFMA compute, fp32 accumulation / residual stream).  SURVEY.md 8d states loss rel <= 2e-2 and predictions max-abs <= 5e-2;
+the bounds below are ~3 x the errors MEASURED on an MI355X (the tests print them with -s; gpurun_out/tests_r02a.log of round 2):
+
+  model (test)                                   loss rel   worst grad rel-L2 (matrix / any)   worst max-abs/max   pred max-abs
+  cfg 1 Tiny SAX, reference golden               7.0e-6     0.75 % / 0.75 %                    0.73 %              0.009
+  mini 4-view (16/32-channel stem), ref goldens  1.5e-4     3.2 %  / 5.8 % (LN vectors, LAX)   7.5 %               0.018
+  midsize 2-view (MFMA-sized) vs live oracle     1.5e-4     1.3 %  / 1.7 %                     3.3 %               0.017
+  cfg 2 Base 4-view 192, b=2 vs live oracle      6.9e-4     1.8 %  (10 named: 0.8 %)           2.3 %               0.027
+
+  loss: relative 2e-3 everywhere;  predictions: max-abs 5e-2 (the stated bound);  metrics (fp32 reductions): relative 1e-4;
+  gradients: per model class below (the 16-channel mini model's LayerNorm-vector gradients are sums with heavy cancellation: 6 % / 12 %).
 """
 
 from __future__ import annotations
@@ -23,9 +30,11 @@ from cinema_amd.vit import get_vit_config  # noqa: E402
 from conftest import load_golden  # noqa: E402
 
 DEV = "cuda"
-LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-2, 5e-2, 6e-2, 12e-2
-# config-2 real-shape first-step parity (test_base_4view_192_first_step_vs_oracle): provisional, replaced by 3 x measured
-CFG2_LOSS_RTOL, CFG2_VIEW_LOSS_RTOL, CFG2_GRAD_NORM_RTOL, CFG2_NAMED_GRAD_L2, CFG2_WORST_GRAD_L2 = 2e-2, 2e-2, 6e-2, 6e-2, 2e-1
+LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-3, 5e-2, 6e-2, 12e-2   # mini goldens (see the table above)
+TINY_GRAD_L2, TINY_GRAD_MAX = 2.5e-2, 2.5e-2                          # cfg 1: measured 0.75 % / 0.73 %
+MID_GRAD_L2, MID_GRAD_MAX = 5.5e-2, 10e-2                             # MFMA-sized models: measured 1.7 % / 3.3 %
+# config-2 real-shape first-step parity (test_base_4view_192_first_step_vs_oracle) = 3 x measured (6.9e-4, 1.2e-3, 5.7e-4, 0.79 %, 1.76 %)
+CFG2_LOSS_RTOL, CFG2_VIEW_LOSS_RTOL, CFG2_GRAD_NORM_RTOL, CFG2_NAMED_GRAD_L2, CFG2_WORST_GRAD_L2 = 2.1e-3, 3.6e-3, 1.8e-3, 2.4e-2, 5.3e-2
 
 
 def split(t: dict, prefix: str) -> dict:
@@ -45,7 +54,8 @@ def mini_kwargs(**kw) -> dict:  # noqa: ANN003
                 enc_embed_dim=64, enc_depth=2, enc_n_heads=4, dec_embed_dim=32, dec_depth=2, dec_n_heads=4, **kw)
 
 
-def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tensor, ref_pred: dict, ref_metrics: dict, ref_grads: dict) -> None:
+def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tensor, ref_pred: dict, ref_metrics: dict, ref_grads: dict,
+                  grad_l2: float = GRAD_L2, grad_max: float = GRAD_MAX) -> None:
     model.zero_grad(set_to_none=True)
     loss, pred, mask_out, metrics = model({k: v.to(DEV) for k, v in images.items()}, 0.75, enc_mask_dict={k: v.to(DEV) for k, v in masks.items()})
     assert loss.dim() == 0 and torch.isfinite(loss)
@@ -70,10 +80,12 @@ def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tens
         l2 = float(diff.norm() / t.norm().clamp_min(1e-12))
         worst[k] = l2
         worst_max[k] = err / max(scale, 1e-30)
-        assert l2 <= GRAD_L2, (k, l2)
-        assert err <= GRAD_MAX * scale + 1e-7, (k, err, scale)
+        assert l2 <= grad_l2, (k, l2)
+        assert err <= grad_max * scale + 1e-7, (k, err, scale)
+    mats = {k: v for k, v in worst.items() if named[k].ndim > 1}
     print("measured: loss rel", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "worst grad rel-L2:", max(worst.items(), key=lambda kv: kv[1]),
-          "worst max-abs/max:", max(worst_max.items(), key=lambda kv: kv[1]))
+          "worst max-abs/max:", max(worst_max.items(), key=lambda kv: kv[1]), "worst matrix rel-L2:", max(mats.items(), key=lambda kv: kv[1]) if mats else None,
+          "pred max-abs:", max(float((pred[v].float().cpu() - t).abs().max()) for v, t in ref_pred.items()) if ref_pred else None)
 
 
 def test_tiny_cfg1_vs_reference_golden() -> None:
@@ -82,7 +94,7 @@ def test_tiny_cfg1_vs_reference_golden() -> None:
     model.load_state_dict(split(g, "param/"))
     model.to(DEV)
     check_against(model, split(g, "image/"), {k: v.bool() for k, v in split(g, "mask/").items()}, g["loss"][0], split(g, "pred/"),
-                  {k: v[0] for k, v in split(g, "metric/").items()}, split(g, "grad/"))
+                  {k: v[0] for k, v in split(g, "metric/").items()}, split(g, "grad/"), grad_l2=TINY_GRAD_L2, grad_max=TINY_GRAD_MAX)
 
 
 @pytest.mark.parametrize(("name", "kw"), [("mini_4view", {}), ("mini_4view_selfattn", {"cross_attn": False}), ("mini_4view_normtarget", {"norm_target": True})])
@@ -128,7 +140,7 @@ def test_midsize_mfma_path_vs_oracle() -> None:
     ref_grads = {k: v.grad for k, v in p.items() if v.grad is not None}
     model.to(DEV)
     check_against(model, images, masks, ref_loss.detach(), {k: v.detach() for k, v in ref_pred.items()},
-                  {k: v.detach() for k, v in ref_metrics.items()}, ref_grads)
+                  {k: v.detach() for k, v in ref_metrics.items()}, ref_grads, grad_l2=MID_GRAD_L2, grad_max=MID_GRAD_MAX)
 
 
 def test_visible_voxel_stem_equals_dense_stem() -> None:
@@ -302,8 +314,9 @@ def test_cpu_tensor_fails_loudly() -> None:
 
 def test_three_step_optimisation_trajectory_vs_reference_golden() -> None:
     """cinema_amd.optim.TrainStep (fused clip + AdamW on flat buffers, 2-group weight decay, LR schedule) against 3 steps of the
-    reference harness (GradScaler + adjust_learning_rate + AdamW) captured on cfg 1.  Adam's first updates are ~lr * sign(g), so
-    parameters are compared through their mean absolute deviation (<= 0.25 * cumulative lr) rather than element-wise."""
+    reference harness (GradScaler + adjust_learning_rate + AdamW) captured on cfg 1.  Adam's first updates are ~lr * sign(g): the
+    parameter UPDATES (p - p_init) are compared by relative L2 error and sign agreement.  Bounds = ~3 x measured on an MI355X (loss rel
+    2.3e-4, grad-norm rel 4.6e-3, update rel-L2 3.0 %, sign agreement 99.7 %, mean-abs deviation 0.006 x cumulative lr)."""
     from cinema_amd.optim import TrainStep, adjust_learning_rate
 
     g = load_golden("tiny_sax_trajectory.safetensors")
@@ -322,11 +335,19 @@ def test_three_step_optimisation_trajectory_vs_reference_golden() -> None:
         image = torch.rand(2, 1, 128, 128, 8, generator=gen)
         assert torch.equal(image.flatten()[:64], g[f"step{i}/image_head"])
         loss, norm, _ = step({"sax": image.to(DEV)}, 0.75, enc_mask_dict={"sax": g[f"step{i}/mask"].bool().to(DEV)})
-        assert abs(float(loss) - float(g[f"step{i}/loss"][0])) <= 3e-2 * float(g[f"step{i}/loss"][0]), (i, float(loss))
-        assert abs(float(norm) - float(g[f"step{i}/grad_norm"][0])) <= 6e-2 * float(g[f"step{i}/grad_norm"][0]), (i, float(norm))
+        assert abs(float(loss) - float(g[f"step{i}/loss"][0])) <= 1e-3 * float(g[f"step{i}/loss"][0]), (i, float(loss))
+        assert abs(float(norm) - float(g[f"step{i}/grad_norm"][0])) <= 1.5e-2 * float(g[f"step{i}/grad_norm"][0]), (i, float(norm))
         for k, t in split(g, f"step{i}/param/").items():
-            dev = (named[k].detach().float().cpu() - t).abs().mean()
-            assert float(dev) <= 0.25 * lr_sum + 1e-7, (i, k, float(dev), lr_sum)
+            got = named[k].detach().float().cpu()
+            dev = (got - t).abs().mean()
+            d_ref, d_got = t - init[k], got - init[k]
+            print(f"trajectory step {i} {k}: loss rel {abs(float(loss) - float(g[f'step{i}/loss'][0])) / float(g[f'step{i}/loss'][0]):.2e} norm rel "
+                  f"{abs(float(norm) - float(g[f'step{i}/grad_norm'][0])) / float(g[f'step{i}/grad_norm'][0]):.2e} mean-abs dev / lr_sum {float(dev) / max(lr_sum, 1e-30):.3f} "
+                  f"update rel-L2 {float((d_got - d_ref).norm() / d_ref.norm().clamp_min(1e-30)):.3f} sign agreement {float((torch.sign(d_got) == torch.sign(d_ref)).float().mean()):.4f}")
+            assert float(dev) <= 0.02 * lr_sum + 1e-7, (i, k, float(dev), lr_sum)
+            if float(d_ref.norm()) > 0:
+                assert float((d_got - d_ref).norm() / d_ref.norm()) <= 0.1, (i, k)
+                assert float((torch.sign(d_got) == torch.sign(d_ref)).float().mean()) >= 0.99, (i, k)
 
 
 # ------------------------------------------------------------------------------------------------ ConvViT
