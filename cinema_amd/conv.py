@@ -303,11 +303,11 @@ class ConvResBlock(nn.Module, _CkptFlag):
 
     def tape_forward(self, tp: T.Tape, x: Volume) -> Volume:
         """x: fp32 channels-last rows; returns fp32 rows with ``out_chans`` channels."""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("dropout > 0 in training mode has no HIP path yet (evaluation / dropout = 0 only).")
         h = T.op_layernorm(tp, x.var, self.norm1.weight, self.norm1.bias, self.norm1.eps, act=1)
         h = T.op_conv_same(tp, h, x.batch, x.spatial, self.conv1.weight, self.conv1.bias, out_f32=True)
         h = T.op_layernorm(tp, h, self.norm2.weight, self.norm2.bias, self.norm2.eps, act=1)
+        if self.training and self.dropout.p > 0:  # nn.Dropout between the activation and conv2 (conv.py:343)
+            h = T.op_dropout(tp, h, float(self.dropout.p))
         if isinstance(self.shortcut, nn.Identity):
             res = x.var
         else:

@@ -439,6 +439,7 @@ class ConvViT(nn.Module):
         images = {v: image_dict[v].float().contiguous() for v in views}
 
         def run(tp: T.Tape):  # noqa: ANN202
+            T.begin_stochastic(self, images[views[0]].device)  # drop-path of the fine-tuning recipes
             cls, feats, _ = self._features(tp, views, images, mask_dict)
             if reduce == "cls":
                 head = self.pred_head_dict["cls"]

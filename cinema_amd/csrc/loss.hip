@@ -361,7 +361,99 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* logits, 
   }
 }
 
+// ---- evaluation path (cinema/segmentation/train.py:148-286): sliding-window aggregation and segmentation metrics ------------------------------
+// One window: softmax over the classes of every window voxel (channels-last fp32 rows of the window's logits), added into the channels-last
+// probability volume at the window's offset; count += 1 there (aggregate_patches, cinema/transform.py:86-124, after F.softmax at train.py:212).
+// Windows are accumulated one launch after the other in grid order, so the sums are formed in the reference's order (deterministic).
+__global__ __launch_bounds__(256) void seg_window_accumulate_kernel(const float* logits, int c, int px, int py, int pz, int sx, int sy, int sz, int X, int Y, int Z,
+                                                                    float* prob_sum, float* count) {
+  const int nvox = px * py * pz;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < nvox; v += gridDim.x * 256) {
+    const int z = v % pz, y = (v / pz) % py, x = v / (pz * py);
+    float p[SEG_MAXC], lse;
+    row_softmax(logits + (size_t)v * c, c, p, lse);
+    const size_t o = ((size_t)(x + sx) * Y + (y + sy)) * Z + (z + sz);
+    for (int j = 0; j < c; j++) prob_sum[o * c + j] += p[j];
+    count[o] += 1.f;
+  }
+  (void)X;
+}
+
+// out[(j * nvox) + v] = log(prob_sum[v][j] / count[v])  (channels-first logits of the aggregated probabilities, train.py:213-214)
+__global__ __launch_bounds__(256) void seg_window_finish_kernel(const float* prob_sum, const float* count, int c, long long nvox, float* out) {
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (long long)gridDim.x * 256) {
+    const float inv = 1.f / count[v];
+    for (int j = 0; j < c; j++) out[(size_t)j * nvox + v] = logf(prob_sum[v * c + j] * inv);
+  }
+}
+
+// Per (sample, class) voxel counts for segmentation_metrics (train.py:224-286): [0] predicted (argmax, first maximum like torch.argmax), [1] true,
+// [2] both (Dice / IoU / volumes); stability_score (cinema/metric.py:21-45): [3] logit - mean >= +1, [4] >= -1, [5] both.  Channels-first logits.
+__global__ __launch_bounds__(256) void seg_metric_counts_kernel(const float* logits, const int* labels, int vox, int c, unsigned int* counts) {
+  __shared__ unsigned int part[SEG_MAXC * 6];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < c * 6; i += 256) part[i] = 0;
+  __syncthreads();
+  const float* base = logits + (size_t)b * c * vox;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < vox; v += gridDim.x * 256) {
+    float l[SEG_MAXC], mean = 0.f;
+    int arg = 0;
+    for (int j = 0; j < c; j++) {
+      l[j] = base[(size_t)j * vox + v];
+      mean += l[j];
+      if (l[j] > l[arg]) arg = j;
+    }
+    mean /= (float)c;
+    const int lab = labels[(size_t)b * vox + v];
+    atomicAdd(&part[arg * 6 + 0], 1u);
+    if (lab >= 0 && lab < c) {
+      atomicAdd(&part[lab * 6 + 1], 1u);
+      if (lab == arg) atomicAdd(&part[lab * 6 + 2], 1u);
+    }
+    for (int j = 0; j < c; j++) {
+      const float n = l[j] - mean;
+      const bool hi = n >= 1.f, lo = n >= -1.f;
+      if (hi) atomicAdd(&part[j * 6 + 3], 1u);
+      if (lo) atomicAdd(&part[j * 6 + 4], 1u);
+      if (hi && lo) atomicAdd(&part[j * 6 + 5], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c * 6; i += 256)
+    if (part[i]) atomicAdd(&counts[(size_t)b * c * 6 + i], part[i]);
+}
+
 }  // namespace
+
+CINEMA_API int cinema_seg_window_accumulate(const float* window_logits, int c, int px, int py, int pz, int sx, int sy, int sz, int X, int Y, int Z,
+                                            float* prob_sum, float* count, void* stream) {
+  if (!window_logits || !prob_sum || !count || c < 2 || px <= 0 || py <= 0 || pz <= 0 || sx < 0 || sy < 0 || sz < 0 || sx + px > X || sy + py > Y || sz + pz > Z)
+    return CINEMA_ERR_BAD_ARG;
+  if (c > SEG_MAXC) return CINEMA_ERR_UNSUPPORTED;
+  int gx = (px * py * pz + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(seg_window_accumulate_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, window_logits, c, px, py, pz, sx, sy, sz, X, Y, Z, prob_sum, count);
+  return launch_status();
+}
+
+CINEMA_API int cinema_seg_window_finish(const float* prob_sum, const float* count, int c, long long n_voxels, float* logits_out, void* stream) {
+  if (!prob_sum || !count || !logits_out || c < 2 || n_voxels <= 0) return CINEMA_ERR_BAD_ARG;
+  long long gx = (n_voxels + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(seg_window_finish_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, prob_sum, count, c, n_voxels, logits_out);
+  return launch_status();
+}
+
+CINEMA_API int cinema_seg_metric_counts(const float* logits, const int* labels, int b, int vox, int c, unsigned int* counts, void* stream) {
+  if (!logits || !labels || !counts || b <= 0 || vox <= 0 || c < 2) return CINEMA_ERR_BAD_ARG;
+  if (c > SEG_MAXC) return CINEMA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(counts, 0, (size_t)b * c * 6 * sizeof(unsigned int), st) != hipSuccess) return CINEMA_ERR_BAD_ARG;
+  int gx = (vox + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(seg_metric_counts_kernel, dim3(gx, b), dim3(256), 0, st, logits, labels, vox, c, counts);
+  return launch_status();
+}
 
 CINEMA_API int cinema_seg_loss_fwd(const float* logits, const int* labels, int b, int vox, int c, float* acc, float* out4, float* coef, void* stream) {
   if (!logits || !labels || !acc || !out4 || !coef || b <= 0 || vox <= 0 || c < 2) return CINEMA_ERR_BAD_ARG;

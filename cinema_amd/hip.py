@@ -118,6 +118,9 @@ _PROTOS = {
     "cinema_row_copy": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "cinema_seg_loss_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cinema_seg_loss_bwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "cinema_seg_window_accumulate": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "cinema_seg_window_finish": [_vp, _vp, _i, _ll, _vp, _vp],
+    "cinema_seg_metric_counts": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "cinema_segment_mean_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp],
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
@@ -428,6 +431,38 @@ def seg_loss_bwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int, co
     _check(load().cinema_seg_loss_bwd(logits_rows.data_ptr(), labels.data_ptr(), batch, rows // batch, c, coef.data_ptr(), out4.data_ptr(), _p(upstream),
                                       d.data_ptr(), _stream()), "seg_loss_bwd")
     return d
+
+
+def seg_window_accumulate(window_rows: torch.Tensor, patch: tuple, start: tuple, size: tuple, prob_sum: torch.Tensor, count: torch.Tensor) -> None:
+    """Add softmax(window_rows) (fp32 [prod(patch), c], channels last) into prob_sum [prod(size), c] / count [prod(size)] at offset ``start``
+    (2-D windows use a leading unit axis)."""
+    _dev(window_rows, prob_sum, count)
+    if window_rows.dtype != torch.float32 or not window_rows.is_contiguous() or prob_sum.dtype != torch.float32 or count.dtype != torch.float32:
+        raise HipLibraryError("seg_window_accumulate: contiguous fp32 tensors")
+    p3, s3, z3 = [(1,) * (3 - len(t)) + tuple(int(v) for v in t) for t in (patch, start, size)]
+    _check(load().cinema_seg_window_accumulate(window_rows.data_ptr(), window_rows.shape[1], *p3, *s3, *z3, prob_sum.data_ptr(), count.data_ptr(), _stream()),
+           "seg_window_accumulate")
+
+
+def seg_window_finish(prob_sum: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
+    """-> fp32 [c, n_voxels] = log(prob_sum / count) (channels first)."""
+    _dev(prob_sum, count)
+    n, c = prob_sum.shape
+    out = torch.empty((c, n), dtype=torch.float32, device=prob_sum.device)
+    _check(load().cinema_seg_window_finish(prob_sum.data_ptr(), count.data_ptr(), c, n, out.data_ptr(), _stream()), "seg_window_finish")
+    return out
+
+
+def seg_metric_counts(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """logits fp32 (b, c, *spatial) contiguous, labels int32 (b, *spatial) -> int32 [b, c, 6] voxel counts (see ``cinema_seg_metric_counts``)."""
+    _dev(logits, labels)
+    if logits.dtype != torch.float32 or labels.dtype != torch.int32 or not logits.is_contiguous() or not labels.is_contiguous():
+        raise HipLibraryError("seg_metric_counts: contiguous fp32 logits (channels first) and int32 labels")
+    b, c = logits.shape[0], logits.shape[1]
+    vox = logits[0, 0].numel()
+    counts = torch.empty((b, c, 6), dtype=torch.int32, device=logits.device)
+    _check(load().cinema_seg_metric_counts(logits.data_ptr(), labels.data_ptr(), b, vox, c, counts.data_ptr(), _stream()), "seg_metric_counts")
+    return counts
 
 
 def segment_mean(x: torch.Tensor, n_seg: int, scale: float | None = None) -> torch.Tensor:

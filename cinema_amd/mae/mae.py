@@ -253,6 +253,7 @@ class CineMA(nn.Module):
         out: dict = {}
 
         def run(tp: T.Tape):  # noqa: ANN202
+            T.begin_stochastic(self, dev)  # drop_path > 0 only (the pre-training recipe uses 0)
             loss, preds, metrics = self._forward_tape(tp, images, masks, n_masked)
             out["views"], out["metric_keys"] = list(preds), list(metrics)
             return [loss], [p.data for p in preds.values()] + list(metrics.values())

@@ -186,6 +186,7 @@ class ConvUNetR(nn.Module):
         images = {v: image_dict[v].float().contiguous() for v in views}
 
         def run(tp: T.Tape):  # noqa: ANN202
+            T.begin_stochastic(self, dev)  # dropout / drop-path of the fine-tuning recipe (acdc/config.yaml:64-65): new masks per forward
             grids = {v: self.enc_down_dict[v].grid_for(tuple(images[v].shape[2:])) for v in views}
             sels = {v: TokenSelection(None, batch, math.prod(grids[v]), dev) for v in views}
             x, skips_all, _cls_rows, view_rows = encode_views(self, tp, views, images, sels, grids)

@@ -542,19 +542,21 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
 
 
 def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parameter, fc2_w: torch.nn.Parameter, fc2_b: torch.nn.Parameter,
-           residual: Var) -> Var:
-    """residual + fc2(gelu(fc1(x))) (timm Mlp / ConvMlp); GELU forward fused into fc1's epilogue, GELU backward into fc2's dgrad."""
+           residual: Var | None) -> Var:
+    """[residual +] fc2(gelu(fc1(x))) (timm Mlp / ConvMlp); GELU forward fused into fc1's epilogue, GELU backward into fc2's dgrad.
+    ``residual=None``: the caller adds it (behind a DropPath, :func:`op_droppath_add`)."""
     w1, w2 = w_plain(fc1_w), w_plain(fc2_w)
     m, hidden = x.data.shape[0], w1.shape[0]
     h = torch.empty((m, hidden), dtype=BF16, device=x.data.device)
     a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h)
-    y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=residual.data, out_dtype=F32))
+    y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
     pv = [tape.pvar(p) for p in (fc1_w, fc1_b, fc2_w, fc2_b)]
 
     def bwd() -> None:
         if y.grad is None:
             return
-        residual.add_grad(y.grad, y.grad16)
+        if residual is not None:
+            residual.add_grad(y.grad, y.grad16)
         dy16 = y.grad_bf16()
         wgrad(tape, dy16, a, pv[2], pv[3], tuple(w2.shape))
         dh = K.gemm(dy16, w2, a_kmajor=True, b_kmajor=False, gelu_in=h)
@@ -635,6 +637,56 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
             xq.add_grad(K.gemm(dq, wq, a_kmajor=True, b_kmajor=False))
         if xk.needs_grad:
             xk.add_grad(K.gemm(dkv, wkv, a_kmajor=True, b_kmajor=False))
+
+    tape.record(bwd)
+    return y
+
+
+def begin_stochastic(module: torch.nn.Module, device: torch.device) -> bool:
+    """Call once at the start of a top-level forward: when ``module`` is in training mode and holds active dropout / drop-path layers, advance
+    the device RNG step (one launch - new masks for this forward, also on every replay of a recorded step).  Returns whether it did."""
+    active = module.__dict__.get("_cinema_stochastic")
+    if active is None:
+        active = module.__dict__["_cinema_stochastic"] = any(
+            (isinstance(m, torch.nn.Dropout) and m.p > 0) or (type(m).__name__ == "DropPath" and getattr(m, "drop_prob", 0.0) > 0) for m in module.modules())
+    if active and module.training:
+        K.rng_advance(device)
+        return True
+    return False
+
+
+def next_salt(tape: Tape) -> int:
+    """Call-site id of a stochastic op inside one forward pass (the Philox counter stream of that op; deterministic in launch order)."""
+    tape.salt = getattr(tape, "salt", 0) + 1
+    return tape.salt
+
+
+def op_dropout(tape: Tape, x: Var, p: float) -> Var:
+    """``nn.Dropout(p)`` in training mode on bf16 rows (``cinema/conv.py:343``): y = x * keep / (1 - p); the backward pass regenerates the mask."""
+    salt = next_salt(tape)
+    y = Var(K.dropout(x.data, p, salt))
+
+    def bwd() -> None:
+        if y.grad is not None and x.needs_grad:
+            x.add_grad(K.dropout(y.grad.contiguous(), p, salt))
+
+    tape.record(bwd)
+    return y
+
+
+def op_droppath_add(tape: Tape, h: Var, residual: Var, batch: int, p: float) -> Var:
+    """residual + DropPath(h) (timm ``DropPath`` as used at ``cinema/vit.py:606-609``): per-sample keep / (1 - p) factor on the fp32 rows of h
+    ([batch * t, c], sample-major).  The factors are kept for the backward pass (batch floats)."""
+    scale = K.droppath_scale(batch, p, next_salt(tape), h.data.device)
+    rps = h.data.shape[0] // batch
+    y = Var(K.scale_rows_add(h.data, scale, rps, residual=residual.data))
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        residual.add_grad(y.grad, y.grad16)
+        if h.needs_grad:
+            h.add_grad(K.scale_rows_add(y.grad.contiguous(), scale, rps))
 
     tape.record(bwd)
     return y

@@ -225,6 +225,35 @@ class Mlp(nn.Module):
         self.drop2 = nn.Dropout(drop)
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm 1.0.15 ``DropPath``, ``scale_by_keep=True``; used at ``cinema/vit.py:561,577``).  Inside ``Block`` the
+    draw and the scaled residual add are HIP launches on the tape; this module holds the rate and serves direct calls on fp32 GPU tensors."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True) -> None:
+        super().__init__()
+        if not scale_by_keep:
+            raise NotImplementedError("DropPath(scale_by_keep=False) is not used by the CineMA models.")
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        from cinema_amd import hip as K
+
+        b = x.shape[0]
+        rows = x.float().reshape(b, -1).contiguous()
+        K.rng_advance(x.device)
+        scale = K.droppath_scale(b, self.drop_prob, 0x5EED, x.device)
+        pad = (-rows.shape[1]) % 4
+        if pad:
+            raise NotImplementedError("DropPath direct call: the per-sample element count must be a multiple of 4")
+        return K.scale_rows_add(rows, scale, 1).reshape(x.shape).to(x.dtype)
+
+    def extra_repr(self) -> str:
+        return f"drop_prob={round(self.drop_prob, 3):0.3f}"
+
+
 class Block(nn.Module, _CkptFlag):
     """Pre-LN transformer block with optional cross-attention keys (reference ``cinema/vit.py:525-609``)."""
 
@@ -234,8 +263,8 @@ class Block(nn.Module, _CkptFlag):
         super().__init__()
         if init_values:
             raise NotImplementedError("LayerScale is a fine-tuning option outside the HIP path.")
-        # stochastic depth (fine-tuning configs use 0.1): identity in eval mode like timm's DropPath; the training-mode sampling has no
-        # HIP path yet, so a training-mode forward with drop_path > 0 raises instead of silently training a different model
+        # stochastic depth (the fine-tuning configs use 0.1, cinema/segmentation/acdc/config.yaml:65): identity in eval mode like timm's DropPath;
+        # in training mode the residual adds go through tape.op_droppath_add (per-sample Philox draws, cinema_droppath_scale)
         self.drop_path_rate = float(drop_path)
         if mlp_layer is not Mlp and getattr(mlp_layer, "__name__", "") != "Mlp":
             raise NotImplementedError("only the GELU Mlp has a HIP path (SwiGLU is unused by the reference configs).")
@@ -243,11 +272,11 @@ class Block(nn.Module, _CkptFlag):
         self.attn = Attention(dim, n_heads=n_heads, qkv_bias=qkv_bias, qk_norm=qk_norm, attn_drop=attn_drop, proj_drop=proj_drop,
                               norm_layer=norm_layer, norm_eps=norm_eps, rotary=rotary)
         self.ls1 = nn.Identity()
-        self.drop_path1 = nn.Identity()
+        self.drop_path1 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = norm_layer(dim, eps=norm_eps)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=proj_drop)
         self.ls2 = nn.Identity()
-        self.drop_path2 = nn.Identity()
+        self.drop_path2 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def _param_list(self) -> list:
         pl = self.__dict__.get("_plist")
@@ -257,15 +286,21 @@ class Block(nn.Module, _CkptFlag):
 
     def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int) -> T.Var:
         """xq: fp32 residual stream [b*tq, c]; xk: bf16 un-normed keys [b*tk, c] or None (``vit.py:589``)."""
-        if self.training and self.drop_path_rate > 0.0:
-            raise NotImplementedError("drop_path > 0 in training mode has no HIP path yet (evaluation, or drop_path = 0).")
+        drop = self.drop_path_rate if self.training else 0.0
         T.mark_params(tp, self._param_list())  # gradient all-reduce of this block may start once its backward ops are launched
         T.wgrad_group(tp)                      # ... which includes the grouped weight-gradient launch: its flush runs before that marker fires
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = self.attn.tape_forward(tp, qn, xk, batch)
-        x1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, residual=xq)
-        xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        y = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1)
+        if drop > 0.0:  # q + drop_path1(path1(q)), q + drop_path2(path2(q)) (vit.py:606-609): the residual adds leave the GEMM epilogues
+            h1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, out_f32=True)
+            x1 = T.op_droppath_add(tp, h1, xq, batch, drop)
+            xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            h2 = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=None)
+            y = T.op_droppath_add(tp, h2, x1, batch, drop)
+        else:
+            x1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, residual=xq)
+            xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            y = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1)
         T.wgrad_group_end(tp)
         return y
 

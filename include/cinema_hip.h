@@ -213,6 +213,16 @@ int cinema_row_copy_multi(const cinema_row_copy_args* segs_host, int count, void
 int cinema_seg_loss_fwd(const float* logits, const int* labels, int b, int vox, int c, float* acc, float* out4, float* coef, void* stream);
 int cinema_seg_loss_bwd(const float* logits, const int* labels, int b, int vox, int c, const float* coef, const float* out4, const float* upstream,
                         float* dlogits, void* stream);
+/* Evaluation path of the segmentation task (reference cinema/segmentation/train.py:148-286, cinema/transform.py:86-124, cinema/metric.py:21-45,84-96).
+ *   seg_window_accumulate: one sliding window - softmax over the c classes of every window voxel (window_logits fp32 channels-last rows
+ *       [px*py*pz][c]) added into prob_sum (channels-last [X*Y*Z][c]) at offset (sx,sy,sz), count [X*Y*Z] += 1 (both zeroed by the caller).
+ *   seg_window_finish: logits_out [c][X*Y*Z] (channels-first) = log(prob_sum / count).
+ *   seg_metric_counts: counts [b][c][6] (uint32, zeroed here) of voxels per (sample, class): argmax prediction, label, both; and the stability-score
+ *       masks (logit - mean over classes >= +1, >= -1, both).  logits fp32 channels-first [b][c][vox], labels int32 [b][vox]. */
+int cinema_seg_window_accumulate(const float* window_logits, int c, int px, int py, int pz, int sx, int sy, int sz, int X, int Y, int Z,
+                                 float* prob_sum, float* count, void* stream);
+int cinema_seg_window_finish(const float* prob_sum, const float* count, int c, long long n_voxels, float* logits_out, void* stream);
+int cinema_seg_metric_counts(const float* logits, const int* labels, int b, int vox, int c, unsigned int* counts, void* stream);
 
 /* Token pooling of the ConvViT heads (reference cinema/convvit.py:523-547, `x.mean(dim=1, keepdim=True)` and the mean over head outputs):
  * out[s][:] = scale * sum of the seg_rows consecutive rows of segment s of x (fp32 [n_seg*seg_rows][c]); bwd broadcasts scale * dy[s] back. */
