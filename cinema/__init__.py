@@ -1,7 +1,7 @@
 """``cinema`` import surface of the reference (``cinema/__init__.py:3-34``) served by the MI355X build ``cinema_amd``.
 
 ``from cinema import CineMA, ConvViT, ConvUNetR, patchify, unpatchify`` and the sub-module imports the reference's training / inference
-scripts use (``cinema.mae.mae``, ``cinema.convvit``, ``cinema.vit``, ``cinema.conv``, ``cinema.rotary``, ``cinema.optim``, ``cinema.device``,
+scripts use (``cinema.mae.mae``, ``cinema.convvit``, ``cinema.vit``, ``cinema.conv``, ``cinema.rotary``, ``cinema.optim``, ``cinema.device``, ``cinema.transform``,
 ``cinema.segmentation.convunetr``, ``cinema.segmentation.train``) resolve to the ``cinema_amd`` modules of the same name: one set of
 classes, two import names.  Only the hot path is aliased; data loading, hydra entry points, metrics for landmark
 heat-maps (``heatmap_soft_argmax``) and the ResNet / UNet baselines are not part of this build and are not faked here.
@@ -17,6 +17,7 @@ _ALIASES = {
     "cinema.rotary": "cinema_amd.rotary",
     "cinema.optim": "cinema_amd.optim",
     "cinema.device": "cinema_amd.device",
+    "cinema.transform": "cinema_amd.transform",
     "cinema.mae": "cinema_amd.mae",
     "cinema.mae.mae": "cinema_amd.mae.mae",
     "cinema.segmentation": "cinema_amd.segmentation",

@@ -439,7 +439,8 @@ def seg_window_accumulate(window_rows: torch.Tensor, patch: tuple, start: tuple,
     _dev(window_rows, prob_sum, count)
     if window_rows.dtype != torch.float32 or not window_rows.is_contiguous() or prob_sum.dtype != torch.float32 or count.dtype != torch.float32:
         raise HipLibraryError("seg_window_accumulate: contiguous fp32 tensors")
-    p3, s3, z3 = [(1,) * (3 - len(t)) + tuple(int(v) for v in t) for t in (patch, start, size)]
+    p3, z3 = [(1,) * (3 - len(t)) + tuple(int(v) for v in t) for t in (patch, size)]
+    s3 = (0,) * (3 - len(start)) + tuple(int(v) for v in start)
     _check(load().cinema_seg_window_accumulate(window_rows.data_ptr(), window_rows.shape[1], *p3, *s3, *z3, prob_sum.data_ptr(), count.data_ptr(), _stream()),
            "seg_window_accumulate")
 

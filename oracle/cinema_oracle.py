@@ -649,3 +649,107 @@ def segmentation_loss_one_view(logits: Tensor, labels: Tensor):  # noqa: ANN201
     dice = (1.0 - (2.0 * inter + 1e-5) / (den + 1e-5)).mean()
     loss = dice + ce
     return loss, {"cross_entropy": ce, "mean_dice_loss": dice, "loss": loss}
+
+
+# ----------------------------------------------------------------------------------------------
+# evaluation path of the segmentation task (cinema/segmentation/train.py:148-286, cinema/transform.py:13-124, cinema/metric.py:21-96)
+# ----------------------------------------------------------------------------------------------
+def patch_grid(image_size: tuple, patch_size: tuple, patch_overlap: tuple) -> np.ndarray:
+    """``get_patch_grid`` (``cinema/transform.py:13-50``): per axis arange(0, size - patch + 1, patch - overlap) plus a last window flush with
+    the border; the grid is the 'ij' product.  PINNED by the reference's own known answers (``cinema/transform_test.py:13-115``) and by
+    ``tests/golden/seg_eval.safetensors``."""
+    axes = []
+    for size, patch, overlap in zip(image_size, patch_size, patch_overlap):
+        if patch > size:
+            raise ValueError(f"Patch size {patch} should be <= image size {size}.")
+        starts = list(range(0, size - patch + 1, patch - overlap))
+        if starts[-1] != size - patch:
+            starts.append(size - patch)
+        axes.append(starts)
+    grid = [()]
+    for starts in axes:
+        grid = [g + (s,) for g in grid for s in starts]
+    return np.array(grid, dtype=np.int64).reshape(-1, len(image_size))
+
+
+def sliding_window_logits(forward, image_dict: dict, patch_size_dict: dict) -> dict:  # noqa: ANN001
+    """``segmentation_forward`` (``cinema/segmentation/train.py:148-221``) around any ``forward(image_dict) -> logits_dict``: one window at a
+    time over the single view that needs patching (half-patch overlap), per-window softmax, overlap mean (``aggregate_patches``,
+    ``cinema/transform.py:86-124``), log; the other views: log of the mean window probability.  PINNED by ``tests/golden/seg_eval.safetensors``."""
+    views = list(image_dict)
+    for v, image in image_dict.items():
+        if any(s < p for s, p in zip(image.shape[2:], patch_size_dict[v])):
+            raise ValueError(f"For view {v}, image size {image.shape[2:]} is smaller than patch size {patch_size_dict[v]}.")
+    need = {v: tuple(image_dict[v].shape[2:]) != tuple(patch_size_dict[v]) for v in views}
+    if not any(need.values()):
+        return forward(image_dict)
+    if sum(need.values()) > 1:
+        raise ValueError(f"Only support patching on one view for now, but got {need}.")
+    if image_dict[views[0]].shape[0] != 1:
+        raise ValueError(f"Expected batch size 1 for patching, but got {image_dict[views[0]].shape[0]}.")
+    vp = next(v for v in views if need[v])
+    image = image_dict[vp][0]
+    size, patch = tuple(image.shape[1:]), tuple(patch_size_dict[vp])
+    starts = patch_grid(size, patch, tuple(s // 2 for s in patch))
+    outs = {v: [] for v in views}
+    for st in starts:
+        sl = (slice(None),) + tuple(slice(int(a), int(a) + p) for a, p in zip(st, patch))
+        res = forward({v: image[sl][None] if v == vp else image_dict[v] for v in views})
+        for v in views:
+            outs[v].append(res[v])
+    result = {}
+    for v in views:
+        prob = torch.softmax(torch.cat(outs[v], dim=0), dim=1)
+        if v == vp:
+            acc = torch.zeros((prob.shape[1], *size), dtype=prob.dtype)
+            cnt = torch.zeros(size, dtype=torch.float32)
+            for i, st in enumerate(starts):
+                sl = tuple(slice(int(a), int(a) + p) for a, p in zip(st, patch))
+                acc[(slice(None), *sl)] += prob[i]
+                cnt[sl] += 1
+            result[v] = torch.log(acc / cnt[None])[None]
+        else:
+            result[v] = torch.log(prob.mean(dim=0))[None]
+    return result
+
+
+def _iou_ignore_empty(y_pred: Tensor, y: Tensor) -> Tensor:
+    """monai 1.5.2 ``compute_iou(y_pred, y)`` with its defaults (include_background=True, ignore_empty=True): per (batch, channel)
+    |y & y_pred| / (|y| + |y_pred| - |y & y_pred|), NaN where y is empty.  PINNED through ``stability_score`` by the reference's known answers
+    (``cinema/metric_test.py:60-102``)."""
+    axes = tuple(range(2, y.ndim))
+    inter = (y * y_pred).sum(axes).float()
+    y_o, p_o = y.sum(axes).float(), y_pred.sum(axes).float()
+    return torch.where(y_o > 0, inter / (y_o + p_o - inter), torch.full_like(inter, float("nan")))
+
+
+def stability_score(logits: Tensor, threshold: float = 0.0, threshold_offset: float = 1.0) -> Tensor:
+    """``cinema/metric.py:21-45``: IoU between the masks (logits - class mean) >= threshold + offset and >= threshold - offset."""
+    norm = logits - logits.mean(dim=1, keepdim=True)
+    return _iou_ignore_empty((norm >= threshold + threshold_offset).long(), (norm >= threshold - threshold_offset).long())
+
+
+def segmentation_metrics(logits: Tensor, labels: Tensor, spacing: tuple) -> dict:
+    """``segmentation_metrics`` (``cinema/segmentation/train.py:224-286``) without the Hausdorff distance: argmax one-hot prediction, monai
+    ``compute_dice`` (2 |A & B| / (|A| + |B|), NaN where the ground truth is empty: ``ignore_empty=True``) and ``compute_iou``, stability score,
+    volumes in ml (``cinema/metric.py:84-96``).  ``compute_dice`` is PARITY-UNPINNED (monai absent, no reference value); it is cross-checked in
+    the tests against an independent float64 count-based derivation."""
+    n_classes = logits.shape[1] - 1
+    lab = labels.squeeze(1).long()
+    pred = F.one_hot(torch.argmax(logits, dim=1), n_classes + 1).movedim(-1, 1)
+    true = F.one_hot(lab, n_classes + 1).movedim(-1, 1)
+    axes = tuple(range(2, pred.ndim))
+    inter = (pred * true).sum(axes).float()
+    t_o, p_o = true.sum(axes).float(), pred.sum(axes).float()
+    dice = torch.where(t_o > 0, 2.0 * inter / (t_o + p_o), torch.full_like(inter, float("nan")))
+    iou = _iou_ignore_empty(pred, true)
+    stab = stability_score(logits)
+    vox = float(np.prod(spacing)) / 1000.0
+    out = {}
+    for i in range(n_classes):
+        k = i + 1
+        out[f"class_{k}_dice_score"], out[f"class_{k}_iou_score"], out[f"class_{k}_stability_score"] = dice[:, k], iou[:, k], stab[:, k]
+        out[f"class_{k}_true_volume"], out[f"class_{k}_pred_volume"] = t_o[:, k] * vox, p_o[:, k] * vox
+    out["mean_dice_score"], out["mean_iou_score"] = dice[:, 1:].mean(-1), iou[:, 1:].mean(-1)
+    out["mean_stability_score"] = stab[:, 1:].mean(-1)
+    return out

@@ -263,3 +263,112 @@ def test_segmentation_loss_known_answer() -> None:
     assert float(loss) == pytest.approx(ce + dice, rel=1e-6)
     loss.backward()
     assert torch.isfinite(logits.grad).all() and float(logits.grad[0, :, 3].abs().sum()) > 0  # the ignored voxel still feeds the Dice sums
+
+
+# ------------------------------------------------------------------------------------------------ evaluation path
+# known answers of the reference's own test (cinema/transform_test.py:13-96): (patch_size, image_size, patch_overlap) -> start indices
+_GRID_KATS = [
+    ((3, 5), (3, 5), (0, 0), [[0, 0]]),
+    ((3, 5), (3, 7), (0, 0), [[0, 0], [0, 2]]),
+    ((4, 5, 6), (8, 10, 6), (2, 1, 4), [[0, 0, 0], [0, 4, 0], [0, 5, 0], [2, 0, 0], [2, 4, 0], [2, 5, 0], [4, 0, 0], [4, 4, 0], [4, 5, 0]]),
+    ((128, 128, 128), (192, 128, 128), (64, 0, 0), [[0, 0, 0], [64, 0, 0]]),
+]
+
+
+def test_patch_grid_and_aggregation_vs_reference() -> None:
+    """Oracle ``patch_grid`` and the product's ``get_patch_grid`` / ``patch_grid_sample`` / ``aggregate_patches`` (host helpers) against the
+    reference's known answers and generated vectors (oracle/make_golden_seg_eval.py)."""
+    import numpy as np
+
+    from cinema_amd.transform import aggregate_patches, crop_start, get_patch_grid, patch_grid_sample
+
+    for patch, size, ov, want in _GRID_KATS:
+        assert O.patch_grid(size, patch, ov).tolist() == want
+        assert get_patch_grid(size, patch, ov).tolist() == want
+    g = load_golden("seg_eval.safetensors")
+    for i in range(4):
+        a = g[f"grid/{i}/args"].tolist()
+        n = len(a) // 3
+        size, patch, ov = tuple(a[:n]), tuple(a[n:2 * n]), tuple(a[2 * n:])
+        assert O.patch_grid(size, patch, ov).tolist() == g[f"grid/{i}/starts"].tolist()
+        assert get_patch_grid(size, patch, ov).tolist() == g[f"grid/{i}/starts"].tolist()
+    with pytest.raises(ValueError, match="should be <= image size"):
+        get_patch_grid((4, 4), (5, 4), (0, 0))
+    starts = get_patch_grid((8, 10, 6), (4, 5, 6), (2, 1, 4))
+    assert torch.equal(aggregate_patches(g["agg/patches"], starts, (8, 10, 6)), g["agg/out"])
+    img = aggregate_patches(g["agg/sampled"], starts, (8, 10, 6))  # windows of one image average back to the image (transform_test.py:180-182)
+    assert torch.equal(patch_grid_sample(img, starts, (4, 5, 6)), g["agg/sampled"])
+    assert patch_grid_sample(img[0], starts, (4, 5, 6)).shape == (9, 4, 5, 6)
+    assert crop_start(np.zeros((2, 3, 4)), (1, 2, 3)).shape == (1, 2, 3)
+    with pytest.raises(ValueError, match="same length"):
+        crop_start(np.zeros((2, 3)), (1, 2, 3))
+
+
+def test_sliding_window_forward_vs_reference() -> None:
+    """Oracle ``sliding_window_logits`` around the oracle ConvUNetR against the reference's ``segmentation_forward`` on its own model (12 windows)."""
+    g = load_golden("seg_eval.safetensors")
+    meta, cfg = _unetr_setup()
+    params = {k: v for k, v in split(load_golden("convunetr_mini.safetensors"), "param/").items() if not k.startswith(("resblock", "updec"))}
+
+    def fwd(images: dict) -> dict:
+        with torch.no_grad():
+            return O.convunetr_forward(params, cfg, tuple(meta["kwargs"]["dec_chans"]), meta["n_layers_wo_skip"], meta["n_downsample_layers"], images)
+
+    images = split(g, "fwd/image/")
+    out = O.sliding_window_logits(fwd, images, {"sax": (64, 64, 4), "lax_4c": (64, 64)})
+    for v, t in split(g, "fwd/logits/").items():
+        assert out[v].shape == t.shape and torch.allclose(out[v], t, rtol=1e-4, atol=1e-4), (v, float((out[v] - t).abs().max()))
+    whole = {"sax": images["sax"][:, :, :64, :64, :4].contiguous(), "lax_4c": images["lax_4c"]}
+    out2 = O.sliding_window_logits(fwd, whole, {"sax": (64, 64, 4), "lax_4c": (64, 64)})
+    assert torch.allclose(out2["sax"], g["fwd/whole_logits/sax"], rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError, match="smaller than patch size"):
+        O.sliding_window_logits(fwd, whole, {"sax": (64, 64, 8), "lax_4c": (64, 64)})
+
+
+# cinema/metric_test.py:60-75 (default threshold 0, offset 1): logits (1, 3, 2, 2) -> stability per class
+_STABILITY_KATS = [
+    ([[[[0.8, 2.3], [-1.0, 1.1]], [[-1.8, -2.0], [1.5, -1.3]], [[1.0, -0.3], [-0.5, 0.2]]]], [0.5, 1.0, 0.25]),
+    ([[[[0.8, 1.3], [-1.0, 1.1]], [[-0.8, -3.0], [1.5, -1.3]], [[2.0, -1.3], [-0.5, 0.2]]]], [0.5, 1.0, 0.25]),
+]
+
+
+def test_segmentation_metrics_oracle_known_answers_and_independent_dice() -> None:
+    """stability_score against the reference's own known answers (pins the compute_iou restatement); Dice / IoU / volumes against an
+    independent float64 derivation by explicit voxel counting (monai absent: compute_dice itself stays unpinned against the reference);
+    the Dice LOSS restatement against a second derivation in float64 with explicit loops."""
+    for logits, want in _STABILITY_KATS:
+        got = O.stability_score(torch.tensor(logits))
+        assert torch.allclose(torch.nan_to_num(got), torch.tensor([want]), rtol=1e-5, atol=1e-5)
+    torch.manual_seed(0)
+    logits = torch.randn(2, 4, 6, 5, 3)
+    labels = torch.randint(0, 3, (2, 1, 6, 5, 3))  # class 3 never occurs: NaN scores (ignore_empty)
+    m = O.segmentation_metrics(logits, labels, (1.5, 1.5, 10.0))
+    pred = logits.argmax(1)
+    for b in range(2):
+        for k in (1, 2, 3):
+            p, t = (pred[b] == k), (labels[b, 0] == k)
+            inter, ps, ts = float((p & t).sum()), float(p.sum()), float(t.sum())
+            if ts == 0:
+                assert math.isnan(float(m[f"class_{k}_dice_score"][b])) and math.isnan(float(m[f"class_{k}_iou_score"][b]))
+            else:
+                assert float(m[f"class_{k}_dice_score"][b]) == pytest.approx(2 * inter / (ps + ts), rel=1e-6)
+                assert float(m[f"class_{k}_iou_score"][b]) == pytest.approx(inter / (ps + ts - inter), rel=1e-6)
+            assert float(m[f"class_{k}_true_volume"][b]) == pytest.approx(ts * 22.5 / 1000.0, rel=1e-6)
+            assert float(m[f"class_{k}_pred_volume"][b]) == pytest.approx(ps * 22.5 / 1000.0, rel=1e-6)
+    assert "mean_hausdorff_distance_95" not in m and math.isnan(float(m["mean_dice_score"][0]))
+    # Dice loss, second derivation: float64, explicit loops over samples / classes / voxels
+    lg = torch.randn(2, 3, 4, 5, dtype=torch.float64)
+    lb = torch.randint(-1, 3, (2, 1, 4, 5))
+    _, mm = O.segmentation_loss_one_view(lg.float(), lb)
+    prob = torch.softmax(lg, dim=1)
+    terms = []
+    for b in range(2):
+        for c in (1, 2):
+            inter = den = 0.0
+            for i in range(4):
+                for j in range(5):
+                    t = 1.0 if max(int(lb[b, 0, i, j]), 0) == c else 0.0
+                    inter += float(prob[b, c, i, j]) * t
+                    den += float(prob[b, c, i, j]) + t
+            terms.append(1.0 - (2.0 * inter + 1e-5) / (den + 1e-5))
+    assert float(mm["mean_dice_loss"]) == pytest.approx(sum(terms) / len(terms), rel=1e-5)

@@ -1,0 +1,269 @@
+"""GPU checks of the segmentation fine-tuning / evaluation path (BASELINE config 4): dropout / drop-path
+kernels, the fused training step with the ACDC recipe (dropout 0.1, drop_path 0.1), sliding-window inference and the metric kernel.
+
+Stated tolerances: segmentation argmax agreement >= 99.5 %, Dice abs-diff <= 0.01 against the CPU reference path."""
+
+from __future__ import annotations
+
+import json
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cinema_oracle as O  # noqa: E402
+from cinema_amd import hip as K  # noqa: E402
+from cinema_amd.segmentation.convunetr import ConvUNetR  # noqa: E402
+from conftest import GOLDEN, load_golden  # noqa: E402
+from test_model_gpu import split  # noqa: E402
+from test_oracle_golden import _STABILITY_KATS  # noqa: E402
+
+DEV = "cuda"
+
+
+def mini_unetr(**over) -> tuple:  # noqa: ANN003
+    meta = json.loads((GOLDEN / "convunetr_meta.json").read_text())
+    kw = dict(meta["kwargs"])
+    for key in ("image_size_dict", "enc_patch_size_dict", "enc_scale_factor_dict", "dec_patch_size_dict", "dec_scale_factor_dict"):
+        kw[key] = {v: tuple(s) for v, s in kw[key].items()}
+    kw["dec_chans"] = tuple(kw["dec_chans"])
+    kw.update(over)
+    g = load_golden("convunetr_mini.safetensors")
+    model = ConvUNetR(**kw)
+    model.load_state_dict({k: v for k, v in split(g, "param/").items() if not k.startswith(("resblock", "updec"))})
+    return model, g, meta
+
+
+# ---------------------------------------------------------------------------------------------------- stochastic kernels
+def test_dropout_kernel_statistics_and_mask_regeneration() -> None:
+    """nn.Dropout semantics (cinema/conv.py:343): kept elements scaled by 1 / (1 - p), dropped ones zero, keep rate ~ 1 - p; the same call on
+    another tensor reproduces the SAME mask (that is the backward pass); a new RNG step or another call site gives a different mask."""
+    K.rng_seed(torch.device(DEV), 1234)
+    n, p = 1 << 20, 0.1
+    x = torch.ones(n, dtype=torch.bfloat16, device=DEV)
+    y = K.dropout(x, p, salt=7)
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 3e-3
+    assert torch.all(y[kept] == torch.tensor(1.0 / (1 - p)).bfloat16().to(DEV))
+    g = torch.full((n,), 2.0, dtype=torch.bfloat16, device=DEV)
+    gy = K.dropout(g, p, salt=7)
+    assert torch.equal(gy != 0, kept)
+    assert not torch.equal(K.dropout(x, p, salt=8) != 0, kept)
+    K.rng_advance(torch.device(DEV))
+    y2 = K.dropout(x, p, salt=7)
+    assert not torch.equal(y2 != 0, kept) and abs(float((y2 != 0).float().mean()) - (1 - p)) < 3e-3
+    # neighbouring elements are independent: the pair-keep rate is (1 - p)^2
+    pair = (kept[:-1] & kept[1:]).float().mean()
+    assert abs(float(pair) - (1 - p) ** 2) < 4e-3
+    odd = torch.ones(1003, dtype=torch.bfloat16, device=DEV)  # tail of a non-multiple-of-8 length
+    assert K.dropout(odd, 0.5, salt=1).shape == (1003,)
+
+
+def test_droppath_scale_and_scaled_residual_add() -> None:
+    """timm DropPath (cinema/vit.py:561-577): per-sample factor 0 or 1 / keep; out = residual + factor[sample] * h; the gradient w.r.t. h is
+    the same scaling."""
+    K.rng_seed(torch.device(DEV), 99)
+    s = K.droppath_scale(4096, 0.25, salt=3, device=torch.device(DEV))
+    vals = sorted(torch.unique(s).tolist())
+    assert len(vals) == 2 and vals[0] == 0.0 and vals[1] == pytest.approx(1 / 0.75)
+    assert abs(float((s > 0).float().mean()) - 0.75) < 0.03
+    b, t, c = 6, 5, 8
+    h, res = torch.randn(b * t, c, device=DEV), torch.randn(b * t, c, device=DEV)
+    sc = torch.tensor([0.0, 2.0, 1.0, 0.0, 0.5, 3.0], device=DEV)
+    out = K.scale_rows_add(h, sc, t, residual=res)
+    want = res + sc.repeat_interleave(t)[:, None] * h
+    assert torch.allclose(out, want, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(K.scale_rows_add(h, sc, t), sc.repeat_interleave(t)[:, None] * h, rtol=1e-6, atol=1e-6)
+
+
+def test_block_with_drop_path_matches_manual_formula() -> None:
+    """Block(drop_path=0.5) in training mode: y = q + s1 * path1(q); y = y + s2 * path2(y) with the per-sample factors the kernels drew;
+    checked by re-running the SAME draws (same RNG step and call sites) through the two paths of an identical drop-free block; eval mode == no
+    drop; gradients flow (dropped samples get the identity gradient)."""
+    from torch import nn
+
+    from cinema_amd.vit import Block, Mlp
+
+    torch.manual_seed(0)
+    kw = dict(dim=64, n_heads=4, mlp_ratio=4, norm_layer=nn.LayerNorm, norm_eps=1e-5, qkv_bias=True, rotary=False, act_layer=nn.GELU, mlp_layer=Mlp)
+    blk, ref = Block(drop_path=0.5, **kw), Block(drop_path=0.0, **kw)
+    ref.load_state_dict(blk.state_dict())
+    blk.to(DEV).train()
+    ref.to(DEV).train()
+    b, t = 8, 16
+    x = torch.randn(b, t, 64, device=DEV)
+    K.rng_seed(torch.device(DEV), 5)
+    xg = x.clone().requires_grad_(True)
+    y = blk(xg)
+    s1 = K.droppath_scale(b, 0.5, salt=1, device=torch.device(DEV))  # the block's two call sites in launch order
+    s2 = K.droppath_scale(b, 0.5, salt=2, device=torch.device(DEV))
+    assert 0 < int((s1 == 0).sum()) < b
+    # manual: path outputs from the drop-free block: ref(x) = x + p1(x) + p2(x + p1(x))
+    zero_mlp = Block(drop_path=0.0, **kw).to(DEV)
+    zero_mlp.load_state_dict(ref.state_dict())
+    for p in (zero_mlp.mlp.fc2.weight, zero_mlp.mlp.fc2.bias):
+        torch.nn.init.zeros_(p)
+    p1 = zero_mlp(x) - x                       # path1(x) (path 2 contributes exactly zero)
+    x1 = x + s1[:, None, None] * p1
+    zero_attn = Block(drop_path=0.0, **kw).to(DEV)
+    zero_attn.load_state_dict(ref.state_dict())
+    for p in (zero_attn.attn.proj.weight, zero_attn.attn.proj.bias):
+        torch.nn.init.zeros_(p)
+    p2 = zero_attn(x1) - x1                    # path2(x1)
+    want = x1 + s2[:, None, None] * p2
+    assert (y - want).abs().max() <= 3e-2 * want.abs().max()
+    y.sum().backward()
+    dropped = (s1 == 0) & (s2 == 0)
+    if bool(dropped.any()):
+        assert torch.allclose(xg.grad[dropped], torch.ones_like(xg.grad[dropped]))  # identity for fully dropped samples
+    blk.eval()
+    ref.eval()
+    assert (blk(x) - ref(x)).abs().max() <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------- training with the ACDC recipe
+def test_convunetr_trains_with_dropout_and_drop_path() -> None:
+    """The reference's own recipe (cinema/segmentation/acdc/config.yaml:64-65: dropout 0.1, drop_path 0.1; layer decay 0.75, betas (0.9, 0.95),
+    clip 5) through SegTrainStep: finite losses, the loss on a fixed batch falls, training-mode forwards differ between steps (new masks),
+    eval-mode logits are deterministic and equal the dropout-free model's (parity with dropout 0 is unchanged)."""
+    from cinema_amd.segmentation.train import SegTrainStep
+
+    K.rng_seed(torch.device(DEV), 7)
+    model, g, _ = mini_unetr(dropout=0.1, drop_path=0.1)
+    plain, _, _ = mini_unetr()
+    model.to(DEV)
+    plain.to(DEV).eval()
+    images = {k: v.to(DEV) for k, v in split(g, "image/").items()}
+    model.eval()
+    with torch.no_grad():
+        le, lp = model(images), plain(images)
+    for v in images:
+        assert float((le[v] - lp[v]).abs().max()) <= 1e-5, v
+        assert (le[v].float().cpu() - g[f"logits/{v}"]).abs().max() <= 5e-2 * max(1.0, float(g[f"logits/{v}"].abs().max()))
+    model.train()
+    with torch.no_grad():
+        a, b = model(images), model(images)
+    assert not torch.equal(a["sax"], b["sax"])  # two training-mode forwards draw different masks
+    views = list(images)
+    gen = torch.Generator().manual_seed(2)
+    batch = {f"{v}_image": images[v] for v in views}
+    # labels the model can learn: the image intensity quantised into the 4 classes
+    batch.update({f"{v}_label": torch.clamp((images[v] * 4).long(), 0, 3) for v in views})
+    step = SegTrainStep(model, views, lr=2e-3, layer_decay=0.75, clip_grad=5.0)
+    assert len(step.flat.ranges) > 4 and len({round(gr["lr"], 12) for gr in step.optimizer.param_groups}) > 2  # layer-decay groups
+    losses = []
+    for _ in range(12):
+        loss, gn, metrics = step(batch)
+        losses.append(float(loss))
+        assert math.isfinite(losses[-1]) and math.isfinite(float(gn))
+    assert set(metrics) >= {"loss", "cross_entropy", "mean_dice_loss", "sax_cross_entropy", "lax_4c_mean_dice_loss"}
+    assert min(losses[-3:]) < losses[0] - 0.1 and losses[5] < losses[0], losses  # measured 2.26 -> 2.07 in 12 steps
+    del gen
+    assert step.optimizer.step_count == 12 and step.optimizer.n_skipped == 0
+
+
+def test_config4_shape_training_step_properties() -> None:
+    """BASELINE config 4 at its real shape (ConvUNetR ViT-Base, SAX 256 x 256 x 12, 4 classes, ACDC decoder recipe, dropout / drop_path 0.1) at
+    batch 1: too large for the CPU oracle inside a test, so size-independent properties: logits shape, finite loss and gradient norm, a falling
+    loss on a fixed batch, label -1 voxels ignored by the cross entropy."""
+    from cinema_amd.segmentation.train import SegTrainStep
+    from cinema_amd.vit import get_vit_config
+
+    vit = get_vit_config("base")
+    torch.manual_seed(0)
+    model = ConvUNetR(image_size_dict={"sax": (256, 256, 12)}, in_chans_dict={"sax": 1}, out_chans=4, enc_patch_size_dict={"sax": (4, 4, 1)},
+                      enc_scale_factor_dict={"sax": (2, 2, 1)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2, enc_embed_dim=vit["enc_embed_dim"],
+                      enc_depth=vit["enc_depth"], enc_n_heads=vit["enc_n_heads"], dec_chans=(32, 64, 128, 256, 512), dec_patch_size_dict={"sax": (2, 2, 1)},
+                      dec_scale_factor_dict={"sax": (2, 2, 1)}, dropout=0.1, drop_path=0.1).to(DEV)
+    gen = torch.Generator().manual_seed(1)
+    image = torch.rand(1, 1, 256, 256, 12, generator=gen)
+    labels = torch.clamp((image * 4).long(), 0, 3)  # learnable: the intensity quantised into the 4 classes
+    labels[:, :, :8] = -1  # padded region (ignore_index)
+    batch = {"sax_image": image.to(DEV), "sax_label": labels.to(DEV)}
+    step = SegTrainStep(model, ["sax"], lr=3e-4, layer_decay=0.75)
+    losses = []
+    for _ in range(8):
+        loss, gn, _ = step(batch)
+        losses.append(float(loss))
+        assert math.isfinite(losses[-1]) and math.isfinite(float(gn))
+    assert losses[-1] < losses[0], losses
+    model.eval()
+    with torch.no_grad():
+        out = model({"sax": batch["sax_image"]})
+    assert out["sax"].shape == (1, 4, 256, 256, 12)
+
+
+# ---------------------------------------------------------------------------------------------------- evaluation path
+def test_metric_counts_kernel_vs_oracle_metrics() -> None:
+    """cinema_seg_metric_counts + segmentation_metrics against the oracle restatement (argmax one-hot Dice / IoU with NaN for empty ground truth,
+    stability score, volumes) and the reference's stability known answers (cinema/metric_test.py:60-75); counts are integers: exact."""
+    from cinema_amd.segmentation.train import segmentation_metrics
+
+    for logits, want in _STABILITY_KATS:
+        lg = torch.tensor(logits, dtype=torch.float32).to(DEV)
+        counts = K.seg_metric_counts(lg, torch.zeros(1, 2, 2, dtype=torch.int32, device=DEV)).float()
+        stab = torch.where(counts[..., 4] > 0, counts[..., 5] / (counts[..., 3] + counts[..., 4] - counts[..., 5]), torch.nan)
+        assert torch.allclose(torch.nan_to_num(stab.cpu()), torch.tensor([want]), rtol=1e-5, atol=1e-5)
+    torch.manual_seed(0)
+    logits = torch.randn(3, 4, 40, 36, 5)
+    labels = torch.randint(0, 3, (3, 1, 40, 36, 5))  # class 3 absent: NaN
+    want = O.segmentation_metrics(logits, labels, (1.25, 1.25, 10.0))
+    got = segmentation_metrics(logits.to(DEV), labels.to(DEV), (1.25, 1.25, 10.0))
+    assert set(got) == set(want)
+    for k, t in want.items():
+        assert torch.allclose(got[k].cpu(), t, rtol=1e-6, atol=1e-7, equal_nan=True), k
+
+
+def test_sliding_window_forward_vs_reference_golden() -> None:
+    """segmentation_forward on the HIP path (windows batched through the model, softmax / overlap mean / log in kernels) against the
+    reference's own ``segmentation_forward`` output on its model (tests/golden/seg_eval.safetensors: 12 half-overlapping SAX windows + a whole LAX
+    view): argmax agreement >= 99.5 %, Dice of the argmax segmentations (GPU vs reference) abs-diff from 1 <= 0.01, log-probabilities close."""
+    from cinema_amd.segmentation.train import segmentation_forward, segmentation_metrics
+
+    model, _, _ = mini_unetr()
+    model.to(DEV).eval()
+    g = load_golden("seg_eval.safetensors")
+    images = {k: v.to(DEV) for k, v in split(g, "fwd/image/").items()}
+    patch = {"sax": (64, 64, 4), "lax_4c": (64, 64)}
+    for wb in (1, 5, 16):
+        out = segmentation_forward(model, images, patch, torch.bfloat16, window_batch=wb)
+        for v, t in split(g, "fwd/logits/").items():
+            got = out[v].float().cpu()
+            assert got.shape == t.shape
+            agree = float((got.argmax(1) == t.argmax(1)).float().mean())
+            assert agree >= 0.995, (v, wb, agree)
+            assert float((got - t).abs().max()) <= 5e-2, (v, wb, float((got - t).abs().max()))  # log-probabilities of O(1)
+            ref_seg = t.argmax(1, keepdim=True).to(DEV)
+            m = segmentation_metrics(out[v], ref_seg, (1.0,) * (t.ndim - 2))
+            dice = float(torch.nanmean(torch.stack([m[f"class_{k}_dice_score"] for k in (1, 2, 3)])))
+            assert abs(dice - 1.0) <= 0.01, (v, dice)
+    whole = {"sax": images["sax"][:, :, :64, :64, :4].contiguous(), "lax_4c": images["lax_4c"]}
+    out2 = segmentation_forward(model, whole, patch, torch.bfloat16)
+    assert float((out2["sax"].float().cpu() - g["fwd/whole_logits/sax"]).abs().max()) <= 5e-2 * max(1.0, float(g["fwd/whole_logits/sax"].abs().max()))
+    with pytest.raises(ValueError, match="smaller than patch size"):
+        segmentation_forward(model, whole, {"sax": (64, 64, 8), "lax_4c": (64, 64)}, torch.bfloat16)
+    with pytest.raises(ValueError, match="Expected batch size 1"):
+        segmentation_forward(model, {k: v.repeat(2, *([1] * (v.ndim - 1))) for k, v in images.items()}, patch, torch.bfloat16)
+
+
+def test_segmentation_eval_crops_and_reports_floats() -> None:
+    """segmentation_eval (cinema/segmentation/train.py:288-355): crop to the un-padded size from the batch's width / height / n_slices, metric
+    dict of floats with per-view and view-mean keys."""
+    from cinema_amd.segmentation.train import segmentation_eval
+
+    model, g, _ = mini_unetr()
+    model.to(DEV).eval()
+    images = split(g, "image/")
+    batch = {"sax_image": images["sax"][:1], "lax_4c_image": images["lax_4c"][:1], "sax_width": torch.tensor([60]), "sax_height": torch.tensor([64]),
+             "lax_4c_width": torch.tensor([64]), "lax_4c_height": torch.tensor([50]), "n_slices": torch.tensor([3])}
+    gen = torch.Generator().manual_seed(0)
+    batch["sax_label"] = torch.randint(0, 4, (1, 1, 64, 64, 4), generator=gen)
+    batch["lax_4c_label"] = torch.randint(0, 4, (1, 1, 64, 64), generator=gen)
+    logits, metrics = segmentation_eval(model, batch, {"sax": (64, 64, 4), "lax_4c": (64, 64)}, {"sax": (1.0, 1.0, 10.0), "lax_4c": (1.0, 1.0)}, torch.bfloat16,
+                                        torch.device(DEV))
+    assert logits["sax"].shape == (1, 4, 60, 64, 3) and logits["lax_4c"].shape == (1, 4, 64, 50)
+    assert {"mean_dice_score", "sax_mean_dice_score", "lax_4c_class_1_iou_score", "class_2_pred_volume"} <= set(metrics)
+    assert all(isinstance(v, float) for v in metrics.values())
+    assert metrics["mean_dice_score"] == pytest.approx(0.5 * (metrics["sax_mean_dice_score"] + metrics["lax_4c_mean_dice_score"]), rel=1e-6)
