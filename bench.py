@@ -113,6 +113,153 @@ def pmc_mfma_util(kernel: str):  # noqa: ANN201
     return None if hit is None else hit.get("mfma_util")
 
 
+SEG_STEP_GFLOP_PER_SAMPLE = 3 * 1412.9  # BASELINE.md section 2, config 4 (ConvUNetR Base, SAX 256x256x12): 3 x forward of the reference graph
+
+
+def seg_kwargs(size: str = "base", sax=(256, 256, 12)) -> dict:  # noqa: ANN001
+    """ConvUNetR of the ACDC recipe (cinema/segmentation/acdc/config.yaml:52-65) at the BASELINE config-4 input size."""
+    from cinema_amd.vit import get_vit_config
+
+    vit = get_vit_config(size)
+    return dict(image_size_dict={"sax": tuple(sax)}, in_chans_dict={"sax": 1}, out_chans=4, enc_patch_size_dict={"sax": (4, 4, 1)},
+                enc_scale_factor_dict={"sax": (2, 2, 1)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2, enc_embed_dim=vit["enc_embed_dim"],
+                enc_depth=vit["enc_depth"], enc_n_heads=vit["enc_n_heads"], dec_chans=(32, 64, 128, 256, 512), dec_patch_size_dict={"sax": (2, 2, 1)},
+                dec_scale_factor_dict={"sax": (2, 2, 1)}, dropout=0.1, drop_path=0.1)
+
+
+def seg_cpu_baseline(kw: dict, state_dict: dict, device: str, budget_s: float) -> tuple:
+    """(cpu_baseline, parity) for the segmentation task: the fp32 CPU oracle's ConvUNetR forward + loss + backward on ONE sample of the same
+    shape (the sample of the baseline), and - the config-4 acceptance - the HIP path's eval-mode logits against the oracle's on that sample:
+    argmax agreement and the Dice of the two argmax segmentations (oracle/cinema_oracle.py, checker only)."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import cinema_oracle as O  # noqa: N812
+
+    from cinema_amd.segmentation.convunetr import ConvUNetR
+    from cinema_amd.segmentation.train import segmentation_metrics
+
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
+    torch.set_num_threads(cores)
+    cfg = O.MAEConfig(image_size_dict=kw["image_size_dict"], in_chans_dict=kw["in_chans_dict"], enc_patch_size_dict=kw["enc_patch_size_dict"],
+                      enc_scale_factor_dict=kw["enc_scale_factor_dict"], enc_conv_chans=kw["enc_conv_chans"], enc_conv_n_blocks=kw["enc_conv_n_blocks"],
+                      enc_embed_dim=kw["enc_embed_dim"], enc_depth=kw["enc_depth"], enc_n_heads=kw["enc_n_heads"], dec_embed_dim=16, dec_depth=1, dec_n_heads=2)
+    gen = torch.Generator().manual_seed(99)
+    image = torch.rand(1, 1, *kw["image_size_dict"]["sax"], generator=gen)
+    labels = torch.clamp((image * 4).long(), 0, 3)
+    p = {k: v.detach().float().cpu().clone().requires_grad_(not k.endswith("pos_embed")) for k, v in state_dict.items()}
+    t0 = time.perf_counter()
+    logits = O.convunetr_forward(p, cfg, tuple(kw["dec_chans"]), 1, 1, {"sax": image})["sax"]
+    loss, _ = O.segmentation_loss_one_view(logits, labels)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    model = ConvUNetR(**kw)
+    model.load_state_dict({k: v.detach().float().cpu() for k, v in state_dict.items()})
+    model.to(device).eval()
+    with torch.no_grad():
+        got = model({"sax": image.to(device)})["sax"].float()
+    ref = logits.detach()
+    agree = float((got.argmax(1).cpu() == ref.argmax(1)).float().mean())
+    m = segmentation_metrics(got, ref.argmax(1, keepdim=True).to(device), (1.0, 1.0, 10.0))
+    dice = float(torch.nanmean(torch.stack([m[f"class_{k}_dice_score"] for k in (1, 2, 3)])))
+    parity = {"argmax_agreement": round(agree, 5), "dice_gpu_vs_cpu_segmentation": round(dice, 5), "logits_max_abs": round(float((got.cpu() - ref).abs().max()), 4),
+              "logits_abs_max_ref": round(float(ref.abs().max()), 3),
+              "what": "eval-mode logits of the HIP path vs the fp32 CPU oracle on one identical sample and identical weights (random init): fraction of voxels "
+                      "with the same argmax class, and the foreground Dice between the two argmax segmentations (acceptance: >= 0.995, |1 - Dice| <= 0.01)"}
+    del budget_s
+    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "sample": f"1 forward + CE/Dice loss + backward of the same ConvUNetR config at batch 1 (fp32 torch-CPU oracle, no optimiser update), {dt:.1f} s, "
+                      f"{cores} intra-op threads of the host's {host_cores} cores"}, parity
+
+
+def seg_main(args, rank: int, world: int, device: str, sync) -> None:  # noqa: ANN001
+    """BASELINE config 4: ConvUNetR fine-tuning step (forward, CE + Dice, backward, [gradient all-reduce], clip 5, layer-decay AdamW) on synthetic
+    SAX volumes resident in HBM; dropout / drop_path 0.1 as in the reference recipe; weak scaling, whole-job samples/s."""
+    import torch.distributed as dist
+
+    from cinema_amd import hip as K
+    from cinema_amd.segmentation.convunetr import ConvUNetR
+    from cinema_amd.segmentation.train import SegTrainStep
+
+    batch_size = args.batch if args.batch != 16 else 4  # reference batch_size_per_device (acdc/config.yaml:42); --batch overrides
+    sax = tuple(int(v) for v in args.sax.split(",")) if args.sax != "192,192,16" else (256, 256, 12)
+    kw = seg_kwargs(args.size, sax)
+    torch.manual_seed(0)
+    model = ConvUNetR(**kw)
+    cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model.to(device).train()
+    step = SegTrainStep(model, ["sax"], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, layer_decay=0.75, clip_grad=5.0, synchronizer=sync)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    batches = []
+    for _ in range(2):
+        image = torch.rand(batch_size, 1, *sax, generator=gen)
+        batches.append({"sax_image": image.to(device), "sax_label": torch.clamp((image * 4).long(), 0, 3).to(torch.int8).to(device)})
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    extra_untimed = max(0, min(args.prewarm, 5) - args.warmup)
+    for i in range(extra_untimed + args.warmup):
+        loss, gnorm, _ = step(batches[i % 2])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, gnorm, _ = step(batches[i % 2])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+    peak_gib = round(torch.cuda.max_memory_reserved() / 2**30, 1)
+    roofline = None
+    if args.profile_steps > 0:
+        from cinema_amd import tape as T_
+
+        side, T_.SIDE_WGRAD = T_.SIDE_WGRAD, False
+        step(batches[0])
+        if rank == 0:
+            K.GEMM_PROFILE = []
+        for i in range(args.profile_steps):
+            step(batches[i % 2])
+        barrier()
+        prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        T_.SIDE_WGRAD = side
+        if rank == 0:
+            agg: dict = {}
+            for kind, flops, e0, e1, _shape in prof:
+                a = agg.setdefault(kind, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[2] += 1
+            kind = max(agg, key=lambda k: agg[k][1])
+            flops, secs, n = agg[kind]
+            achieved = flops / secs / 1e12
+            roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n // args.profile_steps,
+                        "avg_launch_us": round(secs / n * 1e6, 2), "gflop_per_launch": round(flops / n / 1e9, 3),
+                        "timing": "HIP events on the launch stream around every launch of this kernel, live in this process",
+                        "gemm_ms_per_step": round(sum(v[1] for v in agg.values()) / args.profile_steps * 1e3, 2),
+                        "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
+                                                                      "launches_per_step": v[2] // args.profile_steps} for k, v in agg.items()}}
+    if rank == 0:
+        samples_per_s = world * batch_size * args.steps / dt
+        out = {"metric": "ConvUNetR segmentation fine-tune samples/sec (SAX 256x256x12, 4 classes; BASELINE config 4)", "value": round(samples_per_s, 2),
+               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": extra_untimed + args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"ConvUNetR ViT-{args.size.capitalize()} (ACDC decoder recipe), SAX {'x'.join(str(v) for v in sax)}, 4 classes, per-GPU batch "
+                                      f"{batch_size}, dropout 0.1 / drop_path 0.1, fwd + CE/Dice + bwd + clip(5.0) + layer-decay(0.75) AdamW, random-init weights",
+                          "global_batch": world * batch_size, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5), "peak_mem_gib": peak_gib,
+                          "host": "module code issues every launch (eager)",
+                          "reference_equiv_tflops_per_gpu": round(samples_per_s / world * SEG_STEP_GFLOP_PER_SAMPLE / 1e3, 1) if sax == (256, 256, 12) and args.size == "base" else None},
+               "roofline": roofline}
+        if world == 1 and args.cpu_budget > 0:
+            out["cpu_baseline"], out["parity"] = seg_cpu_baseline(kw, cpu_state, device, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +273,8 @@ def main() -> None:
     ap.add_argument("--prewarm", type=int, default=20, help="untimed steps run in total before the timed region (>= --warmup); 0 for profiling runs")
     ap.add_argument("--force-sync", action="store_true", help="N=1 only: still issue the gradient collectives (RCCL path check)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the per-kernel roofline")
+    ap.add_argument("--task", default="mae", choices=["mae", "seg"], help="mae: the BASELINE metric (config 2 / 3 / 5 shapes); seg: BASELINE config 4, the "
+                    "ConvUNetR segmentation fine-tuning step (SAX 256x256x12, 4 classes, per-GPU batch 4, dropout / drop_path 0.1)")
     ap.add_argument("--eager", action="store_true", help="issue every launch from the module code instead of the recorded launch list (A/B)")
     args = ap.parse_args()
 
@@ -154,6 +303,12 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29533")
         ddp_setup(0, 1, backend="nccl")
         sync = GradientSynchronizer(1, force_collectives=True)
+
+    if args.task == "seg":
+        seg_main(args, rank, world, device, sync)
+        if world > 1 or args.force_sync:
+            dist.destroy_process_group()
+        return
 
     kw = base_kwargs(args.size, tuple(int(v) for v in args.sax.split(",")), tuple(int(v) for v in args.lax.split(",")))
     torch.manual_seed(0)  # identical weights on every rank (config.seed, mae/config.yaml:1)

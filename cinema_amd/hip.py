@@ -624,6 +624,13 @@ def colsum(x: torch.Tensor, out: torch.Tensor, row_idx: torch.Tensor | None = No
     """out[n] += sum_i x[row(i), n] (x bf16/fp32 2-D, out fp32; ``row_idx`` int32 selects rows)."""
     _dev(x, out, row_idx)
     m = x.shape[0] if row_idx is None else row_idx.numel()
+    n = x.shape[1]
+    if row_idx is None and n < 8 and 64 % n == 0 and x.is_contiguous() and (m * n) % 64 == 0 and m * n >= (1 << 16):
+        # a narrow, tall matrix (bias gradient of a 4-class head over millions of voxels): the vectorised kernels want >= 8 / 4 columns per thread
+        # group, so fold 64 / n rows into one 64-wide row, sum those columns, then sum the 64 / n groups of n
+        tmp = zeros((64,), torch.float32, x.device)
+        colsum(x.view(-1, 64), tmp)
+        return colsum(tmp.view(64 // n, n), out)
     _check(load().cinema_colsum(x.data_ptr(), _DT[x.dtype], _p(row_idx), m, x.shape[1], _rowmajor(x, "x"), out.data_ptr(), _stream()), "colsum")
     return out
 

@@ -184,6 +184,12 @@ def test_gemm_strided_views_and_colsum() -> None:
         acc = torch.full((n,), 2.0, dtype=torch.float32, device=DEV)
         K.colsum(x32, acc, row_idx=idx)
         close(acc, x32[idx.long()].sum(0) + 2.0, 1e-4, 2e-3, f"gathered fp32 colsum n={n}")
+    # narrow tall matrices (bias gradient of the 4-class segmentation head over millions of voxels): folded into 64-wide rows
+    for n, dt in ((4, torch.bfloat16), (2, torch.float32), (1, torch.bfloat16)):
+        tall = rnd(1 << 17, n, dtype=dt, seed=16)
+        acc = torch.full((n,), -1.0, dtype=torch.float32, device=DEV)
+        K.colsum(tall, acc)
+        close(acc, tall.float().sum(0) - 1.0, 1e-3, 2e-2, f"narrow colsum n={n}")
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
