@@ -6,7 +6,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* out) {
+// Squared L2 norm in two deterministic passes: every block writes ONE partial (fixed thread -> element map, fixed in-block tree), a single block
+// adds the partials in a fixed order.  (fp32 atomics gave run-to-run / rank-to-rank differences in the 7th digit of the norm: data-parallel
+// replicas that clip with slightly different coefficients drift apart bit by bit.)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* partial) {
   __shared__ float part[4];
   float s = 0.f;
   const long long n4 = n >> 2;
@@ -18,7 +21,17 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_finish_kernel(const float* partial, int n_partial, float* out) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)).
@@ -83,13 +96,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
 
 }  // namespace
 
-CINEMA_API int cinema_sqnorm_f32(const float* g, long long n, float* out, void* stream) {
-  if (!g || !out || n <= 0) return CINEMA_ERR_BAD_ARG;
+CINEMA_API int cinema_sqnorm_f32(const float* g, long long n, float* out, float* workspace, void* stream) {
+  if (!g || !out || !workspace || n <= 0) return CINEMA_ERR_BAD_ARG;
   if (((uintptr_t)g) & 15) return CINEMA_ERR_UNSUPPORTED;
   long long grid = (n / 4 + 255) / 256;
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, workspace);
+  hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid, out);
   return launch_status();
 }
 

@@ -61,6 +61,7 @@ class GradientSynchronizer:
         self.min_early = 1 << 18  # elements (1 MiB)
         self._early: list = []   # (begin, end) ranges already handed to a collective in this backward pass
         self._works: list = []
+        self.n_early_last = 0    # early (overlapped) collectives of the last completed exchange (diagnostics / tests)
 
     def attach(self, flat) -> None:  # noqa: ANN001
         self.flat = flat
@@ -69,6 +70,12 @@ class GradientSynchronizer:
         self.buckets = [flat.flat_grad[i:min(n, i + per)] for i in range(0, n, per)]
         if self.world_size > 1 or self.force:
             dist.broadcast(flat.flat_param, src=0, group=self.group)  # rank 0's weights everywhere (DDP's _sync_module_states)
+            # the masters changed under the bf16 operand shadows: re-derive them (a rank that was initialised differently would otherwise keep
+            # computing with its own weights while holding rank 0's masters)
+            flat.refresh_shadows()
+            from cinema_amd import tape as T
+
+            T.WEIGHTS.invalidate()
         if self.overlap:
             from cinema_amd import tape as T
 
@@ -124,6 +131,7 @@ class GradientSynchronizer:
             w.wait()
         if dist.get_backend(self.group) != "nccl":
             self.flat.flat_grad.div_(self.world_size)
+        self.n_early_last = len(self._early)
         self._early, self._works, self.armed = [], [], False
 
     def all_finite(self, loss: torch.Tensor) -> torch.Tensor:

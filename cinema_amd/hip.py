@@ -147,7 +147,7 @@ _PROTOS = {
     "cinema_mse_bwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _vp, _f, _vp, _i, _vp],
     "cinema_patch_stats": [_vp, C.POINTER(PatchGeom), _vp, _vp],
     "cinema_mean_finite": [_vp, _i, _vp, _vp, _vp],
-    "cinema_sqnorm_f32": [_vp, _ll, _vp, _vp],
+    "cinema_sqnorm_f32": [_vp, _ll, _vp, _vp, _vp],
     "cinema_clip_coef": [_vp, _f, _vp, _vp, _vp, _vp],
     "cinema_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
 }
@@ -1038,7 +1038,8 @@ def mean_finite(vals: torch.Tensor, mean_out: torch.Tensor, coef_out: torch.Tens
 
 def sqnorm(g: torch.Tensor, out: torch.Tensor) -> None:
     _dev(g, out)
-    _check(load().cinema_sqnorm_f32(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "sqnorm")
+    ws = _workspace("sqnorm", 2048, g.device)
+    _check(load().cinema_sqnorm_f32(g.data_ptr(), g.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "sqnorm")
 
 
 def clip_coef(sq: torch.Tensor, max_norm: float, coef_out: torch.Tensor | None, norm_out: torch.Tensor | None, step_state: torch.Tensor | None = None) -> None:

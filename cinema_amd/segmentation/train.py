@@ -262,7 +262,7 @@ def segmentation_eval(model, batch: dict, patch_size_dict: dict, spacing_dict: d
         metrics_v = metrics_fn(logits_dict[v], crop(batch[f"{v}_label"].to(device), v), spacing_dict[v])
         metric_keys = list(metrics_v.keys())
         for k, val in metrics_v.items():
-            metrics[f"{v}_{k}"] = float(val.cpu().to(dtype=torch.float32).numpy())
+            metrics[f"{v}_{k}"] = float(val.detach().to(dtype=torch.float32).reshape(-1)[0])  # batch size 1 (train.py:350)
     for k in metric_keys:
         metrics[k] = float(np.mean([metrics[f"{v}_{k}"] for v in views]))
     return logits_dict, metrics

@@ -314,7 +314,7 @@ int cinema_mean_finite(const float* vals, int n, float* mean_out, float* coef_ou
 /* ---------------------------------------------------------------------------------------------------------
  * Optimiser (reference harness: torch.optim.AdamW + clip_grad_norm_ via GradScaler, cinema/optim.py:204-215,
  * cinema/mae/pretrain.py:365-366).  Flat fp32 buffers.
- *   sqnorm: out[0] += sum g^2.
+ *   sqnorm: out[0] += sum g^2, deterministic (per-block partials in `workspace`, >= 2048 floats of scratch, then one fixed-order sum).
  *   clip_coef: coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: 1); a NON-FINITE norm gives coef = 0 = "skip this update"
  *           (cinema/mae/pretrain.py:255-257 NaN-loss skip; torch GradScaler.step inf/NaN skip).  step_state (int32[2], may be NULL):
  *           [0] += 1 when the update will be applied, [1] += 1 when it is skipped.
@@ -323,7 +323,7 @@ int cinema_mean_finite(const float* vals, int n, float* mean_out, float* coef_ou
  *           without touching anything when *clip_coef is not > 0, and takes the Adam step for the bias corrections from step_state[0]
  *           (bias_corr1/2 are ignored) - the whole NaN decision stays on the device.
  */
-int cinema_sqnorm_f32(const float* g, long long n, float* out, void* stream);
+int cinema_sqnorm_f32(const float* g, long long n, float* out, float* workspace, void* stream);
 int cinema_clip_coef(const float* sqnorm, float max_norm, float* coef_out, float* norm_out, int* step_state, void* stream);
 int cinema_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, float bias_corr1, float bias_corr2, const float* clip_coef, uint16_t* p_bf16, const int* step_state,

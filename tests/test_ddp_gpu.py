@@ -1,0 +1,110 @@
+"""The data-parallel PRODUCT step with world_size = 2 on one MI355X: two processes share cuda:0 and exchange gradients through a gloo group on
+device tensors (RCCL refuses two ranks on one device; the collectives, their order, the overlapped per-block schedule from the real backward
+hooks and the flat-buffer bookkeeping are the same code - only the transport differs).  Multi-GPU RCCL runs are the driver's (bench.py --gpus N)."""
+
+from __future__ import annotations
+
+import math
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from conftest import ROOT  # noqa: E402
+
+
+def _kwargs() -> dict:
+    views = ["sax", "lax_2c"]
+    return dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1),
+                enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)}, enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)},
+                enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=2, enc_n_heads=4, dec_embed_dim=128, dec_depth=2, dec_n_heads=4)
+
+
+def _worker(rank: int, world: int, port: int, tmp: str) -> None:
+    for p in (str(ROOT), str(ROOT / "oracle")):
+        sys.path.insert(0, p)
+    import cinema_oracle as O  # noqa: N812  (mask recipe only)
+    from cinema_amd import CineMA
+    from cinema_amd.ddp import GradientSynchronizer, ddp_setup
+    from cinema_amd.optim import FlatModel, TrainStep
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    torch.cuda.set_device(0)
+    ddp_setup(rank, world, port=port, backend="gloo")
+    kw = _kwargs()
+    cfg = O.MAEConfig(**kw)
+    gen = torch.Generator().manual_seed(3)
+    images = {v: torch.rand(4, 1, *s, generator=gen) for v, s in kw["image_size_dict"].items()}
+    masks = {v: O.random_patch_mask(4, math.prod(cfg.grid_size(v)), 0.75, gen) for v in images}
+    half = slice(2 * rank, 2 * rank + 2)
+
+    # (a) eager step, injected masks: mean over ranks of the half-batch gradients == full-batch gradient, through the REAL backward hooks
+    torch.manual_seed(100 + rank)  # different initial weights per rank: attach() must broadcast rank 0's
+    model = CineMA(**kw).to("cuda")
+    flat = FlatModel(model, 0.05)
+    sync = GradientSynchronizer(world)
+    sync.min_early = 1 << 12  # the test model's blocks are small: let the overlapped per-block collectives fire
+    sync.attach(flat)
+    loss, _, _, _ = model({v: images[v][half].cuda() for v in images}, 0.75, enc_mask_dict={v: masks[v][half].cuda() for v in images})
+    sync.arm(True)
+    loss.backward()
+    sync.all_reduce()
+    torch.cuda.synchronize()
+    torch.save({"grad": flat.flat_grad.cpu(), "param": flat.flat_param.cpu(), "n_early": sync.n_early_last, "loss": float(loss)}, f"{tmp}/a{rank}.pt")
+    if rank == 0:  # single-process reference on the full batch, same weights (rank 0's), no synchroniser
+        from cinema_amd import tape as T
+
+        hook, T.PARAMS_DONE_HOOK = T.PARAMS_DONE_HOOK, None
+        ref = CineMA(**kw)
+        ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        ref.to("cuda")
+        rflat = FlatModel(ref, 0.05)
+        rloss, _, _, _ = ref({v: images[v].cuda() for v in images}, 0.75, enc_mask_dict={v: masks[v].cuda() for v in images})
+        rloss.backward()
+        torch.cuda.synchronize()
+        torch.save({"grad": rflat.flat_grad.cpu(), "loss": float(rloss)}, f"{tmp}/full.pt")
+        T.PARAMS_DONE_HOOK = hook
+    torch.distributed.barrier()
+
+    # (b) the way bench.py runs: TrainStep(replay=True) + synchroniser, rank-local data and random masks; the ranks must stay bit-identical
+    torch.manual_seed(7 + rank)
+    model2 = CineMA(**kw).to("cuda")
+    sync2 = GradientSynchronizer(world)
+    sync2.min_early = 1 << 12
+    step = TrainStep(model2, lr=1e-3, synchronizer=sync2, replay=True)
+    torch.manual_seed(1000 + rank)  # per-rank mask / data streams (cinema/mae/pretrain.py:309-310)
+    batches = [{v: torch.rand(2, 1, *s, device="cuda") for v, s in kw["image_size_dict"].items()} for _ in range(2)]
+    early, losses = [], []
+    for i in range(5):
+        loss, gn, _ = step(batches[i % 2], 0.75)
+        losses.append((float(loss), float(gn)))
+        early.append(sync2.n_early_last)
+    rec = next(iter(step._recorded.values()))  # noqa: SLF001
+    torch.cuda.synchronize()
+    torch.save({"param": step.flat.flat_param.cpu(), "losses": losses, "early": early, "host_entries": sum(1 for fn, _ in rec.calls if fn is None)},
+               f"{tmp}/b{rank}.pt")
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_product_step_on_one_gpu(tmp_path: Path) -> None:
+    from cinema_amd.ddp import get_free_port
+
+    mp.spawn(_worker, args=(2, get_free_port(), str(tmp_path)), nprocs=2, join=True)
+    a0, a1, full = (torch.load(tmp_path / f) for f in ("a0.pt", "a1.pt", "full.pt"))
+    assert torch.equal(a0["param"], a1["param"])                    # rank 0's weights everywhere
+    assert torch.equal(a0["grad"], a1["grad"])                      # every rank holds the same (mean) gradient
+    assert a0["n_early"] >= 2 and a0["n_early"] == a1["n_early"]    # per-block collectives were issued from the backward hooks, matched across ranks
+    rel = float((a0["grad"] - full["grad"]).norm() / full["grad"].norm())
+    assert rel <= 2e-2, rel                                         # 2-rank split batch == 1-rank full batch (bf16 compute, different tile shapes)
+    assert abs(0.5 * (a0["loss"] + a1["loss"]) - full["loss"]) <= 2e-3 * abs(full["loss"])
+    b0, b1 = torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt")
+    assert torch.equal(b0["param"], b1["param"])                    # replayed steps with overlapped exchange: replicas stay bit-identical
+    assert b0["host_entries"] >= 2 and b0["early"] == b1["early"] and min(b0["early"]) >= 2  # the hooks are host entries of the recording and fire on every replay
+    assert [g for _, g in b0["losses"]] == [g for _, g in b1["losses"]]  # the pre-clip norm is computed from the reduced gradient: identical
+    assert b0["losses"] != b1["losses"]                             # different data per rank: different local losses
+    assert all(math.isfinite(l) and math.isfinite(g) for l, g in b0["losses"])
