@@ -143,6 +143,8 @@ _PROTOS = {
     "cinema_transpose_cast": [_vp, _i, _i, _i, _vp, _vp],
     "cinema_gelu_fwd": [_vp, _vp, _ll, _vp],
     "cinema_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "cinema_zoom_resample": [_vp, _i, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp],
+    "cinema_scale_intensity_pad": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp],
     "cinema_mse_fwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "cinema_mse_bwd": [_vp, C.POINTER(PatchGeom), _vp, _i, _i, _i, _f, _vp, _f, _vp, _i, _vp],
     "cinema_patch_stats": [_vp, C.POINTER(PatchGeom), _vp, _vp],
@@ -1007,6 +1009,23 @@ def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     dx = torch.empty_like(x)
     _check(load().cinema_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "gelu_bwd")
     return dx
+
+
+def zoom_scale_pad(src: torch.Tensor, zoom: tuple, dst: torch.Tensor, cubic: bool = False) -> None:
+    """One sample of the input pipeline: fp32 image / volume ``src`` (*size) -> zoom (keep size) -> ScaleIntensity to [0, 1] -> written into the
+    zero-padded slot ``dst`` (*padded_size).  Two launches + a one-thread init; scratch from the per-stream workspace."""
+    _dev(src, dst)
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_contiguous() or not dst.is_contiguous() or src.dim() != dst.dim() or src.dim() not in (2, 3):
+        raise HipLibraryError("zoom_scale_pad: contiguous fp32 2-D / 3-D tensors")
+    if any(d < s for d, s in zip(dst.shape, src.shape)):
+        raise HipLibraryError("zoom_scale_pad: the destination must be at least as large as the source")
+    s3 = tuple(src.shape) + (1,) * (3 - src.dim())
+    d3 = tuple(dst.shape) + (1,) * (3 - dst.dim())
+    z3 = tuple(float(z) for z in zoom) + (1.0,) * (3 - len(zoom))
+    ws = _workspace("zoom", src.numel() + 4, src.device)
+    tmp, mm = ws[4:4 + src.numel()], ws[:2]
+    _check(load().cinema_zoom_resample(src.data_ptr(), *s3, *z3, int(cubic), tmp.data_ptr(), mm.data_ptr(), _stream()), "zoom_resample")
+    _check(load().cinema_scale_intensity_pad(tmp.data_ptr(), *s3, mm.data_ptr(), dst.data_ptr(), *d3, _stream()), "scale_intensity_pad")
 
 
 def mse_fwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_target: bool, eps: float, loss_out: torch.Tensor,

@@ -312,6 +312,17 @@ int cinema_patch_stats(const float* image, const cinema_patch_geom* geom_all_hos
 int cinema_mean_finite(const float* vals, int n, float* mean_out, float* coef_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * GPU input pipeline (reference cinema/mae/pretrain.py:157-200: monai RandZoomd -> ScaleIntensityd -> SpatialPadd(method="end") in the CPU workers).
+ * fp32 single-channel image / volume src [X][Y][Z] (Z = 1 for 2-D).
+ *   zoom_resample: monai Zoom(keep_size=True, padding_mode="constant"): interpolate to floor(size*zoom) (align_corners=False; mode 0 = (tri)linear,
+ *       mode 1 = bicubic a=-0.75 over (x, y), Z must be 1), centred zero-pad / crop back to [X][Y][Z]; minmax (2 x uint32, order-preserving float
+ *       encoding, initialised here) receives min / max of the result.  zoom = 1 is the identity.
+ *   scale_intensity_pad: dst [PX][PY][PZ] = (src - min) / (max - min) inside [X][Y][Z], 0 in the end padding; all zeros when max == min. */
+int cinema_zoom_resample(const float* src, int X, int Y, int Z, float zoom_x, float zoom_y, float zoom_z, int mode, float* dst, unsigned int* minmax,
+                         void* stream);
+int cinema_scale_intensity_pad(const float* src, int X, int Y, int Z, const unsigned int* minmax, float* dst, int PX, int PY, int PZ, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Optimiser (reference harness: torch.optim.AdamW + clip_grad_norm_ via GradScaler, cinema/optim.py:204-215,
  * cinema/mae/pretrain.py:365-366).  Flat fp32 buffers.
  *   sqnorm: out[0] += sum g^2, deterministic (per-block partials in `workspace`, >= 2048 floats of scratch, then one fixed-order sum).

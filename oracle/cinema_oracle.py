@@ -753,3 +753,33 @@ def segmentation_metrics(logits: Tensor, labels: Tensor, spacing: tuple) -> dict
     out["mean_dice_score"], out["mean_iou_score"] = dice[:, 1:].mean(-1), iou[:, 1:].mean(-1)
     out["mean_stability_score"] = stab[:, 1:].mean(-1)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# input transforms of the pre-training loader (cinema/mae/pretrain.py:157-200) -- monai 1.5.2 restated, PARITY UNPINNED (monai absent, no
+# reference value test): Zoom(keep_size=True, padding_mode="constant") = interpolate(scale_factor, recompute_scale_factor=True, align_corners
+# False) + centred pad / crop; ScaleIntensity(minv=0, maxv=1) = (x - min) / (max - min), zeros for a constant image; SpatialPad(method="end").
+# ----------------------------------------------------------------------------------------------
+def input_transform(x: Tensor, zoom: float, padded_size: tuple, cubic: bool) -> Tensor:
+    """x (*size) fp32 -> (*padded_size)."""
+    size = tuple(x.shape)
+    if zoom != 1.0:
+        mode = "bicubic" if cubic else ("trilinear" if x.dim() == 3 else "bilinear")
+        y = F.interpolate(x[None, None], scale_factor=[float(zoom)] * x.dim(), mode=mode, align_corners=False, recompute_scale_factor=True)[0, 0]
+        out = torch.zeros(size, dtype=x.dtype)
+        src, dst = [], []
+        for s, o in zip(size, y.shape):
+            if o < s:
+                b = (s - o) // 2
+                src.append(slice(0, o)); dst.append(slice(b, b + o))
+            else:
+                b = (o - s) // 2
+                src.append(slice(b, b + s)); dst.append(slice(0, s))
+        out[tuple(dst)] = y[tuple(src)]
+        x = out
+    mn, mx = x.min(), x.max()
+    x = (x - mn) / (mx - mn) if float(mx) > float(mn) else torch.zeros_like(x)
+    pad = []
+    for s, p in zip(reversed(size), reversed(tuple(padded_size))):
+        pad += [0, p - s]
+    return F.pad(x, pad)
