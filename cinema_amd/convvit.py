@@ -293,6 +293,17 @@ class MultiScaleFusion(nn.Module, _CkptFlag):
         return T.op_layernorm(tp, x, self.norm.weight, self.norm.bias, self.norm.eps, out_f32=out_f32)
 
 
+def _same_stem_geometry(model, a: str, b: str, images: dict, sels: dict) -> bool:  # noqa: ANN001
+    """Two views whose stems issue identical launch sequences: same image shape, same stem configuration, same token selection sizes."""
+    ea, eb = model.enc_down_dict[a], model.enc_down_dict[b]
+    if tuple(images[a].shape) != tuple(images[b].shape) or ea.patch_sizes != eb.patch_sizes:
+        return False
+    if [tuple(p.shape) for p in ea.parameters()] != [tuple(p.shape) for p in eb.parameters()]:
+        return False
+    sa, sb = sels[a], sels[b]
+    return (sa.n_keep, sa.n_drop, sa.all_tokens, sa.mask is None) == (sb.n_keep, sb.n_drop, sb.all_tokens, sb.mask is None)
+
+
 def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids: dict):  # noqa: ANN001, ANN201
     """Stem -> kept-token embedding (+ positional table) -> [cls | view tokens] sequence -> ``model.encoder`` -> LN, shared by
     ``CineMA`` and ``ConvViT`` (reference ``mae.py:535-562``, ``convvit.py:478-493``).
@@ -309,15 +320,35 @@ def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids
 
     cls_rows = rows_of(0, 1)
     segs, skips_all, view_rows = [T.Segment(cls_rows, src=model.encoder.cls_token)], {}, {}
-    off = 1
+    offs, off = {}, 1
     for v, nk in zip(views, n_keep):
+        offs[v] = off
+        off += nk
+
+    def stem(v: str) -> None:
         enc = model.enc_down_dict[v]
         skips_all[v], tok = enc.tape_forward(tp, images[v], sels[v], grids[v])
-        rows = rows_of(off, nk)
+        rows = rows_of(offs[v], sels[v].n_keep)
         view_rows[v] = rows
         pe = enc.interpolate_pos_encoding(grids[v]).detach().reshape(-1, e)
         segs.append(T.Segment(rows, src=tok, add=pe, add_idx=sels[v].keep_pos))
-        off += nk
+
+    # consecutive views of identical geometry (the three long-axis views: same shapes, separate weights) run as ONE lane group: their ~45 forward /
+    # ~95 backward tiny stem launches each go out zipped, one wide launch per position (hip.lanes; the views share nothing inside the stems)
+    i = 0
+    while i < len(views):
+        j = i + 1
+        while j < len(views) and j - i < 4 and _same_stem_geometry(model, views[i], views[j], images, sels):
+            j += 1
+        if j - i >= 2 and images[views[i]].is_cuda:
+            with T.lane_group(tp, j - i) as grp:
+                for lane, v in enumerate(views[i:j]):
+                    grp.select(lane)
+                    stem(v)
+        else:
+            for v in views[i:j]:
+                stem(v)
+        i = j
     x = T.op_assemble(tp, batch * t_e, e, segs, dev)
     x = model.encoder.tape_forward(tp, x, batch)
     return x, skips_all, cls_rows, view_rows

@@ -607,14 +607,14 @@ CINEMA_API int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* 
   hipStream_t st = (hipStream_t)stream;
   if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo}, {q, k, v, o})) {
     dim3 grid((tq + 127) / 128, h, b);
-    if (hd == 64) hipLaunchKernelGGL(attn_fwd_mfma<64>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(attn_fwd_mfma<32>, grid, dim3(256), 0, st, p);
+    if (hd == 64) CINEMA_LAUNCH(attn_fwd_mfma<64>, grid, dim3(256), 0, st, p);
+    else CINEMA_LAUNCH(attn_fwd_mfma<32>, grid, dim3(256), 0, st, p);
     return launch_status();
   }
   const size_t smem = (size_t)4 * tk * sizeof(float);
   if (smem > 150 * 1024) return CINEMA_ERR_UNSUPPORTED;
   const long long rows = (long long)b * h * tq;
-  hipLaunchKernelGGL(attn_fwd_generic, dim3((unsigned)((rows + 3) / 4)), dim3(256), smem, st, p);
+  CINEMA_LAUNCH(attn_fwd_generic, dim3((unsigned)((rows + 3) / 4)), dim3(256), smem, st, p);
   return launch_status();
 }
 
@@ -637,24 +637,24 @@ CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* 
     // delta is produced by the dQ kernel (from its O / dO row fragments) and consumed by the dK/dV kernel behind it
   } else if (pow2 && !(ldo & 7) && !(lddo & 7) && !(((uintptr_t)o) & 15) && !(((uintptr_t)d_o) & 15)) {
     const long long rows = (long long)b * tq;
-    hipLaunchKernelGGL(attn_delta_vec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    CINEMA_LAUNCH(attn_delta_vec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   } else {
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, p);
+    CINEMA_LAUNCH(attn_delta_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, p);
   }
   if (mfma && mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv})) {
     dim3 gq((tq + 127) / 128, h, b), gk((tk + 127) / 128, h, b);
     if (hd == 64) {
-      hipLaunchKernelGGL(attn_bwd_dq_mfma<64>, gq, dim3(256), 0, st, p);
-      hipLaunchKernelGGL(attn_bwd_dkv_mfma<64>, gk, dim3(256), 0, st, p);
+      CINEMA_LAUNCH(attn_bwd_dq_mfma<64>, gq, dim3(256), 0, st, p);
+      CINEMA_LAUNCH(attn_bwd_dkv_mfma<64>, gk, dim3(256), 0, st, p);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dq_mfma<32>, gq, dim3(256), 0, st, p);
-      hipLaunchKernelGGL(attn_bwd_dkv_mfma<32>, gk, dim3(256), 0, st, p);
+      CINEMA_LAUNCH(attn_bwd_dq_mfma<32>, gq, dim3(256), 0, st, p);
+      CINEMA_LAUNCH(attn_bwd_dkv_mfma<32>, gk, dim3(256), 0, st, p);
     }
     return launch_status();
   }
   if ((size_t)4 * tk * sizeof(float) > 150 * 1024 || (size_t)8 * tq * sizeof(float) > 150 * 1024) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_bwd_q_generic, dim3((unsigned)((nq + 3) / 4)), dim3(256), (size_t)4 * tk * sizeof(float), st, p);
+  CINEMA_LAUNCH(attn_bwd_q_generic, dim3((unsigned)((nq + 3) / 4)), dim3(256), (size_t)4 * tk * sizeof(float), st, p);
   const long long nk = (long long)b * h * tk;
-  hipLaunchKernelGGL(attn_bwd_kv_generic, dim3((unsigned)((nk + 3) / 4)), dim3(256), (size_t)8 * tq * sizeof(float), st, p);
+  CINEMA_LAUNCH(attn_bwd_kv_generic, dim3((unsigned)((nk + 3) / 4)), dim3(256), (size_t)8 * tq * sizeof(float), st, p);
   return launch_status();
 }

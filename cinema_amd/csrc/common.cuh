@@ -17,6 +17,59 @@ typedef __attribute__((ext_vector_type(16))) float float16v;
 
 static inline int launch_status() { return (int)hipGetLastError(); }
 
+// ---- lane groups (stream.hip): independent, identically shaped launch sequences zipped into merged launches -------------------------------------
+// The three long-axis views of an MAE step run the same ~45 (forward) / ~95 (backward) tiny stem kernels on different pointers: 550 launches of 5-10 us
+// whose cost is launch latency, not work.  Between cinema_lanes_begin(n) and cinema_lanes_end() the launches of the library are not issued but
+// recorded per lane (cinema_lanes_select(i) switches the lane); at the end the n sequences are walked in lock step and every position whose n
+// launches are the same kernel with the same launch geometry becomes ONE launch of the kernel's *_lanes form (grid x n in the dimension the
+// kernel does not use; block (.., lane, ..) reads parameter block `lane`).  Positions that do not match (or kernels without a lanes form) are
+// issued one by one in lane order - each lane keeps its own order, and lanes are independent by contract, so any interleaving is valid.
+constexpr int MAX_LANES = 4;
+template <typename P>
+struct Lanes { P p[MAX_LANES]; };
+bool lanes_active();
+// Record (inside a lane group) or issue (outside) one launch.  `relaunch(fn_single, grid, block, smem, stream, params)` issues the single form from the
+// stored parameter bytes; fn_lanes (may be NULL) is the merged form taking Lanes<P> when the parameter bytes are ONE struct P.
+typedef int (*lane_relaunch_t)(const void* fn, dim3 grid, dim3 block, size_t smem, hipStream_t st, const void* params);
+int lane_submit(lane_relaunch_t relaunch, const void* fn_single, const void* fn_lanes, int lane_dim, dim3 grid, dim3 block, size_t smem, hipStream_t st,
+                const void* params, size_t psize);
+inline int lane_relaunch_struct(const void* fn, dim3 grid, dim3 block, size_t smem, hipStream_t st, const void* params) {
+  void* args[] = {const_cast<void*>(params)};
+  return (int)hipLaunchKernel(fn, grid, block, args, smem, st);
+}
+// a kernel with ONE struct parameter and a lanes form: lane_dim 1 = blockIdx.y, 2 = blockIdx.z selects the lane (that grid dimension must be 1)
+template <typename P>
+inline void launch_lanes(void (*single)(P), void (*lanes)(Lanes<P>), int lane_dim, dim3 g, dim3 b, size_t smem, hipStream_t st, const P& p) {
+  (void)lane_submit(lane_relaunch_struct, (const void*)single, (const void*)lanes, lane_dim, g, b, smem, st, &p, sizeof(P));
+}
+// any other kernel: the arguments are packed into a POD tuple so that the launch can be replayed in order at the end of a lane group
+template <typename... A> struct ArgPack;
+template <> struct ArgPack<> {};
+template <typename H, typename... T> struct ArgPack<H, T...> { H h; ArgPack<T...> t; };
+template <typename... KA, typename... Done>
+inline void argpack_launch(void (*k)(KA...), dim3 g, dim3 b, size_t smem, hipStream_t st, const ArgPack<>&, Done... d) { hipLaunchKernelGGL(k, g, b, smem, st, d...); }
+template <typename... KA, typename H, typename... T, typename... Done>
+inline void argpack_launch(void (*k)(KA...), dim3 g, dim3 b, size_t smem, hipStream_t st, const ArgPack<H, T...>& p, Done... d) {
+  argpack_launch(k, g, b, smem, st, p.t, d..., p.h);
+}
+template <typename... KA>
+inline int lane_relaunch_pack(const void* fn, dim3 grid, dim3 block, size_t smem, hipStream_t st, const void* params) {
+  argpack_launch(reinterpret_cast<void (*)(KA...)>(const_cast<void*>(fn)), grid, block, smem, st, *reinterpret_cast<const ArgPack<KA...>*>(params));
+  return (int)hipPeekAtLastError();
+}
+template <typename... KA> inline void argpack_fill(ArgPack<KA...>&) {}
+template <typename H, typename... T, typename A0, typename... A>
+inline void argpack_fill(ArgPack<H, T...>& p, A0&& a0, A&&... a) { p.h = static_cast<H>(a0); argpack_fill(p.t, static_cast<A&&>(a)...); }
+template <typename... KA, typename... A>
+inline void launch_any(void (*kernel)(KA...), dim3 g, dim3 b, size_t smem, hipStream_t st, A&&... a) {
+  static_assert(sizeof...(KA) == sizeof...(A), "argument count");
+  if (!lanes_active()) { hipLaunchKernelGGL(kernel, g, b, smem, st, static_cast<KA>(a)...); return; }
+  ArgPack<KA...> pk;
+  argpack_fill(pk, static_cast<A&&>(a)...);
+  (void)lane_submit(lane_relaunch_pack<KA...>, (const void*)kernel, nullptr, 0, g, b, smem, st, &pk, sizeof(pk));
+}
+#define CINEMA_LAUNCH(kernel, grid, block, smem, st, ...) launch_any(kernel, grid, block, smem, st, __VA_ARGS__)
+
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // fp32 -> bf16, round-to-nearest-even, on the gfx950 hardware converter (v_cvt_pk_bf16_f32: one instruction per PAIR;
 // a bit-twiddled software rounding costs ~8 VALU instructions per element and showed up in every epilogue)

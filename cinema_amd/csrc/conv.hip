@@ -318,7 +318,7 @@ __device__ __forceinline__ long long patch_src_offset(const PatchP& g, int row, 
 
 // VEC=4: c % 4 == 0 and sc == 1 (channels-last source), 4 consecutive features share one patch voxel
 template <typename TS, typename TO, int VEC>
-__global__ void patch_gather_kernel(const TS* src, TO* out, int ld_out, PatchP g) {
+__device__ __forceinline__ void patch_gather_body(const TS* src, TO* out, int ld_out, PatchP g) {
   const int F = g.px * g.py * g.pz * g.c;
   const long long total = (long long)g.n_rows * (F / VEC);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -329,9 +329,14 @@ __global__ void patch_gather_kernel(const TS* src, TO* out, int ld_out, PatchP g
     for (int v = 0; v < VEC; v++) stf<TO>(out + (size_t)row * ld_out + f + v, ldf<TS>(src + off + v));
   }
 }
-
+template <typename TS, typename TO, int VEC>
+struct PGatherP { const TS* src; TO* out; int ld_out; PatchP g; };
+template <typename TS, typename TO, int VEC>
+__global__ void patch_gather_kernel(PGatherP<TS, TO, VEC> q) { patch_gather_body<TS, TO, VEC>(q.src, q.out, q.ld_out, q.g); }
+template <typename TS, typename TO, int VEC>
+__global__ void patch_gather_lanes_kernel(Lanes<PGatherP<TS, TO, VEC>> L) { const PGatherP<TS, TO, VEC>& q = L.p[blockIdx.y]; patch_gather_body<TS, TO, VEC>(q.src, q.out, q.ld_out, q.g); }
 template <typename TR, typename TD, int VEC>
-__global__ void patch_scatter_kernel(const TR* rows, int ld_rows, TD* dst, int accumulate, PatchP g) {
+__device__ __forceinline__ void patch_scatter_body(const TR* rows, int ld_rows, TD* dst, int accumulate, PatchP g) {
   const int F = g.px * g.py * g.pz * g.c;
   const long long total = (long long)g.n_rows * (F / VEC);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -346,7 +351,12 @@ __global__ void patch_scatter_kernel(const TR* rows, int ld_rows, TD* dst, int a
     }
   }
 }
-
+template <typename TR, typename TD, int VEC>
+struct PScatterP { const TR* rows; int ld_rows; TD* dst; int accumulate; PatchP g; };
+template <typename TR, typename TD, int VEC>
+__global__ void patch_scatter_kernel(PScatterP<TR, TD, VEC> q) { patch_scatter_body<TR, TD, VEC>(q.rows, q.ld_rows, q.dst, q.accumulate, q.g); }
+template <typename TR, typename TD, int VEC>
+__global__ void patch_scatter_lanes_kernel(Lanes<PScatterP<TR, TD, VEC>> L) { const PScatterP<TR, TD, VEC>& q = L.p[blockIdx.y]; patch_scatter_body<TR, TD, VEC>(q.rows, q.ld_rows, q.dst, q.accumulate, q.g); }
 PatchP to_dev(const cinema_patch_geom* g) {
   PatchP p;
   p.b = g->b; p.c = g->c; p.gx = g->gx; p.gy = g->gy; p.gz = g->gz; p.px = g->px; p.py = g->py; p.pz = g->pz;
@@ -377,12 +387,12 @@ static int dw_launch_fwd(const DwP& p, hipStream_t st) {
     const long long npos = (long long)p.b * p.X * p.Y;
     dim3 zgrid((unsigned)((npos + 31) / 32), (p.c + 63) / 64, nzb);
     const size_t wsmem = (size_t)p.kx * p.ky * 5 * 64 * sizeof(float);
-    if (p.Z == 16) hipLaunchKernelGGL((dwconv_zcol_kernel<16, true>), zgrid, dim3(256), wsmem, st, p);
-    else hipLaunchKernelGGL((dwconv_zcol_kernel<16, false>), zgrid, dim3(256), wsmem, st, p);
+    if (p.Z == 16) CINEMA_LAUNCH((dwconv_zcol_kernel<16, true>), zgrid, dim3(256), wsmem, st, p);
+    else CINEMA_LAUNCH((dwconv_zcol_kernel<16, false>), zgrid, dim3(256), wsmem, st, p);
     return launch_status();
   }
   const size_t smem = (size_t)p.kx * p.ky * p.kz * 32 * sizeof(float);
-  hipLaunchKernelGGL(dwconv_fwd_kernel, grid, dim3(256), smem, st, p);
+  CINEMA_LAUNCH(dwconv_fwd_kernel, grid, dim3(256), smem, st, p);
   return launch_status();
 }
 
@@ -418,18 +428,18 @@ CINEMA_API int cinema_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, f
     const int taps = kx * ky * kz;
     const long long need = (long long)grid.x * c * (taps + 1) * 4;
     p.ws = (workspace && workspace_bytes >= need && !(c & 63)) ? workspace : nullptr;  // every (block, channel, tap) slot is written when c % 64 == 0
-    if (Z == 16) hipLaunchKernelGGL((dwconv_wgrad_walk_kernel<5, 16>), grid, dim3(threads), 0, st, p, cpb);
-    else hipLaunchKernelGGL((dwconv_wgrad_walk_kernel<5, 0>), grid, dim3(threads), 0, st, p, cpb);
+    if (Z == 16) CINEMA_LAUNCH((dwconv_wgrad_walk_kernel<5, 16>), grid, dim3(threads), 0, st, p, cpb);
+    else CINEMA_LAUNCH((dwconv_wgrad_walk_kernel<5, 0>), grid, dim3(threads), 0, st, p, cpb);
     if (p.ws) {
       const int total = c * (taps + 1);
-      hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((total + 255) / 256, 16), dim3(256), 0, st, (const float*)p.ws, (int)grid.x, c * taps, c, dw, dbias);
+      CINEMA_LAUNCH(dwconv_wgrad_reduce_kernel, dim3((total + 255) / 256, 16), dim3(256), 0, st, (const float*)p.ws, (int)grid.x, c * taps, c, dw, dbias);
     }
     return launch_status();
   }
   const long long nvox = (long long)b * X * Y * Z;
   long long vpb = (nvox + 511) / 512;
   if (vpb < 64) vpb = 64;
-  hipLaunchKernelGGL(dwconv_wgrad_naive_kernel, dim3((unsigned)((nvox + vpb - 1) / vpb)), dim3(256), 0, st, p, vpb);
+  CINEMA_LAUNCH(dwconv_wgrad_naive_kernel, dim3((unsigned)((nvox + vpb - 1) / vpb)), dim3(256), 0, st, p, vpb);
   return launch_status();
 }
 
@@ -443,8 +453,8 @@ CINEMA_API int cinema_patch_gather(const void* src, int src_dtype, void* out, in
   const int grid = grid_for((long long)g.n_rows * F / (vec ? 4 : 1), 256);
 #define CINEMA_PG(TS, TO)                                                                                                  \
   do {                                                                                                                     \
-    if (vec) hipLaunchKernelGGL((patch_gather_kernel<TS, TO, 4>), dim3(grid), dim3(256), 0, st, (const TS*)src, (TO*)out, ld_out, g); \
-    else hipLaunchKernelGGL((patch_gather_kernel<TS, TO, 1>), dim3(grid), dim3(256), 0, st, (const TS*)src, (TO*)out, ld_out, g);     \
+    if (vec) launch_lanes(patch_gather_kernel<TS, TO, 4>, patch_gather_lanes_kernel<TS, TO, 4>, 1, dim3(grid), dim3(256), 0, st, PGatherP<TS, TO, 4>{(const TS*)src, (TO*)out, ld_out, g}); \
+    else launch_lanes(patch_gather_kernel<TS, TO, 1>, patch_gather_lanes_kernel<TS, TO, 1>, 1, dim3(grid), dim3(256), 0, st, PGatherP<TS, TO, 1>{(const TS*)src, (TO*)out, ld_out, g});     \
   } while (0)
   if (src_dtype == 1 && out_dtype == 0) CINEMA_PG(float, bf16_t);
   else if (src_dtype == 1 && out_dtype == 1) CINEMA_PG(float, float);
@@ -465,8 +475,8 @@ CINEMA_API int cinema_patch_scatter(const void* rows, int rows_dtype, int ld_row
   const int grid = grid_for((long long)g.n_rows * F / (vec ? 4 : 1), 256);
 #define CINEMA_PS(TR, TD)                                                                                                                 \
   do {                                                                                                                                    \
-    if (vec) hipLaunchKernelGGL((patch_scatter_kernel<TR, TD, 4>), dim3(grid), dim3(256), 0, st, (const TR*)rows, ld_rows, (TD*)dst, accumulate, g); \
-    else hipLaunchKernelGGL((patch_scatter_kernel<TR, TD, 1>), dim3(grid), dim3(256), 0, st, (const TR*)rows, ld_rows, (TD*)dst, accumulate, g);     \
+    if (vec) launch_lanes(patch_scatter_kernel<TR, TD, 4>, patch_scatter_lanes_kernel<TR, TD, 4>, 1, dim3(grid), dim3(256), 0, st, PScatterP<TR, TD, 4>{(const TR*)rows, ld_rows, (TD*)dst, accumulate, g}); \
+    else launch_lanes(patch_scatter_kernel<TR, TD, 1>, patch_scatter_lanes_kernel<TR, TD, 1>, 1, dim3(grid), dim3(256), 0, st, PScatterP<TR, TD, 1>{(const TR*)rows, ld_rows, (TD*)dst, accumulate, g});     \
   } while (0)
   if (rows_dtype == 0 && dst_dtype == 0) CINEMA_PS(bf16_t, bf16_t);
   else if (rows_dtype == 0 && dst_dtype == 1) CINEMA_PS(bf16_t, float);
@@ -569,7 +579,7 @@ CINEMA_API int cinema_im2col(const uint16_t* x, uint16_t* cols, int ld_cols, int
     return CINEMA_ERR_UNSUPPORTED;
   ColP p{}; p.x = x; p.cols = cols; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.ld = ld_cols;
   const long long items = (long long)b * X * Y * Z * ((c & 7) ? ld_cols : ld_cols / 8);
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  CINEMA_LAUNCH(im2col_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
 
@@ -579,6 +589,6 @@ CINEMA_API int cinema_col2im(const uint16_t* dcols, int ld_cols, uint16_t* dx, i
     return CINEMA_ERR_UNSUPPORTED;
   ColP p{}; p.dcols = dcols; p.dx = dx; p.b = b; p.X = X; p.Y = Y; p.Z = Z; p.c = c; p.kx = kx; p.ky = ky; p.kz = kz; p.ld = ld_cols;
   const long long items = (long long)b * X * Y * Z * ((c & 7) ? c : c / 8);
-  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  CINEMA_LAUNCH(col2im_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }

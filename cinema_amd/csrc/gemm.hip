@@ -560,11 +560,10 @@ __device__ __forceinline__ void half_epilogue(const GemmP& p, const float16v (&a
 // 128x128x32 kernel, 2 stages of 16 KiB, three workgroups per CU (see TileIO32).  gridDim.z = split-K slices as in the BK = 64 kernel;
 // no split tail, no bias-gradient row sums; K % 32 == 0.
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
-__global__ __launch_bounds__(256, 3) void gemm_mfma_k32_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_mfma_k32_body(const GemmP& p, char* smem) {
   using AIO = TileIO32<A_KMAJ>;
   using BIO = TileIO32<B_KMAJ>;
   constexpr int STAGE = AIO::BYTES + BIO::BYTES;  // 16 KiB
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
@@ -622,6 +621,17 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k32_kernel(GemmP p) {
   float* stg = reinterpret_cast<float*>(smem + wave * 8192);  // 8 KiB per wave: one 32x64 half at a time
   half_epilogue<EPI>(p, acc[0], m0 + wm, n0 + wn, lane, zsplit, stg);
   half_epilogue<EPI>(p, acc[1], m0 + wm + 32, n0 + wn, lane, zsplit, stg);
+}
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_mfma_k32_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO32<A_KMAJ>::BYTES + TileIO32<B_KMAJ>::BYTES)];
+  gemm_mfma_k32_body<A_KMAJ, B_KMAJ, EPI>(p, smem);
+}
+// lanes form (common.cuh): blockIdx.y = lane, one parameter block per lane (identical shapes, different pointers)
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_mfma_k32_lanes_kernel(Lanes<GemmP> L) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO32<A_KMAJ>::BYTES + TileIO32<B_KMAJ>::BYTES)];
+  gemm_mfma_k32_body<A_KMAJ, B_KMAJ, EPI>(L.p[blockIdx.y], smem);
 }
 
 // One 128x128 output tile (or k-slice of one) of problem p: everything after the work-item decoding of the kernels below.
@@ -732,15 +742,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
 }
 
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
-  using AIO = TileIO<A_KMAJ>;
-  using BIO = TileIO<B_KMAJ>;
-  constexpr int STAGE = AIO::BYTES + BIO::BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int tiles_n = (p.n + BN - 1) / BN, tiles_m = (p.m + BM - 1) / BM;
+__device__ __forceinline__ void gemm_mfma_body(const GemmP& p, char* smem) {
   // linear dispatch id (x fastest, then z) -> logical work item, split-major so that one XCD sees one k-range
   const int nkt = (p.k + BK - 1) / BK;
   int zsplit = 0, tile, kt_begin, kt_end;
@@ -763,6 +765,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
     kt_end = min(nkt, kt_begin + p.ktiles_per_split);
   }
   gemm_tile<A_KMAJ, B_KMAJ, EPI>(p, tile, zsplit, kt_begin, kt_end, tail_dst, smem);
+}
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO<A_KMAJ>::BYTES + TileIO<B_KMAJ>::BYTES)];
+  gemm_mfma_body<A_KMAJ, B_KMAJ, EPI>(p, smem);
+}
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_lanes_kernel(Lanes<GemmP> L) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO<A_KMAJ>::BYTES + TileIO<B_KMAJ>::BYTES)];
+  gemm_mfma_body<A_KMAJ, B_KMAJ, EPI>(L.p[blockIdx.y], smem);
 }
 
 // GROUPED launch: the tiles of up to 8 independent problems in one grid (no split-K).  The four weight gradients of a transformer block
@@ -788,7 +800,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_grouped_kernel(GroupP g) {
 }
 
 // Sums the k-slices of the split-tail tiles and applies the fused epilogue: thread = 8 consecutive columns of one row.
-__global__ __launch_bounds__(256) void tail_fixup_kernel(GemmP p, int tiles_m, int tiles_n) {
+struct TailFixP { GemmP p; int tiles_m, tiles_n; };
+__device__ __forceinline__ void tail_fixup_body(const GemmP& p, int tiles_m, int tiles_n) {
   const int r = blockIdx.x >> 3;
   const int idx = (blockIdx.x & 7) * 256 + threadIdx.x;
   const int row = idx >> 4, c8 = (idx & 15) * 8;
@@ -810,6 +823,8 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(GemmP p, int tiles_m, i
     epilogue_row<8>(p, m, n, v, true);
   }
 }
+__global__ __launch_bounds__(256) void tail_fixup_kernel(TailFixP t) { tail_fixup_body(t.p, t.tiles_m, t.tiles_n); }
+__global__ __launch_bounds__(256) void tail_fixup_lanes_kernel(Lanes<TailFixP> L) { const TailFixP& t = L.p[blockIdx.y]; tail_fixup_body(t.p, t.tiles_m, t.tiles_n); }
 
 // ------------------------------------------------------------------------------------------------
 // Generic kernel: any shape / alignment, fp32 FMA on bf16 inputs, 64x64 tile, 16x16 threads x (4x4).
@@ -869,7 +884,8 @@ __global__ void colsum_kernel(const void* x, int is_f32, const int* row_idx, int
 }
 
 // dst[m][n] (+)= alpha * sum_z ws[z][m][n]   (second pass of the workspace split-K; fully coalesced, deterministic)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splits, int m, int n, float* dst, int ldd, int accumulate, float alpha) {
+struct SplitkP { const float* ws; int splits, m, n; float* dst; int ldd, accumulate; float alpha; };
+__device__ __forceinline__ void splitk_reduce_body(const float* ws, int splits, int m, int n, float* dst, int ldd, int accumulate, float alpha) {
   // grid.y slices the split range (tiny outputs come with hundreds of splits: a single thread summing them serially was
   // latency-bound); slices > 1 combine with fp32 atomics (only ever used with accumulate=1), one slice does a plain RMW
   const long long total4 = (long long)m * n / 4;
@@ -901,6 +917,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
       *d = s;
     }
   }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitkP q) { splitk_reduce_body(q.ws, q.splits, q.m, q.n, q.dst, q.ldd, q.accumulate, q.alpha); }
+__global__ __launch_bounds__(256) void splitk_reduce_lanes_kernel(Lanes<SplitkP> L) {
+  const SplitkP& q = L.p[blockIdx.z];
+  splitk_reduce_body(q.ws, q.splits, q.m, q.n, q.dst, q.ldd, q.accumulate, q.alpha);
 }
 
 // Streaming column sum for dense bf16 matrices (bias gradients): 16-byte loads, 8 columns per lane, 32 lanes x 8 row-lanes
@@ -1034,9 +1055,9 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
         a->kernel_used += 128;  // the BK = 32 instance of the same layout / epilogue class
 #define LAUNCH_K32(E)                                                                                                          \
   do {                                                                                                                         \
-    if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_k32_kernel<true, true, E>), grid, dim3(256), 0, st, p);        \
-    else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_k32_kernel<true, false, E>), grid, dim3(256), 0, st, p); \
-    else hipLaunchKernelGGL((gemm_mfma_k32_kernel<false, false, E>), grid, dim3(256), 0, st, p);                                 \
+    if (a->a_kmajor && a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, true, E>, gemm_mfma_k32_lanes_kernel<true, true, E>, 1, grid, dim3(256), 0, st, p);        \
+    else if (a->a_kmajor && !a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, false, E>, gemm_mfma_k32_lanes_kernel<true, false, E>, 1, grid, dim3(256), 0, st, p); \
+    else launch_lanes(gemm_mfma_k32_kernel<false, false, E>, gemm_mfma_k32_lanes_kernel<false, false, E>, 1, grid, dim3(256), 0, st, p);                                 \
   } while (0)
         switch (epi) {
           case EPI_BF16: LAUNCH_K32(EPI_BF16); break;
@@ -1048,9 +1069,9 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       } else {
 #define LAUNCH_LAYOUT(E)                                                                                                    \
   do {                                                                                                                      \
-    if (a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, true, E>), grid, dim3(256), 0, st, p);        \
-    else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_mfma_kernel<true, false, E>), grid, dim3(256), 0, st, p); \
-    else hipLaunchKernelGGL((gemm_mfma_kernel<false, false, E>), grid, dim3(256), 0, st, p);                                 \
+    if (a->a_kmajor && a->b_kmajor) launch_lanes(gemm_mfma_kernel<true, true, E>, gemm_mfma_lanes_kernel<true, true, E>, 1, grid, dim3(256), 0, st, p);        \
+    else if (a->a_kmajor && !a->b_kmajor) launch_lanes(gemm_mfma_kernel<true, false, E>, gemm_mfma_lanes_kernel<true, false, E>, 1, grid, dim3(256), 0, st, p); \
+    else launch_lanes(gemm_mfma_kernel<false, false, E>, gemm_mfma_lanes_kernel<false, false, E>, 1, grid, dim3(256), 0, st, p);                                 \
   } while (0)
       switch (epi) {
         case EPI_BF16: LAUNCH_LAYOUT(EPI_BF16); break;
@@ -1064,7 +1085,8 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     }
     if (tail) {
       const int rem = ((int)grid.x - p.tail_begin) / p.tail_split;
-      hipLaunchKernelGGL(tail_fixup_kernel, dim3(rem * 8), dim3(256), 0, st, p, (a->m + BM - 1) / BM, (a->n + BN - 1) / BN);
+      const TailFixP tf{p, (a->m + BM - 1) / BM, (a->n + BN - 1) / BN};
+      launch_lanes(tail_fixup_kernel, tail_fixup_lanes_kernel, 1, dim3(rem * 8), dim3(256), 0, st, tf);
     }
     if (two_pass) {
       long long blocks = ((long long)a->m * a->n / 4 + 255) / 256;
@@ -1075,8 +1097,8 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
         if (slices > (gz + 7) / 8) slices = (gz + 7) / 8;
         if (slices < 1) slices = 1;
       }
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks, slices), dim3(256), 0, st, (const float*)a->workspace, gz, a->m, a->n, (float*)a->d, a->ldd,
-                         a->accumulate, a->alpha);
+      const SplitkP sk{(const float*)a->workspace, gz, a->m, a->n, (float*)a->d, a->ldd, a->accumulate, a->alpha};
+      launch_lanes(splitk_reduce_kernel, splitk_reduce_lanes_kernel, 2, dim3((unsigned)blocks, slices), dim3(256), 0, st, sk);
     }
     return launch_status();
   }
@@ -1090,13 +1112,13 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     int chunks = (a->k + 511) / 512;
     if (chunks > 256) chunks = 256;
     const int rpb = (a->k + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colsum_kernel, dim3((a->m + 63) / 64, (a->k + rpb - 1) / rpb), dim3(256), 0, st, a->a, 0, (const int*)nullptr, a->k, a->m, a->lda,
+    CINEMA_LAUNCH(colsum_kernel, dim3((a->m + 63) / 64, (a->k + rpb - 1) / rpb), dim3(256), 0, st, a->a, 0, (const int*)nullptr, a->k, a->m, a->lda,
                        a->a_rowsum, rpb);
   }
   const int a_rs = a->a_kmajor ? a->lda : 1, a_cs = a->a_kmajor ? 1 : a->lda;   // element (m,k) = a[m*a_rs + k*a_cs]
   const int b_rs = a->b_kmajor ? 1 : a->ldb, b_cs = a->b_kmajor ? a->ldb : 1;   // element (k,n) = b[k*b_rs + n*b_cs]
   a->kernel_used = 0;
-  hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, st, p, a_rs, a_cs, b_rs, b_cs);
+  CINEMA_LAUNCH(gemm_generic_kernel, grid, dim3(256), 0, st, p, a_rs, a_cs, b_rs, b_cs);
   return launch_status();
 }
 
@@ -1129,7 +1151,7 @@ CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void*
     args[i].kernel_used = 64;  // the grouped kernel
   }
   for (int i = count + 1; i < 9; i++) g.tile_begin[i] = g.tile_begin[count];
-  hipLaunchKernelGGL((gemm_mfma_grouped_kernel<false, false, EPI_F32>), dim3(g.tile_begin[count]), dim3(256), 0, (hipStream_t)stream, g);
+  CINEMA_LAUNCH((gemm_mfma_grouped_kernel<false, false, EPI_F32>), dim3(g.tile_begin[count]), dim3(256), 0, (hipStream_t)stream, g);
   return launch_status();
 }
 
@@ -1174,7 +1196,7 @@ CINEMA_API int cinema_colsum(const void* x, int x_dtype, const int* row_idx, int
     if (row_chunks > (m + 63) / 64) row_chunks = (m + 63) / 64;
     const int rpb = (((m + row_chunks - 1) / row_chunks) + 7) / 8 * 8;
     dim3 grid(col_blocks, (m + rpb - 1) / rpb);
-    hipLaunchKernelGGL(colsum_bf16_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, m, n, ldx, out, rpb);
+    CINEMA_LAUNCH(colsum_bf16_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, m, n, ldx, out, rpb);
     return launch_status();
   }
   if (x_dtype == 1 && !(n & 3) && !(ldx & 3) && !(((uintptr_t)x) & 15)) {
@@ -1183,13 +1205,13 @@ CINEMA_API int cinema_colsum(const void* x, int x_dtype, const int* row_idx, int
     if (chunks > (m + 31) / 32) chunks = (m + 31) / 32;
     const int rpb = (m + chunks - 1) / chunks;
     dim3 grid(col_blocks, (m + rpb - 1) / rpb);
-    hipLaunchKernelGGL(colsum_f32_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, row_idx, m, n, ldx, out, rpb);
+    CINEMA_LAUNCH(colsum_f32_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, row_idx, m, n, ldx, out, rpb);
     return launch_status();
   }
   int chunks = (m + 511) / 512;
   if (chunks > 256) chunks = 256;
   const int rpb = (m + chunks - 1) / chunks;
   dim3 grid((n + 63) / 64, (m + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_dtype, row_idx, m, n, ldx, out, rpb);
+  CINEMA_LAUNCH(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_dtype, row_idx, m, n, ldx, out, rpb);
   return launch_status();
 }

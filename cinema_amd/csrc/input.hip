@@ -93,10 +93,10 @@ CINEMA_API int cinema_zoom_resample(const float* src, int X, int Y, int Z, float
   ZoomP p{src, dst, minmax, X, Y, Z, (int)floorf(X * zoom_x), (int)floorf(Y * zoom_y), Z == 1 ? 1 : (int)floorf(Z * zoom_z), mode};
   if (p.ox < 1 || p.oy < 1 || p.oz < 1) return CINEMA_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, minmax);
+  CINEMA_LAUNCH(minmax_init_kernel, dim3(1), dim3(1), 0, st, minmax);
   long long g = ((long long)X * Y * Z + 255) / 256;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(zoom_resample_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+  CINEMA_LAUNCH(zoom_resample_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
   return launch_status();
 }
 
@@ -104,6 +104,6 @@ CINEMA_API int cinema_scale_intensity_pad(const float* src, int X, int Y, int Z,
   if (!src || !dst || !minmax || X <= 0 || Y <= 0 || Z <= 0 || PX <= 0 || PY <= 0 || PZ <= 0) return CINEMA_ERR_BAD_ARG;
   long long g = ((long long)PX * PY * PZ + 255) / 256;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(scale_pad_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, X, Y, Z, minmax, dst, PX, PY, PZ);
+  CINEMA_LAUNCH(scale_pad_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, X, Y, Z, minmax, dst, PX, PY, PZ);
   return launch_status();
 }

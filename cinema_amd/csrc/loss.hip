@@ -228,10 +228,10 @@ CINEMA_API int cinema_mse_fwd(const float* image, const cinema_patch_geom* geom,
                               float eps, float inv_count, float* loss_out, float* max_out, void* stream) {
   if (!image || !geom || !pred || !loss_out || geom->n_rows <= 0) return CINEMA_ERR_BAD_ARG;
   if (fast_patch(geom))
-    hipLaunchKernelGGL(mse_fwd_kernel<true>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+    CINEMA_LAUNCH(mse_fwd_kernel<true>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
                        norm_target, eps, inv_count, loss_out, max_out);
   else
-    hipLaunchKernelGGL(mse_fwd_kernel<false>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+    CINEMA_LAUNCH(mse_fwd_kernel<false>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
                        norm_target, eps, inv_count, loss_out, max_out);
   return launch_status();
 }
@@ -240,10 +240,10 @@ CINEMA_API int cinema_mse_bwd(const float* image, const cinema_patch_geom* geom,
                               float eps, const float* upstream, float host_scale, uint16_t* dpred, int ld_dpred, void* stream) {
   if (!image || !geom || !pred || !dpred || geom->n_rows <= 0) return CINEMA_ERR_BAD_ARG;
   if (fast_patch(geom))
-    hipLaunchKernelGGL(mse_bwd_kernel<true>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+    CINEMA_LAUNCH(mse_bwd_kernel<true>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
                        norm_target, eps, upstream, host_scale, dpred, ld_dpred);
   else
-    hipLaunchKernelGGL(mse_bwd_kernel<false>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
+    CINEMA_LAUNCH(mse_bwd_kernel<false>, dim3(rows_grid(geom->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom), pred, pred_dtype, ld_pred,
                        norm_target, eps, upstream, host_scale, dpred, ld_dpred);
   return launch_status();
 }
@@ -251,17 +251,17 @@ CINEMA_API int cinema_mse_bwd(const float* image, const cinema_patch_geom* geom,
 CINEMA_API int cinema_patch_stats(const float* image, const cinema_patch_geom* geom_all, float* out2, void* stream) {
   if (!image || !geom_all || !out2 || geom_all->n_rows <= 0) return CINEMA_ERR_BAD_ARG;
   if (fast_patch(geom_all))
-    hipLaunchKernelGGL(patch_stats_kernel<true>, dim3(rows_grid(geom_all->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom_all),
+    CINEMA_LAUNCH(patch_stats_kernel<true>, dim3(rows_grid(geom_all->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom_all),
                        1.f / (float)geom_all->n_rows, out2);
   else
-    hipLaunchKernelGGL(patch_stats_kernel<false>, dim3(rows_grid(geom_all->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom_all),
+    CINEMA_LAUNCH(patch_stats_kernel<false>, dim3(rows_grid(geom_all->n_rows)), dim3(256), 0, (hipStream_t)stream, image, to_dev(geom_all),
                        1.f / (float)geom_all->n_rows, out2);
   return launch_status();
 }
 
 CINEMA_API int cinema_mean_finite(const float* vals, int n, float* mean_out, float* coef_out, void* stream) {
   if (!vals || !mean_out || n <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(mean_finite_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vals, n, mean_out, coef_out);
+  CINEMA_LAUNCH(mean_finite_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vals, n, mean_out, coef_out);
   return launch_status();
 }
 
@@ -432,7 +432,7 @@ CINEMA_API int cinema_seg_window_accumulate(const float* window_logits, int c, i
   if (c > SEG_MAXC) return CINEMA_ERR_UNSUPPORTED;
   int gx = (px * py * pz + 255) / 256;
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(seg_window_accumulate_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, window_logits, c, px, py, pz, sx, sy, sz, X, Y, Z, prob_sum, count);
+  CINEMA_LAUNCH(seg_window_accumulate_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, window_logits, c, px, py, pz, sx, sy, sz, X, Y, Z, prob_sum, count);
   return launch_status();
 }
 
@@ -440,7 +440,7 @@ CINEMA_API int cinema_seg_window_finish(const float* prob_sum, const float* coun
   if (!prob_sum || !count || !logits_out || c < 2 || n_voxels <= 0) return CINEMA_ERR_BAD_ARG;
   long long gx = (n_voxels + 255) / 256;
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(seg_window_finish_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, prob_sum, count, c, n_voxels, logits_out);
+  CINEMA_LAUNCH(seg_window_finish_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, prob_sum, count, c, n_voxels, logits_out);
   return launch_status();
 }
 
@@ -451,7 +451,7 @@ CINEMA_API int cinema_seg_metric_counts(const float* logits, const int* labels, 
   if (hipMemsetAsync(counts, 0, (size_t)b * c * 6 * sizeof(unsigned int), st) != hipSuccess) return CINEMA_ERR_BAD_ARG;
   int gx = (vox + 255) / 256;
   if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(seg_metric_counts_kernel, dim3(gx, b), dim3(256), 0, st, logits, labels, vox, c, counts);
+  CINEMA_LAUNCH(seg_metric_counts_kernel, dim3(gx, b), dim3(256), 0, st, logits, labels, vox, c, counts);
   return launch_status();
 }
 
@@ -462,8 +462,8 @@ CINEMA_API int cinema_seg_loss_fwd(const float* logits, const int* labels, int b
   if (hipMemsetAsync(acc, 0, ((size_t)b * c * 3 + 2) * sizeof(float), st) != hipSuccess) return CINEMA_ERR_BAD_ARG;
   int gx = (vox + 255) / 256;
   if (gx > 512) gx = 512;
-  hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(gx, b), dim3(256), 0, st, logits, labels, vox, c, acc, acc + (size_t)b * c * 3);
-  hipLaunchKernelGGL(seg_loss_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)acc, (const float*)(acc + (size_t)b * c * 3), b, c, 1e-5f, 1e-5f, out4, coef);
+  CINEMA_LAUNCH(seg_loss_fwd_kernel, dim3(gx, b), dim3(256), 0, st, logits, labels, vox, c, acc, acc + (size_t)b * c * 3);
+  CINEMA_LAUNCH(seg_loss_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)acc, (const float*)(acc + (size_t)b * c * 3), b, c, 1e-5f, 1e-5f, out4, coef);
   return launch_status();
 }
 
@@ -473,6 +473,6 @@ CINEMA_API int cinema_seg_loss_bwd(const float* logits, const int* labels, int b
   if (c > SEG_MAXC) return CINEMA_ERR_UNSUPPORTED;
   int gx = (vox + 255) / 256;
   if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, logits, labels, vox, c, coef, out4, upstream, dlogits);
+  CINEMA_LAUNCH(seg_loss_bwd_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, logits, labels, vox, c, coef, out4, upstream, dlogits);
   return launch_status();
 }

@@ -34,7 +34,7 @@ struct LnFwdP {
 };
 
 template <int CPL>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) {
+__device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & (p.lpr - 1);
   const int rows_per_wave = 64 / p.lpr;
@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) {
     }
   }
 }
-
+template <int CPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) { ln_fwd_body<CPL>(p); }
+template <int CPL>
+__global__ __launch_bounds__(256) void ln_fwd_lanes_kernel(Lanes<LnFwdP> L) { ln_fwd_body<CPL>(L.p[blockIdx.y]); }
 struct LnBwdP {
   const void* dy; int dy_bf16; int lddy;
   const void* x; int x_bf16; int ldx;
@@ -99,7 +102,7 @@ struct LnBwdP {
 // RG = independent row groups per wave iteration: narrow rows (CPL <= 2) carry only 2-4 16-byte loads per lane, too few
 // bytes in flight to cover the HBM latency (measured 2.5 TB/s at C = 64), so those instantiations interleave RG groups.
 template <int CPL, int RG>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
+__device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   float* red = reinterpret_cast<float*>(dyn_smem);  // [n_waves_in_block][2][c]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
     }
   }
 }
-
+template <int CPL, int RG>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) { ln_bwd_body<CPL, RG>(p); }
+template <int CPL, int RG>
+__global__ __launch_bounds__(256) void ln_bwd_lanes_kernel(Lanes<LnBwdP> L) { ln_bwd_body<CPL, RG>(L.p[blockIdx.y]); }
 // dgamma[col] += sum_blocks ws[block][0][col], dbeta likewise.  Workgroup = 64 columns of the [2c] row x 4 sub-slices of the block range
 // (combined through LDS), grid.y = 16 slices: 64 independent partial rows per column group in flight, 16 atomics per column.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* ws, int nblocks, int c, float* dgamma, float* dbeta) {
@@ -332,7 +338,7 @@ CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const
   LnFwdP p{x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, pick_lpr(c)};
   if ((c & 3) || (ldx & 3) || (ldy & 3)) {
     if (c > 64) return CINEMA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(ln_fwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    CINEMA_LAUNCH(ln_fwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
   }
   const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
@@ -340,7 +346,7 @@ CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const
   int grid = (rows + rows_per_block - 1) / rows_per_block;
   if (grid > 8192) grid = 8192;
   return dispatch_cpl<LnFwdP>(cpl, [&](auto tag) {
-    hipLaunchKernelGGL((ln_fwd_kernel<decltype(tag)::value>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    launch_lanes(ln_fwd_kernel<decltype(tag)::value>, ln_fwd_lanes_kernel<decltype(tag)::value>, 1, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
   });
 }
@@ -356,7 +362,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int lddy, const vo
            pick_lpr(c), nullptr};
   if ((c & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) {
     if (c > 64) return CINEMA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(ln_bwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    CINEMA_LAUNCH(ln_bwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
   }
   const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
@@ -370,9 +376,9 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int lddy, const vo
     if (grid > cap) grid = cap;
     const bool two_pass = (dgamma || dbeta) && workspace && workspace_bytes >= (long long)grid * 2 * c * 4 && grid >= 64;
     if (two_pass) p.ws = workspace;
-    hipLaunchKernelGGL((ln_bwd_kernel<CPL, RG>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    launch_lanes(ln_bwd_kernel<CPL, RG>, ln_bwd_lanes_kernel<CPL, RG>, 1, dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
     if (two_pass && deferred_partials) *deferred_partials = grid;  // the caller reduces `grid` partial rows later (cinema_ln_param_reduce_batched)
-    else if (two_pass) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, grid, c, dgamma, dbeta);
+    else if (two_pass) CINEMA_LAUNCH(ln_param_reduce_kernel, dim3((2 * c + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, grid, c, dgamma, dbeta);
     return launch_status();
   });
 }
@@ -449,7 +455,7 @@ CINEMA_API int cinema_ln_param_reduce_batched(const cinema_ln_reduce_item* items
       if (!b.it[i].partials || b.it[i].n_partials <= 0 || b.it[i].c <= 0) return CINEMA_ERR_BAD_ARG;
       if (b.it[i].c > cmax) cmax = b.it[i].c;
     }
-    hipLaunchKernelGGL(ln_param_reduce_batched_kernel, dim3((2 * cmax + 63) / 64, 16, n), dim3(256), 0, (hipStream_t)stream, b);
+    CINEMA_LAUNCH(ln_param_reduce_batched_kernel, dim3((2 * cmax + 63) / 64, 16, n), dim3(256), 0, (hipStream_t)stream, b);
   }
   return launch_status();
 }

@@ -102,14 +102,14 @@ CINEMA_API int cinema_sqnorm_f32(const float* g, long long n, float* out, float*
   long long grid = (n / 4 + 255) / 256;
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, workspace);
-  hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid, out);
+  CINEMA_LAUNCH(sqnorm_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g, n, workspace);
+  CINEMA_LAUNCH(sqnorm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid, out);
   return launch_status();
 }
 
 CINEMA_API int cinema_clip_coef(const float* sqnorm, float max_norm, float* coef_out, float* norm_out, int* step_state, void* stream) {
   if (!sqnorm) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sqnorm, max_norm, coef_out, norm_out, step_state);
+  CINEMA_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sqnorm, max_norm, coef_out, norm_out, step_state);
   return launch_status();
 }
 
@@ -124,6 +124,6 @@ CINEMA_API int cinema_adamw(float* p, const float* g, float* m, float* v, long l
   long long grid = (n / 4 + 255) / 256;
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  CINEMA_LAUNCH(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }

@@ -34,7 +34,7 @@ struct RowP {
 };
 
 template <int VEC>
-__global__ void row_copy_kernel(RowP p) {
+__device__ __forceinline__ void row_copy_body(const RowP& p) {
   const int per_row = p.c / VEC;
   const long long total = (long long)p.n_rows * per_row;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -55,7 +55,10 @@ __global__ void row_copy_kernel(RowP p) {
     }
   }
 }
-
+template <int VEC>
+__global__ void row_copy_kernel(RowP p) { row_copy_body<VEC>(p); }
+template <int VEC>
+__global__ void row_copy_lanes_kernel(Lanes<RowP> L) { row_copy_body<VEC>(L.p[blockIdx.y]); }
 // several independent row copies in one grid (blockIdx.y = segment): the token assembly / split ops of a step are 4-9 small copies each
 struct RowMultiP { RowP seg[12]; };
 __global__ __launch_bounds__(256) void row_copy_multi_kernel(RowMultiP m) {
@@ -84,13 +87,15 @@ __global__ __launch_bounds__(256) void row_copy_multi_kernel(RowMultiP m) {
   }
 }
 
-__global__ void cast_kernel(const void* src, int sd, void* dst, int dd, long long n) {
+__device__ __forceinline__ void cast_body(const void* src, int sd, void* dst, int dd, long long n) {
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
     st4(dst, dd, (size_t)i * 4, ld4(src, sd, (size_t)i * 4));
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1(dst, dd, (size_t)(n4 * 4 + threadIdx.x), ld1(src, sd, (size_t)(n4 * 4 + threadIdx.x)));
 }
-
+struct CastP { const void* src; int sd; void* dst; int dd; long long n; };
+__global__ void cast_kernel(CastP q) { cast_body(q.src, q.sd, q.dst, q.dd, q.n); }
+__global__ void cast_lanes_kernel(Lanes<CastP> L) { const CastP& q = L.p[blockIdx.y]; cast_body(q.src, q.sd, q.dst, q.dd, q.n); }
 // dst[c][r] = src[r][c]; 64x64 tile through LDS (+1 pad)
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const void* src, int sd, int rows, int cols, bf16_t* dst) {
   __shared__ float tile[64][65];
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(const float* x, float al
 //   direction 1: w_grad[(o * c + i) * kvol + jm] += rows_f32[o][jj * c + i]
 // with jm = jmap ? jmap[jj] : jj (voxel permutation of the visible-voxel stem).  One launch replaces permute + contiguous + cast
 // (forward, every step for every k == s conv) and permute + contiguous + accumulate (end of the backward pass).
-__global__ __launch_bounds__(256) void patch_weight_relayout_kernel(float* w, void* rows, int rows_bf16, int outer, int c, int kvol, int ld, const int* jmap,
+__device__ __forceinline__ void patch_weight_relayout_body(float* w, void* rows, int rows_bf16, int outer, int c, int kvol, int ld, const int* jmap,
                                                                    int direction) {
   const long long total = (long long)outer * ld;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -187,11 +192,15 @@ __global__ __launch_bounds__(256) void patch_weight_relayout_kernel(float* w, vo
     }
   }
 }
-
-__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* dst, uint32_t word, long long n_words) {
+struct RelayoutP { float* w; void* rows; int rows_bf16; int outer; int c; int kvol; int ld; const int* jmap; int direction; };
+__global__ __launch_bounds__(256) void patch_weight_relayout_kernel(RelayoutP q) { patch_weight_relayout_body(q.w, q.rows, q.rows_bf16, q.outer, q.c, q.kvol, q.ld, q.jmap, q.direction); }
+__global__ __launch_bounds__(256) void patch_weight_relayout_lanes_kernel(Lanes<RelayoutP> L) { const RelayoutP& q = L.p[blockIdx.y]; patch_weight_relayout_body(q.w, q.rows, q.rows_bf16, q.outer, q.c, q.kvol, q.ld, q.jmap, q.direction); }
+__device__ __forceinline__ void fill_u32_body(uint32_t* dst, uint32_t word, long long n_words) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (long long)gridDim.x * 256) dst[i] = word;
 }
-
+struct FillP { uint32_t* dst; uint32_t word; long long n_words; };
+__global__ __launch_bounds__(256) void fill_u32_kernel(FillP q) { fill_u32_body(q.dst, q.word, q.n_words); }
+__global__ __launch_bounds__(256) void fill_u32_lanes_kernel(Lanes<FillP> L) { const FillP& q = L.p[blockIdx.y]; fill_u32_body(q.dst, q.word, q.n_words); }
 __global__ __launch_bounds__(256) void mul_scalar_kernel(const float* x, const float* s, float* y, long long n) {
   const float f = s[0];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * f;
@@ -218,8 +227,8 @@ CINEMA_API int cinema_row_copy(void* dst, int dst_dtype, int ld_dst, const int* 
   if (!dst || n_rows <= 0 || c <= 0 || (!src && !add)) return CINEMA_ERR_BAD_ARG;
   RowP p{dst, dst_dtype, ld_dst, dst_idx, src, src_dtype, ld_src, src_idx, add, add_dtype, ld_add, add_idx, n_rows, c, accumulate};
   const bool vec = !(c & 3) && !(ld_dst & 3) && (!src || !(ld_src & 3)) && (!add || !(ld_add & 3)) && a16(dst) && (!src || a16(src)) && (!add || a16(add));
-  if (vec) hipLaunchKernelGGL(row_copy_kernel<4>, dim3(grid_for((long long)n_rows * c / 4, 256)), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(row_copy_kernel<1>, dim3(grid_for((long long)n_rows * c, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  if (vec) launch_lanes(row_copy_kernel<4>, row_copy_lanes_kernel<4>, 1, dim3(grid_for((long long)n_rows * c / 4, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  else launch_lanes(row_copy_kernel<1>, row_copy_lanes_kernel<1>, 1, dim3(grid_for((long long)n_rows * c, 256)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
 
@@ -237,7 +246,7 @@ CINEMA_API int cinema_row_copy_multi(const cinema_row_copy_args* segs, int count
       const long long work = (long long)a.n_rows * a.c / 4 + 1;
       if (work > most) most = work;
     }
-    hipLaunchKernelGGL(row_copy_multi_kernel, dim3(grid_for(most, 256), n), dim3(256), 0, (hipStream_t)stream, m);
+    CINEMA_LAUNCH(row_copy_multi_kernel, dim3(grid_for(most, 256), n), dim3(256), 0, (hipStream_t)stream, m);
   }
   return launch_status();
 }
@@ -245,44 +254,44 @@ CINEMA_API int cinema_row_copy_multi(const cinema_row_copy_args* segs, int count
 CINEMA_API int cinema_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream) {
   if (!src || !dst || n <= 0) return CINEMA_ERR_BAD_ARG;
   if (!a16(src) || !a16(dst)) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, dst, dst_dtype, n);
+  launch_lanes(cast_kernel, cast_lanes_kernel, 1, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, CastP{src, src_dtype, dst, dst_dtype, n});
   return launch_status();
 }
 
 CINEMA_API int cinema_transpose_cast(const void* src, int src_dtype, int rows, int cols, uint16_t* dst, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(transpose_cast_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, src_dtype, rows, cols, dst);
+  CINEMA_LAUNCH(transpose_cast_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, src_dtype, rows, cols, dst);
   return launch_status();
 }
 
 CINEMA_API int cinema_gelu_fwd(const uint16_t* x, uint16_t* y, long long n, void* stream) {
   if (!x || !y || n <= 0) return CINEMA_ERR_BAD_ARG;
   if (!a16(x) || !a16(y)) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  CINEMA_LAUNCH(gelu_fwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
   return launch_status();
 }
 CINEMA_API int cinema_gelu_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, long long n, void* stream) {
   if (!x || !dy || !dx || n <= 0) return CINEMA_ERR_BAD_ARG;
   if (!a16(x) || !a16(dy) || !a16(dx)) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+  CINEMA_LAUNCH(gelu_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
   return launch_status();
 }
 
 CINEMA_API int cinema_segment_mean_fwd(const float* x, int ldx, int n_seg, int seg_rows, int c, float scale, float* out, void* stream) {
   if (!x || !out || n_seg <= 0 || seg_rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3((c + 255) / 256, n_seg), dim3(256), 0, (hipStream_t)stream, x, ldx, seg_rows, c, scale, out);
+  CINEMA_LAUNCH(segment_mean_fwd_kernel, dim3((c + 255) / 256, n_seg), dim3(256), 0, (hipStream_t)stream, x, ldx, seg_rows, c, scale, out);
   return launch_status();
 }
 
 CINEMA_API int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, float scale, float* dx, int lddx, int accumulate, void* stream) {
   if (!dy || !dx || n_seg <= 0 || seg_rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3((c + 255) / 256, n_seg), dim3(256), 0, (hipStream_t)stream, dy, seg_rows, c, scale, dx, lddx, accumulate);
+  CINEMA_LAUNCH(segment_mean_bwd_kernel, dim3((c + 255) / 256, n_seg), dim3(256), 0, (hipStream_t)stream, dy, seg_rows, c, scale, dx, lddx, accumulate);
   return launch_status();
 }
 
 CINEMA_API int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream) {
   if (!x || !y || n <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, n);
+  CINEMA_LAUNCH(scale_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, n);
   return launch_status();
 }
 
@@ -290,8 +299,8 @@ CINEMA_API int cinema_patch_weight_relayout(float* w, void* rows, int rows_is_bf
                                             void* stream) {
   if (!w || !rows || outer <= 0 || c <= 0 || kvol <= 0 || ld < c * kvol || (direction != 0 && direction != 1)) return CINEMA_ERR_BAD_ARG;
   if (direction == 1 && rows_is_bf16) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(patch_weight_relayout_kernel, dim3(grid_for((long long)outer * ld, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, rows_is_bf16, outer, c,
-                     kvol, ld, jmap, direction);
+  launch_lanes(patch_weight_relayout_kernel, patch_weight_relayout_lanes_kernel, 1, dim3(grid_for((long long)outer * ld, 256)), dim3(256), 0, (hipStream_t)stream,
+               RelayoutP{w, rows, rows_is_bf16, outer, c, kvol, ld, jmap, direction});
   return launch_status();
 }
 
@@ -300,7 +309,7 @@ CINEMA_API int cinema_patch_weight_relayout(float* w, void* rows, int rows_is_bf
 CINEMA_API int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream) {
   if (!dst || n_words < 0 || (((uintptr_t)dst) & 3)) return CINEMA_ERR_BAD_ARG;
   if (n_words == 0) return 0;
-  hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)dst, (uint32_t)word, n_words);
+  launch_lanes(fill_u32_kernel, fill_u32_lanes_kernel, 1, dim3(grid_for(n_words, 256)), dim3(256), 0, (hipStream_t)stream, FillP{(uint32_t*)dst, (uint32_t)word, n_words});
   return launch_status();
 }
 
@@ -353,10 +362,10 @@ CINEMA_API int cinema_rope_heads(uint16_t* x, int ld, long long rows, int n_slot
   const bool vec = (half % 8 == 0) && (head_dim % 8 == 0) && (ld % 8 == 0) && ((((uintptr_t)x) & 15) == 0);
   const long long total = rows * n_slots * (vec ? half / 8 : half);
   if (vec)
-    hipLaunchKernelGGL(rope_heads_kernel<8>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, n_slots, heads, head_dim, half,
+    CINEMA_LAUNCH(rope_heads_kernel<8>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, n_slots, heads, head_dim, half,
                        cos_table, sin_table, inverse);
   else
-    hipLaunchKernelGGL(rope_heads_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, n_slots, heads, head_dim, half,
+    CINEMA_LAUNCH(rope_heads_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, n_slots, heads, head_dim, half,
                        cos_table, sin_table, inverse);
   return launch_status();
 }
@@ -430,20 +439,20 @@ __global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* h, con
 
 CINEMA_API int cinema_rng_advance(unsigned long long* state, void* stream) {
   if (!state) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+  CINEMA_LAUNCH(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
   return launch_status();
 }
 
 CINEMA_API int cinema_dropout_bf16(const uint16_t* x, uint16_t* y, long long n, float p, const unsigned long long* state, unsigned int salt, void* stream) {
   if (!x || !y || !state || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return CINEMA_ERR_BAD_ARG;
   if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, state, salt);
+  CINEMA_LAUNCH(dropout_bf16_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, state, salt);
   return launch_status();
 }
 
 CINEMA_API int cinema_droppath_scale(float* scale, int batch, float p, const unsigned long long* state, unsigned int salt, void* stream) {
   if (!scale || !state || batch <= 0 || !(p >= 0.f) || !(p < 1.f)) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(droppath_scale_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, scale, batch, p, state, salt);
+  CINEMA_LAUNCH(droppath_scale_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, scale, batch, p, state, salt);
   return launch_status();
 }
 
@@ -451,7 +460,7 @@ CINEMA_API int cinema_scale_rows_add(const float* h, const float* residual, cons
                                      void* stream) {
   if (!h || !scale || !out || rows <= 0 || c <= 0 || rows_per_sample <= 0) return CINEMA_ERR_BAD_ARG;
   if ((c & 3) || ((((uintptr_t)h) | ((uintptr_t)out) | ((uintptr_t)residual)) & 15)) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(scale_rows_add_kernel, dim3(grid_for(rows * (c >> 2), 256)), dim3(256), 0, (hipStream_t)stream, h, residual, scale, out, rows, c,
+  CINEMA_LAUNCH(scale_rows_add_kernel, dim3(grid_for(rows * (c >> 2), 256)), dim3(256), 0, (hipStream_t)stream, h, residual, scale, out, rows, c,
                      rows_per_sample);
   return launch_status();
 }
@@ -459,6 +468,6 @@ CINEMA_API int cinema_scale_rows_add(const float* h, const float* residual, cons
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;
-  hipLaunchKernelGGL(mul_scalar_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, s, y, n);
+  CINEMA_LAUNCH(mul_scalar_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, s, y, n);
   return launch_status();
 }

@@ -78,7 +78,7 @@ struct VisP {
 
 // one thread per (kept token r, row offset q): idx1[r * block_vol + q] = flat id, in the (batch, *grid*block) stage-1 volume, of the voxel
 // stored at row offset q of token r (inv1[q] = its raster index inside the token's block); q == 0 also writes rank[keep[r]] = r
-__global__ __launch_bounds__(256) void visible_index_kernel(VisP p) {
+__device__ __forceinline__ void visible_index_body(const VisP& p) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)p.n_rows * p.block_vol) return;
   const int r = (int)(idx / p.block_vol), q = (int)(idx - (long long)r * p.block_vol);
@@ -99,15 +99,16 @@ __global__ __launch_bounds__(256) void visible_index_kernel(VisP p) {
   v = v * (p.g[2] * p.bl[2]) + (tz * p.bl[2] + uz);
   p.idx1[idx] = (int)v;
 }
-
+__global__ __launch_bounds__(256) void visible_index_kernel(VisP p) { visible_index_body(p); }
+__global__ __launch_bounds__(256) void visible_index_lanes_kernel(Lanes<VisP> L) { visible_index_body(L.p[blockIdx.y]); }
 }  // namespace
 
 CINEMA_API int cinema_mask_select(const float* noise, uint8_t* mask, int batch, int n, int n_keep, int* keep_pos, int* drop_pos, int* keep, int* drop,
                                   void* stream) {
   if (!mask || batch <= 0 || n <= 0 || n_keep < 0 || n_keep > n) return CINEMA_ERR_BAD_ARG;
-  if (noise) hipLaunchKernelGGL(mask_rank_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, noise, mask, n, n_keep);
+  if (noise) CINEMA_LAUNCH(mask_rank_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, noise, mask, n, n_keep);
   if (keep_pos || drop_pos || keep || drop)
-    hipLaunchKernelGGL(mask_select_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)mask, n, keep_pos, drop_pos, keep, drop);
+    CINEMA_LAUNCH(mask_select_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)mask, n, keep_pos, drop_pos, keep, drop);
   return launch_status();
 }
 
@@ -121,6 +122,6 @@ CINEMA_API int cinema_visible_index(const int* keep, int n_rows, int n_dims, con
   p.n_tok_all = p.g[0] * p.g[1] * p.g[2];
   p.block_vol = p.bl[0] * p.bl[1] * p.bl[2];
   const long long total = (long long)n_rows * p.block_vol;
-  hipLaunchKernelGGL(visible_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  launch_lanes(visible_index_kernel, visible_index_lanes_kernel, 1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }

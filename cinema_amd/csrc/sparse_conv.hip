@@ -110,7 +110,7 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
 // (tap << 24 | row); built once per mask and stage (one wave per row: 64 taps per pass, ballot-compacted) and reused by the forward and
 // data-gradient passes of every conv block of the stage.  nbr: [rows][NBR_STRIDE], cnt: [rows].
 constexpr int NBR_STRIDE = 128;
-__global__ __launch_bounds__(256) void sparse_nbr_build_kernel(SpP p, int* nbr, int* cnt) {
+__device__ __forceinline__ void sparse_nbr_build_body(SpP p, int* nbr, int* cnt) {
   const int lane = threadIdx.x & 63;
   const int Bv = p.bx * p.by * p.bz, T = p.tx * p.ty * p.tz, taps = p.kx * p.ky * p.kz;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -144,10 +144,12 @@ __global__ __launch_bounds__(256) void sparse_nbr_build_kernel(SpP p, int* nbr, 
   }
   if (lane == 0) cnt[row] = total;
 }
-
+struct SpNbrP { SpP p; int* nbr; int* cnt; };
+__global__ __launch_bounds__(256) void sparse_nbr_build_kernel(SpNbrP q) { sparse_nbr_build_body(q.p, q.nbr, q.cnt); }
+__global__ __launch_bounds__(256) void sparse_nbr_build_lanes_kernel(Lanes<SpNbrP> L) { const SpNbrP& q = L.p[blockIdx.y]; sparse_nbr_build_body(q.p, q.nbr, q.cnt); }
 // y[row] = bias + sum over the row's neighbour list of w[tap] * x[source row]: thread = (row, channel group of 8), a workgroup walks
 // groups of 32 rows with the 64-channel weight slab in LDS as [tap][channel] fp32; loads of 4 list entries are issued together.
-__global__ __launch_bounds__(256) void sparse_dwconv_list_kernel(SpP p, const int* nbr, const int* cnt, int n_rows) {
+__device__ __forceinline__ void sparse_dwconv_list_body(SpP p, const int* nbr, const int* cnt, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   float* wl = reinterpret_cast<float*>(dyn_smem);
   const int taps = p.kx * p.ky * p.kz;
@@ -195,12 +197,14 @@ __global__ __launch_bounds__(256) void sparse_dwconv_list_kernel(SpP p, const in
     *reinterpret_cast<uint4*>(p.y + (size_t)row * p.c + ch) = ov;
   }
 }
-
+struct SpListP { SpP p; const int* nbr; const int* cnt; int n_rows; };
+__global__ __launch_bounds__(256) void sparse_dwconv_list_kernel(SpListP q) { sparse_dwconv_list_body(q.p, q.nbr, q.cnt, q.n_rows); }
+__global__ __launch_bounds__(256) void sparse_dwconv_list_lanes_kernel(Lanes<SpListP> L) { const SpListP& q = L.p[blockIdx.z]; sparse_dwconv_list_body(q.p, q.nbr, q.cnt, q.n_rows); }
 // Weight gradient: thread = (in-plane tap, channel group of 8) holds dw for its kz taps; a workgroup walks a chunk of kept
 // tokens (halo of x and the token's dy block in LDS) and writes ONE partial slab [c][taps] + [c] at the end
 // (reduced by the kernel below, deterministic).  LDS: tile [Hvox][64] bf16 | dyb [Bv][64] bf16 | pos [Bv] int
 template <int KZ>
-__global__ __launch_bounds__(256) void sparse_dwconv_wgrad_kernel(SpP p) {
+__device__ __forceinline__ void sparse_dwconv_wgrad_body(const SpP& p) {
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   const int Bv = p.bx * p.by * p.bz, nxy = p.kx * p.ky, taps = nxy * KZ;
   const Halo h = make_halo(p);
@@ -274,9 +278,12 @@ __global__ __launch_bounds__(256) void sparse_dwconv_wgrad_kernel(SpP p) {
     for (int i = 0; i < 8; i++) slab[(size_t)p.c * taps + ch + i] = accb[i];
   }
 }
-
+template <int KZ>
+__global__ __launch_bounds__(256) void sparse_dwconv_wgrad_kernel(SpP p) { sparse_dwconv_wgrad_body<KZ>(p); }
+template <int KZ>
+__global__ __launch_bounds__(256) void sparse_dwconv_wgrad_lanes_kernel(Lanes<SpP> L) { sparse_dwconv_wgrad_body<KZ>(L.p[blockIdx.z]); }
 // dw[i] += sum_blocks slab[block][i]  (i < c*taps), dbias[j] += sum_blocks slab[block][c*taps + j]
-__global__ __launch_bounds__(256) void sparse_wgrad_reduce_kernel(const float* ws, int nblocks, int n_w, int n_b, float* dw, float* dbias) {
+__device__ __forceinline__ void sparse_wgrad_reduce_body(const float* ws, int nblocks, int n_w, int n_b, float* dw, float* dbias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = n_w + n_b;
   if (i >= total) return;
@@ -287,7 +294,9 @@ __global__ __launch_bounds__(256) void sparse_wgrad_reduce_kernel(const float* w
   if (i < n_w) unsafeAtomicAdd(dw + i, s);
   else if (dbias) unsafeAtomicAdd(dbias + (i - n_w), s);
 }
-
+struct SpRedP { const float* ws; int nblocks; int n_w; int n_b; float* dw; float* dbias; };
+__global__ __launch_bounds__(256) void sparse_wgrad_reduce_kernel(SpRedP q) { sparse_wgrad_reduce_body(q.ws, q.nblocks, q.n_w, q.n_b, q.dw, q.dbias); }
+__global__ __launch_bounds__(256) void sparse_wgrad_reduce_lanes_kernel(Lanes<SpRedP> L) { const SpRedP& q = L.p[blockIdx.z]; sparse_wgrad_reduce_body(q.ws, q.nblocks, q.n_w, q.n_b, q.dw, q.dbias); }
 int fill(SpP& p, const cinema_sparse_geom* g, int c, int kx, int ky, int kz) {
   if (!g || !g->keep || !g->rank || !g->pos || g->b <= 0 || g->tx <= 0 || g->ty <= 0 || g->tz <= 0 || g->bx <= 0 || g->by <= 0 || g->bz <= 0 || g->n_tok <= 0)
     return CINEMA_ERR_BAD_ARG;
@@ -312,7 +321,7 @@ CINEMA_API int cinema_sparse_nbr_build(const cinema_sparse_geom* geom, int kx, i
   if (int e = fill(p, geom, 8, kx, ky, kz)) return e;
   const long long rows = (long long)p.n_tok * p.bx * p.by * p.bz;
   if (kx * ky * kz > NBR_STRIDE || rows >= (1 << 24)) return CINEMA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sparse_nbr_build_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, nbr, cnt);
+  launch_lanes(sparse_nbr_build_kernel, sparse_nbr_build_lanes_kernel, 1, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, SpNbrP{p, nbr, cnt});
   return launch_status();
 }
 
@@ -327,7 +336,7 @@ CINEMA_API int cinema_sparse_dwconv_fwd(const uint16_t* x, const float* w, const
   const int n_rows = p.n_tok * p.bx * p.by * p.bz;
   int blocks = (n_rows + 31) / 32;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sparse_dwconv_list_kernel, dim3(blocks, (c + 63) / 64), dim3(256), (size_t)taps * 64 * 4, (hipStream_t)stream, p, nbr, cnt, n_rows);
+  launch_lanes(sparse_dwconv_list_kernel, sparse_dwconv_list_lanes_kernel, 2, dim3(blocks, (c + 63) / 64), dim3(256), (size_t)taps * 64 * 4, (hipStream_t)stream, SpListP{p, nbr, cnt, n_rows});
   return launch_status();
 }
 
@@ -350,8 +359,8 @@ CINEMA_API int cinema_sparse_dwconv_bwd_weight(const uint16_t* x, const uint16_t
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)sparse_dwconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sparse_dwconv_wgrad_kernel<5>, dim3(blocks, (c + 63) / 64), dim3(256), smem, st, p);
+  launch_lanes(sparse_dwconv_wgrad_kernel<5>, sparse_dwconv_wgrad_lanes_kernel<5>, 2, dim3(blocks, (c + 63) / 64), dim3(256), smem, st, p);
   const int total = c * (taps + 1);
-  hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3((total + 255) / 256, 16), dim3(256), 0, st, (const float*)workspace, blocks, c * taps, c, dw, dbias);
+  launch_lanes(sparse_wgrad_reduce_kernel, sparse_wgrad_reduce_lanes_kernel, 2, dim3((total + 255) / 256, 16), dim3(256), 0, st, SpRedP{(const float*)workspace, blocks, c * taps, c, dw, dbias});
   return launch_status();
 }

@@ -134,6 +134,9 @@ _PROTOS = {
     "cinema_mask_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_visible_index": [_vp, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp, _vp, _vp],
     "cinema_stream_fork": [_vp, _vp],
+    "cinema_lanes_begin": [_i],
+    "cinema_lanes_select": [_i],
+    "cinema_lanes_end": [_vp, _vp],
     "cinema_marker_record": [_vp],
     "cinema_marker_done": [_ll],
     "cinema_launch_probe": [_i, _vp],
@@ -244,6 +247,25 @@ class on_stream:  # noqa: N801
         _STREAM_OVERRIDE = self.prev
 
 
+def _empty(*args, **kw) -> torch.Tensor:  # noqa: ANN002, ANN003
+    """torch.empty; inside a lane group the buffer is held until the group's deferred launches have been issued (the caching allocator would
+    otherwise hand a dropped temporary of one lane to the next lane while the first lane's kernels have not even been launched)."""
+    t = torch.empty(*args, **kw)
+    if LANE is not None:
+        _LANE_KEEP.append(t)
+    return t
+
+
+def _empty_like(x: torch.Tensor, **kw) -> torch.Tensor:  # noqa: ANN003
+    t = torch.empty_like(x, **kw)
+    if LANE is not None:
+        _LANE_KEEP.append(t)
+    return t
+
+
+empty, empty_like = _empty, _empty_like
+
+
 def stream_fork(from_stream: int, to_stream: int) -> None:
     _check(load().cinema_stream_fork(from_stream, to_stream), "stream_fork")
 
@@ -270,6 +292,50 @@ def _dev(*ts: torch.Tensor | None) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
             raise HipLibraryError("cinema_amd kernels need GPU (HIP) tensors; got a CPU tensor. There is no CPU fallback.")
+    if LANE is not None:  # launches are deferred to the end of the lane group: nothing they touch may go back to the allocator before that
+        _LANE_KEEP.extend(t for t in ts if t is not None)
+
+
+# ---- lane groups (include/cinema_hip.h: cinema_lanes_*): independent, identically shaped launch sequences merged into wide launches -------------
+LANE: int | None = None      # lane being recorded, None outside a group
+LANES_ENABLED = bool(int(os.environ.get("CINEMA_LANES", "1")))
+LANE_STATS = [0, 0]          # merged / single launches issued by the lane groups so far (diagnostics)
+_LANE_KEEP: list = []
+
+
+class lanes:  # noqa: N801
+    """``with lanes(n) as g: g.select(0); <launches of lane 0>; g.select(1); ...``: the launches issued inside are recorded by the library and
+    go out, zipped across the lanes, when the block ends.  The lanes must be independent.  Inactive (plain immediate launches) when
+    ``CINEMA_LANES=0``, when a group is already open, or while single launches are being timed (``GEMM_PROFILE``)."""
+
+    def __init__(self, n: int) -> None:
+        self.n = n
+        self.active = LANES_ENABLED and LANE is None and GEMM_PROFILE is None and 2 <= n <= 4
+
+    def __enter__(self) -> "lanes":
+        global LANE  # noqa: PLW0603
+        if self.active:
+            _check(load().cinema_lanes_begin(self.n), "lanes_begin")
+            LANE = 0
+        return self
+
+    def select(self, lane: int) -> None:
+        global LANE  # noqa: PLW0603
+        if self.active:
+            _check(load().cinema_lanes_select(lane), "lanes_select")
+            LANE = lane
+
+    def __exit__(self, *exc) -> None:  # noqa: ANN002
+        global LANE  # noqa: PLW0603
+        if self.active:
+            LANE = None
+            m, s1 = C.c_int(0), C.c_int(0)
+            rc = load().cinema_lanes_end(C.byref(m), C.byref(s1))
+            LANE_STATS[0] += m.value
+            LANE_STATS[1] += s1.value
+            _LANE_KEEP.clear()
+            if exc[0] is None:
+                _check(rc, "lanes_end")
 
 
 def _rowmajor(t: torch.Tensor, name: str) -> int:
@@ -289,12 +355,12 @@ def _workspace(tag: str, n_floats: int, device: torch.device) -> torch.Tensor:
     reduce / fix-up), so a single buffer per stream serves all launches on it, and a launch redirected by :func:`on_stream` never
     borrows memory the allocator believes to belong to torch's current stream.  Outgrown buffers are parked, not freed (a kernel on the
     other stream may still be reading them; there are only a handful of growth steps per process)."""
-    key = (tag, device.index, _stream())
+    key = (tag, device.index, _stream(), LANE)  # per lane inside a lane group: the merged launch runs the lanes' kernels side by side
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < n_floats:
         if ws is not None:
             _RETIRED_WORKSPACES.append(ws)
-        ws = _WORKSPACES[key] = torch.empty(n_floats, dtype=torch.float32, device=device)
+        ws = _WORKSPACES[key] = _empty(n_floats, dtype=torch.float32, device=device)
     return ws
 
 
@@ -320,7 +386,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     if k != kb:
         raise HipLibraryError(f"gemm reduction mismatch: {k} vs {kb}")
     if out is None:
-        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+        out = _empty((m, n), dtype=out_dtype, device=a.device)
     elif tuple(out.shape) != (m, n):
         raise HipLibraryError(f"gemm out shape {tuple(out.shape)} != {(m, n)}")
     g = GemmArgs()
@@ -359,7 +425,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     elif split_k == 1 and k >= 768:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
         ws = _tail_workspace(a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    if GEMM_PROFILE is None:
+    if GEMM_PROFILE is None or LANE is not None:
         _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
         if g.kernel_used == 0 and not g.force_generic and 2.0 * m * n * k > 1e9:
             _warn_generic(m, n, k, a, b, out)
@@ -418,9 +484,9 @@ def seg_loss_fwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int):  
     if logits_rows.dtype != torch.float32 or labels.dtype != torch.int32 or not logits_rows.is_contiguous() or not labels.is_contiguous():
         raise HipLibraryError("seg_loss: logits fp32 rows and int32 labels, both contiguous")
     rows, c = logits_rows.shape
-    acc = torch.empty(batch * c * 3 + 2, dtype=torch.float32, device=logits_rows.device)
-    out4 = torch.empty(4, dtype=torch.float32, device=logits_rows.device)
-    coef = torch.empty(batch * c * 2, dtype=torch.float32, device=logits_rows.device)
+    acc = _empty(batch * c * 3 + 2, dtype=torch.float32, device=logits_rows.device)
+    out4 = _empty(4, dtype=torch.float32, device=logits_rows.device)
+    coef = _empty(batch * c * 2, dtype=torch.float32, device=logits_rows.device)
     _check(load().cinema_seg_loss_fwd(logits_rows.data_ptr(), labels.data_ptr(), batch, rows // batch, c, acc.data_ptr(), out4.data_ptr(), coef.data_ptr(),
                                       _stream()), "seg_loss_fwd")
     return out4, coef
@@ -429,7 +495,7 @@ def seg_loss_fwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int):  
 def seg_loss_bwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int, coef: torch.Tensor, out4: torch.Tensor, upstream: torch.Tensor | None):  # noqa: ANN201
     _dev(logits_rows, labels, coef, out4, upstream)
     rows, c = logits_rows.shape
-    d = torch.empty_like(logits_rows)
+    d = _empty_like(logits_rows)
     _check(load().cinema_seg_loss_bwd(logits_rows.data_ptr(), labels.data_ptr(), batch, rows // batch, c, coef.data_ptr(), out4.data_ptr(), _p(upstream),
                                       d.data_ptr(), _stream()), "seg_loss_bwd")
     return d
@@ -451,7 +517,7 @@ def seg_window_finish(prob_sum: torch.Tensor, count: torch.Tensor) -> torch.Tens
     """-> fp32 [c, n_voxels] = log(prob_sum / count) (channels first)."""
     _dev(prob_sum, count)
     n, c = prob_sum.shape
-    out = torch.empty((c, n), dtype=torch.float32, device=prob_sum.device)
+    out = _empty((c, n), dtype=torch.float32, device=prob_sum.device)
     _check(load().cinema_seg_window_finish(prob_sum.data_ptr(), count.data_ptr(), c, n, out.data_ptr(), _stream()), "seg_window_finish")
     return out
 
@@ -463,7 +529,7 @@ def seg_metric_counts(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tenso
         raise HipLibraryError("seg_metric_counts: contiguous fp32 logits (channels first) and int32 labels")
     b, c = logits.shape[0], logits.shape[1]
     vox = logits[0, 0].numel()
-    counts = torch.empty((b, c, 6), dtype=torch.int32, device=logits.device)
+    counts = _empty((b, c, 6), dtype=torch.int32, device=logits.device)
     _check(load().cinema_seg_metric_counts(logits.data_ptr(), labels.data_ptr(), b, vox, c, counts.data_ptr(), _stream()), "seg_metric_counts")
     return counts
 
@@ -475,7 +541,7 @@ def segment_mean(x: torch.Tensor, n_seg: int, scale: float | None = None) -> tor
         raise HipLibraryError("segment_mean: x must be fp32")
     rows, c = x.shape
     seg_rows = rows // n_seg
-    out = torch.empty((n_seg, c), dtype=torch.float32, device=x.device)
+    out = _empty((n_seg, c), dtype=torch.float32, device=x.device)
     _check(load().cinema_segment_mean_fwd(x.data_ptr(), _rowmajor(x, "x"), n_seg, seg_rows, c, 1.0 / seg_rows if scale is None else scale, out.data_ptr(),
                                           _stream()), "segment_mean_fwd")
     return out
@@ -484,7 +550,7 @@ def segment_mean(x: torch.Tensor, n_seg: int, scale: float | None = None) -> tor
 def segment_mean_bwd(dy: torch.Tensor, seg_rows: int, scale: float | None = None) -> torch.Tensor:
     _dev(dy)
     n_seg, c = dy.shape
-    dx = torch.empty((n_seg * seg_rows, c), dtype=torch.float32, device=dy.device)
+    dx = _empty((n_seg * seg_rows, c), dtype=torch.float32, device=dy.device)
     _check(load().cinema_segment_mean_bwd(dy.data_ptr(), n_seg, seg_rows, c, 1.0 / seg_rows if scale is None else scale, dx.data_ptr(), c, 0, _stream()),
            "segment_mean_bwd")
     return dx
@@ -494,7 +560,7 @@ def scale(x: torch.Tensor, alpha: float) -> torch.Tensor:
     _dev(x)
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise HipLibraryError("scale: contiguous fp32 only")
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     _check(load().cinema_scale_f32(x.data_ptr(), alpha, y.data_ptr(), x.numel(), _stream()), "scale")
     return y
 
@@ -504,7 +570,7 @@ def mul_scalar(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     _dev(x, s)
     if x.dtype != torch.float32 or s.dtype != torch.float32 or not x.is_contiguous() or s.numel() != 1:
         raise HipLibraryError("mul_scalar: contiguous fp32 x, one-element fp32 s")
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     _check(load().cinema_mul_scalar_f32(x.data_ptr(), s.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mul_scalar")
     return y
 
@@ -551,14 +617,14 @@ def dropout(x: torch.Tensor, p: float, salt: int, out: torch.Tensor | None = Non
     _dev(x, out)
     if x.dtype != torch.bfloat16 or not x.is_contiguous():
         raise HipLibraryError("dropout: contiguous bf16 only")
-    y = torch.empty_like(x) if out is None else out
+    y = _empty_like(x) if out is None else out
     _check(load().cinema_dropout_bf16(x.data_ptr(), y.data_ptr(), x.numel(), float(p), rng_state(x.device).data_ptr(), salt & 0xFFFFFFFF, _stream()), "dropout")
     return y
 
 
 def droppath_scale(batch: int, p: float, salt: int, device: torch.device) -> torch.Tensor:
     """fp32 [batch]: 0 or 1 / (1 - p) per sample (timm ``DropPath``, ``scale_by_keep=True``)."""
-    s = torch.empty(batch, dtype=torch.float32, device=device)
+    s = _empty(batch, dtype=torch.float32, device=device)
     _dev(s)
     _check(load().cinema_droppath_scale(s.data_ptr(), batch, float(p), rng_state(device).data_ptr(), salt & 0xFFFFFFFF, _stream()), "droppath_scale")
     return s
@@ -569,7 +635,7 @@ def scale_rows_add(h: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, r
     _dev(h, scale, residual)
     if h.dtype != torch.float32 or not h.is_contiguous() or (residual is not None and (residual.dtype != torch.float32 or not residual.is_contiguous())):
         raise HipLibraryError("scale_rows_add: contiguous fp32 rows")
-    out = torch.empty_like(h)
+    out = _empty_like(h)
     _check(load().cinema_scale_rows_add(h.data_ptr(), _p(residual), scale.data_ptr(), out.data_ptr(), h.shape[0], h.shape[1], rows_per_sample, _stream()),
            "scale_rows_add")
     return out
@@ -578,7 +644,7 @@ def scale_rows_add(h: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, r
 def full(shape, value: float, dtype: torch.dtype = torch.float32, device=None) -> torch.Tensor:  # noqa: ANN001
     """torch.full / torch.zeros as a launch of this library (so that it is part of a recorded step, see cinema_amd/replay.py): fp32 with
     any value, other dtypes with zero only; the tensor must span whole 32-bit words."""
-    t = torch.empty(shape, dtype=dtype, device=device)
+    t = _empty(shape, dtype=dtype, device=device)
     _dev(t)
     nbytes = t.numel() * t.element_size()
     if value == 0:
@@ -605,7 +671,7 @@ def patch_weight_rows(w: torch.Tensor, jmap: torch.Tensor | None = None, pad_to:
     out, c = w.shape[0], w.shape[1]
     kvol = w[0, 0].numel()
     ld = (kvol * c + pad_to - 1) // pad_to * pad_to
-    rows = torch.empty((out, ld), dtype=torch.bfloat16, device=w.device)
+    rows = _empty((out, ld), dtype=torch.bfloat16, device=w.device)
     _check(load().cinema_patch_weight_relayout(w.data_ptr(), rows.data_ptr(), 1, out, c, kvol, ld, _p(jmap), 0, _stream()), "patch_weight_relayout")
     return rows
 
@@ -642,10 +708,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     """x: [rows, c] fp32/bf16 -> (y_bf16 | None, y_f32 | None, mean, rstd)."""
     _dev(x, gamma, beta)
     rows, c = x.shape
-    y16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
-    y32 = torch.empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None
-    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    y16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    y32 = _empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None
+    mean = _empty(rows, dtype=torch.float32, device=x.device)
+    rstd = _empty(rows, dtype=torch.float32, device=x.device)
     _check(load().cinema_layernorm_fwd(x.data_ptr(), int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), beta.data_ptr(),
                                        rows, c, eps, act, _p(y16), _p(y32), c, mean.data_ptr(), rstd.data_ptr(), _stream()), "layernorm_fwd")
     return y16, y32, mean, rstd
@@ -659,14 +725,14 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: 
     by a later :func:`ln_param_reduce_batched` over the entries appended to that list."""
     _dev(dy, x, gamma, mean, rstd, dx_residual, dgamma, dbeta)
     rows, c = x.shape
-    dx32 = dx_f32_out if dx_f32_out is not None else (torch.empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
-    dx16 = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    dx32 = dx_f32_out if dx_f32_out is not None else (_empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
+    dx16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
         raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
     if deferred is not None and (dgamma is not None or dbeta is not None):
         # the per-block partial sums stay in a buffer of their own until ln_param_reduce_batched adds them up (end of the backward pass)
         # sized from the launch's actual grid (a fixed 2048-block buffer was 12.6 MB per LayerNorm at c = 768: ~1 GB held across a step)
-        ws = torch.empty(max(load().cinema_layernorm_bwd_workspace_bytes(rows, c) // 4, 4), dtype=torch.float32, device=x.device)
+        ws = _empty(max(load().cinema_layernorm_bwd_workspace_bytes(rows, c) // 4, 4), dtype=torch.float32, device=x.device)
         n_part = C.c_int(0)
         _check(load().cinema_layernorm_bwd_deferred(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
                                                     int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
@@ -706,8 +772,8 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     b, tq, cdim = q.shape
     tk, hd = k.shape[1], cdim // heads
     (qp, ldq), (kp, ldk), (vp, ldv) = _attn_view(q, heads, hd, "q"), _attn_view(k, heads, hd, "k"), _attn_view(v, heads, hd, "v")
-    o = torch.empty((b, tq, cdim), dtype=torch.bfloat16, device=q.device)
-    lse = torch.empty((b, heads, tq), dtype=torch.float32, device=q.device)
+    o = _empty((b, tq, cdim), dtype=torch.bfloat16, device=q.device)
+    lse = _empty((b, heads, tq), dtype=torch.float32, device=q.device)
     _check(load().cinema_attention_fwd(qp, ldq, kp, ldk, vp, ldv, o.data_ptr(), cdim, lse.data_ptr(), b, heads, tq, tk, hd, scale,
                                        int(force_generic or FORCE_GENERIC), _stream()), "attention_fwd")
     return o, lse
@@ -720,7 +786,7 @@ def attention_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Te
     b, tq, cdim = q.shape
     tk, hd = k.shape[1], cdim // heads
     ptrs = [_attn_view(t, heads, hd, n) for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv"))]
-    delta = torch.empty((b, heads, tq), dtype=torch.float32, device=q.device)
+    delta = _empty((b, heads, tq), dtype=torch.float32, device=q.device)
     _check(load().cinema_attention_bwd(ptrs[0][0], ptrs[0][1], ptrs[1][0], ptrs[1][1], ptrs[2][0], ptrs[2][1], ptrs[3][0], ptrs[3][1],
                                        ptrs[4][0], ptrs[4][1], lse.data_ptr(), delta.data_ptr(), ptrs[5][0], ptrs[5][1], ptrs[6][0], ptrs[6][1],
                                        ptrs[7][0], ptrs[7][1], b, heads, tq, tk, hd, scale, int(force_generic or FORCE_GENERIC), _stream()),
@@ -741,7 +807,7 @@ def dwconv_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None) -> t
     _dev(x, w, bias)
     if not x.is_contiguous() or x.dtype != torch.bfloat16 or w.dtype != torch.float32 or not w.is_contiguous():
         raise HipLibraryError("dwconv: x must be contiguous bf16 channels-last, w contiguous fp32")
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     b, X, Y, Z, c, kx, ky, kz = _dw_dims(x, tuple(w.shape[2:]))  # noqa: N806
     _check(load().cinema_dwconv_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), b, X, Y, Z, c, kx, ky, kz, _stream()), "dwconv_fwd")
     return y
@@ -749,7 +815,7 @@ def dwconv_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None) -> t
 
 def dwconv_bwd_data(dy: torch.Tensor, w: torch.Tensor, out_mask: torch.Tensor | None = None) -> torch.Tensor:
     _dev(dy, w, out_mask)
-    dx = torch.empty_like(dy)
+    dx = _empty_like(dy)
     b, X, Y, Z, c, kx, ky, kz = _dw_dims(dy, tuple(w.shape[2:]))  # noqa: N806
     _check(load().cinema_dwconv_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(out_mask), b, X, Y, Z, c, kx, ky, kz, _stream()), "dwconv_bwd_data")
     return dx
@@ -779,7 +845,7 @@ def im2col(x: torch.Tensor, ks: tuple) -> torch.Tensor:
         raise HipLibraryError("im2col: x must be contiguous bf16 channels-last")
     b, X, Y, Z, c, kx, ky, kz = _vol_dims(tuple(x.shape), ks)  # noqa: N806
     ld = (kx * ky * kz * c + 7) // 8 * 8
-    cols = torch.empty((b * X * Y * Z, ld), dtype=torch.bfloat16, device=x.device)
+    cols = _empty((b * X * Y * Z, ld), dtype=torch.bfloat16, device=x.device)
     _check(load().cinema_im2col(x.data_ptr(), cols.data_ptr(), ld, b, X, Y, Z, c, kx, ky, kz, _stream()), "im2col")
     return cols
 
@@ -788,7 +854,7 @@ def col2im(dcols: torch.Tensor, shape: tuple, ks: tuple) -> torch.Tensor:
     """Data gradient of :func:`im2col`: dcols bf16 [b*prod(spatial), ld] -> dx bf16 [b, *spatial, c]."""
     _dev(dcols)
     b, X, Y, Z, c, kx, ky, kz = _vol_dims(tuple(shape), ks)  # noqa: N806
-    dx = torch.empty(shape, dtype=torch.bfloat16, device=dcols.device)
+    dx = _empty(shape, dtype=torch.bfloat16, device=dcols.device)
     _check(load().cinema_col2im(dcols.data_ptr(), _rowmajor(dcols, "dcols"), dx.data_ptr(), b, X, Y, Z, c, kx, ky, kz, _stream()), "col2im")
     return dx
 
@@ -799,7 +865,7 @@ def random_mask(noise: torch.Tensor, n_keep: int) -> torch.Tensor:
     if noise.dtype != torch.float32 or noise.dim() != 2 or not noise.is_contiguous():
         raise HipLibraryError("random_mask: contiguous fp32 [batch, n] noise")
     b, n = noise.shape
-    mask = torch.empty((b, n), dtype=torch.bool, device=noise.device)
+    mask = _empty((b, n), dtype=torch.bool, device=noise.device)
     _check(load().cinema_mask_select(noise.data_ptr(), mask.data_ptr(), b, n, n_keep, None, None, None, None, _stream()), "mask_select")
     return mask
 
@@ -810,7 +876,7 @@ def mask_select(mask: torch.Tensor, n_keep: int) -> tuple:
     if mask.dtype != torch.bool or mask.dim() != 2 or not mask.is_contiguous():
         raise HipLibraryError("mask_select: contiguous bool [batch, n] mask")
     b, n = mask.shape
-    outs = [torch.empty(b * k, dtype=torch.int32, device=mask.device) for k in (n_keep, n - n_keep, n_keep, n - n_keep)]
+    outs = [_empty(b * k, dtype=torch.int32, device=mask.device) for k in (n_keep, n - n_keep, n_keep, n - n_keep)]
     _check(load().cinema_mask_select(None, mask.data_ptr(), b, n, n_keep, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
                                      _stream()), "mask_select")
     return tuple(outs)
@@ -829,9 +895,9 @@ def visible_index(keep: torch.Tensor, batch: int, grid: tuple, block: tuple, inv
         vol *= int(b_)
     if inv1.numel() != vol:
         raise HipLibraryError("visible_index: inv1 must have one entry per voxel of a token block")
-    rank = torch.empty(n_all, dtype=torch.int32, device=keep.device)
+    rank = _empty(n_all, dtype=torch.int32, device=keep.device)
     _check(load().cinema_fill_u32(rank.data_ptr(), 0xFFFFFFFF, n_all, _stream()), "fill")  # -1
-    idx1 = torch.empty(keep.numel() * vol, dtype=torch.int32, device=keep.device)
+    idx1 = _empty(keep.numel() * vol, dtype=torch.int32, device=keep.device)
     garr, barr = (C.c_int * nd)(*[int(v) for v in grid]), (C.c_int * nd)(*[int(v) for v in block])
     _check(load().cinema_visible_index(keep.data_ptr(), keep.numel(), nd, garr, barr, inv1.data_ptr(), rank.data_ptr(), idx1.data_ptr(), _stream()), "visible_index")
     return rank, idx1
@@ -857,7 +923,7 @@ def _sparse_nbr(geom: SparseGeom, kdims: tuple, device: torch.device) -> tuple:
     hit = geom.nbr_lists.get(kdims)
     if hit is None:
         rows = geom.n_tok * geom.bx * geom.by * geom.bz
-        buf = torch.empty(load().cinema_sparse_nbr_ints(rows), dtype=torch.int32, device=device)
+        buf = _empty(load().cinema_sparse_nbr_ints(rows), dtype=torch.int32, device=device)
         nbr, cnt = buf[:rows * 128], buf[rows * 128:]
         _check(load().cinema_sparse_nbr_build(C.byref(geom), *kdims, nbr.data_ptr(), cnt.data_ptr(), _stream()), "sparse_nbr_build")
         hit = geom.nbr_lists[kdims] = (nbr, cnt)
@@ -876,7 +942,7 @@ def sparse_dwconv(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, g
         raise HipLibraryError("sparse_dwconv: x must be contiguous bf16 rows, w contiguous fp32")
     c = x.shape[1]
     kx, ky, kz = _kernel3(w)
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     nbr, cnt = _sparse_nbr(geom, (kx, ky, kz), x.device)
     _check(load().cinema_sparse_dwconv_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), C.byref(geom), nbr.data_ptr(), cnt.data_ptr(), c, kx, ky, kz,
                                            int(flip), _stream()), "sparse_dwconv")
@@ -920,7 +986,7 @@ def patch_geom(batch: int, chans: int, grid: tuple, patch: tuple, strides: tuple
 def patch_gather(src: torch.Tensor, geom: PatchGeom, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
     _dev(src)
     feat = geom.px * geom.py * geom.pz * geom.c
-    out = torch.empty((geom.n_rows, feat), dtype=out_dtype, device=src.device)
+    out = _empty((geom.n_rows, feat), dtype=out_dtype, device=src.device)
     _check(load().cinema_patch_gather(src.data_ptr(), _DT[src.dtype], out.data_ptr(), _DT[out_dtype], feat, C.byref(geom), _stream()), "patch_gather")
     return out
 
@@ -982,7 +1048,7 @@ def cast(src: torch.Tensor, dtype: torch.dtype, out: torch.Tensor | None = None)
     if not src.is_contiguous():
         raise HipLibraryError("cast needs a contiguous source")
     if out is None:
-        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+        out = _empty(src.shape, dtype=dtype, device=src.device)
     _check(load().cinema_cast(src.data_ptr(), _DT[src.dtype], out.data_ptr(), _DT[out.dtype], src.numel(), _stream()), "cast")
     return out
 
@@ -992,21 +1058,21 @@ def transpose_cast(src: torch.Tensor, out: torch.Tensor | None = None) -> torch.
     _dev(src, out)
     r, c = src.shape
     if out is None:
-        out = torch.empty((c, r), dtype=torch.bfloat16, device=src.device)
+        out = _empty((c, r), dtype=torch.bfloat16, device=src.device)
     _check(load().cinema_transpose_cast(src.data_ptr(), _DT[src.dtype], r, c, out.data_ptr(), _stream()), "transpose_cast")
     return out
 
 
 def gelu_fwd(x: torch.Tensor) -> torch.Tensor:
     _dev(x)
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     _check(load().cinema_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gelu_fwd")
     return y
 
 
 def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     _dev(x, dy)
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     _check(load().cinema_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "gelu_bwd")
     return dx
 
@@ -1039,7 +1105,7 @@ def mse_fwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_targe
 def mse_bwd(image: torch.Tensor, geom: PatchGeom, pred: torch.Tensor, norm_target: bool, eps: float, upstream: torch.Tensor | None,
             host_scale: float) -> torch.Tensor:
     _dev(image, pred, upstream)
-    dpred = torch.empty(pred.shape, dtype=torch.bfloat16, device=pred.device)
+    dpred = _empty(pred.shape, dtype=torch.bfloat16, device=pred.device)
     _check(load().cinema_mse_bwd(image.data_ptr(), C.byref(geom), pred.data_ptr(), _DT[pred.dtype], _rowmajor(pred, "pred"), int(norm_target), eps,
                                  _p(upstream), host_scale, dpred.data_ptr(), dpred.stride(0), _stream()), "mse_bwd")
     return dpred

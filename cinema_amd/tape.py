@@ -279,6 +279,47 @@ class Tape:
         self.ops = []
 
 
+class lane_group:  # noqa: N801
+    """Forward AND backward lane group (``hip.lanes``) over n independent, identically shaped op sequences recorded on ``tape``::
+
+        with lane_group(tape, 3) as g:
+            for i, view in enumerate(views):
+                g.select(i)
+                ...ops of this view...
+
+    The launches of the n sequences go out zipped (one wide launch per position) when the block ends; the backward closures recorded inside
+    run later under a mirrored group.  The sequences must not share parameters, gradient buffers or activations."""
+
+    def __init__(self, tape: "Tape", n: int) -> None:
+        self.tape, self.n = tape, n
+        self.fwd = K.lanes(n)
+        self.bwd = None
+
+    def __enter__(self) -> "lane_group":
+        self.tape.record(self._bwd_close)  # runs LAST in the reversed backward order
+        self.fwd.__enter__()
+        return self
+
+    def select(self, lane: int) -> None:
+        self.fwd.select(lane)
+        self.tape.record(lambda: self.bwd.select(lane - 1) if (lane > 0 and self.bwd is not None) else None)  # runs after lane `lane`'s backward ops
+
+    def __exit__(self, *exc) -> None:  # noqa: ANN002
+        self.fwd.__exit__(*exc)
+        if exc[0] is None:
+            self.tape.record(self._bwd_open)  # runs FIRST in the backward pass
+
+    def _bwd_open(self) -> None:
+        self.bwd = K.lanes(self.n)
+        self.bwd.__enter__()
+        self.bwd.select(self.n - 1)
+
+    def _bwd_close(self) -> None:
+        if self.bwd is not None:
+            self.bwd.__exit__(None, None, None)
+            self.bwd = None
+
+
 def flush_ln(tape: "Tape") -> None:
     """Add the LayerNorm parameter-gradient partials collected so far into dgamma / dbeta (one batched launch)."""
     items, tape.pending_ln = tape.pending_ln, []
@@ -405,7 +446,8 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
         K.stream_fork(K._stream(), side)
         with K.on_stream(side):  # raw redirection: no torch stream context, no event objects (this runs ~200x per step)
             fn()
-        if K.RECORD is not None or torch._C._cuda_isCurrentStreamCapturing():  # recorded / captured step: no completion queries at replay time, so the
+        if K.RECORD is not None or K.LANE is not None or torch._C._cuda_isCurrentStreamCapturing():  # recorded / captured step (or a lane group, whose
+            # launches go out later): no completion queries at replay time, so the
             # allocator must not reuse an operand before the join (which is itself part of the recording)
             _SIDE_KEEP.append((None, operands))
             return
@@ -547,7 +589,7 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     ``residual=None``: the caller adds it (behind a DropPath, :func:`op_droppath_add`)."""
     w1, w2 = w_plain(fc1_w), w_plain(fc2_w)
     m, hidden = x.data.shape[0], w1.shape[0]
-    h = torch.empty((m, hidden), dtype=BF16, device=x.data.device)
+    h = K.empty((m, hidden), dtype=BF16, device=x.data.device)
     a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h)
     y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
     pv = [tape.pvar(p) for p in (fc1_w, fc1_b, fc2_w, fc2_b)]
@@ -588,7 +630,7 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
     def bwd() -> None:
         if y.grad is None:
             return
-        dqkv = torch.empty_like(qkv)
+        dqkv = K.empty_like(qkv)
         d3 = dqkv.view(batch, t, 3 * c)
         K.attention_bwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], o, y.grad.view(batch, t, c), lse, heads, scale, d3[..., :c],
                         d3[..., c:2 * c], d3[..., 2 * c:])
@@ -627,7 +669,7 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
     def bwd() -> None:
         if y.grad is None:
             return
-        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        dq, dkv = K.empty_like(q), K.empty_like(kv)
         dkv3 = dkv.view(batch, tk, 2 * c)
         K.attention_bwd(q3, kv3[..., :c], kv3[..., c:], o, y.grad.view(batch, tq, c), lse, heads, scale, dq.view(batch, tq, c), dkv3[..., :c],
                         dkv3[..., c:])
@@ -843,11 +885,11 @@ def op_conv_transpose(tape: Tape, x: Var, batch: int, spatial: tuple, weight: to
     n_out = batch * math.prod(out_spatial)
     geom = K.patch_geom(batch, c_out, spatial, ks, _chan_last_strides(c_out, out_spatial))
     if skip is not None:
-        dst = torch.empty((n_out, c_out), dtype=F32, device=x.data.device)
+        dst = K.empty((n_out, c_out), dtype=F32, device=x.data.device)
         K.row_copy(dst, skip.data)
         K.patch_scatter(rows, dst, geom, accumulate=True)
     else:
-        dst = torch.empty((n_out, c_out), dtype=F32, device=x.data.device)
+        dst = K.empty((n_out, c_out), dtype=F32, device=x.data.device)
         K.patch_scatter(rows, dst, geom)
     y = Var(dst)
     wv, bv = tape.pvar(weight), tape.pvar(bias)
@@ -901,7 +943,7 @@ def op_patch_gather(tape: Tape, x: Var, geom, dst_shape: tuple | None = None) ->
         if y.grad is None or not x.needs_grad:
             return
         subset = geom.token_idx is not None
-        dx = zeros(x.data.shape, F32, x.data.device) if subset else torch.empty(x.data.shape, dtype=F32, device=x.data.device)
+        dx = zeros(x.data.shape, F32, x.data.device) if subset else K.empty(x.data.shape, dtype=F32, device=x.data.device)
         K.patch_scatter(y.grad, dx, geom)
         x.add_grad(dx)
 
@@ -913,7 +955,7 @@ def op_split_rows(tape: Tape, x: Var, idx_list: list) -> list:
     """ys[i] = x[idx_list[i]] (int32 row indices, disjoint across the list).  One zeroed gradient buffer is shared; all the gathers (and,
     backward, all the scatters) go out as one multi-segment launch."""
     c = x.data.shape[1]
-    outs = [torch.empty((idx.numel(), c), dtype=x.data.dtype, device=x.data.device) for idx in idx_list]
+    outs = [K.empty((idx.numel(), c), dtype=x.data.dtype, device=x.data.device) for idx in idx_list]
     K.row_copy_multi([dict(dst=out, src=x.data, src_idx=idx) for out, idx in zip(outs, idx_list)])
     ys = [Var(out) for out in outs]
 
@@ -942,7 +984,7 @@ class Segment:
 def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.device) -> Var:
     """Build a token matrix [n_rows, c] (fp32) from row segments (replaces torch.cat / bool-mask selects / pos-embed adds:
     cinema/vit.py:672-674, cinema/mae/mae.py:98-104,580-585, cinema/convvit.py:205)."""
-    out = torch.empty((n_rows, c), dtype=F32, device=device)
+    out = K.empty((n_rows, c), dtype=F32, device=device)
     copies = []
     for s in segments:  # disjoint destination rows: one multi-segment launch
         n = s.dst_idx.numel()
@@ -963,7 +1005,7 @@ def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.d
         for s in segments:
             if isinstance(s.src, Var):
                 if s.src.needs_grad:
-                    g = torch.empty((s.dst_idx.numel(), c), dtype=F32, device=device)
+                    g = K.empty((s.dst_idx.numel(), c), dtype=F32, device=device)
                     gathers.append(dict(dst=g, src=y.grad, src_idx=s.dst_idx))
                     targets.append((s.src, g))
             elif s.src is not None and s.src.requires_grad:
@@ -996,9 +1038,9 @@ def op_mse(tape: Tape, pred: Var, image: torch.Tensor, geom_masked, norm_target:
 def op_mean_finite(tape: Tape, losses: list) -> Var:
     """Mean over the finite per-view losses (cinema/mae/mae.py:604-608) without a host round trip."""
     dev = losses[0].data.device
-    vals = torch.empty(len(losses), dtype=F32, device=dev)
+    vals = K.empty(len(losses), dtype=F32, device=dev)
     K.row_copy_multi([dict(dst=vals[i:i + 1].view(1, 1), src=lv.data.view(1, 1)) for i, lv in enumerate(losses)])
-    mean, coef = torch.empty(1, dtype=F32, device=dev), torch.empty(len(losses), dtype=F32, device=dev)
+    mean, coef = K.empty(1, dtype=F32, device=dev), K.empty(len(losses), dtype=F32, device=dev)
     K.mean_finite(vals, mean, coef)
     y = Var(mean)
 

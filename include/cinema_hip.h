@@ -260,6 +260,17 @@ int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* strea
  *                         tickets may be outstanding per device.
  *   cinema_marker_done:   1 = complete, 0 = still running, < 0 = error. */
 int cinema_stream_fork(void* from_stream, void* to_stream);
+/* Lane groups: n independent, identically shaped launch sequences (the three long-axis views of an MAE step run the same ~45 forward / ~95 backward
+ * tiny stem kernels on different pointers; their cost is launch latency, not work).  Between cinema_lanes_begin(n) (n <= 4) and cinema_lanes_end()
+ * every launch of this library - and every cinema_stream_fork - is RECORDED in the current lane's sequence instead of being issued;
+ * cinema_lanes_select(i) switches the lane.  cinema_lanes_end walks the n sequences in lock step: a position at which all lanes hold the same kernel
+ * with the same launch geometry goes out as ONE launch of the kernel's lanes form (grid x n, one parameter block per lane); anything else goes out one
+ * by one in lane order (also when the sequences differ in length).  Contract: the lanes are independent of each other; buffers touched inside the
+ * group stay allocated until the group ends; scratch handed to the library is per lane.  merged_out / single_out (may be NULL) receive the number of
+ * merged / single kernel launches issued. */
+int cinema_lanes_begin(int n);
+int cinema_lanes_select(int lane);
+int cinema_lanes_end(int* merged_out, int* single_out);
 long long cinema_marker_record(void* stream);
 int cinema_marker_done(long long ticket);
 /* n back-to-back launches of an empty kernel (measures the host cost of one launch; used by tools/launch_rate.py and DESIGN.md section 5). */
