@@ -293,15 +293,14 @@ class MultiScaleFusion(nn.Module, _CkptFlag):
         return T.op_layernorm(tp, x, self.norm.weight, self.norm.bias, self.norm.eps, out_f32=out_f32)
 
 
-def _same_stem_geometry(model, a: str, b: str, images: dict, sels: dict) -> bool:  # noqa: ANN001
-    """Two views whose stems issue identical launch sequences: same image shape, same stem configuration, same token selection sizes."""
-    ea, eb = model.enc_down_dict[a], model.enc_down_dict[b]
-    if tuple(images[a].shape) != tuple(images[b].shape) or ea.patch_sizes != eb.patch_sizes:
-        return False
-    if [tuple(p.shape) for p in ea.parameters()] != [tuple(p.shape) for p in eb.parameters()]:
-        return False
-    sa, sb = sels[a], sels[b]
-    return (sa.n_keep, sa.n_drop, sa.all_tokens, sa.mask is None) == (sb.n_keep, sb.n_drop, sb.all_tokens, sb.mask is None)
+def stem_geometry(model, v: str, images: dict, sels: dict) -> tuple:  # noqa: ANN001
+    """Everything that determines the launch sequence of a view's stem / fusion / head ops: views with equal keys issue identical sequences."""
+    enc = model.enc_down_dict[v]
+    shapes = enc.__dict__.get("_cinema_param_shapes")
+    if shapes is None:
+        shapes = enc.__dict__["_cinema_param_shapes"] = tuple(tuple(p.shape) for p in enc.parameters())
+    s = sels[v]
+    return (tuple(images[v].shape), tuple(enc.patch_sizes), shapes, s.n_keep, s.n_drop, s.all_tokens, s.mask is None)
 
 
 def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids: dict):  # noqa: ANN001, ANN201
@@ -335,20 +334,7 @@ def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids
 
     # consecutive views of identical geometry (the three long-axis views: same shapes, separate weights) run as ONE lane group: their ~45 forward /
     # ~95 backward tiny stem launches each go out zipped, one wide launch per position (hip.lanes; the views share nothing inside the stems)
-    i = 0
-    while i < len(views):
-        j = i + 1
-        while j < len(views) and j - i < 4 and _same_stem_geometry(model, views[i], views[j], images, sels):
-            j += 1
-        if j - i >= 2 and images[views[i]].is_cuda:
-            with T.lane_group(tp, j - i) as grp:
-                for lane, v in enumerate(views[i:j]):
-                    grp.select(lane)
-                    stem(v)
-        else:
-            for v in views[i:j]:
-                stem(v)
-        i = j
+    T.run_in_lanes(tp, list(views), lambda v: stem_geometry(model, v, images, sels), stem, enabled=images[views[0]].is_cuda)
     x = T.op_assemble(tp, batch * t_e, e, segs, dev)
     x = model.encoder.tape_forward(tp, x, batch)
     return x, skips_all, cls_rows, view_rows

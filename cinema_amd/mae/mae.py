@@ -26,7 +26,7 @@ from torch import nn
 from cinema_amd import hip as K
 from cinema_amd import tape as T
 from cinema_amd.conv import Linear
-from cinema_amd.convvit import DownsampleEncoder, MultiScaleFusion, TokenSelection, encode_views
+from cinema_amd.convvit import DownsampleEncoder, MultiScaleFusion, TokenSelection, encode_views, stem_geometry
 from cinema_amd.vit import Mlp, ViTDecoder, ViTEncoder, get_pos_embed, get_tokens, get_vit_config, init_weights, patchify
 
 
@@ -151,10 +151,16 @@ class CineMA(nn.Module):
         parts = T.op_split_rows(tp, x, [cls_rows] + [view_rows[v] for v in views])
         d = self.dec_linear.out_features
         z_cls = T.op_linear(tp, T.op_cast_bf16(tp, parts[0]), self.dec_linear.weight, self.dec_linear.bias, out_f32=True)
-        z_views = {}
-        for i, v in enumerate(views):
-            fused = self.enc_fusion_dict[v].tape_forward(tp, skips_all[v], parts[i + 1], sels[v], grids[v])
-            z_views[v] = T.op_linear(tp, fused, self.dec_linear.weight, self.dec_linear.bias, out_f32=True)
+        z_views, fused = {}, {}
+        part_of = {v: parts[i + 1] for i, v in enumerate(views)}
+
+        def fuse(v: str) -> None:
+            fused[v] = self.enc_fusion_dict[v].tape_forward(tp, skips_all[v], part_of[v], sels[v], grids[v])
+
+        geom = lambda v: stem_geometry(self, v, images, sels)  # noqa: E731
+        T.run_in_lanes(tp, views, geom, fuse, enabled=dev.type == "cuda")  # per-view weights, nothing shared: the long-axis views go out as one lane group
+        for v in views:  # dec_linear is SHARED by the views (one weight-gradient buffer): not a lane group
+            z_views[v] = T.op_linear(tp, fused[v], self.dec_linear.weight, self.dec_linear.bias, out_f32=True)
 
         # decoder sequences (mae.py:569-585)
         n_keep = [sels[v].n_keep for v in views]
@@ -197,8 +203,9 @@ class CineMA(nn.Module):
         # heads + loss (mae.py:589-608)
         live = [v for v in views if sels[v].n_drop > 0]
         dec_parts = dict(zip(live, T.op_split_rows(tp, xd, [mask_rows[v] for v in live]))) if live else {}
-        preds, losses, metrics = {}, [], {}
-        for v in views:
+        preds, loss_of, metrics = {}, {}, {}
+
+        def head(v: str) -> None:
             img = images[v]
             chans = img.shape[1]
             patch = self.dec_patch_size_dict[v]
@@ -208,18 +215,23 @@ class CineMA(nn.Module):
             if v not in dec_parts:
                 preds[v] = T.Var(torch.empty((0, math.prod(patch) * chans), dtype=torch.float32, device=dev), needs_grad=False)
                 nan = T.Var(K.full((1,), float("nan"), torch.float32, dev), needs_grad=False)
-                losses.append(nan)
+                loss_of[v] = nan
                 metrics[f"{v}_mse_loss"] = nan.data[0]
-                continue
-            head = self.pred_head_dict[v]
-            pred = T.op_linear(tp, dec_parts[v], head.weight, head.bias, out_f32=True)
-            geom = K.patch_geom(batch, chans, grids[v], patch, tuple(img.stride()), token_idx=sels[v].drop)
-            loss_v, maxes = T.op_mse(tp, pred, img, geom, self.norm_target)
+                return
+            hd = self.pred_head_dict[v]
+            pred = T.op_linear(tp, dec_parts[v], hd.weight, hd.bias, out_f32=True)
+            geom_m = K.patch_geom(batch, chans, grids[v], patch, tuple(img.stride()), token_idx=sels[v].drop)
+            loss_v, maxes = T.op_mse(tp, pred, img, geom_m, self.norm_target)
             preds[v] = pred
-            losses.append(loss_v)
+            loss_of[v] = loss_v
             metrics[f"{v}_mse_loss"] = loss_v.data[0]
             if maxes is not None:
                 metrics[f"{v}_normed_target_max"], metrics[f"{v}_pred_max"] = maxes[0], maxes[1]
+
+        T.run_in_lanes(tp, views, geom, head, enabled=dev.type == "cuda")  # prediction heads + losses: per-view weights and accumulators
+        preds = {v: preds[v] for v in views}
+        metrics = {k: metrics[k] for v in views for k in metrics if k.startswith(f"{v}_")}
+        losses = [loss_of[v] for v in views]
         loss = T.op_mean_finite(tp, losses)
         return loss, preds, metrics
 

@@ -320,6 +320,24 @@ class lane_group:  # noqa: N801
             self.bwd = None
 
 
+def run_in_lanes(tape: "Tape", items: list, key: Callable, body: Callable, enabled: bool = True) -> None:
+    """``body(item)`` for every item, in order; runs of 2-4 consecutive items with equal ``key(item)`` (identical launch geometry, nothing shared)
+    are issued as one lane group."""
+    i = 0
+    while i < len(items):
+        j = i + 1
+        while enabled and j < len(items) and j - i < 4 and key(items[j]) == key(items[i]):
+            j += 1
+        if j - i >= 2:
+            with lane_group(tape, j - i) as grp:
+                for lane, it in enumerate(items[i:j]):
+                    grp.select(lane)
+                    body(it)
+        else:
+            body(items[i])
+        i = j
+
+
 def flush_ln(tape: "Tape") -> None:
     """Add the LayerNorm parameter-gradient partials collected so far into dgamma / dbeta (one batched launch)."""
     items, tape.pending_ln = tape.pending_ln, []
