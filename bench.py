@@ -275,6 +275,8 @@ def main() -> None:
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the per-kernel roofline")
     ap.add_argument("--task", default="mae", choices=["mae", "seg"], help="mae: the BASELINE metric (config 2 / 3 / 5 shapes); seg: BASELINE config 4, the "
                     "ConvUNetR segmentation fine-tuning step (SAX 256x256x12, 4 classes, per-GPU batch 4, dropout / drop_path 0.1)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the transformer blocks' forward projections on e4m3 operands (BASELINE config 5, "
+                    "with --size large --sax 256,256,24 --lax 256,256 --batch 8); backward GEMMs stay bf16.  The BASELINE metric (config 2) is bf16")
     ap.add_argument("--eager", action="store_true", help="issue every launch from the module code instead of the recorded launch list (A/B)")
     args = ap.parse_args()
 
@@ -292,8 +294,11 @@ def main() -> None:
 
     from cinema_amd import CineMA
     from cinema_amd import hip as K
+    from cinema_amd import tape as T_fp8
     from cinema_amd.ddp import GradientSynchronizer, ddp_setup
     from cinema_amd.optim import TrainStep
+
+    T_fp8.FP8_FORWARD = args.dtype == "fp8"
 
     sync = None
     if world > 1:
@@ -404,7 +409,7 @@ def main() -> None:
         out = {
             "metric": "MAE-pretrain samples/sec (4-view cine, 75% mask)", "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "untimed_steps": extra_untimed + args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("bf16" if args.dtype == "bf16" else "fp8 (e4m3 forward projections, per-tensor current scaling; bf16 backward)"), "data": "synthetic",
             "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX {args.sax.replace(',', 'x')} + LAX 2C/3C/4C {args.lax.replace(',', 'x')}), mask 0.75, "
                                    f"per-GPU batch {args.batch}, fwd+bwd+clip(5.0)+AdamW, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),

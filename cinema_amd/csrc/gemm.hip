@@ -25,6 +25,8 @@ struct GemmP {
   // + slice][128][128]; tail_fixup_kernel sums the slices and runs the fused epilogue.  tail_split == 0: off.
   int tail_begin, tail_split, tail_ktiles;
   float* tail_ws;
+  // fp8 (e4m3) operands: per-tensor dequantisation scales in device memory (the product multiplies alpha); NULL for bf16 operands
+  const float* scale_a; const float* scale_b;
 };
 
 __device__ __forceinline__ float frag_sum8(const short8v& f) {
@@ -635,7 +637,20 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k32_lanes_kernel(Lanes<GemmP
 }
 
 // One 128x128 output tile (or k-slice of one) of problem p: everything after the work-item decoding of the kernels below.
-template <bool A_KMAJ, bool B_KMAJ, int EPI>
+// FP8: the operands are e4m3 bytes, k-major; the host describes them as bf16 matrices of HALF the reduction length (p.k, p.lda, p.ldb count byte
+// pairs), so the tile loader moves the same 128-byte rows (= 128 fp8 values of k); only the fragment reads and the MFMA differ:
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 = 127), twice the multiply-accumulates per cycle of the bf16 instruction.
+typedef int int8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int8v frag_fp8(const char* lds, int base, int ks, int lane) {
+  const int row = base + (lane & 31);
+  const int c0 = ks * 4 + (lane >> 5) * 2;  // the lane's 32 consecutive k values = two 16-byte chunks of the 128-byte row
+  const uint4 lo = *reinterpret_cast<const uint4*>(lds + swz_off<128>(row, c0)), hi = *reinterpret_cast<const uint4*>(lds + swz_off<128>(row, c0 + 1));
+  int8v out;
+  out[0] = lo.x; out[1] = lo.y; out[2] = lo.z; out[3] = lo.w; out[4] = hi.x; out[5] = hi.y; out[6] = hi.z; out[7] = hi.w;
+  return out;
+}
+
+template <bool A_KMAJ, bool B_KMAJ, int EPI, bool FP8 = false>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, int kt_begin, int kt_end, float* tail_dst, char* smem) {
   using AIO = TileIO<A_KMAJ>;
   using BIO = TileIO<B_KMAJ>;
@@ -684,6 +699,22 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + AIO::BYTES;
     const bool more = kt + 1 < kt_end;
+    if constexpr (FP8) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        int8v fa[2], fb[2];
+        fa[0] = frag_fp8(sa, wm, ks, lane);
+        fa[1] = frag_fp8(sa, wm + 32, ks, lane);
+        fb[0] = frag_fp8(sb, wn, ks, lane);
+        fb[1] = frag_fp8(sb, wn + 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        if (ks == 0 && more) load_tile(cur ^ 1, kt + 1);
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       short8v fa[2], fb[2];
@@ -731,6 +762,12 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
     }
     return;
   }
+  if constexpr (FP8) {  // dequantisation: alpha x scale_a x scale_b (per-tensor scales from device memory)
+    GemmP q = p;
+    q.alpha = p.alpha * p.scale_a[0] * p.scale_b[0];
+    tile_epilogue<EPI>(q, acc, m0 + wm, n0 + wn, lane, zsplit, stg);
+    return;
+  }
   // fp32 partial of a split-tail k-slice: plain [128][128] rows (address = base + m * 128 + n with the tile origin folded into base)
   if (tail_dst) tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, 0, stg, tail_dst - ((long long)m0 * BN + n0), BN);
   else tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, zsplit, stg);
@@ -741,7 +778,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
 #endif
 }
 
-template <bool A_KMAJ, bool B_KMAJ, int EPI>
+template <bool A_KMAJ, bool B_KMAJ, int EPI, bool FP8 = false>
 __device__ __forceinline__ void gemm_mfma_body(const GemmP& p, char* smem) {
   // linear dispatch id (x fastest, then z) -> logical work item, split-major so that one XCD sees one k-range
   const int nkt = (p.k + BK - 1) / BK;
@@ -764,7 +801,12 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmP& p, char* smem) {
     kt_begin = zsplit * p.ktiles_per_split;
     kt_end = min(nkt, kt_begin + p.ktiles_per_split);
   }
-  gemm_tile<A_KMAJ, B_KMAJ, EPI>(p, tile, zsplit, kt_begin, kt_end, tail_dst, smem);
+  gemm_tile<A_KMAJ, B_KMAJ, EPI, FP8>(p, tile, zsplit, kt_begin, kt_end, tail_dst, smem);
+}
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO<true>::BYTES + TileIO<true>::BYTES)];
+  gemm_mfma_body<true, true, EPI, true>(p, smem);
 }
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
@@ -987,6 +1029,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = a->residual_bf16; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
+  p.scale_a = nullptr; p.scale_b = nullptr;
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -1122,6 +1165,37 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   return launch_status();
 }
 
+// fp8 (OCP e4m3) forward GEMM: D[M,N] = epilogue(alpha * scale_a * scale_b * A8 @ B8^T), A8 [M][lda] and B8 [N][ldb] bytes, k-major (the nn.Linear
+// layout), K % 16 == 0, lda / ldb % 16 == 0, 16-byte aligned; epilogue terms as cinema_gemm_bf16's forward classes: bias, exact GELU with optional
+// bf16 pre-activation copy (aux_out), fp32 residual; bf16 or fp32 output.  No split-K / split tail.
+CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
+  if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0 || !a->scale_a || !a->scale_b) return CINEMA_ERR_BAD_ARG;
+  if (!a->a_kmajor || !a->b_kmajor || a->accumulate || a->split_k > 1 || a->gelu_in || a->row_mask || a->residual_bf16 || a->a_rowsum) return CINEMA_ERR_UNSUPPORTED;
+  auto al = [](long long v, int q) { return (v % q) == 0; };
+  if (!al(a->k, 16) || !al(a->lda, 16) || !al(a->ldb, 16) || !al(a->ldd, 8) || !al(a->n, 8) || !al((uintptr_t)a->a, 16) || !al((uintptr_t)a->b, 16) ||
+      !al((uintptr_t)a->d, 16) || (a->bias && !al((uintptr_t)a->bias, 16)) || (a->residual_f32 && (!al(a->ld_res, 8) || !al((uintptr_t)a->residual_f32, 16))) ||
+      (a->aux_out && (!al(a->ld_aux, 8) || !al((uintptr_t)a->aux_out, 16))))
+    return CINEMA_ERR_UNSUPPORTED;
+  GemmP p;
+  p.a = (const bf16_t*)a->a; p.b = (const bf16_t*)a->b; p.d = a->d;
+  p.m = a->m; p.n = a->n; p.k = a->k / 2; p.lda = a->lda / 2; p.ldb = a->ldb / 2; p.ldd = a->ldd;  // byte pairs: see gemm_tile<.., FP8>
+  p.alpha = a->alpha;
+  p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
+  p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
+  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
+  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.scale_a = a->scale_a; p.scale_b = a->scale_b;
+  const int nkt = (p.k + BK - 1) / BK;
+  p.ktiles_per_split = nkt;
+  dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (!p.out_f32 && !p.res_f32 && p.act == 0 && !p.aux_out) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16; }
+  else if (!p.out_f32 && !p.res_f32 && p.act == 1) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16_GELU>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16_GELU; }
+  else if (p.out_f32 && p.act == 0 && !p.aux_out) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_F32>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_F32; }
+  else return CINEMA_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
 CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void* stream) {
   if (!args || count < 1 || count > 8) return CINEMA_ERR_BAD_ARG;
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -1146,7 +1220,7 @@ CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void*
     p.ld_res = a->ldd;
     p.ktiles_per_split = (a->k + BK - 1) / BK;
     p.ws = nullptr; p.a_rowsum = a->a_rowsum;
-    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr;
     g.tile_begin[i + 1] = g.tile_begin[i] + ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN);
     args[i].kernel_used = 64;  // the grouped kernel
   }

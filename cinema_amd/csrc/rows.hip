@@ -465,6 +465,100 @@ CINEMA_API int cinema_scale_rows_add(const float* h, const float* residual, cons
   return launch_status();
 }
 
+// ---- per-tensor e4m3 quantisation (fp8 forward GEMMs, BASELINE config 5) -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_bf16_kernel(const bf16_t* x, long long n8, unsigned int* amax_bits) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) m = fmaxf(m, fabsf(bf2f(v.v[j])));
+  }
+  __shared__ float part[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // ONE atomic per block (thousands of same-address atomics serialise: the first form took 100 us for 17 MB)
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m > 0.f) atomicMax(amax_bits, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  }
+}
+
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_t* x, long long n8, uint8_t* y, const unsigned int* amax_bits, float* scale_out) {
+  const float amax = __uint_as_float(amax_bits[0]);
+  const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / scale;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = scale;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[0]) * inv, bf2f(v.v[1]) * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[2]) * inv, bf2f(v.v[3]) * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[4]) * inv, bf2f(v.v[5]) * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[6]) * inv, bf2f(v.v[7]) * inv, hi, true);
+    reinterpret_cast<int2*>(y)[i] = make_int2(lo, hi);
+  }
+}
+
+// the same over many segments of one flat bf16 buffer at once (the weight shadows of a whole model: one scale per segment), blockIdx.y = segment
+__global__ __launch_bounds__(256) void amax_bf16_seg_kernel(const bf16_t* x, const long long* seg, unsigned int* amax_bits) {
+  const long long b8 = seg[2 * blockIdx.y] >> 3, e8 = seg[2 * blockIdx.y + 1] >> 3;
+  float m = 0.f;
+  for (long long i = b8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < e8; i += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) m = fmaxf(m, fabsf(bf2f(v.v[j])));
+  }
+  __shared__ float part[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m > 0.f) atomicMax(amax_bits + blockIdx.y, __float_as_uint(m));
+  }
+}
+
+__global__ __launch_bounds__(256) void quantize_fp8_seg_kernel(const bf16_t* x, const long long* seg, uint8_t* y, const unsigned int* amax_bits, float* scales) {
+  const long long b8 = seg[2 * blockIdx.y] >> 3, e8 = seg[2 * blockIdx.y + 1] >> 3;
+  const float amax = __uint_as_float(amax_bits[blockIdx.y]);
+  const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / scale;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scales[blockIdx.y] = scale;
+  for (long long i = b8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < e8; i += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[0]) * inv, bf2f(v.v[1]) * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[2]) * inv, bf2f(v.v[3]) * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[4]) * inv, bf2f(v.v[5]) * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[6]) * inv, bf2f(v.v[7]) * inv, hi, true);
+    reinterpret_cast<int2*>(y)[i] = make_int2(lo, hi);
+  }
+}
+
+CINEMA_API int cinema_quantize_fp8_segments(const uint16_t* x, const long long* seg_bounds, int n_seg, uint8_t* y, float* scales, unsigned int* amax_ws,
+                                            void* stream) {
+  if (!x || !seg_bounds || !y || !scales || !amax_ws || n_seg <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CINEMA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  CINEMA_LAUNCH(fill_u32_kernel, dim3(grid_for(n_seg, 256)), dim3(256), 0, st, FillP{(uint32_t*)amax_ws, 0u, n_seg});
+  CINEMA_LAUNCH(amax_bf16_seg_kernel, dim3(32, n_seg), dim3(256), 0, st, x, seg_bounds, amax_ws);
+  CINEMA_LAUNCH(quantize_fp8_seg_kernel, dim3(32, n_seg), dim3(256), 0, st, x, seg_bounds, y, (const unsigned int*)amax_ws, scales);
+  return launch_status();
+}
+
+CINEMA_API int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, float* scale_out, unsigned int* amax_ws, void* stream) {
+  if (!x || !y || !scale_out || !amax_ws || n <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((n & 7) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CINEMA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int g = grid_for(n / 8, 256);
+  if (g > 2048) g = 2048;
+  int ga = g > 512 ? 512 : g;
+  CINEMA_LAUNCH(fill_u32_kernel, dim3(1), dim3(256), 0, st, FillP{(uint32_t*)amax_ws, 0u, 1});
+  CINEMA_LAUNCH(amax_bf16_kernel, dim3(ga), dim3(256), 0, st, x, n / 8, amax_ws);
+  CINEMA_LAUNCH(quantize_fp8_kernel, dim3(g), dim3(256), 0, st, x, n / 8, y, (const unsigned int*)amax_ws, scale_out);
+  return launch_status();
+}
+
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;

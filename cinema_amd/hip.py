@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("aux_out", C.c_void_p), ("ld_aux", C.c_int),
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
+        ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
         ("kernel_used", C.c_int),
     ]
 
@@ -94,6 +95,9 @@ _PROTOS = {
     "cinema_hip_info": [C.POINTER(C.c_int)],
     "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "cinema_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i, _vp],
+    "cinema_gemm_fp8": [C.POINTER(GemmArgs), _vp],
+    "cinema_quantize_fp8": [_vp, _ll, _vp, _vp, _vp, _vp],
+    "cinema_quantize_fp8_segments": [_vp, _vp, _i, _vp, _vp, _vp, _vp],
     "cinema_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _vp],
@@ -439,6 +443,62 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
 
 
 _WARNED_GENERIC: set = set()
+
+
+def quantize_fp8(x: torch.Tensor) -> tuple:
+    """Per-tensor e4m3 quantisation of a contiguous bf16 matrix: -> (uint8 tensor of the same shape, fp32 [1] dequantisation scale = amax / 448)."""
+    _dev(x)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.numel() % 8:
+        raise HipLibraryError("quantize_fp8: contiguous bf16 with a multiple of 8 elements")
+    y = _empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = _empty(1, dtype=torch.float32, device=x.device)
+    ws = _workspace("fp8_amax", 4, x.device)
+    _check(load().cinema_quantize_fp8(x.data_ptr(), x.numel(), y.data_ptr(), scale.data_ptr(), ws.data_ptr(), _stream()), "quantize_fp8")
+    return y, scale
+
+
+def quantize_fp8_segments(x: torch.Tensor, seg_bounds: torch.Tensor, y: torch.Tensor, scales: torch.Tensor) -> None:
+    """Segments [seg_bounds[i, 0], seg_bounds[i, 1]) of the flat bf16 buffer ``x`` -> e4m3 in ``y`` (uint8, same layout), one scale per segment."""
+    _dev(x, seg_bounds, y, scales)
+    if x.dtype != torch.bfloat16 or y.dtype != torch.uint8 or seg_bounds.dtype != torch.int64 or scales.dtype != torch.float32 or not seg_bounds.is_contiguous():
+        raise HipLibraryError("quantize_fp8_segments: bf16 source, uint8 destination, int64 [n, 2] bounds, fp32 scales")
+    n = seg_bounds.shape[0]
+    ws = _workspace("fp8_amax_seg", n, x.device)
+    _check(load().cinema_quantize_fp8_segments(x.data_ptr(), seg_bounds.data_ptr(), n, y.data_ptr(), scales.data_ptr(), ws.data_ptr(), _stream()),
+           "quantize_fp8_segments")
+
+
+def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16,
+             bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, aux_out: torch.Tensor | None = None, act: int = 0,
+             alpha: float = 1.0, out: torch.Tensor | None = None) -> torch.Tensor:
+    """D = epilogue(alpha * scale_a * scale_b * A8 @ B8^T): e4m3 operands a8 [M, K], b8 [N, K] (uint8 storage, k-major), per-tensor fp32 [1] scales;
+    bias / exact GELU (+ bf16 pre-activation copy) / fp32 residual epilogue like :func:`gemm`."""
+    _dev(a8, scale_a, b8, scale_b, bias, residual, aux_out)
+    if a8.dtype != torch.uint8 or b8.dtype != torch.uint8 or a8.shape[1] != b8.shape[1]:
+        raise HipLibraryError("gemm_fp8: uint8 (e4m3) operands [M, K] and [N, K]")
+    m, k = a8.shape
+    n = b8.shape[0]
+    if out is None:
+        out = _empty((m, n), dtype=torch.float32 if residual is not None else out_dtype, device=a8.device)
+    elif tuple(out.shape) != (m, n):
+        raise HipLibraryError(f"gemm_fp8 out shape {tuple(out.shape)} != {(m, n)}")
+    _dev(out)
+    g = GemmArgs()
+    g.a, g.b, g.d = a8.data_ptr(), b8.data_ptr(), out.data_ptr()
+    g.m, g.n, g.k, g.lda, g.ldb, g.ldd = m, n, k, _rowmajor(a8, "a8"), _rowmajor(b8, "b8"), _rowmajor(out, "out")
+    g.a_kmajor, g.b_kmajor, g.alpha, g.split_k = 1, 1, alpha, 1
+    g.scale_a, g.scale_b = scale_a.data_ptr(), scale_b.data_ptr()
+    if bias is not None:
+        g.bias = bias.data_ptr()
+    if residual is not None:
+        if residual.dtype != torch.float32:
+            raise HipLibraryError("gemm_fp8: fp32 residual only")
+        g.residual_f32, g.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
+    if aux_out is not None:
+        g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
+    g.act, g.out_f32 = act, int(out.dtype == torch.float32)
+    _check(load().cinema_gemm_fp8(C.byref(g), _stream()), "gemm_fp8")
+    return out
 
 
 def gemm_wgrad_grouped(problems: list) -> None:

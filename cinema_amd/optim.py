@@ -93,6 +93,7 @@ class FlatModel:
                 p._cinema_flat_grad = p.grad  # noqa: SLF001  (tape.PVar accumulates straight into this view)
                 if self.flat_shadow is not None:
                     p._cinema_shadow = self.flat_shadow[off:off + p.numel()]  # noqa: SLF001
+                    p._cinema_flat = self  # noqa: SLF001  (tape.w_fp8 asks the owner for the e4m3 shadow)
                 self.offsets[id(p)] = (off, off + n)
                 off += n
             self.ranges.append((start, off))
@@ -101,6 +102,31 @@ class FlatModel:
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
+
+    # ---- e4m3 weight shadows for the fp8 forward GEMMs (BASELINE config 5): one scale per matrix parameter, all of them re-quantised from the
+    # bf16 shadows in three launches whenever the weights changed (cinema_quantize_fp8_segments); created on first use
+    def fp8_shadow(self, p: nn.Parameter):  # noqa: ANN201
+        """-> (uint8 view of p's e4m3 shadow [numel], fp32 [1] scale) in sync with the current bf16 shadow, or None for a parameter outside the
+        flat buffers / without a fresh bf16 shadow."""
+        rng = self.offsets.get(id(p))
+        if rng is None or self.flat_shadow is None or getattr(p, "_cinema_shadow_version", -1) != p._version or p.dim() < 2:  # noqa: SLF001
+            return None
+        if getattr(self, "_fp8", None) is None:
+            mats = [q for q in self.params if q.dim() >= 2]
+            bounds = torch.tensor([[self.offsets[id(q)][0], self.offsets[id(q)][0] + q.numel() // 8 * 8] for q in mats], dtype=torch.int64,
+                                  device=self.flat_param.device)
+            self._fp8 = {"index": {id(q): i for i, q in enumerate(mats)}, "bounds": bounds, "epoch": None,
+                         "data": torch.zeros(self.numel, dtype=torch.uint8, device=self.flat_param.device),
+                         "scales": torch.ones(len(mats), dtype=torch.float32, device=self.flat_param.device)}
+        st = self._fp8
+        if p.numel() % 8 or id(p) not in st["index"]:
+            return None
+        if st["epoch"] != T.WEIGHTS.epoch:  # the optimiser bumps the epoch after every update
+            K.quantize_fp8_segments(self.flat_shadow, st["bounds"], st["data"], st["scales"])
+            st["epoch"] = T.WEIGHTS.epoch
+        i = st["index"][id(p)]
+        a = rng[0]
+        return st["data"][a:a + p.numel()], st["scales"][i:i + 1]
 
     def refresh_shadows(self) -> None:
         """Re-derive every bf16 shadow from the fp32 masters (after construction / ``load_state_dict``); the optimiser keeps

@@ -370,6 +370,26 @@ def w_plain(weight: torch.nn.Parameter) -> torch.Tensor:
     return WEIGHTS.get((weight,), "plain", lambda: K.cast(weight.detach().reshape(weight.shape[0], -1), BF16))
 
 
+# fp8 forward GEMMs (BASELINE config 5, "fp8 MFMA path"): the q / kv / proj / fc1 / fc2 projections of the transformer blocks multiply e4m3 operands
+# (per-tensor current scaling: activations quantised right before the GEMM, weights once per optimiser step) on the MX-scaled MFMA; every backward
+# GEMM stays bf16 on the bf16 activations / weights that are kept anyway.  Off by default (the BASELINE metric is quoted in bf16).
+FP8_FORWARD = bool(int(os.environ.get("CINEMA_FP8", "0")))
+
+
+def w_fp8(weight: torch.nn.Parameter) -> tuple:
+    """(uint8 [out, in] e4m3 shadow, fp32 [1] scale) of a Linear weight."""
+    flat = getattr(weight, "_cinema_flat", None)
+    hit = flat.fp8_shadow(weight) if flat is not None else None
+    if hit is not None:
+        return hit[0].view(weight.shape[0], -1), hit[1]
+    return WEIGHTS.get((weight,), "fp8", lambda: K.quantize_fp8(w_plain(weight).contiguous()))
+
+
+def _fp8_ok(x: torch.Tensor, *weights: torch.nn.Parameter) -> bool:
+    return (FP8_FORWARD and x.is_cuda and x.dtype == BF16 and x.is_contiguous() and x.shape[1] % 16 == 0 and x.numel() % 8 == 0
+            and all(w.shape[0] % 8 == 0 and math.prod(w.shape[1:]) % 16 == 0 for w in weights))
+
+
 def _hip_layout(fn: Callable, jmap: torch.Tensor | None) -> Callable:
     """Tag a to-parameter-layout function with what the HIP re-layout kernel needs to add the gradient straight into the flat buffer."""
     fn.hip_relayout = (jmap,)
@@ -577,11 +597,17 @@ def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.P
 
 def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None, *, residual: Var | None = None,
               out_f32: bool = False, row_mask: torch.Tensor | None = None, w16: torch.Tensor | None = None,
-              to_param_layout: Callable | None = None) -> Var:
+              to_param_layout: Callable | None = None, fp8: bool = False) -> Var:
     """y = x W^T + b (+ residual); x bf16 [m,k]; W given as nn.Linear / 1x1-conv weight (or a pre-built shadow ``w16``)."""
     w = w16 if w16 is not None else w_plain(weight)
-    y = Var(K.gemm(x.data, w, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
-                   out_dtype=F32 if (out_f32 or residual is not None) else BF16, row_mask=row_mask))
+    if fp8 and w16 is None and row_mask is None and _fp8_ok(x.data, weight) and (residual is None or residual.data.dtype == F32):
+        x8, sx = K.quantize_fp8(x.data)
+        w8, sw = w_fp8(weight)
+        y = Var(K.gemm_fp8(x8, sx, w8, sw, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
+                           out_dtype=F32 if (out_f32 or residual is not None) else BF16))
+    else:
+        y = Var(K.gemm(x.data, w, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
+                       out_dtype=F32 if (out_f32 or residual is not None) else BF16, row_mask=row_mask))
     wv, bv = tape.pvar(weight), tape.pvar(bias)
 
     def bwd() -> None:
@@ -602,14 +628,20 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
 
 
 def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parameter, fc2_w: torch.nn.Parameter, fc2_b: torch.nn.Parameter,
-           residual: Var | None) -> Var:
+           residual: Var | None, fp8: bool = False) -> Var:
     """[residual +] fc2(gelu(fc1(x))) (timm Mlp / ConvMlp); GELU forward fused into fc1's epilogue, GELU backward into fc2's dgrad.
     ``residual=None``: the caller adds it (behind a DropPath, :func:`op_droppath_add`)."""
     w1, w2 = w_plain(fc1_w), w_plain(fc2_w)
     m, hidden = x.data.shape[0], w1.shape[0]
     h = K.empty((m, hidden), dtype=BF16, device=x.data.device)
-    a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h)
-    y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
+    if fp8 and _fp8_ok(x.data, fc1_w, fc2_w) and (residual is None or residual.data.dtype == F32):
+        x8, sx = K.quantize_fp8(x.data)
+        a = K.gemm_fp8(x8, sx, *w_fp8(fc1_w), bias=fc1_b.detach(), act=1, aux_out=h)
+        a8, sa = K.quantize_fp8(a)
+        y = Var(K.gemm_fp8(a8, sa, *w_fp8(fc2_w), bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
+    else:
+        a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h)
+        y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
     pv = [tape.pvar(p) for p in (fc1_w, fc1_b, fc2_w, fc2_b)]
 
     def bwd() -> None:
@@ -628,14 +660,20 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     return y
 
 
-def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, rope: tuple | None = None) -> Var:  # noqa: ANN001
+def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, rope: tuple | None = None, fp8: bool = False) -> Var:  # noqa: ANN001
     """Fused q|k|v projection (one N=3C GEMM on concatenated shadow weights) + flash attention.  x bf16 [b*t, c].
     ``rope`` = (cos, sin) fp32 [heads, hd/2]: the reference's head-indexed rotary embedding (``cinema/vit.py:496-499``), applied in place to the
     q|k columns of the projection; the backward pass rotates dq|dk back before the weight / data gradients."""
     c = x.data.shape[1]
     w = w_cat((q_w, kv_w))
     bias = b_cat((q_b, kv_b)) if q_b is not None else None
-    qkv = K.gemm(x.data, w, bias=bias)
+    if fp8 and _fp8_ok(x.data, q_w, kv_w):  # per-tensor weight scales: q and kv are two GEMMs into the column blocks of one buffer
+        x8, sx = K.quantize_fp8(x.data)
+        qkv = K.empty((x.data.shape[0], 3 * c), dtype=BF16, device=x.data.device)
+        K.gemm_fp8(x8, sx, *w_fp8(q_w), bias=None if q_b is None else q_b.detach(), out=qkv[:, :c])
+        K.gemm_fp8(x8, sx, *w_fp8(kv_w), bias=None if kv_b is None else kv_b.detach(), out=qkv[:, c:])
+    else:
+        qkv = K.gemm(x.data, w, bias=bias)
     if rope is not None:
         K.rope_heads(qkv, 2 * heads, heads, c // heads, rope[0], rope[1])
     t = qkv.shape[0] // batch
@@ -671,12 +709,16 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
     return y
 
 
-def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b) -> Var:  # noqa: ANN001
+def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, fp8: bool = False) -> Var:  # noqa: ANN001
     """q from xq (bf16 [b*tq, c]), k|v from xk (bf16 [b*tk, c], shared by every decoder block, not normed)."""
     c = xq.data.shape[1]
     wq, wkv = w_plain(q_w), w_plain(kv_w)
-    q = K.gemm(xq.data, wq, bias=None if q_b is None else q_b.detach())
-    kv = K.gemm(xk.data, wkv, bias=None if kv_b is None else kv_b.detach())
+    if fp8 and _fp8_ok(xq.data, q_w) and _fp8_ok(xk.data, kv_w):
+        q = K.gemm_fp8(*K.quantize_fp8(xq.data), *w_fp8(q_w), bias=None if q_b is None else q_b.detach())
+        kv = K.gemm_fp8(*K.quantize_fp8(xk.data), *w_fp8(kv_w), bias=None if kv_b is None else kv_b.detach())
+    else:
+        q = K.gemm(xq.data, wq, bias=None if q_b is None else q_b.detach())
+        kv = K.gemm(xk.data, wkv, bias=None if kv_b is None else kv_b.detach())
     tq, tk = q.shape[0] // batch, kv.shape[0] // batch
     q3, kv3 = q.view(batch, tq, c), kv.view(batch, tk, 2 * c)
     scale = (c // heads) ** -0.5

@@ -190,8 +190,8 @@ class Attention(nn.Module):
                 dev = xq.data.device
                 rope = T.const(("rope_tables", self.n_heads, self.head_dim, self.rotary.base, self.rotary.scaling_factor, str(dev)),
                                lambda: self.rotary.head_tables(self.n_heads, dev))
-            return T.op_self_attention(tp, xq, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, rope=rope)
-        return T.op_cross_attention(tp, xq, xk, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias)
+            return T.op_self_attention(tp, xq, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, rope=rope, fp8=T.FP8_FORWARD)
+        return T.op_cross_attention(tp, xq, xk, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, fp8=T.FP8_FORWARD)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor | None = None) -> torch.Tensor:
         b, tq, c = q.shape
@@ -292,15 +292,15 @@ class Block(nn.Module, _CkptFlag):
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = self.attn.tape_forward(tp, qn, xk, batch)
         if drop > 0.0:  # q + drop_path1(path1(q)), q + drop_path2(path2(q)) (vit.py:606-609): the residual adds leave the GEMM epilogues
-            h1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, out_f32=True)
+            h1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, out_f32=True, fp8=T.FP8_FORWARD)
             x1 = T.op_droppath_add(tp, h1, xq, batch, drop)
             xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            h2 = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=None)
+            h2 = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=None, fp8=T.FP8_FORWARD)
             y = T.op_droppath_add(tp, h2, x1, batch, drop)
         else:
-            x1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, residual=xq)
+            x1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, residual=xq, fp8=T.FP8_FORWARD)
             xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            y = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1)
+            y = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1, fp8=T.FP8_FORWARD)
         T.wgrad_group_end(tp)
         return y
 

@@ -59,10 +59,23 @@ typedef struct {
                                  into k-slices (partial tiles here, a fix-up launch applies the epilogue); contents are scratch, use is stream-ordered */
   long long workspace_bytes;
   float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
+  const float* scale_a;       /* cinema_gemm_fp8 only: per-tensor dequantisation scales of the e4m3 operands (device scalars); NULL for cinema_gemm_bf16 */
+  const float* scale_b;
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
                                  + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped */
 } cinema_gemm_args;
 int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
+/* fp8 forward GEMM (BASELINE config 5: "fp8 MFMA path"; the reference picks its autocast dtype at cinema/device.py:58-66): the same call with OCP e4m3
+ * operands a [M][lda] / b [N][ldb] (bytes, k-major: a_kmajor = b_kmajor = 1), per-tensor scales scale_a / scale_b, K % 16 == 0:
+ * D = epilogue(alpha * scale_a * scale_b * A8 B8^T) on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales).  Epilogue: bias, exact GELU (+ bf16
+ * pre-activation copy), fp32 residual; bf16 or fp32 D.  Backward GEMMs stay bf16. */
+int cinema_gemm_fp8(cinema_gemm_args* args_host, void* stream);
+/* Per-tensor e4m3 quantisation of a bf16 buffer (current scaling): amax = max|x|, scale = amax / 448 (1 when amax == 0), y = e4m3(x / scale)
+ * (v_cvt_pk_fp8_f32, OCP format on gfx950); *scale_out = scale.  amax_ws: 4 bytes of scratch.  n % 8 == 0, 16-byte aligned x, 8-byte aligned y. */
+int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, float* scale_out, unsigned int* amax_ws, void* stream);
+/* The same for n_seg segments [seg_bounds[2i], seg_bounds[2i+1]) (element offsets, multiples of 8, device int64) of ONE flat bf16 buffer - the weight
+ * shadows of a whole model in three launches; y has the layout of x, scales [n_seg], amax_ws n_seg words of scratch. */
+int cinema_quantize_fp8_segments(const uint16_t* x, const long long* seg_bounds, int n_seg, uint8_t* y, float* scales, unsigned int* amax_ws, void* stream);
 /* The tiles of up to 8 independent weight-gradient GEMMs (a_kmajor = b_kmajor = 0, fp32 D, optional accumulate and a_rowsum, no other
  * epilogue term, split_k ignored) in ONE launch with whole-K tiles: the four dW of a transformer block (cinema/vit.py:525-609) have
  * 36-144 output tiles each and would otherwise be cut into k-slices with fp32 slabs and a reduce launch each. */

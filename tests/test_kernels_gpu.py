@@ -609,3 +609,46 @@ def test_segmentation_loss_vs_oracle(shape: tuple, c: int) -> None:
     for k in ("cross_entropy", "mean_dice_loss", "loss"):
         assert float(m[k]) == pytest.approx(float(ref_m[k]), rel=2e-5, abs=1e-6), k  # fp32 both sides, different summation order
     close(x.grad, ref_in.grad.to(DEV), 1e-3, 1e-7, "seg loss grad")
+
+
+# ------------------------------------------------------------------------------------------------ fp8 forward GEMM (BASELINE config 5)
+def _e4m3_decode(u: torch.Tensor) -> torch.Tensor:
+    """OCP e4m3fn bytes -> fp32 (bias 7, no infinities, 0x7f / 0xff = NaN), independent of any torch fp8 dtype support."""
+    u = u.to(torch.int32)
+    sign = torch.where((u & 0x80) != 0, -1.0, 1.0)
+    e, m = (u >> 3) & 0xF, (u & 7).float()
+    val = torch.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * torch.pow(2.0, (e - 7).float()))
+    return sign * val
+
+
+def test_quantize_fp8_and_fp8_gemm_vs_dequantised_reference() -> None:
+    """cinema_quantize_fp8: scale = amax / 448, every value within half an e4m3 step of x / scale; cinema_gemm_fp8 (MX-scaled MFMA with unit block
+    scales) == fp32 matmul of the DEQUANTISED operands (the products of e4m3 values are exact in fp32, only the accumulation order differs), with
+    the bias / GELU + pre-activation / fp32-residual epilogues; a transpose-detecting (asymmetric) operand pair."""
+    m, n, k = 300, 256, 384
+    a, w = rnd(m, k, seed=50, scale=2.0), rnd(n, k, seed=51, scale=0.5)
+    a8, sa = K.quantize_fp8(a)
+    w8, sw = K.quantize_fp8(w)
+    assert float(sa) == pytest.approx(float(a.float().abs().max()) / 448.0, rel=1e-6)
+    da, dw = _e4m3_decode(a8.cpu()) * float(sa), _e4m3_decode(w8.cpu()) * float(sw)
+    assert float((da - a.float().cpu()).abs().max()) <= float(a.float().abs().max()) / 448.0 * 16.0 + 1e-6  # top binade: step 32 -> half step 16
+    rel = (da - a.float().cpu()).abs() / a.float().cpu().abs().clamp_min(float(sa) * 2.0 ** -6)
+    assert float(rel.max()) <= 0.0626  # 3 mantissa bits: relative rounding error <= 2^-4
+    ref = da @ dw.t()
+    got = K.gemm_fp8(a8, sa, w8, sw, out_dtype=torch.float32)
+    close(got, ref.to(DEV), 1e-3, 2e-5 * float(ref.abs().max()), "fp8 gemm fp32 out")
+    bias = rnd(n, dtype=torch.float32, seed=52)
+    h = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    y = K.gemm_fp8(a8, sa, w8, sw, bias=bias, act=1, aux_out=h)
+    pre = ref.to(DEV) + bias
+    close(h, pre, 1e-2, 1e-2 * float(pre.abs().max()), "fp8 gemm pre-activation")
+    close(y, torch.nn.functional.gelu(pre), 1e-2, 1e-2 * float(pre.abs().max()), "fp8 gemm gelu")
+    res = rnd(m, n, dtype=torch.float32, seed=53)
+    z = K.gemm_fp8(a8, sa, w8, sw, bias=bias, residual=res)
+    close(z, pre + res, 1e-3, 1e-4 * float(pre.abs().max()), "fp8 gemm residual")
+    # the real config-5 shape of one encoder projection (ViT-Large: 13832 x 1024 x 1024): against the bf16 kernel on the same operands
+    big_a, big_w = rnd(13832, 1024, seed=54), rnd(1024, 1024, seed=55, scale=0.03)
+    qa, qsa = K.quantize_fp8(big_a)
+    qw, qsw = K.quantize_fp8(big_w)
+    y8, y16 = K.gemm_fp8(qa, qsa, qw, qsw, out_dtype=torch.float32), K.gemm(big_a, big_w, out_dtype=torch.float32)
+    assert float((y8 - y16).norm() / y16.norm()) <= 6e-2  # two e4m3-quantised operands: ~2 x 2^-4 / sqrt(3) relative per product, averaged over K
