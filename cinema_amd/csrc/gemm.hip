@@ -27,6 +27,7 @@ struct GemmP {
   float* tail_ws;
   // fp8 (e4m3) operands: per-tensor dequantisation scales in device memory (the product multiplies alpha); NULL for bf16 operands
   const float* scale_a; const float* scale_b;
+  int scale_a_rows;  // 1: scale_a holds one scale per row of A (per-token activation scaling), 0: one scalar
 };
 
 __device__ __forceinline__ float frag_sum8(const short8v& f) {
@@ -138,8 +139,9 @@ __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u <<
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 template <int W>
 __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (&v)[W], const float (&bv)[W], const EpiPre<W>& e) {
+  const float al = p.scale_a_rows ? p.alpha * p.scale_a[m] : p.alpha;  // fp8 operands with per-row activation scales (p.alpha already holds scale_b)
 #pragma unroll
-  for (int i = 0; i < W; i++) v[i] = fmaf(v[i], p.alpha, bv[i]);
+  for (int i = 0; i < W; i++) v[i] = fmaf(v[i], al, bv[i]);
   auto store_bf16 = [&](bf16_t* dst) {
     if (W == 8) {
       u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[W - 4], v[W - 3]), pack_bf2(v[W - 2], v[W - 1])};
@@ -764,7 +766,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
   }
   if constexpr (FP8) {  // dequantisation: alpha x scale_a x scale_b (per-tensor scales from device memory)
     GemmP q = p;
-    q.alpha = p.alpha * p.scale_a[0] * p.scale_b[0];
+    q.alpha = p.alpha * p.scale_b[0] * (p.scale_a_rows ? 1.0f : p.scale_a[0]);
     tile_epilogue<EPI>(q, acc, m0 + wm, n0 + wn, lane, zsplit, stg);
     return;
   }
@@ -1029,7 +1031,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = a->residual_bf16; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
-  p.scale_a = nullptr; p.scale_b = nullptr;
+  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -1184,7 +1186,7 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
-  p.scale_a = a->scale_a; p.scale_b = a->scale_b;
+  p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0;
   const int nkt = (p.k + BK - 1) / BK;
   p.ktiles_per_split = nkt;
   dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);
@@ -1220,7 +1222,7 @@ CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void*
     p.ld_res = a->ldd;
     p.ktiles_per_split = (a->k + BK - 1) / BK;
     p.ws = nullptr; p.a_rowsum = a->a_rowsum;
-    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr;
+    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.scale_a_rows = 0;
     g.tile_begin[i + 1] = g.tile_begin[i] + ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN);
     args[i].kernel_used = 64;  // the grouped kernel
   }

@@ -31,6 +31,7 @@ struct LnFwdP {
   bf16_t* y_bf16; float* y_f32; int ldy;
   float* mean; float* rstd;
   int lpr;  // lanes per row (power of two, <= 64)
+  uint8_t* y_fp8; float* row_scale;  // optional e4m3 copy of y with ONE scale per row (amax(row) / 448): the A operand of cinema_gemm_fp8(row scales)
 };
 
 template <int CPL>
@@ -69,6 +70,7 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
       if (p.mean) p.mean[row] = mu;
       if (p.rstd) p.rstd[row] = rs;
     }
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < CPL; i++) {
       const int ch = sub + i * p.lpr;
@@ -81,6 +83,21 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
       if (p.act == 1) { gelu2(y.x, y.y); gelu2(y.z, y.w); }
       if (p.y_bf16) store4_bf16(p.y_bf16 + (size_t)row * p.ldy + ch * 4, y);
       if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + (size_t)row * p.ldy + ch * 4) = y;
+      if (p.y_fp8) { v[i] = y; amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))); }
+    }
+    if (p.y_fp8) {  // per-row e4m3 copy: the row's maximum is a reduction over the row's own lanes only, so the quantisation costs no extra pass
+      for (int o = p.lpr >> 1; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / scale;
+      if (sub == 0) p.row_scale[row] = scale;
+#pragma unroll
+      for (int i = 0; i < CPL; i++) {
+        const int ch = sub + i * p.lpr;
+        if (ch >= nch) continue;
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, w, true);
+        *reinterpret_cast<int*>(p.y_fp8 + (size_t)row * p.c + ch * 4) = w;
+      }
     }
   }
 }
@@ -332,12 +349,24 @@ int dispatch_cpl(int cpl, F&& f) {
 
 }  // namespace
 
+static int layernorm_fwd_impl(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act, uint16_t* y_bf16,
+                              float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream);
 CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
                                     int act, uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, void* stream) {
+  return layernorm_fwd_impl(x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, nullptr, nullptr, stream);
+}
+// the same, also writing an e4m3 copy of y ([rows][c] bytes, dense) with one dequantisation scale per row (fp8 forward GEMMs)
+CINEMA_API int cinema_layernorm_fwd_fp8(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
+                                        int act, uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream) {
+  if (!y_fp8 || !row_scale || (c & 3)) return CINEMA_ERR_BAD_ARG;
+  return layernorm_fwd_impl(x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, y_fp8, row_scale, stream);
+}
+static int layernorm_fwd_impl(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act, uint16_t* y_bf16,
+                              float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream) {
   if (!x || !gamma || !beta || rows <= 0 || c <= 0 || (!y_bf16 && !y_f32)) return CINEMA_ERR_BAD_ARG;
-  LnFwdP p{x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, pick_lpr(c)};
+  LnFwdP p{x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, pick_lpr(c), y_fp8, row_scale};
   if ((c & 3) || (ldx & 3) || (ldy & 3)) {
-    if (c > 64) return CINEMA_ERR_UNSUPPORTED;
+    if (c > 64 || y_fp8) return CINEMA_ERR_UNSUPPORTED;
     CINEMA_LAUNCH(ln_fwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
   }

@@ -535,6 +535,41 @@ __global__ __launch_bounds__(256) void quantize_fp8_seg_kernel(const bf16_t* x, 
   }
 }
 
+// per-ROW e4m3 quantisation of a dense bf16 matrix [rows][c] (c % 8 == 0): one wave per row, two passes over the row from L1/L2 in one launch
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const bf16_t* x, int rows, int c, uint8_t* y, float* row_scale) {
+  const int lane = threadIdx.x & 63, c8 = c >> 3;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(x + row * c);
+    float m = 0.f;
+    for (int i = lane; i < c8; i += 64) {
+      const bf16x8 v = src[i];
+#pragma unroll
+      for (int j = 0; j < 8; j++) m = fmaxf(m, fabsf(bf2f(v.v[j])));
+    }
+    m = wave_max(m);
+    const float scale = m > 0.f ? m * (1.0f / 448.0f) : 1.0f, inv = 1.0f / scale;
+    if (lane == 0) row_scale[row] = scale;
+    for (int i = lane; i < c8; i += 64) {
+      const bf16x8 v = src[i];
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[0]) * inv, bf2f(v.v[1]) * inv, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[2]) * inv, bf2f(v.v[3]) * inv, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[4]) * inv, bf2f(v.v[5]) * inv, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.v[6]) * inv, bf2f(v.v[7]) * inv, hi, true);
+      reinterpret_cast<int2*>(y + row * c)[i] = make_int2(lo, hi);
+    }
+  }
+}
+
+CINEMA_API int cinema_quantize_fp8_rows(const uint16_t* x, int rows, int c, uint8_t* y, float* row_scale, void* stream) {
+  if (!x || !y || !row_scale || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((c & 7) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CINEMA_ERR_UNSUPPORTED;
+  int g = (rows + 3) / 4;
+  if (g > 8192) g = 8192;
+  CINEMA_LAUNCH(quantize_fp8_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, rows, c, y, row_scale);
+  return launch_status();
+}
+
 CINEMA_API int cinema_quantize_fp8_segments(const uint16_t* x, const long long* seg_bounds, int n_seg, uint8_t* y, float* scales, unsigned int* amax_ws,
                                             void* stream) {
   if (!x || !seg_bounds || !y || !scales || !amax_ws || n_seg <= 0) return CINEMA_ERR_BAD_ARG;

@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
         ("aux_out", C.c_void_p), ("ld_aux", C.c_int),
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
-        ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
+        ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
         ("kernel_used", C.c_int),
     ]
 
@@ -97,6 +97,8 @@ _PROTOS = {
     "cinema_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i, _vp],
     "cinema_gemm_fp8": [C.POINTER(GemmArgs), _vp],
     "cinema_quantize_fp8": [_vp, _ll, _vp, _vp, _vp, _vp],
+    "cinema_quantize_fp8_rows": [_vp, _i, _i, _vp, _vp, _vp],
+    "cinema_layernorm_fwd_fp8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_quantize_fp8_segments": [_vp, _vp, _i, _vp, _vp, _vp, _vp],
     "cinema_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
@@ -457,6 +459,17 @@ def quantize_fp8(x: torch.Tensor) -> tuple:
     return y, scale
 
 
+def quantize_fp8_rows(x: torch.Tensor) -> tuple:
+    """Per-row e4m3 quantisation of a contiguous bf16 matrix [rows, c]: -> (uint8 [rows, c], fp32 [rows] scales); one launch."""
+    _dev(x)
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or not x.is_contiguous() or x.shape[1] % 8:
+        raise HipLibraryError("quantize_fp8_rows: contiguous bf16 [rows, c] with c % 8 == 0")
+    y = _empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = _empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _check(load().cinema_quantize_fp8_rows(x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), scale.data_ptr(), _stream()), "quantize_fp8_rows")
+    return y, scale
+
+
 def quantize_fp8_segments(x: torch.Tensor, seg_bounds: torch.Tensor, y: torch.Tensor, scales: torch.Tensor) -> None:
     """Segments [seg_bounds[i, 0], seg_bounds[i, 1]) of the flat bf16 buffer ``x`` -> e4m3 in ``y`` (uint8, same layout), one scale per segment."""
     _dev(x, seg_bounds, y, scales)
@@ -488,6 +501,9 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
     g.m, g.n, g.k, g.lda, g.ldb, g.ldd = m, n, k, _rowmajor(a8, "a8"), _rowmajor(b8, "b8"), _rowmajor(out, "out")
     g.a_kmajor, g.b_kmajor, g.alpha, g.split_k = 1, 1, alpha, 1
     g.scale_a, g.scale_b = scale_a.data_ptr(), scale_b.data_ptr()
+    if scale_a.numel() not in (1, m) or scale_b.numel() != 1 or scale_a.dtype != torch.float32 or scale_b.dtype != torch.float32:
+        raise HipLibraryError("gemm_fp8: scale_a fp32 [1] or [M] (per row), scale_b fp32 [1]")
+    g.scale_a_rows = int(scale_a.numel() == m and m > 1)
     if bias is not None:
         g.bias = bias.data_ptr()
     if residual is not None:
@@ -764,14 +780,20 @@ def colsum(x: torch.Tensor, out: torch.Tensor, row_idx: torch.Tensor | None = No
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, act: int = 0, want_bf16: bool = True,
-                  want_f32: bool = False):  # noqa: ANN201
-    """x: [rows, c] fp32/bf16 -> (y_bf16 | None, y_f32 | None, mean, rstd)."""
+                  want_f32: bool = False, want_fp8: bool = False):  # noqa: ANN201
+    """x: [rows, c] fp32/bf16 -> (y_bf16 | None, y_f32 | None, mean, rstd) [+ (y_fp8 uint8 [rows, c], row_scale fp32 [rows]) with ``want_fp8``]."""
     _dev(x, gamma, beta)
     rows, c = x.shape
     y16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     y32 = _empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None
     mean = _empty(rows, dtype=torch.float32, device=x.device)
     rstd = _empty(rows, dtype=torch.float32, device=x.device)
+    if want_fp8:
+        y8 = _empty((rows, c), dtype=torch.uint8, device=x.device)
+        rscale = _empty(rows, dtype=torch.float32, device=x.device)
+        _check(load().cinema_layernorm_fwd_fp8(x.data_ptr(), int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), beta.data_ptr(), rows, c, eps, act,
+                                               _p(y16), _p(y32), c, mean.data_ptr(), rstd.data_ptr(), y8.data_ptr(), rscale.data_ptr(), _stream()), "layernorm_fwd_fp8")
+        return y16, y32, mean, rstd, (y8, rscale)
     _check(load().cinema_layernorm_fwd(x.data_ptr(), int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), beta.data_ptr(),
                                        rows, c, eps, act, _p(y16), _p(y32), c, mean.data_ptr(), rstd.data_ptr(), _stream()), "layernorm_fwd")
     return y16, y32, mean, rstd

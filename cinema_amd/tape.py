@@ -31,13 +31,14 @@ class Var:
     gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
     """
 
-    __slots__ = ("data", "grad", "grad16", "needs_grad")
+    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = True) -> None:
         self.data = data
         self.grad: torch.Tensor | None = None
         self.grad16: torch.Tensor | None = None
         self.needs_grad = needs_grad
+        self.fp8: tuple | None = None  # (e4m3 copy of data, per-row scales) when the producer emitted one (op_layernorm(fp8=True))
 
     def add_grad(self, g: torch.Tensor, g16: torch.Tensor | None = None) -> None:
         if not self.needs_grad:
@@ -390,6 +391,11 @@ def _fp8_ok(x: torch.Tensor, *weights: torch.nn.Parameter) -> bool:
             and all(w.shape[0] % 8 == 0 and math.prod(w.shape[1:]) % 16 == 0 for w in weights))
 
 
+def a_fp8(x: Var) -> tuple:
+    """(e4m3 rows, per-row scales) of a bf16 activation: the producer's copy when it made one (LayerNorm), else one per-row quantisation launch."""
+    return x.fp8 if x.fp8 is not None else K.quantize_fp8_rows(x.data)
+
+
 def _hip_layout(fn: Callable, jmap: torch.Tensor | None) -> Callable:
     """Tag a to-parameter-layout function with what the HIP re-layout kernel needs to add the gradient straight into the flat buffer."""
     fn.hip_relayout = (jmap,)
@@ -571,10 +577,16 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
 # --------------------------------------------------------------------------------------------------------------
 # ops
 # --------------------------------------------------------------------------------------------------------------
-def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.Parameter, eps: float, *, act: int = 0, out_f32: bool = False) -> Var:
+def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.Parameter, eps: float, *, act: int = 0, out_f32: bool = False,
+                 fp8: bool = False) -> Var:
     """y = [gelu](LN(x)); x fp32/bf16 [rows, c]; output bf16 (GEMM operand) or fp32 (residual stream)."""
-    y16, y32, mean, rstd = K.layernorm_fwd(x.data, gamma.detach(), beta.detach(), eps, act=act, want_bf16=not out_f32, want_f32=out_f32)
-    y = Var(y32 if out_f32 else y16)
+    if fp8 and not out_f32 and FP8_FORWARD and x.data.is_cuda and x.data.shape[1] % 16 == 0:
+        y16, y32, mean, rstd, q8 = K.layernorm_fwd(x.data, gamma.detach(), beta.detach(), eps, act=act, want_bf16=True, want_f32=False, want_fp8=True)
+        y = Var(y16)
+        y.fp8 = q8
+    else:
+        y16, y32, mean, rstd = K.layernorm_fwd(x.data, gamma.detach(), beta.detach(), eps, act=act, want_bf16=not out_f32, want_f32=out_f32)
+        y = Var(y32 if out_f32 else y16)
     gv, bv = tape.pvar(gamma), tape.pvar(beta)
 
     def bwd() -> None:
@@ -601,7 +613,7 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
     """y = x W^T + b (+ residual); x bf16 [m,k]; W given as nn.Linear / 1x1-conv weight (or a pre-built shadow ``w16``)."""
     w = w16 if w16 is not None else w_plain(weight)
     if fp8 and w16 is None and row_mask is None and _fp8_ok(x.data, weight) and (residual is None or residual.data.dtype == F32):
-        x8, sx = K.quantize_fp8(x.data)
+        x8, sx = a_fp8(x)
         w8, sw = w_fp8(weight)
         y = Var(K.gemm_fp8(x8, sx, w8, sw, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
                            out_dtype=F32 if (out_f32 or residual is not None) else BF16))
@@ -635,9 +647,9 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     m, hidden = x.data.shape[0], w1.shape[0]
     h = K.empty((m, hidden), dtype=BF16, device=x.data.device)
     if fp8 and _fp8_ok(x.data, fc1_w, fc2_w) and (residual is None or residual.data.dtype == F32):
-        x8, sx = K.quantize_fp8(x.data)
+        x8, sx = a_fp8(x)
         a = K.gemm_fp8(x8, sx, *w_fp8(fc1_w), bias=fc1_b.detach(), act=1, aux_out=h)
-        a8, sa = K.quantize_fp8(a)
+        a8, sa = K.quantize_fp8_rows(a)
         y = Var(K.gemm_fp8(a8, sa, *w_fp8(fc2_w), bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
     else:
         a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h)
@@ -668,7 +680,7 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
     w = w_cat((q_w, kv_w))
     bias = b_cat((q_b, kv_b)) if q_b is not None else None
     if fp8 and _fp8_ok(x.data, q_w, kv_w):  # per-tensor weight scales: q and kv are two GEMMs into the column blocks of one buffer
-        x8, sx = K.quantize_fp8(x.data)
+        x8, sx = a_fp8(x)
         qkv = K.empty((x.data.shape[0], 3 * c), dtype=BF16, device=x.data.device)
         K.gemm_fp8(x8, sx, *w_fp8(q_w), bias=None if q_b is None else q_b.detach(), out=qkv[:, :c])
         K.gemm_fp8(x8, sx, *w_fp8(kv_w), bias=None if kv_b is None else kv_b.detach(), out=qkv[:, c:])
@@ -714,8 +726,10 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
     c = xq.data.shape[1]
     wq, wkv = w_plain(q_w), w_plain(kv_w)
     if fp8 and _fp8_ok(xq.data, q_w) and _fp8_ok(xk.data, kv_w):
-        q = K.gemm_fp8(*K.quantize_fp8(xq.data), *w_fp8(q_w), bias=None if q_b is None else q_b.detach())
-        kv = K.gemm_fp8(*K.quantize_fp8(xk.data), *w_fp8(kv_w), bias=None if kv_b is None else kv_b.detach())
+        q = K.gemm_fp8(*a_fp8(xq), *w_fp8(q_w), bias=None if q_b is None else q_b.detach())
+        if xk.fp8 is None:  # the keys are the same tensor for every decoder block: quantise once
+            xk.fp8 = K.quantize_fp8_rows(xk.data)
+        kv = K.gemm_fp8(*xk.fp8, *w_fp8(kv_w), bias=None if kv_b is None else kv_b.detach())
     else:
         q = K.gemm(xq.data, wq, bias=None if q_b is None else q_b.detach())
         kv = K.gemm(xk.data, wkv, bias=None if kv_b is None else kv_b.detach())

@@ -289,17 +289,17 @@ class Block(nn.Module, _CkptFlag):
         drop = self.drop_path_rate if self.training else 0.0
         T.mark_params(tp, self._param_list())  # gradient all-reduce of this block may start once its backward ops are launched
         T.wgrad_group(tp)                      # ... which includes the grouped weight-gradient launch: its flush runs before that marker fires
-        qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps, fp8=True)
         att = self.attn.tape_forward(tp, qn, xk, batch)
         if drop > 0.0:  # q + drop_path1(path1(q)), q + drop_path2(path2(q)) (vit.py:606-609): the residual adds leave the GEMM epilogues
             h1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, out_f32=True, fp8=T.FP8_FORWARD)
             x1 = T.op_droppath_add(tp, h1, xq, batch, drop)
-            xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps, fp8=True)
             h2 = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=None, fp8=T.FP8_FORWARD)
             y = T.op_droppath_add(tp, h2, x1, batch, drop)
         else:
             x1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, residual=xq, fp8=T.FP8_FORWARD)
-            xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps, fp8=True)
             y = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x1, fp8=T.FP8_FORWARD)
         T.wgrad_group_end(tp)
         return y

@@ -61,6 +61,7 @@ typedef struct {
   float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
   const float* scale_a;       /* cinema_gemm_fp8 only: per-tensor dequantisation scales of the e4m3 operands (device scalars); NULL for cinema_gemm_bf16 */
   const float* scale_b;
+  int scale_a_rows;           /* cinema_gemm_fp8: 1 = scale_a holds one scale per row of A (per-token activation scaling), 0 = one scalar */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
                                  + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped */
 } cinema_gemm_args;
@@ -75,6 +76,8 @@ int cinema_gemm_fp8(cinema_gemm_args* args_host, void* stream);
 int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, float* scale_out, unsigned int* amax_ws, void* stream);
 /* The same for n_seg segments [seg_bounds[2i], seg_bounds[2i+1]) (element offsets, multiples of 8, device int64) of ONE flat bf16 buffer - the weight
  * shadows of a whole model in three launches; y has the layout of x, scales [n_seg], amax_ws n_seg words of scratch. */
+/* Per-row form: x dense bf16 [rows][c] (c % 8 == 0) -> y e4m3 [rows][c], row_scale[rows] = amax(row) / 448; one launch (the row maximum is local). */
+int cinema_quantize_fp8_rows(const uint16_t* x, int rows, int c, uint8_t* y, float* row_scale, void* stream);
 int cinema_quantize_fp8_segments(const uint16_t* x, const long long* seg_bounds, int n_seg, uint8_t* y, float* scales, unsigned int* amax_ws, void* stream);
 /* The tiles of up to 8 independent weight-gradient GEMMs (a_kmajor = b_kmajor = 0, fp32 D, optional accumulate and a_rowsum, no other
  * epilogue term, split_k ignored) in ONE launch with whole-K tiles: the four dW of a transformer block (cinema/vit.py:525-609) have
@@ -96,6 +99,10 @@ int cinema_colsum(const void* x, int x_dtype, const int* row_idx, int m, int n, 
  */
 int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
                          int act, uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, void* stream);
+/* cinema_layernorm_fwd that also writes an e4m3 copy of y ([rows][c] bytes, dense) with one dequantisation scale per row - the quantisation of the
+ * GEMM input costs no pass of its own (the row maximum is a reduction over the lanes that already hold the row). */
+int cinema_layernorm_fwd_fp8(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act, uint16_t* y_bf16,
+                             float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream);
 int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
                          const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                          const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,

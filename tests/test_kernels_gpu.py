@@ -652,3 +652,29 @@ def test_quantize_fp8_and_fp8_gemm_vs_dequantised_reference() -> None:
     qw, qsw = K.quantize_fp8(big_w)
     y8, y16 = K.gemm_fp8(qa, qsa, qw, qsw, out_dtype=torch.float32), K.gemm(big_a, big_w, out_dtype=torch.float32)
     assert float((y8 - y16).norm() / y16.norm()) <= 6e-2  # two e4m3-quantised operands: ~2 x 2^-4 / sqrt(3) relative per product, averaged over K
+
+
+def test_fp8_per_row_scales_and_layernorm_fused_quantisation() -> None:
+    """Per-row (per-token) activation scaling: cinema_quantize_fp8_rows, the GEMM epilogue's row-scale vector, and the e4m3 copy written by the
+    LayerNorm forward itself (same bytes / scales as quantising its bf16 output per row would give, up to the bf16 rounding the copy skips)."""
+    m, n, k = 333, 128, 256
+    a = rnd(m, k, seed=60) * (torch.arange(m, device=DEV).float()[:, None] * 0.05 + 0.1).bfloat16()  # rows of very different magnitude
+    w = rnd(n, k, seed=61, scale=0.3)
+    a8, sa = K.quantize_fp8_rows(a.contiguous())
+    w8, sw = K.quantize_fp8(w)
+    assert sa.shape == (m,) and torch.allclose(sa.cpu(), a.float().abs().amax(1).cpu() / 448.0, rtol=1e-6)
+    da = _e4m3_decode(a8.cpu()) * sa.cpu()[:, None]
+    ref = da @ (_e4m3_decode(w8.cpu()) * float(sw)).t()
+    got = K.gemm_fp8(a8, sa, w8, sw, out_dtype=torch.float32)
+    close(got, ref.to(DEV), 1e-3, 2e-5 * float(ref.abs().max()), "fp8 gemm with row scales")
+    rel_rows = ((da - a.float().cpu()).norm(dim=1) / a.float().cpu().norm(dim=1))
+    assert float(rel_rows.max()) <= 0.04  # every row keeps e4m3's relative precision whatever its magnitude
+    x = rnd(m, k, dtype=torch.float32, seed=62, scale=3.0) + 1.0
+    gamma, beta = rnd(k, dtype=torch.float32, seed=63) * 0.2 + 1.0, rnd(k, dtype=torch.float32, seed=64) * 0.1
+    y16, _, mean, rstd, (y8, rs) = K.layernorm_fwd(x, gamma, beta, 1e-5, want_fp8=True)
+    y16b, _, mean_b, rstd_b = K.layernorm_fwd(x, gamma, beta, 1e-5)
+    assert torch.equal(y16, y16b) and torch.equal(mean, mean_b) and torch.equal(rstd, rstd_b)
+    yf = torch.nn.functional.layer_norm(x, (k,), gamma, beta, 1e-5)
+    assert torch.allclose(rs, yf.abs().amax(1) / 448.0, rtol=1e-4)
+    dq = (_e4m3_decode(y8.cpu()) * rs.cpu()[:, None])
+    assert float(((dq - yf.cpu()).norm(dim=1) / yf.cpu().norm(dim=1)).max()) <= 0.04
