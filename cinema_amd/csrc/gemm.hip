@@ -28,6 +28,11 @@ struct GemmP {
   // fp8 (e4m3) operands: per-tensor dequantisation scales in device memory (the product multiplies alpha); NULL for bf16 operands
   const float* scale_a; const float* scale_b;
   int scale_a_rows;  // 1: scale_a holds one scale per row of A (per-token activation scaling), 0: one scalar
+  // implicit-GEMM "same" convolution (MODE_CONV): A is not a stored matrix but the channels-last volume x [batch][cX][cY][cZ][cC] (p.a); row r of the
+  // virtual im2col matrix is output voxel r, its 16-byte k-chunk j (8 channels of one tap) is read at x[(r + tap_rows[j]) * cC + tap_ci[j]] when
+  // the neighbour lies inside the volume, zeros otherwise.  conv_taps[j] = {row delta, packed (dx+1, dy+1, dz+1), first channel, valid}.
+  const int4* conv_taps;
+  int cX, cY, cZ, cC;
 };
 
 __device__ __forceinline__ float frag_sum8(const short8v& f) {
@@ -652,8 +657,10 @@ __device__ __forceinline__ int8v frag_fp8(const char* lds, int base, int ks, int
   return out;
 }
 
-template <bool A_KMAJ, bool B_KMAJ, int EPI, bool FP8 = false>
+enum { MODE_PLAIN = 0, MODE_FP8 = 1, MODE_CONV = 2 };
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int MODE = MODE_PLAIN>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, int kt_begin, int kt_end, float* tail_dst, char* smem) {
+  constexpr bool FP8 = MODE == MODE_FP8, CONV = MODE == MODE_CONV;
   using AIO = TileIO<A_KMAJ>;
   using BIO = TileIO<B_KMAJ>;
   constexpr int STAGE = AIO::BYTES + BIO::BYTES;
@@ -682,7 +689,44 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
   const typename BIO::Src4 bsrc = BIO::src4(p.b, p.ldb, n0, p.n, lane, wave_u);
   const size_t astep = AIO::k_step(p.lda), bstep = BIO::k_step(p.ldb);
   const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  // implicit convolution: the lane's four tile rows (one per DMA piece) as voxel coordinates, and the 16-byte chunk column it fills in every k-tile
+  int cvx[4], cvy[4], cvz[4];
+  long long cvrow[4];
+  int conv_chunk = 0;
+  int4 conv_ent = make_int4(0, 0, 0, 0);
+  if constexpr (CONV) {
+#pragma unroll
+    for (int pss = 0; pss < 4; pss++) {
+      const int row = (pss * 4 + wave_u) * 8 + (lane >> 3);
+      int rg = m0 + row;
+      rg = rg < p.m ? rg : p.m - 1;
+      cvrow[pss] = rg;
+      cvz[pss] = rg % p.cZ;
+      const int t = rg / p.cZ;
+      cvy[pss] = t % p.cY;
+      cvx[pss] = (t / p.cY) % p.cX;
+    }
+    const int row0 = wave_u * 8 + (lane >> 3);
+    conv_chunk = (lane & 7) ^ ((row0 >> 1) & 7);  // the same for the lane's four pieces (their rows differ by multiples of 32)
+    conv_ent = p.conv_taps[kt_begin * 8 + conv_chunk];
+  }
   auto load_tile = [&](int stage, int kt) {  // operands of k-tile kt -> stage
+    if constexpr (CONV) {
+      const int4 e = conv_ent;
+      const int dx = (e.y & 3) - 1, dy = ((e.y >> 2) & 3) - 1, dz = ((e.y >> 4) & 3) - 1;
+      const bf16_t* src[4];
+#pragma unroll
+      for (int pss = 0; pss < 4; pss++) {
+        const bool ok = e.w && (unsigned)(cvx[pss] + dx) < (unsigned)p.cX && (unsigned)(cvy[pss] + dy) < (unsigned)p.cY && (unsigned)(cvz[pss] + dz) < (unsigned)p.cZ;
+        src[pss] = ok ? p.a + ((cvrow[pss] + e.x) * p.cC + e.z) : zero_page;
+      }
+      const uint32_t a0 = smem_addr + stage * STAGE + wave_u * 1024;
+      glds16x4(a0, a0 + 4096, a0 + 8192, a0 + 12288, src[0], src[1], src[2], src[3]);
+      if ((kt + 1) * BK <= p.k) BIO::glds_at(smem_addr + stage * STAGE + AIO::BYTES, bsrc, (size_t)kt * bstep, wave_u);
+      else BIO::glds(smem + stage * STAGE + AIO::BYTES, p.b, p.ldb, n0, p.n, kt * BK, p.k, lane, wave_u, zero_page);
+      if (kt + 1 < kt_end) conv_ent = p.conv_taps[(kt + 1) * 8 + conv_chunk];  // next tile's table entry: lands under this tile's MFMAs
+      return;
+    }
     if ((kt + 1) * BK <= p.k) {
       AIO::glds_at(smem_addr + stage * STAGE, asrc, (size_t)kt * astep, wave_u);
       BIO::glds_at(smem_addr + stage * STAGE + AIO::BYTES, bsrc, (size_t)kt * bstep, wave_u);
@@ -780,7 +824,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
 #endif
 }
 
-template <bool A_KMAJ, bool B_KMAJ, int EPI, bool FP8 = false>
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int MODE = MODE_PLAIN>
 __device__ __forceinline__ void gemm_mfma_body(const GemmP& p, char* smem) {
   // linear dispatch id (x fastest, then z) -> logical work item, split-major so that one XCD sees one k-range
   const int nkt = (p.k + BK - 1) / BK;
@@ -803,12 +847,17 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmP& p, char* smem) {
     kt_begin = zsplit * p.ktiles_per_split;
     kt_end = min(nkt, kt_begin + p.ktiles_per_split);
   }
-  gemm_tile<A_KMAJ, B_KMAJ, EPI, FP8>(p, tile, zsplit, kt_begin, kt_end, tail_dst, smem);
+  gemm_tile<A_KMAJ, B_KMAJ, EPI, MODE>(p, tile, zsplit, kt_begin, kt_end, tail_dst, smem);
 }
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO<true>::BYTES + TileIO<true>::BYTES)];
-  gemm_mfma_body<true, true, EPI, true>(p, smem);
+  gemm_mfma_body<true, true, EPI, MODE_FP8>(p, smem);
+}
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_conv_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO<true>::BYTES + TileIO<true>::BYTES)];
+  gemm_mfma_body<true, true, EPI, MODE_CONV>(p, smem);
 }
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
@@ -1031,7 +1080,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = a->residual_bf16; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
-  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
+  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr;
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -1186,7 +1235,7 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
-  p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0;
+  p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0; p.conv_taps = nullptr;
   const int nkt = (p.k + BK - 1) / BK;
   p.ktiles_per_split = nkt;
   dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);
@@ -1194,6 +1243,41 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   if (!p.out_f32 && !p.res_f32 && p.act == 0 && !p.aux_out) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16; }
   else if (!p.out_f32 && !p.res_f32 && p.act == 1) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16_GELU>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16_GELU; }
   else if (p.out_f32 && p.act == 0 && !p.aux_out) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_F32>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_F32; }
+  else return CINEMA_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
+// Implicit-GEMM "same" convolution on channels-last bf16 volumes (reference: the dense 3^n convs of ConvResBlock, cinema/conv.py:320-345, and their data
+// gradient): D[r][n] = epilogue(sum_j sum_c x[nbr_j(r)][c] * B[n][j*C + c]) - the im2col matrix is never materialised, the A tiles of the MFMA kernel are
+// gathered straight from the volume by the LDS-DMA (one 16-byte piece = 8 channels of one tap; out-of-volume neighbours read a zero page).
+//   args->a = x [batch*X*Y*Z][C] (C % 8 == 0), args->m = batch*X*Y*Z, args->b = weights [N][ldb] bf16 with features (tap, channel) zero-padded to
+//   ldb = k (k % 8 == 0), conv_taps = device int4 table with k / 8 entries {row delta, (dx+1) | (dy+1) << 2 | (dz+1) << 4, first channel, valid}.
+//   Epilogue: bias, fp32 residual; bf16 or fp32 D.
+CINEMA_API int cinema_conv_gemm_bf16(cinema_gemm_args* a, void* stream) {
+  if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0 || !a->conv_taps || a->conv_x <= 0 || a->conv_y <= 0 || a->conv_z <= 0 || a->conv_c <= 0)
+    return CINEMA_ERR_BAD_ARG;
+  auto al = [](long long v, int q) { return (v % q) == 0; };
+  if (a->m % ((long long)a->conv_x * a->conv_y * a->conv_z) != 0) return CINEMA_ERR_BAD_ARG;
+  if (!al(a->k, 8) || !al(a->ldb, 8) || !al(a->conv_c, 8) || !al(a->n, 8) || !al(a->ldd, 8) || !al((uintptr_t)a->a, 16) || !al((uintptr_t)a->b, 16) ||
+      !al((uintptr_t)a->d, 16) || !al((uintptr_t)a->conv_taps, 16) || (a->bias && !al((uintptr_t)a->bias, 16)) ||
+      (a->residual_f32 && (!al(a->ld_res, 8) || !al((uintptr_t)a->residual_f32, 16))))
+    return CINEMA_ERR_UNSUPPORTED;
+  if (a->accumulate || a->split_k > 1 || a->gelu_in || a->row_mask || a->residual_bf16 || a->a_rowsum || a->aux_out || a->act) return CINEMA_ERR_UNSUPPORTED;
+  GemmP p;
+  p.a = (const bf16_t*)a->a; p.b = (const bf16_t*)a->b; p.d = a->d;
+  p.m = a->m; p.n = a->n; p.k = a->k; p.lda = 0; p.ldb = a->ldb; p.ldd = a->ldd;
+  p.alpha = a->alpha;
+  p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
+  p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
+  p.act = 0; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
+  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
+  p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c;
+  p.ktiles_per_split = (p.k + BK - 1) / BK;
+  dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (p.out_f32) { CINEMA_LAUNCH(gemm_conv_kernel<EPI_F32>, grid, dim3(256), 0, st, p); a->kernel_used = 512 + EPI_F32; }
+  else if (!p.res_f32) { CINEMA_LAUNCH(gemm_conv_kernel<EPI_BF16>, grid, dim3(256), 0, st, p); a->kernel_used = 512 + EPI_BF16; }
   else return CINEMA_ERR_UNSUPPORTED;
   return launch_status();
 }
@@ -1222,7 +1306,7 @@ CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void*
     p.ld_res = a->ldd;
     p.ktiles_per_split = (a->k + BK - 1) / BK;
     p.ws = nullptr; p.a_rowsum = a->a_rowsum;
-    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.scale_a_rows = 0;
+    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.scale_a_rows = 0;
     g.tile_begin[i + 1] = g.tile_begin[i] + ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN);
     args[i].kernel_used = 64;  // the grouped kernel
   }

@@ -594,6 +594,26 @@ CINEMA_API int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, f
   return launch_status();
 }
 
+// rows[ci][tap * c_out + co] = bf16(w[co][ci][tap]): the B operand of the implicit-GEMM data gradient of a dense convolution (gemm.hip cinema_conv_gemm_bf16)
+__global__ __launch_bounds__(256) void conv_weight_dgrad_kernel(const float* w, bf16_t* rows, int c_out, int c_in, int kvol, int ld) {
+  const long long total = (long long)c_in * ld;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / ld), f = (int)(i % ld);
+    float v = 0.f;
+    if (f < kvol * c_out) {
+      const int tap = f / c_out, co = f - tap * c_out;
+      v = w[((long long)co * c_in + ci) * kvol + tap];
+    }
+    rows[i] = f2bf(v);
+  }
+}
+
+CINEMA_API int cinema_conv_weight_dgrad(const float* w, uint16_t* rows, int c_out, int c_in, int kvol, int ld, void* stream) {
+  if (!w || !rows || c_out <= 0 || c_in <= 0 || kvol <= 0 || ld < kvol * c_out) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(conv_weight_dgrad_kernel, dim3(grid_for((long long)c_in * ld, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, c_out, c_in, kvol, ld);
+  return launch_status();
+}
+
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;

@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
+        ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int),
         ("kernel_used", C.c_int),
     ]
 
@@ -96,6 +97,8 @@ _PROTOS = {
     "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "cinema_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i, _vp],
     "cinema_gemm_fp8": [C.POINTER(GemmArgs), _vp],
+    "cinema_conv_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "cinema_conv_weight_dgrad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cinema_quantize_fp8": [_vp, _ll, _vp, _vp, _vp, _vp],
     "cinema_quantize_fp8_rows": [_vp, _i, _i, _vp, _vp, _vp],
     "cinema_layernorm_fwd_fp8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
@@ -918,6 +921,71 @@ def _vol_dims(shape: tuple, ks: tuple) -> tuple:
     sp = (1,) * (3 - len(shape[1:-1])) + tuple(shape[1:-1])
     k3 = (1,) * (3 - len(ks)) + tuple(ks)
     return (b, *sp, c, *k3)
+
+
+def conv_tap_table(c: int, ks: tuple, spatial: tuple, ld: int, transpose: bool, device: torch.device) -> torch.Tensor:
+    """int32 [ld / 8, 4] table for :func:`conv_gemm`: per 16-byte k-chunk (8 channels of one tap) {row delta of the neighbour voxel, packed
+    (dx+1, dy+1, dz+1), first channel, valid}.  ``transpose``: the offsets of the data gradient (the neighbour is at MINUS the tap offset)."""
+    k3 = (1,) * (3 - len(ks)) + tuple(int(v) for v in ks)
+    sp = (1,) * (3 - len(spatial)) + tuple(int(v) for v in spatial)
+    if any(k not in (1, 3) for k in k3):
+        raise HipLibraryError("conv_gemm: kernel extents 1 or 3 only")
+    taps = k3[0] * k3[1] * k3[2]
+    rows = []
+    for j in range(ld // 8):
+        kk = j * 8
+        tap, ci = kk // c, kk % c
+        if tap >= taps:
+            rows.append((0, 21, 0, 0))
+            continue
+        tz, ty, tx = tap % k3[2], (tap // k3[2]) % k3[1], tap // (k3[2] * k3[1])
+        d = [tx - k3[0] // 2, ty - k3[1] // 2, tz - k3[2] // 2]
+        if transpose:
+            d = [-v for v in d]
+        rows.append((d[0] * sp[1] * sp[2] + d[1] * sp[2] + d[2], (d[0] + 1) | ((d[1] + 1) << 2) | ((d[2] + 1) << 4), ci, 1))
+    while len(rows) % 8:  # the kernel reads one entry per 16-byte chunk of whole 64-wide k-tiles
+        rows.append((0, 21, 0, 0))
+    return torch.tensor(rows, dtype=torch.int32).to(device)
+
+
+def conv_gemm(x: torch.Tensor, w: torch.Tensor, taps: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None,
+              residual: torch.Tensor | None = None) -> torch.Tensor:
+    """Implicit-GEMM "same" convolution: x bf16 channels-last [b, *spatial, c] (c % 8 == 0), w bf16 [n, ld] with features (tap, channel), ``taps``
+    from :func:`conv_tap_table` -> rows [b * prod(spatial), n] (+ bias, + fp32 residual); the im2col matrix is never materialised."""
+    _dev(x, w, taps, bias, residual)
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not x.is_contiguous() or taps.dtype != torch.int32 or taps.dim() != 2 or taps.shape[1] != 4 or taps.shape[0] < (w.shape[1] + 63) // 64 * 8:
+        raise HipLibraryError("conv_gemm: contiguous bf16 volume, bf16 weights [n, ld], int32 [ld / 8, 4] tap table")
+    b, c = x.shape[0], x.shape[-1]
+    sp = (1,) * (3 - (x.dim() - 2)) + tuple(x.shape[1:-1])
+    m, n = b * sp[0] * sp[1] * sp[2], w.shape[0]
+    out = _empty((m, n), dtype=torch.float32 if residual is not None else out_dtype, device=x.device)
+    g = GemmArgs()
+    g.a, g.b, g.d = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.m, g.n, g.k, g.lda, g.ldb, g.ldd = m, n, w.shape[1], 0, _rowmajor(w, "w"), n
+    g.a_kmajor, g.b_kmajor, g.alpha, g.split_k = 1, 1, 1.0, 1
+    g.conv_taps, g.conv_x, g.conv_y, g.conv_z, g.conv_c = taps.data_ptr(), sp[0], sp[1], sp[2], c
+    if bias is not None:
+        g.bias = bias.data_ptr()
+    if residual is not None:
+        if residual.dtype != torch.float32:
+            raise HipLibraryError("conv_gemm: fp32 residual only")
+        g.residual_f32, g.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
+    g.out_f32 = int(out.dtype == torch.float32)
+    _check(load().cinema_conv_gemm_bf16(C.byref(g), _stream()), "conv_gemm")
+    return out
+
+
+def conv_weight_dgrad(w: torch.Tensor) -> torch.Tensor:
+    """Conv weight fp32 (c_out, c_in, *k) -> bf16 [c_in, ld] with features (tap, c_out), ld = taps * c_out rounded up to 8 (data-gradient operand)."""
+    _dev(w)
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        raise HipLibraryError("conv_weight_dgrad: contiguous fp32 weight")
+    c_out, c_in = w.shape[0], w.shape[1]
+    kvol = w[0, 0].numel()
+    ld = (kvol * c_out + 7) // 8 * 8
+    rows = _empty((c_in, ld), dtype=torch.bfloat16, device=w.device)
+    _check(load().cinema_conv_weight_dgrad(w.data_ptr(), rows.data_ptr(), c_out, c_in, kvol, ld, _stream()), "conv_weight_dgrad")
+    return rows
 
 
 def im2col(x: torch.Tensor, ks: tuple) -> torch.Tensor:

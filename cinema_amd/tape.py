@@ -889,12 +889,22 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
     im2col + MFMA GEMM (+ bias, + fp32 residual).  The column matrix is not kept: the backward pass rebuilds it for the weight gradient."""
     ks = tuple(weight.shape[2:])
     c = x.data.shape[1]
+    c_out = weight.shape[0]
     w16 = w_conv_same(weight)
     xs = x.data.view(batch, *spatial, c)
-    cols = K.im2col(xs, ks)
-    y = Var(K.gemm(cols, w16, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
-                   out_dtype=F32 if (out_f32 or residual is not None) else BF16))
-    del cols
+    dev = x.data.device
+    # implicit GEMM (cinema_conv_gemm_bf16): the MFMA kernel gathers its A tiles from the volume, the 27x im2col matrix is never written; the
+    # 1-channel raw-image block (c = 1) and exotic kernel extents keep the im2col path
+    implicit = IMPLICIT_CONV and x.data.is_cuda and c % 8 == 0 and c_out % 8 == 0 and all(k in (1, 3) for k in ks) and (residual is None or residual.data.dtype == F32)
+    if implicit:
+        taps = const(("conv_taps", c, ks, tuple(spatial), w16.shape[1], False, str(dev)), lambda: K.conv_tap_table(c, ks, spatial, w16.shape[1], False, dev))
+        y = Var(K.conv_gemm(xs, w16, taps, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
+                            out_dtype=F32 if (out_f32 or residual is not None) else BF16))
+    else:
+        cols = K.im2col(xs, ks)
+        y = Var(K.gemm(cols, w16, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
+                       out_dtype=F32 if (out_f32 or residual is not None) else BF16))
+        del cols
     wv, bv = tape.pvar(weight), tape.pvar(bias)
 
     def bwd() -> None:
@@ -907,11 +917,20 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
             wgrad(tape, dy16, K.im2col(xs, ks), wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w16.shape),
                   conv_same_grad_to_param(weight))
         if x.needs_grad:
-            dcols = K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False)
-            x.add_grad(K.col2im(dcols, (batch, *spatial, c), ks).view(-1, c))
+            if implicit:  # data gradient = the same implicit convolution on dy with transposed weights and negated tap offsets (no col2im pass)
+                wt = WEIGHTS.get((weight,), "conv_dgrad", lambda: K.conv_weight_dgrad(weight.detach()))
+                taps_t = const(("conv_taps", c_out, ks, tuple(spatial), wt.shape[1], True, str(dev)),
+                               lambda: K.conv_tap_table(c_out, ks, spatial, wt.shape[1], True, dev))
+                x.add_grad(K.conv_gemm(dy16.contiguous().view(batch, *spatial, c_out), wt, taps_t))
+            else:
+                dcols = K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False)
+                x.add_grad(K.col2im(dcols, (batch, *spatial, c), ks).view(-1, c))
 
     tape.record(bwd)
     return y
+
+
+IMPLICIT_CONV = bool(int(os.environ.get("CINEMA_IMPLICIT_CONV", "1")))  # 0: im2col + GEMM everywhere (A/B)
 
 
 def _chan_last_strides(chans: int, spatial: tuple) -> tuple:

@@ -62,6 +62,8 @@ typedef struct {
   const float* scale_a;       /* cinema_gemm_fp8 only: per-tensor dequantisation scales of the e4m3 operands (device scalars); NULL for cinema_gemm_bf16 */
   const float* scale_b;
   int scale_a_rows;           /* cinema_gemm_fp8: 1 = scale_a holds one scale per row of A (per-token activation scaling), 0 = one scalar */
+  const void* conv_taps;      /* cinema_conv_gemm_bf16 only: device int4 [k / 8] tap table; conv_x/y/z/c = volume size and channels */
+  int conv_x, conv_y, conv_z, conv_c;
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
                                  + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped */
 } cinema_gemm_args;
@@ -71,6 +73,15 @@ int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
  * D = epilogue(alpha * scale_a * scale_b * A8 B8^T) on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales).  Epilogue: bias, exact GELU (+ bf16
  * pre-activation copy), fp32 residual; bf16 or fp32 D.  Backward GEMMs stay bf16. */
 int cinema_gemm_fp8(cinema_gemm_args* args_host, void* stream);
+/* Implicit-GEMM "same" convolution (dense 3^n convs of ConvResBlock, cinema/conv.py:320-345, forward and data gradient): args->a = channels-last bf16
+ * volume x [batch*X*Y*Z][C] (C % 8 == 0), m = batch*X*Y*Z, b = weights [n][ldb] with features (tap, channel) zero-padded to k = ldb (k % 8 == 0),
+ * conv_taps[j] (one per 16-byte k-chunk = 8 channels of one tap) = {row delta of the neighbour, (dx+1) | (dy+1)<<2 | (dz+1)<<4, first channel, valid}.
+ * D[r][n] = sum over the taps / channels of x at the neighbour voxel (zeros outside the volume) + bias (+ fp32 residual); bf16 or fp32 D.  The im2col
+ * matrix (27 x the activation) is never written: the MFMA kernel's A tiles are gathered from the volume by the LDS-DMA. */
+int cinema_conv_gemm_bf16(cinema_gemm_args* args_host, void* stream);
+/* Weights of the DATA GRADIENT of that convolution: w fp32 (c_out, c_in, kvol) contiguous -> rows [c_in][ld] bf16 with rows[ci][tap * c_out + co] = w[co][ci][tap],
+ * zero-padded to ld (a multiple of 8 >= kvol * c_out). */
+int cinema_conv_weight_dgrad(const float* w, uint16_t* rows, int c_out, int c_in, int kvol, int ld, void* stream);
 /* Per-tensor e4m3 quantisation of a bf16 buffer (current scaling): amax = max|x|, scale = amax / 448 (1 when amax == 0), y = e4m3(x / scale)
  * (v_cvt_pk_fp8_f32, OCP format on gfx950); *scale_out = scale.  amax_ws: 4 bytes of scratch.  n % 8 == 0, 16-byte aligned x, 8-byte aligned y. */
 int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, float* scale_out, unsigned int* amax_ws, void* stream);

@@ -678,3 +678,42 @@ def test_fp8_per_row_scales_and_layernorm_fused_quantisation() -> None:
     assert torch.allclose(rs, yf.abs().amax(1) / 448.0, rtol=1e-4)
     dq = (_e4m3_decode(y8.cpu()) * rs.cpu()[:, None])
     assert float(((dq - yf.cpu()).norm(dim=1) / yf.cpu().norm(dim=1)).max()) <= 0.04
+
+
+# ------------------------------------------------------------------------------------------------ implicit-GEMM convolution (ConvResBlock convs, config 4)
+@pytest.mark.parametrize(("spatial", "c_in", "c_out", "ks"), [((10, 9, 5), 32, 64, (3, 3, 3)), ((12, 11), 64, 32, (3, 3)), ((6, 7, 4), 8, 16, (3, 3, 3)),
+                                                              ((9, 8, 3), 128, 40, (3, 3, 1))])
+def test_implicit_gemm_conv_forward_and_data_gradient(spatial: tuple, c_in: int, c_out: int, ks: tuple) -> None:
+    """cinema_conv_gemm_bf16 (the A tiles gathered from the channels-last volume, no im2col matrix) against torch's conv on the same bf16-rounded
+    operands: forward with bias (+ fp32 residual) and the data gradient (transposed tap offsets + cinema_conv_weight_dgrad weights); also == the
+    im2col + GEMM path it replaces."""
+    import torch.nn.functional as F  # noqa: N812
+
+    b, nd = 2, len(spatial)
+    x = rnd(b, *spatial, c_in, seed=70)
+    w = rnd(c_out, c_in, *ks, dtype=torch.float32, seed=71, scale=0.2)
+    bias = rnd(c_out, dtype=torch.float32, seed=72)
+    conv = F.conv3d if nd == 3 else F.conv2d
+    xc = x.float().movedim(-1, 1)
+    wr = w.bfloat16().float()
+    ref = conv(xc, wr, bias, padding=tuple(k // 2 for k in ks)).movedim(1, -1).reshape(-1, c_out)
+    w16 = K.patch_weight_rows(w, pad_to=8)
+    taps = K.conv_tap_table(c_in, ks, spatial, w16.shape[1], False, x.device)
+    got = K.conv_gemm(x, w16, taps, out_dtype=torch.float32, bias=bias)
+    close(got, ref, 2e-3, 2e-3 * float(ref.abs().max()), "implicit conv forward")
+    cols = K.im2col(x, ks)
+    close(got, K.gemm(cols, w16, bias=bias, out_dtype=torch.float32), 1e-4, 1e-4 * float(ref.abs().max()), "implicit conv == im2col + gemm")
+    res = rnd(ref.shape[0], c_out, dtype=torch.float32, seed=73)
+    close(K.conv_gemm(x, w16, taps, bias=bias, residual=res), ref + res, 2e-3, 2e-3 * float(ref.abs().max()), "implicit conv + residual")
+    ybf = K.conv_gemm(x, w16, taps, bias=bias)
+    assert ybf.dtype == torch.bfloat16
+    close(ybf, ref, 1e-2, 1e-2 * float(ref.abs().max()), "implicit conv bf16 out")
+    # data gradient: dx = conv_transpose(dy, w) = the same kernel on dy with the transposed weights and negated offsets
+    dy = rnd(b, *spatial, c_out, seed=74)
+    xg = xc.clone().requires_grad_(True)
+    conv(xg, wr, None, padding=tuple(k // 2 for k in ks)).backward(dy.float().movedim(-1, 1))
+    want = xg.grad.movedim(1, -1).reshape(-1, c_in)
+    wt = K.conv_weight_dgrad(w)
+    taps_t = K.conv_tap_table(c_out, ks, spatial, wt.shape[1], True, x.device)
+    dx = K.conv_gemm(dy, wt, taps_t, out_dtype=torch.float32)
+    close(dx, want, 2e-3, 2e-3 * float(want.abs().max()), "implicit conv data gradient")
