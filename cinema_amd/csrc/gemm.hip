@@ -33,6 +33,9 @@ struct GemmP {
   // the neighbour lies inside the volume, zeros otherwise.  conv_taps[j] = {row delta, packed (dx+1, dy+1, dz+1), first channel, valid}.
   const int4* conv_taps;
   int cX, cY, cZ, cC;
+  // weight gradient of that convolution (MODE_CONVW): dW[co][(tap, ci)] = sum_r dy[r][co] * x[nbr_tap(r)][ci]: the B operand (reduction-strided,
+  // [rows][taps * C]) is the virtual im2col matrix; conv_coords[r] = x | y << 10 | z << 20 of voxel r (one int per row, shape-only table)
+  const int* conv_coords;
 };
 
 __device__ __forceinline__ float frag_sum8(const short8v& f) {
@@ -657,10 +660,10 @@ __device__ __forceinline__ int8v frag_fp8(const char* lds, int base, int ks, int
   return out;
 }
 
-enum { MODE_PLAIN = 0, MODE_FP8 = 1, MODE_CONV = 2 };
+enum { MODE_PLAIN = 0, MODE_FP8 = 1, MODE_CONV = 2, MODE_CONVW = 3 };
 template <bool A_KMAJ, bool B_KMAJ, int EPI, int MODE = MODE_PLAIN>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, int kt_begin, int kt_end, float* tail_dst, char* smem) {
-  constexpr bool FP8 = MODE == MODE_FP8, CONV = MODE == MODE_CONV;
+  constexpr bool FP8 = MODE == MODE_FP8, CONV = MODE == MODE_CONV, CONVW = MODE == MODE_CONVW;
   using AIO = TileIO<A_KMAJ>;
   using BIO = TileIO<B_KMAJ>;
   constexpr int STAGE = AIO::BYTES + BIO::BYTES;
@@ -710,7 +713,50 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
     conv_chunk = (lane & 7) ^ ((row0 >> 1) & 7);  // the same for the lane's four pieces (their rows differ by multiples of 32)
     conv_ent = p.conv_taps[kt_begin * 8 + conv_chunk];
   }
+  // weight gradient of the implicit convolution: the lane's 16-byte column chunk (8 channels of one tap) is the same for its four DMA pieces and
+  // for every k-tile; the rows (voxels) change with the k-tile and come with their coordinates from conv_coords
+  int wdx = 0, wdy = 0, wdz = 0, wcol_ok = 0, wkr0 = 0;
+  long long wdelta = 0;
+  int wcoord[4] = {0, 0, 0, 0};
+  if constexpr (CONVW) {
+    wkr0 = wave_u * 4 + (lane >> 4);                      // k row of piece 0 inside the tile; piece pss adds 16 * pss
+    const int chunk = (lane & 15) ^ ((wkr0 & 3) << 2);
+    const int col = n0 + chunk * 8;
+    const int ci = col % p.cC;
+    const int4 e = p.conv_taps[min(col, p.n - 8) >> 3];
+    wcol_ok = (col < p.n) && e.w;
+    wdx = (e.y & 3) - 1; wdy = ((e.y >> 2) & 3) - 1; wdz = ((e.y >> 4) & 3) - 1;
+    wdelta = (long long)e.x * p.cC + ci;
+#pragma unroll
+    for (int pss = 0; pss < 4; pss++) {
+      const int r = kt_begin * BK + wkr0 + 16 * pss;
+      wcoord[pss] = r < p.k ? p.conv_coords[r] : -1;
+    }
+  }
   auto load_tile = [&](int stage, int kt) {  // operands of k-tile kt -> stage
+    if constexpr (CONVW) {
+      if ((kt + 1) * BK <= p.k) AIO::glds_at(smem_addr + stage * STAGE, asrc, (size_t)kt * astep, wave_u);
+      else AIO::glds(smem + stage * STAGE, p.a, p.lda, m0, p.m, kt * BK, p.k, lane, wave_u, zero_page);
+      const bf16_t* src[4];
+#pragma unroll
+      for (int pss = 0; pss < 4; pss++) {
+        const int cd = wcoord[pss];
+        const int x = cd & 1023, y = (cd >> 10) & 1023, z = (cd >> 20) & 1023;
+        const bool ok = wcol_ok && cd >= 0 && (unsigned)(x + wdx) < (unsigned)p.cX && (unsigned)(y + wdy) < (unsigned)p.cY && (unsigned)(z + wdz) < (unsigned)p.cZ;
+        const long long r = (long long)kt * BK + wkr0 + 16 * pss;
+        src[pss] = ok ? p.b + (r * p.cC + wdelta) : zero_page;
+      }
+      const uint32_t b0 = smem_addr + stage * STAGE + AIO::BYTES + wave_u * 1024;
+      glds16x4(b0, b0 + 4096, b0 + 8192, b0 + 12288, src[0], src[1], src[2], src[3]);
+      if (kt + 1 < kt_end) {  // next tile's voxel coordinates: land under this tile's MFMAs
+#pragma unroll
+        for (int pss = 0; pss < 4; pss++) {
+          const int r = (kt + 1) * BK + wkr0 + 16 * pss;
+          wcoord[pss] = r < p.k ? p.conv_coords[r] : -1;
+        }
+      }
+      return;
+    }
     if constexpr (CONV) {
       const int4 e = conv_ent;
       const int dx = (e.y & 3) - 1, dy = ((e.y >> 2) & 3) - 1, dz = ((e.y >> 4) & 3) - 1;
@@ -858,6 +904,10 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO<true>::BYTES + TileIO<true>::BYTES)];
   gemm_mfma_body<true, true, EPI, MODE_CONV>(p, smem);
+}
+__global__ __launch_bounds__(256, 2) void gemm_convw_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO<false>::BYTES + TileIO<false>::BYTES)];
+  gemm_mfma_body<false, false, EPI_F32, MODE_CONVW>(p, smem);
 }
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP p) {
@@ -1080,7 +1130,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = a->residual_bf16; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
-  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr;
+  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr;
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -1235,7 +1285,7 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
-  p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0; p.conv_taps = nullptr;
+  p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0; p.conv_taps = nullptr; p.conv_coords = nullptr;
   const int nkt = (p.k + BK - 1) / BK;
   p.ktiles_per_split = nkt;
   dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);
@@ -1272,13 +1322,56 @@ CINEMA_API int cinema_conv_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.act = 0; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
-  p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c;
+  p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c; p.conv_coords = nullptr;
   p.ktiles_per_split = (p.k + BK - 1) / BK;
   dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);
   hipStream_t st = (hipStream_t)stream;
   if (p.out_f32) { CINEMA_LAUNCH(gemm_conv_kernel<EPI_F32>, grid, dim3(256), 0, st, p); a->kernel_used = 512 + EPI_F32; }
   else if (!p.res_f32) { CINEMA_LAUNCH(gemm_conv_kernel<EPI_BF16>, grid, dim3(256), 0, st, p); a->kernel_used = 512 + EPI_BF16; }
   else return CINEMA_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
+// Weight gradient of the implicit convolution: dW[co][(tap, ci)] (+)= sum_r dy[r][co] * x[nbr_tap(r)][ci] (+ bias gradient = column sums of dy through
+// a_rowsum): args->a = dy [rows][lda] bf16 (rows = k, m = c_out), args->b = x volume [rows][C], n = ld of the weight rows (taps * C padded to 8),
+// conv_taps as in cinema_conv_gemm_bf16 (forward offsets), conv_coords[r] = x | y << 10 | z << 20.  fp32 D [c_out][ldd], split-K through the workspace.
+CINEMA_API int cinema_conv_wgrad_bf16(cinema_gemm_args* a, void* stream) {
+  if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0 || !a->conv_taps || !a->conv_coords || a->conv_c <= 0) return CINEMA_ERR_BAD_ARG;
+  auto al = [](long long v, int q) { return (v % q) == 0; };
+  if (!a->out_f32 || !al(a->m, 8) || !al(a->n, 8) || !al(a->lda, 8) || !al(a->ldd, 8) || !al(a->conv_c, 8) || !al((uintptr_t)a->a, 16) || !al((uintptr_t)a->b, 16) ||
+      !al((uintptr_t)a->d, 16) || !al((uintptr_t)a->conv_taps, 16) || a->conv_x > 1023 || a->conv_y > 1023 || a->conv_z > 1023)
+    return CINEMA_ERR_UNSUPPORTED;
+  if (a->bias || a->residual_f32 || a->residual_bf16 || a->gelu_in || a->row_mask || a->aux_out || a->act) return CINEMA_ERR_UNSUPPORTED;
+  const int split = a->split_k < 1 ? 1 : a->split_k;
+  GemmP p;
+  p.a = (const bf16_t*)a->a; p.b = (const bf16_t*)a->b; p.d = a->d;
+  p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldb = 0; p.ldd = a->ldd;
+  p.alpha = a->alpha;
+  p.bias = nullptr; p.res_f32 = nullptr; p.res_bf16 = nullptr; p.ld_res = 0; p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
+  p.act = 0; p.out_f32 = 1; p.accumulate = a->accumulate; p.a_rowsum = a->a_rowsum;
+  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
+  p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c; p.conv_coords = (const int*)a->conv_coords;
+  const int nkt = (a->k + BK - 1) / BK;
+  const int sp = split > nkt ? nkt : split;
+  p.ktiles_per_split = (nkt + sp - 1) / sp;
+  const int gz = (nkt + p.ktiles_per_split - 1) / p.ktiles_per_split;
+  if (!a->workspace || a->workspace_bytes < (long long)gz * a->m * a->n * 4 || (((uintptr_t)a->workspace) & 15)) return CINEMA_ERR_BAD_ARG;
+  p.ws = (float*)a->workspace;
+  dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, gz);
+  hipStream_t st = (hipStream_t)stream;
+  CINEMA_LAUNCH(gemm_convw_kernel, grid, dim3(256), 0, st, p);
+  long long blocks = ((long long)a->m * a->n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  int slices = 1;
+  if (a->accumulate && blocks < 256) {
+    slices = (int)(512 / blocks);
+    if (slices > (gz + 7) / 8) slices = (gz + 7) / 8;
+    if (slices < 1) slices = 1;
+  }
+  const SplitkP sk{(const float*)a->workspace, gz, a->m, a->n, (float*)a->d, a->ldd, a->accumulate, a->alpha};
+  launch_lanes(splitk_reduce_kernel, splitk_reduce_lanes_kernel, 2, dim3((unsigned)blocks, slices), dim3(256), 0, st, sk);
+  a->kernel_used = 1024;
   return launch_status();
 }
 
@@ -1306,7 +1399,7 @@ CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void*
     p.ld_res = a->ldd;
     p.ktiles_per_split = (a->k + BK - 1) / BK;
     p.ws = nullptr; p.a_rowsum = a->a_rowsum;
-    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.scale_a_rows = 0;
+    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.scale_a_rows = 0;
     g.tile_begin[i + 1] = g.tile_begin[i] + ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN);
     args[i].kernel_used = 64;  // the grouped kernel
   }

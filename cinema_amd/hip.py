@@ -40,7 +40,7 @@ class GemmArgs(C.Structure):
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
-        ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int),
+        ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int), ("conv_coords", C.c_void_p),
         ("kernel_used", C.c_int),
     ]
 
@@ -98,6 +98,7 @@ _PROTOS = {
     "cinema_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i, _vp],
     "cinema_gemm_fp8": [C.POINTER(GemmArgs), _vp],
     "cinema_conv_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "cinema_conv_wgrad_bf16": [C.POINTER(GemmArgs), _vp],
     "cinema_conv_weight_dgrad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cinema_quantize_fp8": [_vp, _ll, _vp, _vp, _vp, _vp],
     "cinema_quantize_fp8_rows": [_vp, _i, _i, _vp, _vp, _vp],
@@ -973,6 +974,40 @@ def conv_gemm(x: torch.Tensor, w: torch.Tensor, taps: torch.Tensor, *, out_dtype
     g.out_f32 = int(out.dtype == torch.float32)
     _check(load().cinema_conv_gemm_bf16(C.byref(g), _stream()), "conv_gemm")
     return out
+
+
+def conv_coord_table(batch: int, spatial: tuple, device: torch.device) -> torch.Tensor:
+    """int32 [batch * prod(spatial)]: x | y << 10 | z << 20 of every voxel row of a channels-last volume (2-D: leading unit axis)."""
+    sp = (1,) * (3 - len(spatial)) + tuple(int(v) for v in spatial)
+    if max(sp) > 1023:
+        raise HipLibraryError("conv_coord_table: extents up to 1023")
+    x = torch.arange(sp[0], dtype=torch.int32)[:, None, None]
+    y = torch.arange(sp[1], dtype=torch.int32)[None, :, None]
+    z = torch.arange(sp[2], dtype=torch.int32)[None, None, :]
+    return (x | (y << 10) | (z << 20)).reshape(-1).repeat(batch).contiguous().to(device)
+
+
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, taps: torch.Tensor, coords: torch.Tensor, out: torch.Tensor, split_k: int, a_rowsum: torch.Tensor | None = None) -> None:
+    """out [c_out, ld] fp32 += dy^T im2col(x) without materialising im2col(x): dy bf16 [rows, c_out], x bf16 channels-last [b, *spatial, c],
+    ``taps`` the forward tap table of the weight layout, ``coords`` from :func:`conv_coord_table`; a_rowsum [c_out] += column sums of dy."""
+    _dev(dy, x, taps, coords, out, a_rowsum)
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or out.dtype != torch.float32 or not x.is_contiguous() or coords.dtype != torch.int32:
+        raise HipLibraryError("conv_wgrad: bf16 operands, fp32 destination, int32 coordinates")
+    rows, c_out = dy.shape
+    c = x.shape[-1]
+    sp = (1,) * (3 - (x.dim() - 2)) + tuple(x.shape[1:-1])
+    if coords.numel() != rows or x.numel() // c != rows or out.shape[0] != c_out:
+        raise HipLibraryError("conv_wgrad: shape mismatch")
+    g = GemmArgs()
+    g.a, g.b, g.d = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+    g.m, g.n, g.k, g.lda, g.ldb, g.ldd = c_out, out.shape[1], rows, _rowmajor(dy, "dy"), 0, _rowmajor(out, "out")
+    g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, split_k
+    g.conv_taps, g.conv_x, g.conv_y, g.conv_z, g.conv_c, g.conv_coords = taps.data_ptr(), sp[0], sp[1], sp[2], c, coords.data_ptr()
+    ws = _workspace("splitk", split_k * c_out * out.shape[1], dy.device)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), split_k * c_out * out.shape[1] * 4
+    if a_rowsum is not None:
+        g.a_rowsum = a_rowsum.data_ptr()
+    _check(load().cinema_conv_wgrad_bf16(C.byref(g), _stream()), "conv_wgrad")
 
 
 def conv_weight_dgrad(w: torch.Tensor) -> torch.Tensor:

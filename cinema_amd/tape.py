@@ -913,7 +913,14 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
         if residual is not None:
             residual.add_grad(y.grad, y.grad16)
         dy16 = y.grad_bf16()
-        if weight.requires_grad:
+        if weight.requires_grad and implicit:  # dW = dy^T im2col(x) with the column matrix gathered inside the GEMM (cinema_conv_wgrad_bf16)
+            coords = const(("conv_coords", batch, tuple(spatial), str(dev)), lambda: K.conv_coord_table(batch, spatial, dev))
+            dst = wv.grad_buffer(tuple(w16.shape), conv_same_grad_to_param(weight))
+            db = bv.grad_buffer((c_out,)) if (bias is not None and bias.requires_grad) else None
+            dyc = dy16.contiguous()
+            split = _split_k(dyc.shape[0], c_out, w16.shape[1])
+            _wgrad_launch(lambda: K.conv_wgrad(dyc, xs, taps, coords, dst, split, a_rowsum=db), dyc, xs)
+        elif weight.requires_grad:
             wgrad(tape, dy16, K.im2col(xs, ks), wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w16.shape),
                   conv_same_grad_to_param(weight))
         if x.needs_grad:

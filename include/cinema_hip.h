@@ -64,6 +64,7 @@ typedef struct {
   int scale_a_rows;           /* cinema_gemm_fp8: 1 = scale_a holds one scale per row of A (per-token activation scaling), 0 = one scalar */
   const void* conv_taps;      /* cinema_conv_gemm_bf16 only: device int4 [k / 8] tap table; conv_x/y/z/c = volume size and channels */
   int conv_x, conv_y, conv_z, conv_c;
+  const void* conv_coords;    /* cinema_conv_wgrad_bf16 only: device int [rows], x | y << 10 | z << 20 of every voxel row */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
                                  + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped */
 } cinema_gemm_args;
@@ -79,6 +80,10 @@ int cinema_gemm_fp8(cinema_gemm_args* args_host, void* stream);
  * D[r][n] = sum over the taps / channels of x at the neighbour voxel (zeros outside the volume) + bias (+ fp32 residual); bf16 or fp32 D.  The im2col
  * matrix (27 x the activation) is never written: the MFMA kernel's A tiles are gathered from the volume by the LDS-DMA. */
 int cinema_conv_gemm_bf16(cinema_gemm_args* args_host, void* stream);
+/* Weight gradient of the same convolution, again without an im2col matrix: a = dy [rows][lda] bf16 (k = rows, m = c_out), b = the volume x [rows][C],
+ * n = weight row length (taps * C padded to 8), conv_taps = the FORWARD table, conv_coords[r] = voxel coordinates of row r: D[co][(tap, ci)] fp32 (+)=
+ * sum_r dy[r][co] * x[nbr_tap(r)][ci]; a_rowsum[co] += sum_r dy[r][co] (bias gradient).  Deterministic split-K through `workspace` (>= split_k*m*n*4 B). */
+int cinema_conv_wgrad_bf16(cinema_gemm_args* args_host, void* stream);
 /* Weights of the DATA GRADIENT of that convolution: w fp32 (c_out, c_in, kvol) contiguous -> rows [c_in][ld] bf16 with rows[ci][tap * c_out + co] = w[co][ci][tap],
  * zero-padded to ld (a multiple of 8 >= kvol * c_out). */
 int cinema_conv_weight_dgrad(const float* w, uint16_t* rows, int c_out, int c_in, int kvol, int ld, void* stream);

@@ -717,3 +717,16 @@ def test_implicit_gemm_conv_forward_and_data_gradient(spatial: tuple, c_in: int,
     taps_t = K.conv_tap_table(c_out, ks, spatial, wt.shape[1], True, x.device)
     dx = K.conv_gemm(dy, wt, taps_t, out_dtype=torch.float32)
     close(dx, want, 2e-3, 2e-3 * float(want.abs().max()), "implicit conv data gradient")
+    # weight gradient: dW[co][(tap, ci)] += dy^T im2col(x) with the column matrix gathered on the fly, bias gradient as fused row sums
+    wg = xc.clone()
+    wpar = wr.clone().requires_grad_(True)
+    bpar = bias.clone().requires_grad_(True)
+    conv(wg, wpar, bpar, padding=tuple(k // 2 for k in ks)).backward(dy.float().movedim(-1, 1))
+    want_w = wpar.grad.reshape(c_out, c_in, -1).permute(0, 2, 1).reshape(c_out, -1)  # features (tap, ci)
+    coords = K.conv_coord_table(b, spatial, x.device)
+    dw = torch.full((c_out, w16.shape[1]), 0.5, dtype=torch.float32, device=DEV)
+    db = torch.zeros(c_out, dtype=torch.float32, device=DEV)
+    K.conv_wgrad(dy.reshape(-1, c_out), x, taps, coords, dw, split_k=3, a_rowsum=db)
+    close(dw[:, :want_w.shape[1]] - 0.5, want_w, 3e-3, 3e-3 * float(want_w.abs().max()), "implicit conv weight gradient")
+    assert float((dw[:, want_w.shape[1]:] - 0.5).abs().max()) == 0.0 if dw.shape[1] > want_w.shape[1] else True
+    close(db, bpar.grad, 1e-3, 1e-3 * float(bpar.grad.abs().max()), "implicit conv bias gradient")
