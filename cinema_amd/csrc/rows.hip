@@ -614,6 +614,111 @@ CINEMA_API int cinema_conv_weight_dgrad(const float* w, uint16_t* rows, int c_ou
   return launch_status();
 }
 
+// ---- thin linear layers (the 4-class segmentation head over millions of voxels: N <= 8 outputs, K <= 64 inputs): pure streaming, one thread per row.
+// The MFMA GEMM needs N % 8 == 0 and the generic kernel ran these at 0.6 TF (4.5 ms + a 3.3 ms column sum per step of config 4).
+constexpr int THIN_MAXN = 8, THIN_MAXK = 64;
+struct ThinP { const bf16_t* x; const float* w; const float* bias; float* y; const float* dy; bf16_t* dx; float* dw; float* db; long long rows; int n, k; };
+
+__global__ __launch_bounds__(256) void thin_linear_fwd_kernel(ThinP p) {
+  __shared__ float ws[THIN_MAXN * THIN_MAXK + THIN_MAXN];
+  for (int i = threadIdx.x; i < p.n * p.k; i += 256) ws[i] = p.w[i];
+  for (int i = threadIdx.x; i < p.n; i += 256) ws[p.n * p.k + i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < p.rows; r += (long long)gridDim.x * 256) {
+    float acc[THIN_MAXN];
+#pragma unroll
+    for (int j = 0; j < THIN_MAXN; j++) acc[j] = j < p.n ? ws[p.n * p.k + j] : 0.f;
+    for (int k0 = 0; k0 < p.k; k0 += 8) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.x + r * p.k + k0);
+#pragma unroll
+      for (int j = 0; j < THIN_MAXN; j++)
+        if (j < p.n) {
+#pragma unroll
+          for (int t = 0; t < 8; t++) acc[j] = fmaf(bf2f(v.v[t]), ws[j * p.k + k0 + t], acc[j]);
+        }
+    }
+    for (int j = 0; j < p.n; j++) p.y[r * p.n + j] = acc[j];
+  }
+}
+
+// dx[r][k] = sum_n dy[r][n] W[n][k] (bf16) ; dW[n][k] += sum_r dy[r][n] x[r][k] ; db[n] += sum_r dy[r][n]   (dy fp32 [rows][n])
+__global__ __launch_bounds__(256) void thin_linear_bwd_kernel(ThinP p) {
+  __shared__ float ws[THIN_MAXN * THIN_MAXK];
+  __shared__ float red[THIN_MAXN * THIN_MAXK + THIN_MAXN];
+  for (int i = threadIdx.x; i < p.n * p.k; i += 256) ws[i] = p.w[i];
+  for (int i = threadIdx.x; i < p.n * p.k + p.n; i += 256) red[i] = 0.f;
+  __syncthreads();
+  // weight-gradient partials: lane l of a wave owns column k = l (k <= 64) for every n: a wave walks rows together, x[r][lane] broadcast-free
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gw[THIN_MAXN], gb[THIN_MAXN];
+#pragma unroll
+  for (int j = 0; j < THIN_MAXN; j++) { gw[j] = 0.f; gb[j] = 0.f; }
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * 64; r0 < p.rows; r0 += waves * 64) {
+    // phase 1: each lane handles row r0 + lane for the data gradient (and keeps its dy row for the bias gradient)
+    const long long r = r0 + lane;
+    float d[THIN_MAXN];
+#pragma unroll
+    for (int j = 0; j < THIN_MAXN; j++) d[j] = (j < p.n && r < p.rows) ? p.dy[r * p.n + j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < THIN_MAXN; j++) gb[j] += d[j];
+    if (p.dx && r < p.rows) {
+      for (int k0 = 0; k0 < p.k; k0 += 8) {
+        bf16x8 o;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < THIN_MAXN; j++)
+            if (j < p.n) a = fmaf(d[j], ws[j * p.k + k0 + t], a);
+          o.v[t] = f2bf(a);
+        }
+        *reinterpret_cast<bf16x8*>(p.dx + r * p.k + k0) = o;
+      }
+    }
+    // phase 2: weight gradient - lane = input column k, the 64 rows of this group one after the other (dy of row i comes from lane i by shuffle)
+    if (p.dw) {
+      const int rows_here = (int)min((long long)64, p.rows - r0);
+      for (int i = 0; i < rows_here; i++) {
+        const float xv = lane < p.k ? bf2f(p.x[(r0 + i) * p.k + lane]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < THIN_MAXN; j++)
+          if (j < p.n) gw[j] = fmaf(__shfl(d[j], i, 64), xv, gw[j]);
+      }
+    }
+  }
+  if (p.dw && lane < p.k)
+    for (int j = 0; j < p.n; j++) atomicAdd(&red[j * p.k + lane], gw[j]);
+  for (int j = 0; j < p.n; j++) {
+    const float s = wave_sum(gb[j]);
+    if (lane == 0) atomicAdd(&red[p.n * p.k + j], s);
+  }
+  __syncthreads();
+  if (p.dw)
+    for (int i = threadIdx.x; i < p.n * p.k; i += 256) unsafeAtomicAdd(p.dw + i, red[i]);
+  if (p.db)
+    for (int i = threadIdx.x; i < p.n; i += 256) unsafeAtomicAdd(p.db + i, red[p.n * p.k + i]);
+}
+
+CINEMA_API int cinema_thin_linear_fwd(const uint16_t* x, const float* w, const float* bias, float* y, long long rows, int n, int k, void* stream) {
+  if (!x || !w || !y || rows <= 0 || n <= 0 || k <= 0) return CINEMA_ERR_BAD_ARG;
+  if (n > THIN_MAXN || k > THIN_MAXK || (k & 7) || (((uintptr_t)x) & 15)) return CINEMA_ERR_UNSUPPORTED;
+  ThinP p{x, w, bias, y, nullptr, nullptr, nullptr, nullptr, rows, n, k};
+  CINEMA_LAUNCH(thin_linear_fwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+CINEMA_API int cinema_thin_linear_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, long long rows, int n, int k,
+                                      void* stream) {
+  if (!x || !w || !dy || rows <= 0 || n <= 0 || k <= 0) return CINEMA_ERR_BAD_ARG;
+  if (n > THIN_MAXN || k > THIN_MAXK || (k & 7) || (((uintptr_t)x) & 15) || (dx && (((uintptr_t)dx) & 15))) return CINEMA_ERR_UNSUPPORTED;
+  ThinP p{x, w, nullptr, nullptr, dy, dx, dw, db, rows, n, k};
+  int g = (int)((rows + 255) / 256);
+  if (g > 1024) g = 1024;
+  CINEMA_LAUNCH(thin_linear_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;

@@ -135,6 +135,8 @@ _PROTOS = {
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
     "cinema_fill_u32": [_vp, C.c_uint, _ll, _vp],
+    "cinema_thin_linear_fwd": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "cinema_thin_linear_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_rng_advance": [_vp, _vp],
     "cinema_dropout_bf16": [_vp, _vp, _ll, _f, _vp, C.c_uint, _vp],
     "cinema_droppath_scale": [_vp, _i, _f, _vp, C.c_uint, _vp],
@@ -719,6 +721,27 @@ def scale_rows_add(h: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, r
     _check(load().cinema_scale_rows_add(h.data_ptr(), _p(residual), scale.data_ptr(), out.data_ptr(), h.shape[0], h.shape[1], rows_per_sample, _stream()),
            "scale_rows_add")
     return out
+
+
+def thin_linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """y fp32 [rows, n] = x (bf16 [rows, k]) @ w^T (fp32 [n, k]) + bias for n <= 8, k <= 64 (streaming kernel, no GEMM)."""
+    _dev(x, w, bias)
+    if x.dtype != torch.bfloat16 or w.dtype != torch.float32 or not x.is_contiguous() or not w.is_contiguous():
+        raise HipLibraryError("thin_linear: contiguous bf16 rows, fp32 weight")
+    y = _empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+    _check(load().cinema_thin_linear_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), x.shape[0], w.shape[0], w.shape[1], _stream()), "thin_linear_fwd")
+    return y
+
+
+def thin_linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor | None, db: torch.Tensor | None, want_dx: bool) -> torch.Tensor | None:
+    """Backward of :func:`thin_linear_fwd`: returns dx (bf16) when asked; dw (fp32 [n, k]) / db (fp32 [n]) are accumulated in place."""
+    _dev(x, w, dy, dw, db)
+    if dy.dtype != torch.float32 or not dy.is_contiguous() or tuple(dy.shape) != (x.shape[0], w.shape[0]):
+        raise HipLibraryError("thin_linear_bwd: contiguous fp32 dy [rows, n]")
+    dx = _empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_dx else None
+    _check(load().cinema_thin_linear_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), _p(dw), _p(db), x.shape[0], w.shape[0], w.shape[1], _stream()),
+           "thin_linear_bwd")
+    return dx
 
 
 def full(shape, value: float, dtype: torch.dtype = torch.float32, device=None) -> torch.Tensor:  # noqa: ANN001

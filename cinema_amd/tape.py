@@ -611,6 +611,9 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
               out_f32: bool = False, row_mask: torch.Tensor | None = None, w16: torch.Tensor | None = None,
               to_param_layout: Callable | None = None, fp8: bool = False) -> Var:
     """y = x W^T + b (+ residual); x bf16 [m,k]; W given as nn.Linear / 1x1-conv weight (or a pre-built shadow ``w16``)."""
+    if (w16 is None and out_f32 and residual is None and row_mask is None and weight.dim() >= 2 and weight.shape[0] < 8 and x.data.is_cuda
+            and x.data.dtype == BF16 and x.data.is_contiguous() and math.prod(weight.shape[1:]) == x.data.shape[1] <= 64 and x.data.shape[1] % 8 == 0):
+        return _op_thin_linear(tape, x, weight, bias)
     w = w16 if w16 is not None else w_plain(weight)
     if fp8 and w16 is None and row_mask is None and _fp8_ok(x.data, weight) and (residual is None or residual.data.dtype == F32):
         x8, sx = a_fp8(x)
@@ -634,6 +637,25 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
             wgrad(tape, dy16, x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
         if x.needs_grad:
             x.add_grad(K.gemm(dy16, w, a_kmajor=True, b_kmajor=False, row_mask=row_mask))
+
+    tape.record(bwd)
+    return y
+
+
+def _op_thin_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None) -> Var:
+    """A head with fewer than 8 outputs (the 4-class segmentation head over every voxel): streaming kernels on the fp32 master weight."""
+    w2 = weight.detach().reshape(weight.shape[0], -1)
+    y = Var(K.thin_linear_fwd(x.data, w2, None if bias is None else bias.detach()))
+    wv, bv = tape.pvar(weight), tape.pvar(bias)
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        dw = wv.grad_buffer(tuple(w2.shape)) if weight.requires_grad else None
+        db = bv.grad_buffer((w2.shape[0],)) if (bias is not None and bias.requires_grad) else None
+        dx = K.thin_linear_bwd(x.data, w2, y.grad.contiguous(), dw, db, want_dx=x.needs_grad)
+        if dx is not None:
+            x.add_grad(dx)
 
     tape.record(bwd)
     return y

@@ -286,6 +286,11 @@ int cinema_rng_advance(unsigned long long* state, void* stream);
 int cinema_dropout_bf16(const uint16_t* x, uint16_t* y, long long n, float p, const unsigned long long* state, unsigned int salt, void* stream);
 int cinema_droppath_scale(float* scale, int batch, float p, const unsigned long long* state, unsigned int salt, void* stream);
 int cinema_scale_rows_add(const float* h, const float* residual, const float* scale, float* out, long long rows, int c, int rows_per_sample, void* stream);
+/* Thin linear layer (n <= 8 outputs, k <= 64 inputs, k % 8 == 0; the 4-class segmentation head, cinema/segmentation/convunetr.py pred_head_dict, over millions of
+ * voxels): streaming kernels instead of a GEMM.  fwd: y fp32 [rows][n] = x bf16 [rows][k] . w^T (fp32 [n][k]) + bias.  bwd (dy fp32 [rows][n]): dx bf16 [rows][k] =
+ * dy . w (NULL: skip), dw fp32 [n][k] += dy^T x, db [n] += column sums of dy (NULL: skip). */
+int cinema_thin_linear_fwd(const uint16_t* x, const float* w, const float* bias, float* y, long long rows, int n, int k, void* stream);
+int cinema_thin_linear_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, long long rows, int n, int k, void* stream);
 /* dst[0 .. n_words) = word (32-bit pattern; torch.zeros / torch.full of the reference's host code as a launch of this library). */
 int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream);
 

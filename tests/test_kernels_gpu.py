@@ -730,3 +730,21 @@ def test_implicit_gemm_conv_forward_and_data_gradient(spatial: tuple, c_in: int,
     close(dw[:, :want_w.shape[1]] - 0.5, want_w, 3e-3, 3e-3 * float(want_w.abs().max()), "implicit conv weight gradient")
     assert float((dw[:, want_w.shape[1]:] - 0.5).abs().max()) == 0.0 if dw.shape[1] > want_w.shape[1] else True
     close(db, bpar.grad, 1e-3, 1e-3 * float(bpar.grad.abs().max()), "implicit conv bias gradient")
+
+
+@pytest.mark.parametrize(("rows", "n", "k"), [(100000, 4, 32), (777, 3, 64), (4097, 8, 8)])
+def test_thin_linear_kernels(rows: int, n: int, k: int) -> None:
+    """The 4-class segmentation head as streaming kernels (cinema_thin_linear_fwd / bwd) against fp32 torch on the same bf16-rounded input."""
+    x = rnd(rows, k, seed=80)
+    w, b = rnd(n, k, dtype=torch.float32, seed=81, scale=0.3), rnd(n, dtype=torch.float32, seed=82)
+    y = K.thin_linear_fwd(x, w, b)
+    ref = x.float() @ w.t() + b
+    close(y, ref, 1e-5, 1e-5 * float(ref.abs().max()), "thin linear forward")
+    dy = rnd(rows, n, dtype=torch.float32, seed=83)
+    dw, db = torch.full((n, k), 1.0, device=DEV), torch.zeros(n, device=DEV)
+    dx = K.thin_linear_bwd(x, w, dy, dw, db, want_dx=True)
+    close(dx, dy @ w, 1e-2, 1e-2 * float((dy @ w).abs().max()), "thin linear dx")
+    want_w = dy.t() @ x.float()
+    close(dw - 1.0, want_w, 1e-3, 2e-4 * float(want_w.abs().max()) * (rows ** 0.5) / 30 + 1e-3, "thin linear dw")
+    close(db, dy.sum(0), 1e-3, 1e-4 * rows ** 0.5, "thin linear db")
+    assert K.thin_linear_bwd(x, w, dy, None, None, want_dx=False) is None
