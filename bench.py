@@ -385,16 +385,19 @@ def main() -> None:
         T_.SIDE_WGRAD = side
     if rank == 0 and args.profile_steps > 0:
         agg: dict = {}
-        for kind, flops, e0, e1, _shape in prof:
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
+        for kind, flops, e0, e1, shape in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+            a[3] += shape[-1]
         kind = max(agg, key=lambda k: agg[k][1])
-        flops, secs, n = agg[kind]
+        flops, secs, n, alg_bytes = agg[kind]
+        traffic = pmc_traffic(K.GEMM_KERNEL_NAMES[kind])
         achieved = flops / secs / 1e12
         roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(K.GEMM_KERNEL_NAMES[kind]),
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(alg_bytes / n), "traffic_over_algorithmic": round(traffic / (alg_bytes / n), 2) if traffic else None,
                     "traffic_source": f"committed {PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc_bench.sh); not collected live",
                     "mfma_util": pmc_mfma_util(K.GEMM_KERNEL_NAMES[kind]),
                     "mfma_util_source": f"committed {PMC_MFMA_FILE} (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes, tools/gpu_pmc_mfma.sh); not collected live",

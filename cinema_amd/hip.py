@@ -318,11 +318,12 @@ _LANE_KEEP: list = []
 class lanes:  # noqa: N801
     """``with lanes(n) as g: g.select(0); <launches of lane 0>; g.select(1); ...``: the launches issued inside are recorded by the library and
     go out, zipped across the lanes, when the block ends.  The lanes must be independent.  Inactive (plain immediate launches) when
-    ``CINEMA_LANES=0``, when a group is already open, or while single launches are being timed (``GEMM_PROFILE``)."""
+    ``CINEMA_LANES=0`` or when a group is already open.  (While ``GEMM_PROFILE`` times single launches the group stays active and the launches
+    inside it are not timed: the timed set is then exactly the launches rocprofv3 reports under the single-launch kernel names.)"""
 
     def __init__(self, n: int) -> None:
         self.n = n
-        self.active = LANES_ENABLED and LANE is None and GEMM_PROFILE is None and 2 <= n <= 4
+        self.active = LANES_ENABLED and LANE is None and 2 <= n <= 4
 
     def __enter__(self) -> "lanes":
         global LANE  # noqa: PLW0603
@@ -446,7 +447,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ev0.record()
     _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
     ev1.record()
-    GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k)))
+    ob = out.element_size()
+    extra = sum(t.numel() * t.element_size() for t in (residual, gelu_in, aux_out) if t is not None)
+    alg_bytes = 2.0 * (m * k + k * n) + ob * m * n * (2 if accumulate else 1) + extra  # every operand read once, the result written once
+    GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k, alg_bytes)))
     return out
 
 
@@ -545,7 +549,8 @@ def gemm_wgrad_grouped(problems: list) -> None:
     _check(load().cinema_gemm_bf16_grouped(arr, len(problems), _stream()), "gemm_grouped")
     ev1.record()
     flops = sum(2.0 * g.m * g.n * g.k for g in arr)
-    GEMM_PROFILE.append((64, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems))))
+    alg = sum(2.0 * (g.m * g.k + g.k * g.n) + 8.0 * g.m * g.n for g in arr)
+    GEMM_PROFILE.append((64, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg)))
 
 
 def _warn_generic(m: int, n: int, k: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
