@@ -2,7 +2,7 @@
 
 ``from cinema import CineMA, ConvViT, ConvUNetR, patchify, unpatchify`` and the sub-module imports the reference's training / inference
 scripts use (``cinema.mae.mae``, ``cinema.convvit``, ``cinema.vit``, ``cinema.conv``, ``cinema.rotary``, ``cinema.optim``, ``cinema.device``, ``cinema.transform``,
-``cinema.segmentation.convunetr``, ``cinema.segmentation.train``) resolve to the ``cinema_amd`` modules of the same name: one set of
+``cinema.segmentation.convunetr``, ``cinema.segmentation.train``, ``cinema.classification.train``, ``cinema.regression.train``) resolve to the ``cinema_amd`` modules of the same name: one set of
 classes, two import names.  Only the hot path is aliased; data loading, hydra entry points, metrics for landmark
 heat-maps (``heatmap_soft_argmax``) and the ResNet / UNet baselines are not part of this build and are not faked here.
 """
@@ -23,6 +23,10 @@ _ALIASES = {
     "cinema.segmentation": "cinema_amd.segmentation",
     "cinema.segmentation.convunetr": "cinema_amd.segmentation.convunetr",
     "cinema.segmentation.train": "cinema_amd.segmentation.train",
+    "cinema.classification": "cinema_amd.classification",
+    "cinema.classification.train": "cinema_amd.classification.train",
+    "cinema.regression": "cinema_amd.regression",
+    "cinema.regression.train": "cinema_amd.regression.train",
 }
 for _alias, _target in _ALIASES.items():
     _mod = importlib.import_module(_target)

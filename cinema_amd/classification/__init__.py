@@ -1,0 +1,1 @@
+"""Classification fine-tuning of ConvViT on the HIP path (interface of the reference ``cinema/classification``)."""

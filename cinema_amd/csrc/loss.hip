@@ -222,6 +222,60 @@ PatchG to_dev(const cinema_patch_geom* g) {
 int rows_grid(int n_rows) { int g = (n_rows + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
 bool fast_patch(const cinema_patch_geom* g) { return (long long)g->px * g->py * g->pz * g->c <= 64 * MAXI; }
 
+
+// ---- losses of the ConvViT heads (a handful of rows): one workgroup, forward and gradient in one launch
+// cross entropy with label smoothing (F.cross_entropy(logits, label, label_smoothing = eps), mean over the batch):
+//   loss_i = (1 - eps) * (lse_i - z_i[y_i]) + eps / c * sum_j (lse_i - z_i[j]);   d loss / d z_i[j] = (softmax_i[j] - (1 - eps) [j == y_i] - eps / c) / b
+__global__ __launch_bounds__(256) void head_ce_kernel(const float* logits, const int* labels, int b, int c, float eps, float* out, float* dlogits) {
+  __shared__ float red[256];
+  float part = 0.f;
+  for (int i = threadIdx.x; i < b; i += 256) {
+    const float* z = logits + (size_t)i * c;
+    float mx = z[0];
+    for (int j = 1; j < c; j++) mx = fmaxf(mx, z[j]);
+    float se = 0.f, sz = 0.f;
+    for (int j = 0; j < c; j++) { se += expf(z[j] - mx); sz += z[j]; }
+    const float lse = mx + logf(se);
+    const int y = labels[i];
+    part += (1.f - eps) * (lse - z[y]) + eps * (lse - sz / c);
+    const float inv = 1.f / se;
+    for (int j = 0; j < c; j++) dlogits[(size_t)i * c + j] = (expf(z[j] - mx) * inv - (j == y ? 1.f - eps : 0.f) - eps / c) / b;
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / b;
+}
+// mean squared error over all n = rows * cols elements with the reported values of the reference's regression_loss:
+//   out = {mse, mae, max label, min label, max pred, min pred};  d mse / d pred = 2 (pred - label) / n
+__global__ __launch_bounds__(256) void head_mse_kernel(const float* pred, const float* label, int n, float* out, float* dpred) {
+  __shared__ float red[6][256];
+  float s2 = 0.f, s1 = 0.f, mxl = -INFINITY, mnl = INFINITY, mxp = -INFINITY, mnp = INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = pred[i] - label[i];
+    s2 += d * d; s1 += fabsf(d);
+    mxl = fmaxf(mxl, label[i]); mnl = fminf(mnl, label[i]); mxp = fmaxf(mxp, pred[i]); mnp = fminf(mnp, pred[i]);
+    dpred[i] = 2.f * d / n;
+  }
+  red[0][threadIdx.x] = s2; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = mxl; red[3][threadIdx.x] = mnl; red[4][threadIdx.x] = mxp; red[5][threadIdx.x] = mnp;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const int t = threadIdx.x;
+      red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o];
+      red[2][t] = fmaxf(red[2][t], red[2][t + o]); red[3][t] = fminf(red[3][t], red[3][t + o]);
+      red[4][t] = fmaxf(red[4][t], red[4][t + o]); red[5][t] = fminf(red[5][t], red[5][t + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0] / n; out[1] = red[1][0] / n; out[2] = red[2][0]; out[3] = red[3][0]; out[4] = red[4][0]; out[5] = red[5][0];
+  }
+}
+
 }  // namespace
 
 CINEMA_API int cinema_mse_fwd(const float* image, const cinema_patch_geom* geom, const void* pred, int pred_dtype, int ld_pred, int norm_target,
@@ -474,5 +528,17 @@ CINEMA_API int cinema_seg_loss_bwd(const float* logits, const int* labels, int b
   int gx = (vox + 255) / 256;
   if (gx > 2048) gx = 2048;
   CINEMA_LAUNCH(seg_loss_bwd_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, logits, labels, vox, c, coef, out4, upstream, dlogits);
+  return launch_status();
+}
+
+CINEMA_API int cinema_head_ce(const float* logits, const int* labels, int b, int c, float label_smoothing, float* out1, float* dlogits, void* stream) {
+  if (!logits || !labels || !out1 || !dlogits || b <= 0 || c < 2 || !(label_smoothing >= 0.f && label_smoothing < 1.f)) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(head_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, b, c, label_smoothing, out1, dlogits);
+  return launch_status();
+}
+
+CINEMA_API int cinema_head_mse(const float* pred, const float* label, int n, float* out6, float* dpred, void* stream) {
+  if (!pred || !label || !out6 || !dpred || n <= 0) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(head_mse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, label, n, out6, dpred);
   return launch_status();
 }

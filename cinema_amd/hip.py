@@ -128,6 +128,8 @@ _PROTOS = {
     "cinema_row_copy": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "cinema_seg_loss_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cinema_seg_loss_bwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "cinema_head_ce": [_vp, _vp, _i, _i, _f, _vp, _vp, _vp],
+    "cinema_head_mse": [_vp, _vp, _i, _vp, _vp, _vp],
     "cinema_seg_window_accumulate": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "cinema_seg_window_finish": [_vp, _vp, _i, _ll, _vp, _vp],
     "cinema_seg_metric_counts": [_vp, _vp, _i, _i, _i, _vp, _vp],
@@ -586,6 +588,28 @@ def seg_loss_bwd(logits_rows: torch.Tensor, labels: torch.Tensor, batch: int, co
     _check(load().cinema_seg_loss_bwd(logits_rows.data_ptr(), labels.data_ptr(), batch, rows // batch, c, coef.data_ptr(), out4.data_ptr(), _p(upstream),
                                       d.data_ptr(), _stream()), "seg_loss_bwd")
     return d
+
+
+def head_ce(logits: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0) -> tuple:
+    """Mean cross entropy with label smoothing of fp32 logits [b, c] against int32 labels [b] -> (loss [1], d loss / d logits [b, c])."""
+    _dev(logits, labels)
+    if logits.dtype != torch.float32 or labels.dtype != torch.int32 or logits.dim() != 2 or labels.numel() != logits.shape[0] or \
+            not logits.is_contiguous() or not labels.is_contiguous():
+        raise HipLibraryError("head_ce: contiguous fp32 logits [b, c] and int32 labels [b]")
+    out, d = _empty(1, dtype=torch.float32, device=logits.device), _empty_like(logits)
+    _check(load().cinema_head_ce(logits.data_ptr(), labels.data_ptr(), logits.shape[0], logits.shape[1], float(label_smoothing), out.data_ptr(), d.data_ptr(),
+                                 _stream()), "head_ce")
+    return out, d
+
+
+def head_mse(pred: torch.Tensor, label: torch.Tensor) -> tuple:
+    """-> (out6 = [mse, mae, max label, min label, max pred, min pred], d mse / d pred) for contiguous fp32 tensors of one shape."""
+    _dev(pred, label)
+    if pred.dtype != torch.float32 or label.dtype != torch.float32 or pred.shape != label.shape or not pred.is_contiguous() or not label.is_contiguous():
+        raise HipLibraryError("head_mse: contiguous fp32 predictions and labels of one shape")
+    out, d = _empty(6, dtype=torch.float32, device=pred.device), _empty_like(pred)
+    _check(load().cinema_head_mse(pred.data_ptr(), label.data_ptr(), pred.numel(), out.data_ptr(), d.data_ptr(), _stream()), "head_mse")
+    return out, d
 
 
 def seg_window_accumulate(window_rows: torch.Tensor, patch: tuple, start: tuple, size: tuple, prob_sum: torch.Tensor, count: torch.Tensor) -> None:

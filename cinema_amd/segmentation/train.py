@@ -5,6 +5,7 @@ from __future__ import annotations
 import torch
 
 from cinema_amd import hip as K
+from cinema_amd.train import FineTuneStep
 
 
 class _SegLoss(torch.autograd.Function):
@@ -83,39 +84,17 @@ def segmentation_loss_tensors(model, batch: dict, views: list, device: torch.dev
     return loss, metrics
 
 
-class SegTrainStep:
+class SegTrainStep(FineTuneStep):
     """One optimisation step of the segmentation fine-tuning loop (reference ``cinema/train.py:85-168`` with ``segmentation_loss`` as
     ``loss_fn``): forward -> CE + Dice -> backward into the flat gradient buffer -> (data-parallel mean all-reduce) -> global-norm clip ->
-    fused AdamW over the layer-decay parameter groups (``param_groups_lr_decay``, ``cinema/train.py:262-270``) -> zero_grad.  Returns
-    (loss, grad_norm | None, metrics) as device tensors."""
+    fused AdamW over the layer-decay parameter groups (``param_groups_lr_decay``, ``cinema/train.py:262-270``; ``layer_decay=None``: one group,
+    pass ``weight_decay=0.01`` for torch's default as the reference's from-scratch branch uses it) -> zero_grad.  Returns (loss, grad_norm | None,
+    metrics) as device tensors."""
 
     def __init__(self, model, views: list, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, layer_decay: float | None = 0.75,  # noqa: ANN001
                  clip_grad: float | None = 5.0, synchronizer=None) -> None:  # noqa: ANN001
-        from cinema_amd.convvit import param_groups_lr_decay
-        from cinema_amd.optim import FlatModel, FusedAdamW
-
-        self.model, self.views, self.clip_grad = model, list(views), clip_grad
-        if layer_decay is not None:  # fine-tuning from a pre-trained checkpoint (cinema/train.py:262-268)
-            groups = param_groups_lr_decay(model, no_weight_decay_list=[], weight_decay=weight_decay, layer_decay=layer_decay)
-        else:  # from scratch the reference hands AdamW model.parameters(): one group (pass weight_decay=0.01 for torch's default, train.py:269-270)
-            groups = [{"params": [p for p in model.parameters() if p.requires_grad], "weight_decay": weight_decay}]
-        self.flat = FlatModel(model, weight_decay, param_groups=groups)
-        self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas, synchronizer=synchronizer)
-        self.sync = self.optimizer.synchronizer
-        self.device = self.flat.flat_param.device
-
-    def __call__(self, batch: dict, n_accum_steps: int = 1, update_grad: bool = True) -> tuple:
-        loss, metrics = segmentation_loss_tensors(self.model, batch, self.views, self.device)
-        if self.sync is not None:
-            self.sync.arm(update_grad)
-        (loss / n_accum_steps if n_accum_steps > 1 else loss).backward()
-        grad_norm = None
-        if update_grad:
-            if self.sync is not None:
-                self.sync.all_reduce()
-            grad_norm = self.optimizer.step(self.clip_grad)
-            self.optimizer.zero_grad()
-        return loss.detach(), grad_norm, metrics
+        super().__init__(model, views, segmentation_loss_tensors, lr=lr, betas=betas, weight_decay=weight_decay, layer_decay=layer_decay,
+                         clip_grad=clip_grad, synchronizer=synchronizer)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

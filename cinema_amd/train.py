@@ -1,0 +1,82 @@
+"""The optimisation step of the reference's generic fine-tuning loop (``cinema/train.py:85-168``, ``train_one_epoch``) for any model of this
+build and any ``loss_fn(model, batch, views, device) -> (loss, metrics)``: forward -> loss -> backward into the flat gradient buffer ->
+(data-parallel mean all-reduce) -> global-norm clip -> fused AdamW over the layer-decay parameter groups -> zero_grad.
+
+The hydra / wandb / DataLoader shell around it (``run_train``, ``cinema/train.py:171-351``) is the reference's control plane and is not rebuilt."""
+
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+
+class FineTuneStep:
+    """``step = FineTuneStep(model, views, loss_fn, lr=..., layer_decay=0.75)``; ``loss, grad_norm, metrics = step(batch)``.
+
+    ``layer_decay`` not None: the parameter groups of ``param_groups_lr_decay`` (fine-tuning from a pre-trained checkpoint,
+    ``cinema/train.py:262-268``); None: one group of all trainable parameters (``train.py:269-270``).  ``loss_fn`` returns the loss as a tensor that is
+    differentiable through the model (the ``*_loss_tensors`` functions of this build keep the metrics on the device; the reference-shaped
+    ``*_loss`` functions, which return floats, work as well).  Gradient accumulation as in the reference: ``loss / n_accum_steps`` is
+    back-propagated every call, the update happens when ``update_grad``."""
+
+    def __init__(self, model, views: list, loss_fn: Callable, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05,  # noqa: ANN001
+                 layer_decay: float | None = 0.75, clip_grad: float | None = 5.0, synchronizer=None) -> None:  # noqa: ANN001
+        from cinema_amd.convvit import param_groups_lr_decay
+        from cinema_amd.optim import FlatModel, FusedAdamW
+
+        self.model, self.views, self.loss_fn, self.clip_grad = model, list(views), loss_fn, clip_grad
+        if layer_decay is not None:
+            groups = param_groups_lr_decay(model, no_weight_decay_list=[], weight_decay=weight_decay, layer_decay=layer_decay)
+        else:
+            groups = [{"params": [p for p in model.parameters() if p.requires_grad], "weight_decay": weight_decay}]
+        self.flat = FlatModel(model, weight_decay, param_groups=groups)
+        self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas, synchronizer=synchronizer)
+        self.sync = self.optimizer.synchronizer
+        self.device = self.flat.flat_param.device
+
+    def __call__(self, batch: dict, n_accum_steps: int = 1, update_grad: bool = True) -> tuple:
+        loss, metrics = self.loss_fn(self.model, batch, self.views, self.device)
+        if self.sync is not None:
+            self.sync.arm(update_grad)
+        (loss / n_accum_steps if n_accum_steps > 1 else loss).backward()
+        grad_norm = None
+        if update_grad:
+            if self.sync is not None:
+                self.sync.all_reduce()
+            grad_norm = self.optimizer.step(self.clip_grad)
+            self.optimizer.zero_grad()
+        return loss.detach(), grad_norm, metrics
+
+
+def patch_average_forward(model, image_dict: dict, patch_size_dict: dict, combine: Callable) -> torch.Tensor:  # noqa: ANN001
+    """Shared body of ``classification_forward`` / ``regression_forward`` (reference ``classification/train.py:113-178``, ``regression/train.py:59-123``):
+    the plain forward when every view already has its patch size; otherwise ONE view (batch 1) is cut into half-overlapping patches
+    (``get_patch_grid`` / ``patch_grid_sample``), the model runs once per patch with the other views unchanged, and ``combine`` folds the
+    per-patch outputs [n_patches, n] into [1, n]."""
+    from cinema_amd.transform import get_patch_grid, patch_grid_sample
+
+    for view, image in image_dict.items():
+        if any(s < p for s, p in zip(image.shape[2:], patch_size_dict[view])):
+            raise ValueError(f"For view {view}, image size {image.shape[2:]} is smaller than patch size {patch_size_dict[view]}.")
+    views = list(image_dict.keys())
+    need_patch = {v: tuple(image_dict[v].shape[2:]) != tuple(patch_size_dict[v]) for v in views}
+    if not any(need_patch.values()):
+        with torch.no_grad():
+            return model(image_dict)
+    if sum(need_patch.values()) > 1:
+        raise ValueError(f"Only support patching on one view for now, but got {need_patch}.")
+    batch_size = image_dict[views[0]].shape[0]
+    if batch_size != 1:
+        raise ValueError(f"Expected batch size 1 for patching, but got {batch_size}.")
+    view_to_patch = next(v for v, need in need_patch.items() if need)
+    image = image_dict[view_to_patch][0]
+    patch_size = tuple(patch_size_dict[view_to_patch])
+    starts = get_patch_grid(image_size=tuple(image.shape[1:]), patch_size=patch_size, patch_overlap=tuple(s // 2 for s in patch_size))
+    patches = patch_grid_sample(image, starts, patch_size)
+    outs = []
+    with torch.no_grad():
+        for i in range(patches.shape[0]):
+            patch = patches[i : i + 1].contiguous()
+            outs.append(model({v: patch if v == view_to_patch else image_dict[v] for v in views}).float())
+    return combine(torch.cat(outs, dim=0))

@@ -249,6 +249,13 @@ int cinema_row_copy_multi(const cinema_row_copy_args* segs_host, int count, void
 int cinema_seg_loss_fwd(const float* logits, const int* labels, int b, int vox, int c, float* acc, float* out4, float* coef, void* stream);
 int cinema_seg_loss_bwd(const float* logits, const int* labels, int b, int vox, int c, const float* coef, const float* out4, const float* upstream,
                         float* dlogits, void* stream);
+/* Losses of the ConvViT classification / regression heads (a handful of rows; forward value and gradient in one launch):
+ *   head_ce:  F.cross_entropy(logits, label, label_smoothing) of the reference's classification_loss (cinema/classification/train.py:80-110): logits fp32
+ *       [b][c], labels int32 [b] in [0, c); out1[0] = mean loss, dlogits [b][c] = d loss / d logits.
+ *   head_mse: F.mse_loss(pred, label) with the values regression_loss reports (cinema/regression/train.py:21-56): pred / label fp32 [n] (n = batch x targets);
+ *       out6 = {mse, mae (F.l1_loss), max label, min label, max pred, min pred}, dpred [n] = d mse / d pred. */
+int cinema_head_ce(const float* logits, const int* labels, int b, int c, float label_smoothing, float* out1, float* dlogits, void* stream);
+int cinema_head_mse(const float* pred, const float* label, int n, float* out6, float* dpred, void* stream);
 /* Evaluation path of the segmentation task (reference cinema/segmentation/train.py:148-286, cinema/transform.py:86-124, cinema/metric.py:21-45,84-96).
  *   seg_window_accumulate: one sliding window - softmax over the c classes of every window voxel (window_logits fp32 channels-last rows
  *       [px*py*pz][c]) added into prob_sum (channels-last [X*Y*Z][c]) at offset (sx,sy,sz), count [X*Y*Z] += 1 (both zeroed by the caller).

@@ -783,3 +783,45 @@ def input_transform(x: Tensor, zoom: float, padded_size: tuple, cubic: bool) -> 
     for s, p in zip(reversed(size), reversed(tuple(padded_size))):
         pad += [0, p - s]
     return F.pad(x, pad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ConvViT fine-tuning heads: losses and patch-averaged evaluation forward
+# ---------------------------------------------------------------------------------------------------------------------
+def classification_loss_value(logits: Tensor, labels: Tensor, label_smoothing: float = 0.1) -> Tensor:
+    """``F.cross_entropy(logits, label, label_smoothing=eps)`` as ``classification_loss`` calls it (``cinema/classification/train.py:104-108``), written out:
+    mean_i [(1 - eps) * (-log p_i[y_i]) + eps / c * sum_j (-log p_i[j])]."""
+    logp = logits.double() - torch.logsumexp(logits.double(), dim=1, keepdim=True)
+    nll = -logp.gather(1, labels.long().reshape(-1, 1))[:, 0]
+    smooth = -logp.mean(dim=1)
+    return ((1.0 - label_smoothing) * nll + label_smoothing * smooth).mean().float()
+
+
+def regression_loss_values(preds: Tensor, label: Tensor) -> dict:
+    """The values of ``regression_loss`` (``cinema/regression/train.py:40-55``): ``F.mse_loss`` (the loss), ``F.l1_loss`` and the label / prediction ranges."""
+    d = preds.double() - label.double()
+    return {"mse_loss": float((d * d).mean()), "loss": float((d * d).mean()), "mae_loss": float(d.abs().mean()), "max_label": float(label.max()),
+            "min_label": float(label.min()), "max_pred": float(preds.max()), "min_pred": float(preds.min())}
+
+
+def patch_average_forward(forward, image_dict: dict, patch_size_dict: dict, task: str) -> Tensor:  # noqa: ANN001
+    """``classification_forward`` / ``regression_forward`` (``cinema/classification/train.py:113-178``, ``cinema/regression/train.py:59-123``): ``forward`` maps an
+    image dict to (batch, n).  One over-sized view (batch 1) is cut into half-overlapping patches (``patch_grid`` above, i.e. ``get_patch_grid``); classification
+    averages the per-patch softmax and returns its log, regression averages the predictions."""
+    views = list(image_dict)
+    need = {v: tuple(image_dict[v].shape[2:]) != tuple(patch_size_dict[v]) for v in views}
+    if not any(need.values()):
+        return forward(image_dict)
+    if sum(need.values()) > 1 or image_dict[views[0]].shape[0] != 1:
+        raise ValueError("one over-sized view and batch size 1")
+    v0 = next(v for v in views if need[v])
+    img, ps = image_dict[v0][0], tuple(patch_size_dict[v0])
+    starts = patch_grid(tuple(img.shape[1:]), ps, tuple(s // 2 for s in ps))
+    outs = []
+    for st in starts:
+        sl = (slice(None),) + tuple(slice(int(a), int(a) + b) for a, b in zip(st, ps))
+        outs.append(forward({v: img[sl][None] if v == v0 else image_dict[v] for v in views}))
+    out = torch.cat(outs, dim=0)
+    if task == "classification":
+        return torch.log(torch.softmax(out, dim=1).mean(dim=0, keepdim=True))
+    return out.mean(dim=0, keepdim=True)

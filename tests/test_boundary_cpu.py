@@ -29,6 +29,8 @@ def test_cinema_alias_package_serves_the_reference_import_lines() -> None:
     from cinema.rotary import RotaryEmbedding, apply_rotary_emb, rotate_half  # noqa: F401
     from cinema.segmentation.convunetr import ConvUNetR as SegModel
     from cinema.segmentation.train import segmentation_loss  # noqa: F401
+    from cinema.classification.train import classification_forward, classification_loss, get_classification_or_regression_model  # noqa: F401
+    from cinema.regression.train import regression_forward, regression_loss  # noqa: F401
     from cinema.vit import get_vit_config  # noqa: F401
 
     assert CineMA is cinema_amd.CineMA and ConvViT is cinema_amd.ConvViT and SegModel is cinema_amd.ConvUNetR is ConvUNetR

@@ -221,6 +221,38 @@ def test_convvit_logits_features_and_gradients() -> None:
         O.convvit_forward(params, cfg, images, None, reduce="none")
 
 
+def test_convvit_head_losses_and_patch_averaged_forward() -> None:
+    """Oracle restatement of the fine-tuning heads against the reference's ``classification_loss`` / ``regression_loss`` (values, reported
+    metrics, gradients through the ConvViT oracle) and ``classification_forward`` / ``regression_forward`` (one over-sized view, half-overlapping patches)."""
+    g, h = load_golden("convvit_mini.safetensors"), load_golden("convvit_heads.safetensors")
+    cfg = convvit_cfg()
+    params = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in split(g, "param/").items()}
+    images = split(g, "image/")
+    logits = O.convvit_forward(params, cfg, images)
+    assert torch.allclose(logits, h["cls/logits"], rtol=1e-4, atol=2e-5)
+    loss = O.classification_loss_value(logits, h["cls/label"], 0.1)
+    assert abs(float(loss) - float(h["cls/loss"])) <= 1e-5 and abs(float(loss) - float(h["cls/metrics"][0])) <= 1e-5
+    loss.backward()
+    for k, t in split(h, "cls/grad/").items():
+        assert torch.allclose(params[k].grad, t, rtol=1e-3, atol=1e-6), k
+    for p_ in params.values():
+        p_.grad = None
+    preds = O.convvit_forward(params, cfg, images)
+    vals = O.regression_loss_values(preds.detach(), h["reg/label"])
+    for i, k in enumerate(("mse_loss", "mae_loss", "max_label", "min_label", "max_pred", "min_pred", "loss")):
+        assert abs(vals[k] - float(h["reg/metrics"][i])) <= 1e-5, k
+    ((preds - h["reg/label"]) ** 2).mean().backward()
+    for k, t in split(h, "reg/grad/").items():
+        assert torch.allclose(params[k].grad, t, rtol=1e-3, atol=1e-6), k
+    fwd_images, sizes = split(h, "fwd/image/"), {"sax": (32, 32, 4), "lax_2c": (32, 32)}
+    with torch.no_grad():
+        fwd = lambda d: O.convvit_forward(params, cfg, d)  # noqa: E731
+        assert torch.allclose(O.patch_average_forward(fwd, fwd_images, sizes, "classification"), h["fwd/cls_logits"], rtol=1e-4, atol=2e-5)
+        assert torch.allclose(O.patch_average_forward(fwd, fwd_images, sizes, "regression"), h["fwd/reg_preds"], rtol=1e-4, atol=2e-5)
+        whole = {"sax": fwd_images["sax"][:, :, :32, :32].contiguous(), "lax_2c": fwd_images["lax_2c"]}
+        assert torch.allclose(O.patch_average_forward(fwd, whole, sizes, "classification"), h["fwd/cls_logits_whole"], rtol=1e-4, atol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------------ ConvUNetR (SURVEY 8a row a25)
 def _unetr_setup():  # noqa: ANN202
     meta = json.loads((GOLDEN / "convunetr_meta.json").read_text())
