@@ -140,11 +140,16 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
         a frozen constant, so the resampling is host-side preparation (bicubic 2-D / trilinear 3-D, like the reference)."""
         if tuple(grid_size) == tuple(self.patch_embed.grid_size):
             return self.pos_embed
-        mode = {2: "bicubic", 3: "trilinear"}[len(grid_size)]
-        emb = self.pos_embed.shape[-1]
-        pe = self.pos_embed.float().reshape(1, *self.patch_embed.grid_size, emb).movedim(-1, 1)
-        pe = F.interpolate(pe, size=tuple(grid_size), mode=mode, antialias=False)
-        return pe.movedim(1, -1).reshape(1, -1, emb).to(self.pos_embed.dtype)
+        key = (tuple(grid_size), self.pos_embed.device, self.pos_embed._version)
+        cache = self.__dict__.setdefault("_pe_cache", {})
+        if key not in cache:  # resampled ONCE per grid on the host (a few hundred KB), then kept on the device: no ATen kernel on the step's path
+            mode = {2: "bicubic", 3: "trilinear"}[len(grid_size)]
+            emb = self.pos_embed.shape[-1]
+            pe = self.pos_embed.detach().float().cpu().reshape(1, *self.patch_embed.grid_size, emb).movedim(-1, 1)
+            pe = F.interpolate(pe, size=tuple(grid_size), mode=mode, antialias=False)
+            cache.clear()
+            cache[key] = pe.movedim(1, -1).reshape(1, -1, emb).to(device=self.pos_embed.device, dtype=self.pos_embed.dtype)
+        return cache[key]
 
     def grid_for(self, image_size: tuple) -> tuple:
         return tuple(s // p for s, p in zip(image_size, self.eff_patch_size))

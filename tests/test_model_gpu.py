@@ -399,6 +399,34 @@ def test_three_step_optimisation_trajectory_vs_reference_golden() -> None:
                 assert float((torch.sign(d_got) == torch.sign(d_ref)).float().mean()) >= 0.99, (i, k)
 
 
+# ------------------------------------------------------------------------------------------------ DownsampleEncoder
+@pytest.mark.parametrize("nd", [2, 3])
+def test_downsample_encoder_vs_reference_golden_including_pos_embed_interpolation(nd: int) -> None:
+    """``DownsampleEncoder.forward`` through the HIP path against the reference layer goldens: the built grid with a stem mask (skips + tokens) and an
+    input whose grid differs from the built one, which takes the pos-embed interpolation branch (bicubic 2-D / trilinear 3-D, reference
+    ``convvit.py:140-163``).  bf16 MFMA operands: max-abs 5e-2 on O(1) activations."""
+    from cinema_amd.convvit import DownsampleEncoder
+
+    g = load_golden("layers.safetensors")
+    size = (32, 32) if nd == 2 else (32, 32, 4)
+    enc = DownsampleEncoder(image_size=size, in_chans=1, patch_size=(4, 4, 1)[:nd], scale_factor=(2, 2, 1)[:nd], conv_chans=[8, 16], conv_n_blocks=1,
+                            embed_dim=24, norm="layer")
+    enc.load_state_dict(split(g, f"down{nd}d/param/"))
+    enc.to(DEV)
+    skips, tok = enc(g[f"down{nd}d/image"].to(DEV), g[f"down{nd}d/mask"].bool().to(DEV))
+    assert tok.shape == g[f"down{nd}d/tokens"].shape and (tok.float().cpu() - g[f"down{nd}d/tokens"]).abs().max() <= 5e-2
+    for i, s in enumerate(skips):  # this entry point evaluates every voxel like the reference (the mask only zeroes the depthwise convolution's input)
+        ref = g[f"down{nd}d/skip{i}"]
+        assert s.shape == ref.shape and (s.float().cpu() - ref).abs().max() <= 5e-2, (i, float((s.float().cpu() - ref).abs().max()))
+    other = g[f"down{nd}d/image_other"].to(DEV)
+    _, tok2 = enc(other, None)
+    ref2 = g[f"down{nd}d/tokens_other"]
+    assert tok2.shape == ref2.shape and tok2.shape[1] != tok.shape[1]
+    assert (tok2.float().cpu() - ref2).abs().max() <= 5e-2, float((tok2.float().cpu() - ref2).abs().max())
+    _, tok3 = enc(other, None)  # second call: the resampled table comes from the cache
+    assert torch.equal(tok2, tok3)
+
+
 # ------------------------------------------------------------------------------------------------ ConvViT (SURVEY 8a row a24)
 def _convvit_model():  # noqa: ANN202
     import json
