@@ -614,6 +614,54 @@ CINEMA_API int cinema_conv_weight_dgrad(const float* w, uint16_t* rows, int c_ou
   return launch_status();
 }
 
+// ---- z-blocked implicit convolution (gemm.hip cinema_conv_gemm_bf16, conv_zb > 1): block-banded weights and the fold of their gradient
+__global__ __launch_bounds__(256) void conv_weight_zblock_kernel(const bf16_t* w, int n, int c, int ld_w, int zb, int transpose, bf16_t* out, const float* bias,
+                                                                 float* bias_zb) {
+  const int ld_o = 9 * (zb + 2) * c;
+  const long long total = (long long)zb * n * ld_o;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / ld_o), f = (int)(i % ld_o);
+    const int zo = row / n, co = row - zo * n;
+    const int tapz = f / c, ci = f - tapz * c;
+    const int txy = tapz / (zb + 2), dzi = tapz - txy * (zb + 2);
+    const int tz = transpose ? zo + 2 - dzi : dzi - zo;
+    out[i] = (tz >= 0 && tz <= 2) ? w[(long long)co * ld_w + (txy * 3 + tz) * c + ci] : (bf16_t)0;
+  }
+  if (bias && blockIdx.x == 0)
+    for (int j = threadIdx.x; j < zb * n; j += blockDim.x) bias_zb[j] = bias[j % n];
+}
+__global__ __launch_bounds__(256) void conv_wgrad_zfold_kernel(const float* r, int n, int c, int zb, float* dst, int ld_dst, const float* rowsum_zb, float* db) {
+  const int ld_r = 9 * (zb + 2) * c;
+  const long long total = (long long)n * 27 * c;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i / (27 * c)), f = (int)(i % (27 * c));
+    const int tap = f / c, ci = f - tap * c;
+    const int txy = tap / 3, tz = tap - txy * 3;
+    float s = 0.f;
+    for (int zo = 0; zo < zb; zo++) s += r[(long long)(zo * n + co) * ld_r + (txy * (zb + 2) + zo + tz) * c + ci];
+    dst[(long long)co * ld_dst + f] += s;
+  }
+  if (db && blockIdx.x == 0)
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      float s = 0.f;
+      for (int zo = 0; zo < zb; zo++) s += rowsum_zb[zo * n + j];
+      db[j] += s;
+    }
+}
+
+CINEMA_API int cinema_conv_weight_zblock(const uint16_t* w, int n, int c, int ld_w, int zb, int transpose, uint16_t* w_zb, const float* bias, float* bias_zb,
+                                         void* stream) {
+  if (!w || !w_zb || n <= 0 || c <= 0 || zb < 2 || zb > 6 || ld_w < 27 * c || (bias && !bias_zb)) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(conv_weight_zblock_kernel, dim3(grid_for((long long)zb * n * 9 * (zb + 2) * c, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, n, c, ld_w,
+                zb, transpose, (bf16_t*)w_zb, bias, bias_zb);
+  return launch_status();
+}
+CINEMA_API int cinema_conv_wgrad_zfold(const float* r, int n, int c, int zb, float* dst, int ld_dst, const float* rowsum_zb, float* db, void* stream) {
+  if (!r || !dst || n <= 0 || c <= 0 || zb < 2 || zb > 6 || ld_dst < 27 * c || (db && !rowsum_zb)) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(conv_wgrad_zfold_kernel, dim3(grid_for((long long)n * 27 * c, 256)), dim3(256), 0, (hipStream_t)stream, r, n, c, zb, dst, ld_dst, rowsum_zb, db);
+  return launch_status();
+}
+
 // ---- thin linear layers (the 4-class segmentation head over millions of voxels: N <= 8 outputs, K <= 64 inputs): pure streaming, one thread per row.
 // The MFMA GEMM needs N % 8 == 0 and the generic kernel ran these at 0.6 TF (4.5 ms + a 3.3 ms column sum per step of config 4).
 constexpr int THIN_MAXN = 8, THIN_MAXK = 64;

@@ -40,7 +40,7 @@ class GemmArgs(C.Structure):
         ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
-        ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int), ("conv_coords", C.c_void_p),
+        ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int), ("conv_coords", C.c_void_p), ("conv_zb", C.c_int),
         ("kernel_used", C.c_int),
     ]
 
@@ -129,6 +129,8 @@ _PROTOS = {
     "cinema_seg_loss_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cinema_seg_loss_bwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_head_ce": [_vp, _vp, _i, _i, _f, _vp, _vp, _vp],
+    "cinema_conv_weight_zblock": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "cinema_conv_wgrad_zfold": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "cinema_head_mse": [_vp, _vp, _i, _vp, _vp, _vp],
     "cinema_seg_window_accumulate": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "cinema_seg_window_finish": [_vp, _vp, _i, _ll, _vp, _vp],
@@ -976,15 +978,29 @@ def _vol_dims(shape: tuple, ks: tuple) -> tuple:
     return (b, *sp, c, *k3)
 
 
-def conv_tap_table(c: int, ks: tuple, spatial: tuple, ld: int, transpose: bool, device: torch.device) -> torch.Tensor:
+def conv_tap_table(c: int, ks: tuple, spatial: tuple, ld: int, transpose: bool, device: torch.device, zb: int = 1) -> torch.Tensor:
     """int32 [ld / 8, 4] table for :func:`conv_gemm`: per 16-byte k-chunk (8 channels of one tap) {row delta of the neighbour voxel, packed
-    (dx+1, dy+1, dz+1), first channel, valid}.  ``transpose``: the offsets of the data gradient (the neighbour is at MINUS the tap offset)."""
+    (dx+1, dy+1, dz+1), first channel, valid}.  ``transpose``: the offsets of the data gradient (the neighbour is at MINUS the tap offset).
+    ``zb`` > 1: the z-blocked form (3x3x3 kernels): taps over (3, 3, zb + 2) offsets, dz counted from the first voxel of the row's z group."""
     k3 = (1,) * (3 - len(ks)) + tuple(int(v) for v in ks)
     sp = (1,) * (3 - len(spatial)) + tuple(int(v) for v in spatial)
     if any(k not in (1, 3) for k in k3):
         raise HipLibraryError("conv_gemm: kernel extents 1 or 3 only")
-    taps = k3[0] * k3[1] * k3[2]
     rows = []
+    if zb > 1:
+        if k3 != (3, 3, 3) or sp[2] % zb or ld != 9 * (zb + 2) * c:
+            raise HipLibraryError("conv_gemm: the z-blocked form needs a 3x3x3 kernel, Z % zb == 0 and ld = 9 * (zb + 2) * c")
+        for j in range(ld // 8):
+            tapz, ci = (j * 8) // c, (j * 8) % c
+            txy, dzz = tapz // (zb + 2), tapz % (zb + 2) - 1
+            d = [txy // 3 - 1, txy % 3 - 1]
+            if transpose:
+                d = [-v for v in d]
+            rows.append((d[0] * sp[1] * sp[2] + d[1] * sp[2] + dzz, (d[0] + 1) | ((d[1] + 1) << 2) | ((dzz + 1) << 4), ci, 1))
+        while len(rows) % 8:
+            rows.append((0, 21, 0, 0))
+        return torch.tensor(rows, dtype=torch.int32).to(device)
+    taps = k3[0] * k3[1] * k3[2]
     for j in range(ld // 8):
         kk = j * 8
         tap, ci = kk // c, kk % c
@@ -1002,7 +1018,7 @@ def conv_tap_table(c: int, ks: tuple, spatial: tuple, ld: int, transpose: bool, 
 
 
 def conv_gemm(x: torch.Tensor, w: torch.Tensor, taps: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None,
-              residual: torch.Tensor | None = None) -> torch.Tensor:
+              residual: torch.Tensor | None = None, zb: int = 1) -> torch.Tensor:
     """Implicit-GEMM "same" convolution: x bf16 channels-last [b, *spatial, c] (c % 8 == 0), w bf16 [n, ld] with features (tap, channel), ``taps``
     from :func:`conv_tap_table` -> rows [b * prod(spatial), n] (+ bias, + fp32 residual); the im2col matrix is never materialised."""
     _dev(x, w, taps, bias, residual)
@@ -1010,56 +1026,79 @@ def conv_gemm(x: torch.Tensor, w: torch.Tensor, taps: torch.Tensor, *, out_dtype
         raise HipLibraryError("conv_gemm: contiguous bf16 volume, bf16 weights [n, ld], int32 [ld / 8, 4] tap table")
     b, c = x.shape[0], x.shape[-1]
     sp = (1,) * (3 - (x.dim() - 2)) + tuple(x.shape[1:-1])
-    m, n = b * sp[0] * sp[1] * sp[2], w.shape[0]
+    m, n = b * sp[0] * sp[1] * sp[2] // zb, w.shape[0]  # zb > 1: one row per group of zb z-voxels, n = zb * c_out (w, bias: conv_weight_zblock)
     out = _empty((m, n), dtype=torch.float32 if residual is not None else out_dtype, device=x.device)
     g = GemmArgs()
     g.a, g.b, g.d = x.data_ptr(), w.data_ptr(), out.data_ptr()
     g.m, g.n, g.k, g.lda, g.ldb, g.ldd = m, n, w.shape[1], 0, _rowmajor(w, "w"), n
     g.a_kmajor, g.b_kmajor, g.alpha, g.split_k = 1, 1, 1.0, 1
-    g.conv_taps, g.conv_x, g.conv_y, g.conv_z, g.conv_c = taps.data_ptr(), sp[0], sp[1], sp[2], c
+    g.conv_taps, g.conv_x, g.conv_y, g.conv_z, g.conv_c, g.conv_zb = taps.data_ptr(), sp[0], sp[1], sp[2], c, zb
     if bias is not None:
         g.bias = bias.data_ptr()
     if residual is not None:
-        if residual.dtype != torch.float32:
-            raise HipLibraryError("conv_gemm: fp32 residual only")
-        g.residual_f32, g.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
+        if residual.dtype != torch.float32 or not residual.is_contiguous() or residual.numel() != m * n:
+            raise HipLibraryError("conv_gemm: contiguous fp32 residual of the output's size")
+        g.residual_f32, g.ld_res = residual.data_ptr(), n
     g.out_f32 = int(out.dtype == torch.float32)
     _check(load().cinema_conv_gemm_bf16(C.byref(g), _stream()), "conv_gemm")
     return out
 
 
-def conv_coord_table(batch: int, spatial: tuple, device: torch.device) -> torch.Tensor:
-    """int32 [batch * prod(spatial)]: x | y << 10 | z << 20 of every voxel row of a channels-last volume (2-D: leading unit axis)."""
+def conv_coord_table(batch: int, spatial: tuple, device: torch.device, zb: int = 1) -> torch.Tensor:
+    """int32 [batch * prod(spatial) / zb]: x | y << 10 | z << 20 of every voxel row of a channels-last volume (2-D: leading unit axis); ``zb`` > 1: of the
+    first voxel of every group of zb consecutive z voxels."""
     sp = (1,) * (3 - len(spatial)) + tuple(int(v) for v in spatial)
-    if max(sp) > 1023:
-        raise HipLibraryError("conv_coord_table: extents up to 1023")
+    if max(sp) > 1023 or sp[2] % zb:
+        raise HipLibraryError("conv_coord_table: extents up to 1023, Z % zb == 0")
     x = torch.arange(sp[0], dtype=torch.int32)[:, None, None]
     y = torch.arange(sp[1], dtype=torch.int32)[None, :, None]
-    z = torch.arange(sp[2], dtype=torch.int32)[None, None, :]
+    z = torch.arange(0, sp[2], zb, dtype=torch.int32)[None, None, :]
     return (x | (y << 10) | (z << 20)).reshape(-1).repeat(batch).contiguous().to(device)
 
 
-def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, taps: torch.Tensor, coords: torch.Tensor, out: torch.Tensor, split_k: int, a_rowsum: torch.Tensor | None = None) -> None:
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, taps: torch.Tensor, coords: torch.Tensor, out: torch.Tensor, split_k: int, a_rowsum: torch.Tensor | None = None,
+               zb: int = 1, accumulate: bool = True) -> None:
     """out [c_out, ld] fp32 += dy^T im2col(x) without materialising im2col(x): dy bf16 [rows, c_out], x bf16 channels-last [b, *spatial, c],
     ``taps`` the forward tap table of the weight layout, ``coords`` from :func:`conv_coord_table`; a_rowsum [c_out] += column sums of dy."""
     _dev(dy, x, taps, coords, out, a_rowsum)
     if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or out.dtype != torch.float32 or not x.is_contiguous() or coords.dtype != torch.int32:
         raise HipLibraryError("conv_wgrad: bf16 operands, fp32 destination, int32 coordinates")
-    rows, c_out = dy.shape
+    rows, c_out = dy.shape  # zb > 1: dy is the [voxel rows / zb, zb * c_out] view of the gradient rows, coords / taps the z-blocked tables, out [zb * c_out, 9 (zb + 2) c]
     c = x.shape[-1]
     sp = (1,) * (3 - (x.dim() - 2)) + tuple(x.shape[1:-1])
-    if coords.numel() != rows or x.numel() // c != rows or out.shape[0] != c_out:
+    if coords.numel() != rows or x.numel() // c != rows * zb or out.shape[0] != c_out:
         raise HipLibraryError("conv_wgrad: shape mismatch")
     g = GemmArgs()
     g.a, g.b, g.d = dy.data_ptr(), x.data_ptr(), out.data_ptr()
     g.m, g.n, g.k, g.lda, g.ldb, g.ldd = c_out, out.shape[1], rows, _rowmajor(dy, "dy"), 0, _rowmajor(out, "out")
-    g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, split_k
-    g.conv_taps, g.conv_x, g.conv_y, g.conv_z, g.conv_c, g.conv_coords = taps.data_ptr(), sp[0], sp[1], sp[2], c, coords.data_ptr()
+    g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, int(accumulate), split_k
+    g.conv_taps, g.conv_x, g.conv_y, g.conv_z, g.conv_c, g.conv_coords, g.conv_zb = taps.data_ptr(), sp[0], sp[1], sp[2], c, coords.data_ptr(), zb
     ws = _workspace("splitk", split_k * c_out * out.shape[1], dy.device)
     g.workspace, g.workspace_bytes = ws.data_ptr(), split_k * c_out * out.shape[1] * 4
     if a_rowsum is not None:
         g.a_rowsum = a_rowsum.data_ptr()
     _check(load().cinema_conv_wgrad_bf16(C.byref(g), _stream()), "conv_wgrad")
+
+
+def conv_weight_zblock(w: torch.Tensor, c: int, zb: int, transpose: bool, bias: torch.Tensor | None = None) -> tuple:
+    """Block-banded operand of the z-blocked convolution: w bf16 [n, ld >= 27 c] (features (tap, channel)) -> (bf16 [zb n, 9 (zb + 2) c], bias repeated zb
+    times or None); ``transpose``: for the data-gradient operand (taps pointing the other way)."""
+    _dev(w, bias)
+    if w.dtype != torch.bfloat16 or w.dim() != 2 or w.stride(1) != 1 or w.shape[1] < 27 * c or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != w.shape[0])):
+        raise HipLibraryError("conv_weight_zblock: bf16 rows [n, >= 27 c], fp32 bias [n]")
+    n = w.shape[0]
+    out = _empty((zb * n, 9 * (zb + 2) * c), dtype=torch.bfloat16, device=w.device)
+    b_out = None if bias is None else _empty(zb * n, dtype=torch.float32, device=w.device)
+    _check(load().cinema_conv_weight_zblock(w.data_ptr(), n, c, w.stride(0), zb, int(transpose), out.data_ptr(), _p(bias), _p(b_out), _stream()), "conv_weight_zblock")
+    return out, b_out
+
+
+def conv_wgrad_zfold(r: torch.Tensor, n: int, c: int, zb: int, dst: torch.Tensor, rowsum_zb: torch.Tensor | None = None, db: torch.Tensor | None = None) -> None:
+    """dst fp32 [n, ld >= 27 c] += the zb bands of the z-blocked weight gradient r fp32 [zb n, 9 (zb + 2) c]; db [n] += the zb segments of rowsum_zb."""
+    _dev(r, dst, rowsum_zb, db)
+    if r.dtype != torch.float32 or dst.dtype != torch.float32 or tuple(r.shape) != (zb * n, 9 * (zb + 2) * c) or not r.is_contiguous() or dst.shape[0] != n or dst.stride(1) != 1:
+        raise HipLibraryError("conv_wgrad_zfold: fp32 r [zb n, 9 (zb + 2) c] and dst [n, ld]")
+    _check(load().cinema_conv_wgrad_zfold(r.data_ptr(), n, c, zb, dst.data_ptr(), dst.stride(0), _p(rowsum_zb), _p(db), _stream()), "conv_wgrad_zfold")
 
 
 def conv_weight_dgrad(w: torch.Tensor) -> torch.Tensor:

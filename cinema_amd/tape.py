@@ -918,7 +918,18 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
     # implicit GEMM (cinema_conv_gemm_bf16): the MFMA kernel gathers its A tiles from the volume, the 27x im2col matrix is never written; the
     # 1-channel raw-image block (c = 1) and exotic kernel extents keep the im2col path
     implicit = IMPLICIT_CONV and x.data.is_cuda and c % 8 == 0 and c_out % 8 == 0 and all(k in (1, 3) for k in ks) and (residual is None or residual.data.dtype == F32)
-    if implicit:
+    # narrow layers (c_out <= 64): z-blocked form - a GEMM row is a group of 2 / 4 consecutive z voxels and n = zb * c_out fills the 128-wide tile
+    # (c_out = 32: 50 % useful MACs instead of 25 %, half the gathered bytes per output); see cinema_conv_gemm_bf16
+    zb_f = conv_zblock(c_out, ks, spatial) if implicit else 1
+    zb_d = conv_zblock(c, ks, spatial) if implicit else 1
+    taps = None
+    if implicit and zb_f > 1:
+        pkey = (weight,) if bias is None else (weight, bias)
+        wz, bz = WEIGHTS.get(pkey, f"conv_zb{zb_f}", lambda: K.conv_weight_zblock(w16, c, zb_f, False, None if bias is None else bias.detach()))
+        taps_z = const(("conv_taps", c, ks, tuple(spatial), wz.shape[1], False, str(dev), zb_f), lambda: K.conv_tap_table(c, ks, spatial, wz.shape[1], False, dev, zb=zb_f))
+        y = Var(K.conv_gemm(xs, wz, taps_z, bias=bz, residual=None if residual is None else residual.data.contiguous(),
+                            out_dtype=F32 if (out_f32 or residual is not None) else BF16, zb=zb_f).view(-1, c_out))
+    elif implicit:
         taps = const(("conv_taps", c, ks, tuple(spatial), w16.shape[1], False, str(dev)), lambda: K.conv_tap_table(c, ks, spatial, w16.shape[1], False, dev))
         y = Var(K.conv_gemm(xs, w16, taps, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
                             out_dtype=F32 if (out_f32 or residual is not None) else BF16))
@@ -935,7 +946,24 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
         if residual is not None:
             residual.add_grad(y.grad, y.grad16)
         dy16 = y.grad_bf16()
-        if weight.requires_grad and implicit:  # dW = dy^T im2col(x) with the column matrix gathered inside the GEMM (cinema_conv_wgrad_bf16)
+        if weight.requires_grad and implicit and zb_f > 1:  # z-blocked: R [zb c_out, 9 (zb + 2) c] = dy_groups^T im2col_zb(x), its zb bands folded into dW
+            coords = const(("conv_coords", batch, tuple(spatial), str(dev), zb_f), lambda: K.conv_coord_table(batch, spatial, dev, zb=zb_f))
+            dst = wv.grad_buffer(tuple(w16.shape), conv_same_grad_to_param(weight))
+            db = bv.grad_buffer((c_out,)) if (bias is not None and bias.requires_grad) else None
+            dyz = dy16.contiguous().view(-1, zb_f * c_out)
+            ldz = 9 * (zb_f + 2) * c
+            split = _split_k(dyz.shape[0], zb_f * c_out, ldz)
+
+            # scratch of the side-stream launches: allocated here and handed over as operands, so that it lives until the side stream has been joined
+            r = K.empty((zb_f * c_out, ldz), dtype=F32, device=dev)
+            rs = K.zeros(zb_f * c_out, device=dev) if db is not None else None
+
+            def launch() -> None:
+                K.conv_wgrad(dyz, xs, taps_z, coords, r, split, a_rowsum=rs, zb=zb_f, accumulate=False)
+                K.conv_wgrad_zfold(r, c_out, c, zb_f, dst, rs, db)
+
+            _wgrad_launch(launch, dyz, xs, *((r,) if rs is None else (r, rs)))
+        elif weight.requires_grad and implicit:  # dW = dy^T im2col(x) with the column matrix gathered inside the GEMM (cinema_conv_wgrad_bf16)
             coords = const(("conv_coords", batch, tuple(spatial), str(dev)), lambda: K.conv_coord_table(batch, spatial, dev))
             dst = wv.grad_buffer(tuple(w16.shape), conv_same_grad_to_param(weight))
             db = bv.grad_buffer((c_out,)) if (bias is not None and bias.requires_grad) else None
@@ -948,9 +976,15 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
         if x.needs_grad:
             if implicit:  # data gradient = the same implicit convolution on dy with transposed weights and negated tap offsets (no col2im pass)
                 wt = WEIGHTS.get((weight,), "conv_dgrad", lambda: K.conv_weight_dgrad(weight.detach()))
-                taps_t = const(("conv_taps", c_out, ks, tuple(spatial), wt.shape[1], True, str(dev)),
-                               lambda: K.conv_tap_table(c_out, ks, spatial, wt.shape[1], True, dev))
-                x.add_grad(K.conv_gemm(dy16.contiguous().view(batch, *spatial, c_out), wt, taps_t))
+                if zb_d > 1:
+                    wtz = WEIGHTS.get((weight,), f"conv_dgrad_zb{zb_d}", lambda: K.conv_weight_zblock(wt, c_out, zb_d, True)[0])
+                    taps_t = const(("conv_taps", c_out, ks, tuple(spatial), wtz.shape[1], True, str(dev), zb_d),
+                                   lambda: K.conv_tap_table(c_out, ks, spatial, wtz.shape[1], True, dev, zb=zb_d))
+                    x.add_grad(K.conv_gemm(dy16.contiguous().view(batch, *spatial, c_out), wtz, taps_t, zb=zb_d).view(-1, c))
+                else:
+                    taps_t = const(("conv_taps", c_out, ks, tuple(spatial), wt.shape[1], True, str(dev)),
+                                   lambda: K.conv_tap_table(c_out, ks, spatial, wt.shape[1], True, dev))
+                    x.add_grad(K.conv_gemm(dy16.contiguous().view(batch, *spatial, c_out), wt, taps_t))
             else:
                 dcols = K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False)
                 x.add_grad(K.col2im(dcols, (batch, *spatial, c), ks).view(-1, c))
@@ -960,6 +994,18 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
 
 
 IMPLICIT_CONV = bool(int(os.environ.get("CINEMA_IMPLICIT_CONV", "1")))  # 0: im2col + GEMM everywhere (A/B)
+ZBLOCK_CONV = bool(int(os.environ.get("CINEMA_ZBLOCK_CONV", "1")))  # 0: one GEMM row per voxel for every layer (A/B)
+
+
+def conv_zblock(n_out: int, ks: tuple, spatial: tuple) -> int:
+    """z-blocking factor of the implicit convolution for a layer with ``n_out`` output channels: the largest of 4 / 2 that keeps zb * n_out within the
+    128-wide tile and divides Z (3x3x3 kernels on 3-D volumes only); 1 = plain."""
+    if not ZBLOCK_CONV or len(spatial) != 3 or tuple(ks) != (3, 3, 3):
+        return 1
+    for zb in (4, 2):
+        if zb * n_out <= 128 and spatial[2] % zb == 0:
+            return zb
+    return 1
 
 
 def _chan_last_strides(chans: int, spatial: tuple) -> tuple:

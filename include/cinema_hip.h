@@ -65,6 +65,7 @@ typedef struct {
   const void* conv_taps;      /* cinema_conv_gemm_bf16 only: device int4 [k / 8] tap table; conv_x/y/z/c = volume size and channels */
   int conv_x, conv_y, conv_z, conv_c;
   const void* conv_coords;    /* cinema_conv_wgrad_bf16 only: device int [rows], x | y << 10 | z << 20 of every voxel row */
+  int conv_zb;                /* implicit convolution: 0 / 1 = one row per voxel; ZB > 1 = one row per group of ZB consecutive z voxels (see cinema_conv_gemm_bf16) */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
                                  + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped */
 } cinema_gemm_args;
@@ -80,6 +81,15 @@ int cinema_gemm_fp8(cinema_gemm_args* args_host, void* stream);
  * D[r][n] = sum over the taps / channels of x at the neighbour voxel (zeros outside the volume) + bias (+ fp32 residual); bf16 or fp32 D.  The im2col
  * matrix (27 x the activation) is never written: the MFMA kernel's A tiles are gathered from the volume by the LDS-DMA. */
 int cinema_conv_gemm_bf16(cinema_gemm_args* args_host, void* stream);
+/* z-blocked form of the same convolution for narrow layers (conv_zb = ZB in {2, 4}, kernel 3x3x3, Z % ZB == 0): m = batch*X*Y*Z/ZB rows, n = ZB*c_out - the
+ * output rows are byte-for-byte the plain [voxel][c_out] rows -, k = 9*(ZB+2)*C with taps over (3, 3, ZB+2) offsets (dz field: 3 bits, offset from the
+ * group's first voxel + 1).  cinema_conv_weight_zblock builds the block-banded weights [ZB*n][9*(ZB+2)*c] from the plain [n][27*c] rows (features
+ * (tap, channel)): w_zb[zo*n + co][((tx*3+ty)*(ZB+2) + dzi)*c + ci] = w[co][((tx*3+ty)*3 + tz)*c + ci] with tz = dzi - zo (transpose = 1, the data-gradient
+ * operand whose taps point the other way: tz = zo + 2 - dzi), zero when tz is outside 0..2; bias_zb = bias repeated ZB times (NULL bias: skipped).
+ * The weight gradient of the z-blocked problem is R [ZB*n][9*(ZB+2)*c] (cinema_conv_wgrad_bf16 with conv_zb and group coordinates);
+ * cinema_conv_wgrad_zfold adds its ZB bands into dst [n][ld_dst] (features (tap, channel)) and the ZB row-sum segments into db [n]. */
+int cinema_conv_weight_zblock(const uint16_t* w, int n, int c, int ld_w, int zb, int transpose, uint16_t* w_zb, const float* bias, float* bias_zb, void* stream);
+int cinema_conv_wgrad_zfold(const float* r, int n, int c, int zb, float* dst, int ld_dst, const float* rowsum_zb, float* db, void* stream);
 /* Weight gradient of the same convolution, again without an im2col matrix: a = dy [rows][lda] bf16 (k = rows, m = c_out), b = the volume x [rows][C],
  * n = weight row length (taps * C padded to 8), conv_taps = the FORWARD table, conv_coords[r] = voxel coordinates of row r: D[co][(tap, ci)] fp32 (+)=
  * sum_r dy[r][co] * x[nbr_tap(r)][ci]; a_rowsum[co] += sum_r dy[r][co] (bias gradient).  Deterministic split-K through `workspace` (>= split_k*m*n*4 B). */

@@ -732,6 +732,54 @@ def test_implicit_gemm_conv_forward_and_data_gradient(spatial: tuple, c_in: int,
     close(db, bpar.grad, 1e-3, 1e-3 * float(bpar.grad.abs().max()), "implicit conv bias gradient")
 
 
+@pytest.mark.parametrize(("spatial", "c_in", "c_out", "zb"), [((10, 9, 8), 32, 32, 4), ((7, 6, 12), 16, 64, 2), ((5, 8, 4), 64, 24, 4), ((6, 5, 6), 8, 32, 2)])
+def test_z_blocked_implicit_conv_matches_plain(spatial: tuple, c_in: int, c_out: int, zb: int) -> None:
+    """The z-blocked form of the implicit 3x3x3 convolution (a GEMM row = zb consecutive z voxels, block-banded weights from cinema_conv_weight_zblock):
+    forward (+ bias, + residual), data gradient and weight / bias gradient against torch's conv on the same bf16-rounded operands, and equal to the
+    one-row-per-voxel form up to fp32 summation order."""
+    import torch.nn.functional as F  # noqa: N812
+
+    b, ks = 2, (3, 3, 3)
+    x = rnd(b, *spatial, c_in, seed=90)
+    w = rnd(c_out, c_in, *ks, dtype=torch.float32, seed=91, scale=0.2)
+    bias = rnd(c_out, dtype=torch.float32, seed=92)
+    xc, wr = x.float().movedim(-1, 1), w.bfloat16().float()
+    ref = F.conv3d(xc, wr, bias, padding=1).movedim(1, -1).reshape(-1, c_out)
+    w16 = K.patch_weight_rows(w, pad_to=8)
+    wz, bz = K.conv_weight_zblock(w16, c_in, zb, False, bias)
+    assert wz.shape == (zb * c_out, 9 * (zb + 2) * c_in) and torch.equal(bz, bias.repeat(zb))
+    taps_z = K.conv_tap_table(c_in, ks, spatial, wz.shape[1], False, x.device, zb=zb)
+    got = K.conv_gemm(x, wz, taps_z, out_dtype=torch.float32, bias=bz, zb=zb).view(-1, c_out)
+    close(got, ref, 2e-3, 2e-3 * float(ref.abs().max()), "z-blocked conv forward")
+    plain = K.conv_gemm(x, w16, K.conv_tap_table(c_in, ks, spatial, w16.shape[1], False, x.device), out_dtype=torch.float32, bias=bias)
+    close(got, plain, 1e-4, 1e-4 * float(ref.abs().max()), "z-blocked == plain implicit conv")
+    res = rnd(ref.shape[0], c_out, dtype=torch.float32, seed=93)
+    close(K.conv_gemm(x, wz, taps_z, bias=bz, residual=res, zb=zb).view(-1, c_out), ref + res, 2e-3, 2e-3 * float(ref.abs().max()), "z-blocked conv + residual")
+    # data gradient (z-blocking chosen by the INPUT channel count there; the test uses the same factor)
+    dy = rnd(b, *spatial, c_out, seed=94)
+    xg = xc.clone().requires_grad_(True)
+    F.conv3d(xg, wr, None, padding=1).backward(dy.float().movedim(-1, 1))
+    want = xg.grad.movedim(1, -1).reshape(-1, c_in)
+    wt = K.conv_weight_dgrad(w)
+    wtz, _ = K.conv_weight_zblock(wt, c_out, zb, True)
+    taps_t = K.conv_tap_table(c_out, ks, spatial, wtz.shape[1], True, x.device, zb=zb)
+    dx = K.conv_gemm(dy, wtz, taps_t, out_dtype=torch.float32, zb=zb).view(-1, c_in)
+    close(dx, want, 2e-3, 2e-3 * float(want.abs().max()), "z-blocked conv data gradient")
+    # weight / bias gradient: R = dy_groups^T im2col_zb(x), folded into dW (accumulating) and db
+    wpar, bpar = wr.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    F.conv3d(xc, wpar, bpar, padding=1).backward(dy.float().movedim(-1, 1))
+    want_w = wpar.grad.reshape(c_out, c_in, -1).permute(0, 2, 1).reshape(c_out, -1)
+    coords = K.conv_coord_table(b, spatial, x.device, zb=zb)
+    r = torch.empty(zb * c_out, wz.shape[1], dtype=torch.float32, device=DEV)
+    rs = torch.zeros(zb * c_out, dtype=torch.float32, device=DEV)
+    K.conv_wgrad(dy.reshape(-1, zb * c_out), x, taps_z, coords, r, split_k=3, a_rowsum=rs, zb=zb, accumulate=False)
+    dw = torch.full((c_out, w16.shape[1]), 0.5, dtype=torch.float32, device=DEV)
+    db = torch.full((c_out,), 0.25, dtype=torch.float32, device=DEV)
+    K.conv_wgrad_zfold(r, c_out, c_in, zb, dw, rs, db)
+    close(dw[:, :want_w.shape[1]] - 0.5, want_w, 3e-3, 3e-3 * float(want_w.abs().max()), "z-blocked conv weight gradient")
+    close(db - 0.25, bpar.grad, 1e-3, 1e-3 * float(bpar.grad.abs().max()), "z-blocked conv bias gradient")
+
+
 @pytest.mark.parametrize(("rows", "n", "k"), [(100000, 4, 32), (777, 3, 64), (4097, 8, 8)])
 def test_thin_linear_kernels(rows: int, n: int, k: int) -> None:
     """The 4-class segmentation head as streaming kernels (cinema_thin_linear_fwd / bwd) against fp32 torch on the same bf16-rounded input."""
