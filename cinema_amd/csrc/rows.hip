@@ -767,6 +767,98 @@ CINEMA_API int cinema_thin_linear_bwd(const uint16_t* x, const float* w, const f
   return launch_status();
 }
 
+// ---- fan-out linear layers (k <= 8 inputs, n in {4, 8, 16, 32, 64} outputs): the 1x1 shortcut convolution of the raw-image ConvResBlock (1 -> 32 channels over
+// every voxel).  The MFMA GEMM needs K % 8 == 0; the generic kernel ran the weight gradient (m = 32, n = 1, k = millions of rows) at 0.1 TF plus a column-sum launch.
+constexpr int FAN_MAXN = 64, FAN_MAXK = 8;
+__global__ __launch_bounds__(256) void fanout_linear_fwd_kernel(ThinP p) {
+  __shared__ float ws[FAN_MAXN * FAN_MAXK + FAN_MAXN];
+  for (int i = threadIdx.x; i < p.n * p.k; i += 256) ws[i] = p.w[i];
+  for (int i = threadIdx.x; i < p.n; i += 256) ws[p.n * p.k + i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+  const int g4 = p.n >> 2;
+  const long long total = p.rows * g4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / g4;
+    const int q = (int)(i - r * g4) * 4;
+    float a[4] = {ws[p.n * p.k + q], ws[p.n * p.k + q + 1], ws[p.n * p.k + q + 2], ws[p.n * p.k + q + 3]};
+    for (int kk = 0; kk < p.k; kk++) {
+      const float xv = bf2f(p.x[r * p.k + kk]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) a[j] = fmaf(xv, ws[(q + j) * p.k + kk], a[j]);
+    }
+    *reinterpret_cast<float4*>(p.y + r * p.n + q) = make_float4(a[0], a[1], a[2], a[3]);
+  }
+}
+// thread = (row lane, group of 4 output columns); the n / 4 threads of one row are adjacent lanes (n / 4 is a power of two <= 16)
+__global__ __launch_bounds__(256) void fanout_linear_bwd_kernel(ThinP p) {
+  __shared__ float ws[FAN_MAXN * FAN_MAXK];
+  __shared__ float red[FAN_MAXN * FAN_MAXK + FAN_MAXN];
+  for (int i = threadIdx.x; i < p.n * p.k; i += 256) ws[i] = p.w[i];
+  for (int i = threadIdx.x; i < p.n * p.k + p.n; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int g4 = p.n >> 2, rl = threadIdx.x / g4, q = (threadIdx.x - rl * g4) * 4, lanes = 256 / g4;
+  float gw[4][FAN_MAXK], gb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int kk = 0; kk < FAN_MAXK; kk++) gw[j][kk] = 0.f;
+  for (long long r0 = (long long)blockIdx.x * lanes; r0 < p.rows; r0 += (long long)gridDim.x * lanes) {  // block-uniform trip count (shuffles below)
+    const long long r = r0 + rl;
+    const bool live = r < p.rows;
+    const float4 d4 = live ? *reinterpret_cast<const float4*>(p.dy + r * p.n + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) gb[j] += d[j];
+#pragma unroll
+    for (int kk = 0; kk < FAN_MAXK; kk++) {
+      if (kk < p.k) {
+        const float xv = live ? bf2f(p.x[r * p.k + kk]) : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          gw[j][kk] = fmaf(d[j], xv, gw[j][kk]);
+          a = fmaf(d[j], ws[(q + j) * p.k + kk], a);
+        }
+        if (p.dx) {
+          for (int o = g4 >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+          if (q == 0 && live) p.dx[r * p.k + kk] = f2bf(a);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    atomicAdd(&red[p.n * p.k + q + j], gb[j]);
+#pragma unroll
+    for (int kk = 0; kk < FAN_MAXK; kk++)
+      if (kk < p.k) atomicAdd(&red[(q + j) * p.k + kk], gw[j][kk]);
+  }
+  __syncthreads();
+  if (p.dw)
+    for (int i = threadIdx.x; i < p.n * p.k; i += 256) unsafeAtomicAdd(p.dw + i, red[i]);
+  if (p.db)
+    for (int i = threadIdx.x; i < p.n; i += 256) unsafeAtomicAdd(p.db + i, red[p.n * p.k + i]);
+}
+static bool fanout_ok(int n, int k) { return k >= 1 && k <= FAN_MAXK && (n == 4 || n == 8 || n == 16 || n == 32 || n == 64); }
+CINEMA_API int cinema_fanout_linear_fwd(const uint16_t* x, const float* w, const float* bias, float* y, long long rows, int n, int k, void* stream) {
+  if (!x || !w || !y || rows <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!fanout_ok(n, k) || (((uintptr_t)y) & 15)) return CINEMA_ERR_UNSUPPORTED;
+  ThinP p{x, w, bias, y, nullptr, nullptr, nullptr, nullptr, rows, n, k};
+  CINEMA_LAUNCH(fanout_linear_fwd_kernel, dim3(grid_for(rows * (n >> 2), 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+CINEMA_API int cinema_fanout_linear_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, long long rows, int n, int k,
+                                        void* stream) {
+  if (!x || !w || !dy || rows <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!fanout_ok(n, k) || (((uintptr_t)dy) & 15)) return CINEMA_ERR_UNSUPPORTED;
+  ThinP p{x, w, nullptr, nullptr, dy, dx, dw, db, rows, n, k};
+  const int lanes = 256 / (n >> 2);
+  long long g = (rows + lanes - 1) / lanes;
+  if (g > 2048) g = 2048;
+  CINEMA_LAUNCH(fanout_linear_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;

@@ -141,6 +141,8 @@ _PROTOS = {
     "cinema_fill_u32": [_vp, C.c_uint, _ll, _vp],
     "cinema_thin_linear_fwd": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_thin_linear_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "cinema_fanout_linear_fwd": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "cinema_fanout_linear_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_rng_advance": [_vp, _vp],
     "cinema_dropout_bf16": [_vp, _vp, _ll, _f, _vp, C.c_uint, _vp],
     "cinema_droppath_scale": [_vp, _i, _f, _vp, C.c_uint, _vp],
@@ -772,6 +774,31 @@ def thin_linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dw: torc
     dx = _empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_dx else None
     _check(load().cinema_thin_linear_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), _p(dw), _p(db), x.shape[0], w.shape[0], w.shape[1], _stream()),
            "thin_linear_bwd")
+    return dx
+
+
+def fanout_ok(n: int, k: int) -> bool:
+    return 1 <= k <= 8 and n in (4, 8, 16, 32, 64)
+
+
+def fanout_linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """y fp32 [rows, n] = x (bf16 [rows, k]) @ w^T (fp32 [n, k]) + bias for k <= 8, n in {4, 8, 16, 32, 64} (streaming kernel, no GEMM)."""
+    _dev(x, w, bias)
+    if x.dtype != torch.bfloat16 or w.dtype != torch.float32 or not x.is_contiguous() or not w.is_contiguous() or x.shape[1] != w.shape[1]:
+        raise HipLibraryError("fanout_linear: contiguous bf16 rows [rows, k], fp32 weight [n, k]")
+    y = _empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+    _check(load().cinema_fanout_linear_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), x.shape[0], w.shape[0], w.shape[1], _stream()), "fanout_linear_fwd")
+    return y
+
+
+def fanout_linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor | None, db: torch.Tensor | None, want_dx: bool) -> torch.Tensor | None:
+    """Backward of :func:`fanout_linear_fwd`: returns dx (bf16) when asked; dw (fp32 [n, k]) / db (fp32 [n]) are accumulated in place."""
+    _dev(x, w, dy, dw, db)
+    if dy.dtype != torch.float32 or not dy.is_contiguous() or tuple(dy.shape) != (x.shape[0], w.shape[0]):
+        raise HipLibraryError("fanout_linear_bwd: contiguous fp32 dy [rows, n]")
+    dx = _empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_dx else None
+    _check(load().cinema_fanout_linear_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), _p(dw), _p(db), x.shape[0], w.shape[0], w.shape[1], _stream()),
+           "fanout_linear_bwd")
     return dx
 
 

@@ -614,6 +614,9 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
     if (w16 is None and out_f32 and residual is None and row_mask is None and weight.dim() >= 2 and weight.shape[0] < 8 and x.data.is_cuda
             and x.data.dtype == BF16 and x.data.is_contiguous() and math.prod(weight.shape[1:]) == x.data.shape[1] <= 64 and x.data.shape[1] % 8 == 0):
         return _op_thin_linear(tape, x, weight, bias)
+    if (w16 is None and out_f32 and residual is None and row_mask is None and weight.dim() >= 2 and x.data.is_cuda and x.data.dtype == BF16 and x.data.is_contiguous()
+            and math.prod(weight.shape[1:]) == x.data.shape[1] and K.fanout_ok(weight.shape[0], x.data.shape[1])):
+        return _op_thin_linear(tape, x, weight, bias, fanout=True)  # few inputs, a few dozen outputs (the 1 -> 32 channel shortcut of the raw-image block)
     w = w16 if w16 is not None else w_plain(weight)
     if fp8 and w16 is None and row_mask is None and _fp8_ok(x.data, weight) and (residual is None or residual.data.dtype == F32):
         x8, sx = a_fp8(x)
@@ -642,10 +645,12 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
     return y
 
 
-def _op_thin_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None) -> Var:
-    """A head with fewer than 8 outputs (the 4-class segmentation head over every voxel): streaming kernels on the fp32 master weight."""
+def _op_thin_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Parameter | None, fanout: bool = False) -> Var:
+    """A head with fewer than 8 outputs (the 4-class segmentation head over every voxel) or, ``fanout``, a layer with at most 8 inputs: streaming
+    kernels on the fp32 master weight."""
     w2 = weight.detach().reshape(weight.shape[0], -1)
-    y = Var(K.thin_linear_fwd(x.data, w2, None if bias is None else bias.detach()))
+    fwd_k, bwd_k = (K.fanout_linear_fwd, K.fanout_linear_bwd) if fanout else (K.thin_linear_fwd, K.thin_linear_bwd)
+    y = Var(fwd_k(x.data, w2, None if bias is None else bias.detach()))
     wv, bv = tape.pvar(weight), tape.pvar(bias)
 
     def bwd() -> None:
@@ -653,7 +658,7 @@ def _op_thin_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.
             return
         dw = wv.grad_buffer(tuple(w2.shape)) if weight.requires_grad else None
         db = bv.grad_buffer((w2.shape[0],)) if (bias is not None and bias.requires_grad) else None
-        dx = K.thin_linear_bwd(x.data, w2, y.grad.contiguous(), dw, db, want_dx=x.needs_grad)
+        dx = bwd_k(x.data, w2, y.grad.contiguous(), dw, db, want_dx=x.needs_grad)
         if dx is not None:
             x.add_grad(dx)
 

@@ -308,6 +308,10 @@ int cinema_scale_rows_add(const float* h, const float* residual, const float* sc
  * dy . w (NULL: skip), dw fp32 [n][k] += dy^T x, db [n] += column sums of dy (NULL: skip). */
 int cinema_thin_linear_fwd(const uint16_t* x, const float* w, const float* bias, float* y, long long rows, int n, int k, void* stream);
 int cinema_thin_linear_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, long long rows, int n, int k, void* stream);
+/* The mirrored case, few inputs and a few dozen outputs (the 1x1 shortcut convolution of the raw-image ConvResBlock, 1 -> 32 channels over every voxel,
+ * cinema/conv.py:322-327): k <= 8, n in {4, 8, 16, 32, 64}; x bf16 [rows][k], w fp32 [n][k], y / dy fp32 [rows][n] (16-byte aligned); same contract as the thin pair. */
+int cinema_fanout_linear_fwd(const uint16_t* x, const float* w, const float* bias, float* y, long long rows, int n, int k, void* stream);
+int cinema_fanout_linear_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, long long rows, int n, int k, void* stream);
 /* dst[0 .. n_words) = word (32-bit pattern; torch.zeros / torch.full of the reference's host code as a launch of this library). */
 int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream);
 

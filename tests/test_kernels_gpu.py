@@ -796,3 +796,23 @@ def test_thin_linear_kernels(rows: int, n: int, k: int) -> None:
     close(dw - 1.0, want_w, 1e-3, 2e-4 * float(want_w.abs().max()) * (rows ** 0.5) / 30 + 1e-3, "thin linear dw")
     close(db, dy.sum(0), 1e-3, 1e-4 * rows ** 0.5, "thin linear db")
     assert K.thin_linear_bwd(x, w, dy, None, None, want_dx=False) is None
+
+
+@pytest.mark.parametrize(("rows", "n", "k"), [(100003, 32, 1), (777, 64, 8), (4097, 4, 3), (50, 16, 2)])
+def test_fanout_linear_kernels(rows: int, n: int, k: int) -> None:
+    """Layers with at most 8 inputs as streaming kernels (cinema_fanout_linear_fwd / bwd; the 1 -> 32 channel shortcut of the raw-image ConvResBlock) against
+    fp32 torch on the same bf16-rounded input."""
+    x = rnd(rows, k, seed=95)
+    w, b = rnd(n, k, dtype=torch.float32, seed=96, scale=0.3), rnd(n, dtype=torch.float32, seed=97)
+    y = K.fanout_linear_fwd(x, w, b)
+    ref = x.float() @ w.t() + b
+    close(y, ref, 1e-5, 1e-5 * float(ref.abs().max()), "fanout fwd")
+    dy = rnd(rows, n, dtype=torch.float32, seed=98)
+    dw = torch.full((n, k), 0.5, dtype=torch.float32, device=DEV)
+    db = torch.full((n,), 0.25, dtype=torch.float32, device=DEV)
+    dx = K.fanout_linear_bwd(x, w, dy, dw, db, want_dx=True)
+    want_dw, want_db, want_dx = dy.t() @ x.float(), dy.sum(0), dy @ w
+    close(dw - 0.5, want_dw, 2e-4, 2e-4 * float(want_dw.abs().max()) + 1e-3, "fanout dW")
+    close(db - 0.25, want_db, 2e-4, 2e-4 * float(want_db.abs().max()) + 1e-3, "fanout db")
+    close(dx, want_dx, 1e-2, 1e-2 * float(want_dx.abs().max()), "fanout dx (bf16)")
+    assert K.fanout_linear_bwd(x, w, dy, dw, None, want_dx=False) is None

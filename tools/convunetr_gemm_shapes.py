@@ -48,5 +48,5 @@ for kind, flops, e0, e1, shape in prof:
     a[1] += e0.elapsed_time(e1) * 1e-3
     a[2] += 1
 print(f"all GEMM launches: {sum(v[1] for v in agg.values()) * 1e3:.1f} ms/step")
-for (kind, (m, n, k, ak, bk, sk)), (fl, secs, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+for (kind, (m, n, k, ak, bk, sk, _alg)), (fl, secs, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     print(f"{K.GEMM_KERNEL_NAMES[kind]:36s} m{m:8d} n{n:5d} k{k:8d} aK{ak} bK{bk} sk{sk:3d} x{cnt:3d} {secs / cnt * 1e6:9.1f} us {fl / secs / 1e12:6.1f} TF {secs * 1e3:7.2f} ms")
