@@ -147,3 +147,72 @@ def test_model_builder_and_tensor_metrics() -> None:
     batch["label"] = torch.tensor([1, 1])
     loss, metrics = classification_loss_tensors(model, batch, VIEWS, torch.device(DEV))
     assert loss.requires_grad and not metrics["loss"].requires_grad and float(metrics["loss"]) == float(loss)
+
+
+def test_checkpoint_flow_pretrain_files_to_finetune_and_resume(tmp_path) -> None:  # noqa: ANN001
+    """The file flow of the reference's recipes end to end on the GPU, with local files in the released layout:
+    pre-train a CineMA for two fused steps -> ``cinema.safetensors`` + ``config.yaml`` -> ``CineMA.from_pretrained`` (same loss as the live model) ->
+    ``ConvViT.from_pretrained(config, freeze=False)`` (stem / encoder / fusion arrive, first stem filter tiled over the frames) -> three classification
+    steps -> ``save_checkpoint`` / ``load_checkpoint_and_optimizer`` into a fresh model + optimiser (the next step is identical) -> fine-tuned
+    ``.safetensors`` + config -> ``ConvViT.from_finetuned`` (same logits)."""
+    import yaml
+    from safetensors.torch import save_file
+
+    from cinema_amd import CineMA, ConvViT
+    from cinema_amd.config import to_config
+    from cinema_amd.mae.mae import get_model as get_mae
+    from cinema_amd.optim import GradScaler, TrainStep, load_checkpoint_and_optimizer, save_checkpoint
+
+    mae_cfg = {"grad_ckpt": False, "data": {"sax": {"patch_size": [32, 32, 4], "in_chans": 1}, "lax": {"patch_size": [32, 32], "in_chans": 1}},
+               "model": {"size": "tiny", "patch_size": [2, 2, 1], "scale_factor": [2, 2, 1], "enc_conv_chans": [8, 16], "enc_conv_n_blocks": 1}}
+    torch.manual_seed(0)
+    mae = get_mae(to_config(mae_cfg)).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    images = {v: torch.rand(2, 1, *(mae_cfg["data"]["sax" if v == "sax" else "lax"]["patch_size"]), generator=gen).to(DEV) for v in mae.views}
+    step = TrainStep(mae, lr=1e-3)
+    for _ in range(2):
+        step(images, 0.75)
+    (tmp_path / "config.yaml").write_text(yaml.safe_dump(mae_cfg))
+    save_file({k: v.detach().cpu().contiguous() for k, v in mae.state_dict().items()}, str(tmp_path / "cinema.safetensors"))
+    loaded = CineMA.from_pretrained(model_path=tmp_path / "cinema.safetensors", config_path=tmp_path / "config.yaml").to(DEV)
+    masks = {v: (torch.arange(mae.enc_down_dict[v].patch_embed.n_patches, device=DEV)[None] % 4 != 0).expand(2, -1).contiguous() for v in mae.views}
+    with torch.no_grad():
+        l0 = float(mae(images, 0.75, enc_mask_dict=masks)[0])
+        l1 = float(loaded(images, 0.75, enc_mask_dict=masks)[0])
+    assert l0 == pytest.approx(l1, rel=1e-6)  # same weights; the loss reductions use atomics (last-bit order effects)
+
+    # downstream classifier on two of the views, two frames per view
+    ft_cfg = {"grad_ckpt": False, "data": {**mae_cfg["data"], "class_column": "label", "label": ["a", "b", "c"]},
+              "model": {"name": "convvit", "views": ["sax", "lax_2c"], "n_frames": 2, "out_chans": 3,
+                        "convvit": {"size": "tiny", "enc_patch_size": [2, 2, 1], "enc_scale_factor": [2, 2, 1], "enc_conv_chans": [8, 16], "enc_conv_n_blocks": 1,
+                                    "drop_path": 0.0}}}
+    torch.manual_seed(1)
+    clf = ConvViT.from_pretrained(to_config(ft_cfg), freeze=False, model_path=tmp_path / "cinema.safetensors").to(DEV)
+    sd, msd = clf.state_dict(), mae.state_dict()
+    assert torch.equal(sd["encoder.blocks.0.attn.kv.weight"], msd["encoder.blocks.0.attn.kv.weight"])
+    w, wm = sd["enc_down_dict.sax.conv_blocks.0.patch_embed.conv.weight"], msd["enc_down_dict.sax.conv_blocks.0.patch_embed.conv.weight"]
+    assert w.shape[1] == 2 and torch.equal(w[:, :1], wm) and torch.equal(w[:, 1:], wm)
+    batch = {"sax_image": torch.rand(3, 2, 32, 32, 4, generator=gen), "lax_2c_image": torch.rand(3, 2, 32, 32, generator=gen), "label": torch.tensor([0, 2, 1])}
+    ft = ClsTrainStep(clf, VIEWS, lr=1e-3, layer_decay=0.75)
+    for _ in range(3):
+        ft(batch)
+    scaler = GradScaler()
+    ck = save_checkpoint(tmp_path / "ckpt", 7, clf, ft.optimizer, scaler, n_samples=9)
+    assert ck.name == "ckpt_7.pt"
+    torch.manual_seed(2)
+    clf2 = get_classification_or_regression_model(to_config(ft_cfg)).to(DEV)
+    ft2 = ClsTrainStep(clf2, VIEWS, lr=1e-3, layer_decay=0.75)
+    _, _, _, epoch, n_samples = load_checkpoint_and_optimizer(ck, clf2, ft2.optimizer, GradScaler())
+    assert (epoch, n_samples) == (7, 9) and ft2.optimizer.step_count == 3
+    la, ga, _ = ft(batch)
+    lb, gb, _ = ft2(batch)
+    assert float(la) == pytest.approx(float(lb), rel=1e-5) and float(ga) == pytest.approx(float(gb), rel=1e-4)
+    assert (ft.flat.flat_param - ft2.flat.flat_param).abs().max() <= 1e-5  # one more AdamW step from the restored moments (lr 1e-3)
+
+    (tmp_path / "ft_config.yaml").write_text(yaml.safe_dump(ft_cfg))
+    save_file({k: v.detach().cpu().contiguous() for k, v in clf.state_dict().items()}, str(tmp_path / "ft.safetensors"))
+    again = ConvViT.from_finetuned(model_path=tmp_path / "ft.safetensors", config_path=tmp_path / "ft_config.yaml").to(DEV)
+    clf.eval(), again.eval()
+    imgs = {v: batch[f"{v}_image"].to(DEV) for v in VIEWS}
+    with torch.no_grad():
+        assert (clf(imgs).float() - again(imgs).float()).abs().max() <= 1e-5
