@@ -287,6 +287,11 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # path check of the multi-rank branch on a ONE-GPU box (dev only, never a metric): CINEMA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # CINEMA_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
+    backend = os.environ.get("CINEMA_BENCH_BACKEND", "nccl")
+    if os.environ.get("CINEMA_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
 
@@ -302,7 +307,7 @@ def main() -> None:
 
     sync = None
     if world > 1:
-        ddp_setup(rank, world, backend="nccl")
+        ddp_setup(rank, world, backend=backend)
         sync = GradientSynchronizer(world)
     elif args.force_sync:  # one-process RCCL group: runs the overlapped all-reduce schedule on one GPU (path check, not a metric)
         os.environ.setdefault("MASTER_PORT", "29533")
