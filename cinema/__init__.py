@@ -20,6 +20,7 @@ _ALIASES = {
     "cinema.transform": "cinema_amd.transform",
     "cinema.mae": "cinema_amd.mae",
     "cinema.mae.mae": "cinema_amd.mae.mae",
+    "cinema.mae.pretrain": "cinema_amd.mae.pretrain",
     "cinema.segmentation": "cinema_amd.segmentation",
     "cinema.segmentation.convunetr": "cinema_amd.segmentation.convunetr",
     "cinema.segmentation.train": "cinema_amd.segmentation.train",

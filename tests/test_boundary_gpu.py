@@ -264,3 +264,44 @@ def test_train_step_with_layer_decay_groups_matches_per_group_adamw() -> None:
     for n, p in named.items():
         if p.requires_grad:
             assert torch.allclose(p.detach().cpu(), ref[n].detach(), rtol=2e-5, atol=2e-7), n
+
+
+def test_pretrain_one_epoch_loop_follows_the_reference_schedule() -> None:
+    """``cinema_amd.mae.pretrain.pretrain_one_epoch`` (reference ``pretrain.py:203-284``): learning rate of every iteration = ``adjust_learning_rate`` at the
+    fractional epoch, optimiser updates only on the accumulation boundary, sample counter, logged keys; and the loss of a repeated synthetic set falls."""
+    import math
+
+    from torch.utils.data import DataLoader
+
+    from cinema_amd.config import to_config
+    from cinema_amd.mae.mae import get_model
+    from cinema_amd.mae.pretrain import SyntheticCine, pretrain_one_epoch
+    from cinema_amd.optim import TrainStep, get_n_accum_steps
+
+    cfg = to_config({"grad_ckpt": False, "data": {"sax": {"patch_size": [32, 32, 4], "in_chans": 1}, "lax": {"patch_size": [32, 32], "in_chans": 1}},
+                     "model": {"size": "tiny", "patch_size": [2, 2, 1], "scale_factor": [2, 2, 1], "enc_conv_chans": [8, 16], "enc_conv_n_blocks": 1},
+                     "train": {"batch_size_per_device": 2, "batch_size": 4, "enc_mask_ratio": 0.75, "n_warmup_epochs": 1, "n_epochs": 3, "lr": 2e-3,
+                               "min_lr": 1e-5}})
+    torch.manual_seed(0)
+    model = get_model(cfg).to(DEV)
+    ds = SyntheticCine({"sax": (32, 32, 4), "lax_2c": (32, 32), "lax_3c": (32, 32), "lax_4c": (32, 32)}, dict.fromkeys(model.views, 1), length=8, seed=1)
+    loader = DataLoader(ds, batch_size=2, shuffle=False)
+    n_accum = get_n_accum_steps(batch_size=cfg.train.batch_size, batch_size_per_device=cfg.train.batch_size_per_device, world_size=1)
+    assert n_accum == 2 and len(loader) == 4
+    step = TrainStep(model, lr=cfg.train.lr, clip_grad=5.0)
+    logs, n_samples = [], 0
+    for epoch in range(3):
+        n_samples = pretrain_one_epoch(step, loader, n_accum, 1, cfg, epoch, n_samples, log=logs.append)
+    assert n_samples == 3 * 4 * 2 and step.optimizer.step_count == 3 * 4 // n_accum and len(logs) == 6
+    # update iterations are i = 1, 3 of every epoch; the logged lr is the schedule at the fractional epoch i / 4 + epoch
+    want = []
+    for epoch in range(3):
+        for i in (1, 3):
+            s = i / 4 + epoch
+            want.append(2e-3 * s / 1 if s < 1 else 1e-5 + (2e-3 - 1e-5) * 0.5 * (1 + math.cos(math.pi * (s - 1) / (3 - 1))))
+    assert [round(lg["lr"], 10) for lg in logs] == [round(w, 10) for w in want]
+    assert all(g["lr"] == pytest.approx(logs[-1]["lr"]) for g in step.optimizer.param_groups)
+    assert [lg["n_samples"] for lg in logs] == [4, 8, 12, 16, 20, 24]
+    assert {"loss", "grad_norm", "lr", "n_samples"} <= set(logs[0]) and any(k.endswith("mse_loss") for k in logs[0])
+    assert all(torch.isfinite(lg["grad_norm"]) for lg in logs)
+    assert float(logs[-1]["loss"]) < float(logs[0]["loss"])
