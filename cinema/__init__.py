@@ -24,6 +24,7 @@ _ALIASES = {
     "cinema.segmentation": "cinema_amd.segmentation",
     "cinema.segmentation.convunetr": "cinema_amd.segmentation.convunetr",
     "cinema.segmentation.train": "cinema_amd.segmentation.train",
+    "cinema.train": "cinema_amd.train",
     "cinema.classification": "cinema_amd.classification",
     "cinema.classification.train": "cinema_amd.classification.train",
     "cinema.regression": "cinema_amd.regression",

@@ -2,7 +2,8 @@
 build and any ``loss_fn(model, batch, views, device) -> (loss, metrics)``: forward -> loss -> backward into the flat gradient buffer ->
 (data-parallel mean all-reduce) -> global-norm clip -> fused AdamW over the layer-decay parameter groups -> zero_grad.
 
-The hydra / wandb / DataLoader shell around it (``run_train``, ``cinema/train.py:171-351``) is the reference's control plane and is not rebuilt."""
+``train_one_epoch`` is the reference's epoch loop around that step.  The hydra / wandb / data-set shell (``run_train``, ``cinema/train.py:171-351``) is the
+reference's control plane and is not rebuilt."""
 
 from __future__ import annotations
 
@@ -47,6 +48,30 @@ class FineTuneStep:
             grad_norm = self.optimizer.step(self.clip_grad)
             self.optimizer.zero_grad()
         return loss.detach(), grad_norm, metrics
+
+
+def train_one_epoch(step: FineTuneStep, train_dataloader, epoch: int, n_accum_steps: int, n_samples: int, config, log: Callable | None = None) -> int:  # noqa: ANN001
+    """One fine-tuning epoch around the fused step (reference ``train_one_epoch``, ``cinema/train.py:85-168``): ``model.train()``, the learning rate of every
+    iteration from ``adjust_learning_rate`` at the fractional epoch ``i / len(loader) + epoch`` (scaled per layer-decay group), ``loss / n_accum_steps``,
+    the update on ``(i + 1) % n_accum_steps == 0``, ``n_samples += config.train.batch_size_per_device``; ``log(dict)`` on update iterations with the
+    ``train_``-prefixed metrics, ``grad_norm``, ``lr``, ``n_samples``, ``epoch``.  The non-finite guard is the optimiser's device-side one (the reference
+    reads the loss back every iteration)."""
+    from cinema_amd.optim import adjust_learning_rate
+
+    step.model.train()
+    tr = config.train
+    n_iter = len(train_dataloader)
+    for i, batch in enumerate(train_dataloader):
+        lr = adjust_learning_rate(optimizer=step.optimizer, step=i / n_iter + epoch, warmup_steps=tr.n_warmup_epochs, max_n_steps=tr.n_epochs, lr=tr.lr,
+                                  min_lr=tr.min_lr)
+        update_grad = (i + 1) % n_accum_steps == 0
+        _, grad_norm, metrics = step(batch, n_accum_steps=n_accum_steps, update_grad=update_grad)
+        n_samples += tr.batch_size_per_device
+        if update_grad and log is not None:
+            out = {f"train_{k}": v for k, v in metrics.items()}
+            out.update({"grad_norm": grad_norm, "lr": lr, "n_samples": n_samples, "epoch": epoch})
+            log(out)
+    return n_samples
 
 
 def patch_average_forward(model, image_dict: dict, patch_size_dict: dict, combine: Callable) -> torch.Tensor:  # noqa: ANN001

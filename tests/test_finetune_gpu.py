@@ -216,3 +216,28 @@ def test_checkpoint_flow_pretrain_files_to_finetune_and_resume(tmp_path) -> None
     imgs = {v: batch[f"{v}_image"].to(DEV) for v in VIEWS}
     with torch.no_grad():
         assert (clf(imgs).float() - again(imgs).float()).abs().max() <= 1e-5
+
+
+def test_train_one_epoch_loop_with_layer_decay_learning_rates() -> None:
+    """``cinema_amd.train.train_one_epoch`` (reference ``cinema/train.py:85-168``) around ``ClsTrainStep``: per-iteration LR from the schedule times each group's
+    ``lr_scale``, updates on the accumulation boundary, counters and logged keys."""
+    import math
+
+    from cinema_amd.config import to_config
+    from cinema_amd.train import train_one_epoch
+
+    model, g = _convvit_model()
+    cfg = to_config({"train": {"batch_size_per_device": 2, "n_warmup_epochs": 1, "n_epochs": 2, "lr": 1e-3, "min_lr": 1e-6}})
+    gen = torch.Generator().manual_seed(3)
+    loader = [{**{f"{v}_image": torch.rand(2, *g[f"image/{v}"].shape[1:], generator=gen) for v in VIEWS}, "label": torch.tensor([i % 3, (i + 1) % 3])} for i in range(4)]
+    step = ClsTrainStep(model, VIEWS, lr=1e-3, layer_decay=0.75)
+    logs, n = [], 0
+    for epoch in range(2):
+        n = train_one_epoch(step, loader, epoch, 2, n, cfg, log=logs.append)
+    assert n == 2 * 4 * 2 and step.optimizer.step_count == 4 and len(logs) == 4 and model.training
+    s_last = 3 / 4 + 1
+    lr_last = 1e-6 + (1e-3 - 1e-6) * 0.5 * (1 + math.cos(math.pi * (s_last - 1) / (2 - 1)))
+    assert logs[-1]["lr"] == pytest.approx(lr_last) and logs[0]["lr"] == pytest.approx(1e-3 * 0.25)
+    for grp in step.optimizer.param_groups:
+        assert grp["lr"] == pytest.approx(lr_last * grp["lr_scale"])
+    assert {"train_cross_entropy", "train_loss", "grad_norm", "lr", "n_samples", "epoch"} <= set(logs[0]) and [lg["epoch"] for lg in logs] == [0, 0, 1, 1]
