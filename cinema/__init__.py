@@ -3,8 +3,8 @@
 ``from cinema import CineMA, ConvViT, ConvUNetR, patchify, unpatchify`` and the sub-module imports the reference's training / inference
 scripts use (``cinema.mae.mae``, ``cinema.convvit``, ``cinema.vit``, ``cinema.conv``, ``cinema.rotary``, ``cinema.optim``, ``cinema.device``, ``cinema.transform``,
 ``cinema.segmentation.convunetr``, ``cinema.segmentation.train``, ``cinema.classification.train``, ``cinema.regression.train``) resolve to the ``cinema_amd`` modules of the same name: one set of
-classes, two import names.  Only the hot path is aliased; data loading, hydra entry points, metrics for landmark
-heat-maps (``heatmap_soft_argmax``) and the ResNet / UNet baselines are not part of this build and are not faked here.
+classes, two import names.  Only the hot path is aliased; data loading, hydra entry points, the landmark heat-map helpers of
+``cinema.metric`` and the ResNet / UNet baselines are not part of this build and are not faked here.
 """
 
 import importlib
@@ -18,6 +18,7 @@ _ALIASES = {
     "cinema.optim": "cinema_amd.optim",
     "cinema.device": "cinema_amd.device",
     "cinema.transform": "cinema_amd.transform",
+    "cinema.metric": "cinema_amd.metric",
     "cinema.mae": "cinema_amd.mae",
     "cinema.mae.mae": "cinema_amd.mae.mae",
     "cinema.mae.pretrain": "cinema_amd.mae.pretrain",

@@ -228,3 +228,21 @@ def test_nan_on_one_rank_reaches_every_rank_through_the_gradient_exchange(tmp_pa
     mp.spawn(_nan_worker, args=(2, get_free_port(), str(tmp_path)), nprocs=2, join=True)
     n0, n1 = torch.load(tmp_path / "norm0.pt"), torch.load(tmp_path / "norm1.pt")
     assert not torch.isfinite(n0) and not torch.isfinite(n1)
+
+
+def test_metric_helpers_follow_the_reference_formulas() -> None:
+    """``cinema.metric`` scalars and host-tensor volumes (reference ``cinema/metric.py:84-146``)."""
+    import numpy as np
+    from cinema.metric import NORMAL_EF, REDUCED_EF, coefficient_of_variance, ejection_fraction, get_ef_region, get_volumes
+
+    assert (REDUCED_EF, NORMAL_EF) == (40, 55)
+    assert ejection_fraction(120.0, 50.0) == pytest.approx(58.3333333)
+    assert np.allclose(ejection_fraction(np.array([100.0, 80.0]), np.array([40.0, 60.0])), [60.0, 25.0])
+    assert [get_ef_region(v) for v in (10.0, 40.0, 40.1, 55.0, 55.1)] == [0, 0, 1, 1, 2]
+    x, y = np.array([1.0, 2.0, 4.0]), np.array([1.1, 1.9, 4.4])
+    assert coefficient_of_variance(x, y) == pytest.approx(float(np.sqrt(np.mean(((x - y) ** 2 / 2) / ((x + y) / 2) ** 2))))
+    mask = torch.zeros(2, 3, 4, 5, 2)
+    mask[0, 1, :2] = 1
+    mask[1, 2, :, :3] = 1
+    vol = get_volumes(mask, (1.5, 1.5, 8.0))
+    assert vol.shape == (2, 3) and vol[0, 1] == pytest.approx(2 * 5 * 2 * 18.0 / 1000) and vol[1, 2] == pytest.approx(4 * 3 * 2 * 18.0 / 1000) and float(vol[0, 0]) == 0.0

@@ -267,3 +267,19 @@ def test_segmentation_eval_crops_and_reports_floats() -> None:
     assert {"mean_dice_score", "sax_mean_dice_score", "lax_4c_class_1_iou_score", "class_2_pred_volume"} <= set(metrics)
     assert all(isinstance(v, float) for v in metrics.values())
     assert metrics["mean_dice_score"] == pytest.approx(0.5 * (metrics["sax_mean_dice_score"] + metrics["lax_4c_mean_dice_score"]), rel=1e-6)
+
+
+def test_metric_module_stability_and_volumes_on_the_device() -> None:
+    """``cinema_amd.metric.stability_score`` / ``get_volumes`` on device tensors (voxel-count kernel) against the oracle restatement and a plain sum."""
+    from cinema_amd.metric import get_volumes, stability_score
+
+    g = torch.Generator().manual_seed(21)
+    logits = torch.randn(2, 4, 12, 10, 6, generator=g) * 2
+    got = stability_score(logits.to(DEV)).cpu()
+    want = O.stability_score(logits)
+    assert got.shape == (2, 4) and torch.allclose(got, want, atol=1e-6, equal_nan=True)
+    onehot = torch.nn.functional.one_hot(logits.argmax(1), 4).movedim(-1, 1).float()
+    vol = get_volumes(onehot.to(DEV), (1.25, 1.25, 10.0)).cpu()
+    assert torch.allclose(vol, onehot.sum(dim=(2, 3, 4)) * (1.25 * 1.25 * 10.0) / 1000.0, rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        stability_score(logits.to(DEV), threshold_offset=0.5)
