@@ -8,6 +8,17 @@ from cinema_amd import hip as K
 from cinema_amd.train import FineTuneStep
 
 
+def get_segmentation_model(config):  # noqa: ANN001, ANN201
+    """``config.model.name == "convunetr"`` of the reference's builder (``cinema/segmentation/train.py:31-75``); its UNet baseline is not part of this build."""
+    if config.model.name != "convunetr":
+        raise ValueError(f"Invalid model name {config.model.name}: this build provides the ConvUNetR path only.")
+    from cinema_amd.segmentation.convunetr import get_model
+
+    model = get_model(config)
+    model.set_grad_ckpt(config.grad_ckpt)
+    return model
+
+
 class _SegLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: torch.Tensor, labels: torch.Tensor):  # noqa: ANN001, ANN205

@@ -425,3 +425,20 @@ def test_tape_host_and_const_entries_of_a_recording() -> None:
         assert keep.tolist() == [0, 1] and drop.tolist() == [2, 3] and (keep.data_ptr(), drop.data_ptr()) == ptrs
     finally:
         K.RECORD = None
+
+
+def test_segmentation_model_builder_maps_the_acdc_config() -> None:
+    """``get_segmentation_model`` (reference ``cinema/segmentation/train.py:31-75``) with the ACDC recipe's model section (``acdc/config.yaml:56-66``)."""
+    from cinema_amd.config import to_config
+    from cinema_amd.segmentation.train import get_segmentation_model
+
+    cfg = to_config({"grad_ckpt": True, "data": {"sax": {"patch_size": [64, 64, 4], "in_chans": 1, "spacing": [1.0, 1.0, 10.0]}},
+                     "model": {"name": "convunetr", "views": "sax", "out_chans": 4,
+                               "convunetr": {"size": "tiny", "enc_patch_size": [4, 4, 1], "enc_scale_factor": [2, 2, 1], "enc_conv_chans": [8, 16], "enc_conv_n_blocks": 1,
+                                             "dec_chans": [4, 8, 16, 32, 64], "dec_patch_size": [2, 2, 1], "dec_scale_factor": [2, 2, 1], "dropout": 0.1,
+                                             "drop_path": 0.1}}})
+    model = get_segmentation_model(cfg)
+    assert type(model).__name__ == "ConvUNetR" and model.grad_ckpt is True
+    cfg.model.name = "unet"
+    with pytest.raises(ValueError):
+        get_segmentation_model(cfg)
