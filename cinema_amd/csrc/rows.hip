@@ -859,6 +859,161 @@ CINEMA_API int cinema_fanout_linear_bwd(const uint16_t* x, const float* w, const
   return launch_status();
 }
 
+// ---- "same" convolution of a ONE-channel volume (the first conv of the raw-image ConvResBlock, cinema/conv.py:320-345 with in_chans = 1): 27 taps x n outputs per
+// voxel are too thin for the MFMA path (K = 27), and im2col wrote 32 bf16 per voxel twice per step.  Direct stencil kernels on the fp32 master weights
+// [n][taps], kept in LDS as [tap][n].  Kernel extents 1 or 3 per axis; n in {4, 8, 16, 32, 64}.
+struct Sten1P {
+  const bf16_t* x; const float* w; const float* bias; float* y; const float* dy; bf16_t* dx; float* dw; float* db;
+  int b, X, Y, Z, kx, ky, kz, n;
+};
+__device__ __forceinline__ void sten1_coords(const Sten1P& p, long long r, int& x, int& y, int& z) {
+  z = (int)(r % p.Z);
+  const long long t = r / p.Z;
+  y = (int)(t % p.Y);
+  x = (int)((t / p.Y) % p.X);
+}
+// forward: thread = voxel, all N outputs in registers; per tap one input load, N / 4 broadcast LDS reads of the weights and N FMAs
+template <int N>
+__global__ __launch_bounds__(256) void sten1_fwd_kernel(Sten1P p) {
+  __shared__ __attribute__((aligned(16))) float ws[28 * N];
+  const int taps = p.kx * p.ky * p.kz;
+  for (int i = threadIdx.x; i < N * taps; i += 256) ws[(i % taps) * N + i / taps] = p.w[i];
+  for (int i = threadIdx.x; i < N; i += 256) ws[taps * N + i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+  const long long rows = (long long)p.b * p.X * p.Y * p.Z;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    int x, y, z;
+    sten1_coords(p, r, x, y, z);
+    float a[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) a[j] = ws[taps * N + j];
+    int tap = 0;
+    for (int tx = 0; tx < p.kx; tx++)
+      for (int ty = 0; ty < p.ky; ty++)
+        for (int tz = 0; tz < p.kz; tz++, tap++) {
+          const int dx = tx - (p.kx >> 1), dy = ty - (p.ky >> 1), dz = tz - (p.kz >> 1);
+          if ((unsigned)(x + dx) >= (unsigned)p.X || (unsigned)(y + dy) >= (unsigned)p.Y || (unsigned)(z + dz) >= (unsigned)p.Z) continue;
+          const float xv = bf2f(p.x[r + ((long long)dx * p.Y + dy) * p.Z + dz]);
+#pragma unroll
+          for (int j = 0; j < N; j += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(ws + tap * N + j);
+            a[j] = fmaf(xv, w4.x, a[j]); a[j + 1] = fmaf(xv, w4.y, a[j + 1]); a[j + 2] = fmaf(xv, w4.z, a[j + 2]); a[j + 3] = fmaf(xv, w4.w, a[j + 3]);
+          }
+        }
+#pragma unroll
+    for (int j = 0; j < N; j += 4) *reinterpret_cast<float4*>(p.y + r * N + j) = make_float4(a[j], a[j + 1], a[j + 2], a[j + 3]);
+  }
+}
+// weight / bias gradient: thread = (voxel lane 0..7, tap slot 0..31): slot t < taps accumulates dy[r][:] * x[nbr_t(r)] over the lane's voxels in N registers,
+// slot `taps` the bias gradient (x = 1); the 32 slots of a voxel are adjacent lanes, so the dy row is one broadcast load per 16 bytes.  Block reduction over
+// the 8 voxel lanes through LDS, then one atomic per entry and block.
+template <int N>
+__global__ __launch_bounds__(256) void sten1_wgrad_kernel(Sten1P p) {
+  __shared__ float red[28 * N];
+  const int taps = p.kx * p.ky * p.kz;
+  for (int i = threadIdx.x; i < 28 * N; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int t = threadIdx.x & 31, vl = threadIdx.x >> 5;
+  const int tz = t % p.kz, ty = (t / p.kz) % p.ky, tx = t / (p.kz * p.ky);
+  const int dx = tx - (p.kx >> 1), dy = ty - (p.ky >> 1), dz = tz - (p.kz >> 1);
+  const long long off = ((long long)dx * p.Y + dy) * p.Z + dz;
+  float g[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) g[j] = 0.f;
+  const long long rows = (long long)p.b * p.X * p.Y * p.Z;
+  if (t <= taps) {
+    for (long long r = (long long)blockIdx.x * 8 + vl; r < rows; r += (long long)gridDim.x * 8) {
+      float xv = 1.f;  // the bias slot
+      if (t < taps) {
+        int x, y, z;
+        sten1_coords(p, r, x, y, z);
+        if ((unsigned)(x + dx) >= (unsigned)p.X || (unsigned)(y + dy) >= (unsigned)p.Y || (unsigned)(z + dz) >= (unsigned)p.Z) continue;
+        xv = bf2f(p.x[r + off]);
+      }
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        const float4 d = *reinterpret_cast<const float4*>(p.dy + r * N + j);
+        g[j] = fmaf(d.x, xv, g[j]); g[j + 1] = fmaf(d.y, xv, g[j + 1]); g[j + 2] = fmaf(d.z, xv, g[j + 2]); g[j + 3] = fmaf(d.w, xv, g[j + 3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) atomicAdd(&red[t * N + j], g[j]);
+  }
+  __syncthreads();
+  if (p.dw)
+    for (int i = threadIdx.x; i < N * taps; i += 256) unsafeAtomicAdd(p.dw + i, red[(i % taps) * N + i / taps]);
+  if (p.db)
+    for (int i = threadIdx.x; i < N; i += 256) unsafeAtomicAdd(p.db + i, red[taps * N + i]);
+}
+// data gradient: thread = voxel; dx[r] = sum_tap sum_co dy[r - off(tap)][co] * w[co][tap]
+template <int N>
+__global__ __launch_bounds__(256) void sten1_dgrad_kernel(Sten1P p) {
+  __shared__ __attribute__((aligned(16))) float ws[27 * N];
+  const int taps = p.kx * p.ky * p.kz;
+  for (int i = threadIdx.x; i < N * taps; i += 256) ws[(i % taps) * N + i / taps] = p.w[i];
+  __syncthreads();
+  const long long rows = (long long)p.b * p.X * p.Y * p.Z;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    int x, y, z;
+    sten1_coords(p, r, x, y, z);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int tap = 0;
+    for (int tx = 0; tx < p.kx; tx++)
+      for (int ty = 0; ty < p.ky; ty++)
+        for (int tz = 0; tz < p.kz; tz++, tap++) {
+          const int dx = tx - (p.kx >> 1), dy = ty - (p.ky >> 1), dz = tz - (p.kz >> 1);
+          if ((unsigned)(x - dx) >= (unsigned)p.X || (unsigned)(y - dy) >= (unsigned)p.Y || (unsigned)(z - dz) >= (unsigned)p.Z) continue;
+          const float* drow = p.dy + (r - (((long long)dx * p.Y + dy) * p.Z + dz)) * N;
+#pragma unroll
+          for (int j = 0; j < N; j += 4) {
+            const float4 d = *reinterpret_cast<const float4*>(drow + j);
+            const float4 w4 = *reinterpret_cast<const float4*>(ws + tap * N + j);
+            a0 = fmaf(d.x, w4.x, a0); a1 = fmaf(d.y, w4.y, a1); a2 = fmaf(d.z, w4.z, a2); a3 = fmaf(d.w, w4.w, a3);
+          }
+        }
+    p.dx[r] = f2bf((a0 + a1) + (a2 + a3));
+  }
+}
+static bool sten1_ok(const Sten1P& p) {
+  auto k13 = [](int k) { return k == 1 || k == 3; };
+  return p.b > 0 && p.X > 0 && p.Y > 0 && p.Z > 0 && k13(p.kx) && k13(p.ky) && k13(p.kz) && fanout_ok(p.n, 1);
+}
+#define STEN1_DISPATCH(KERNEL, GRID)                                                                        \
+  switch (n) {                                                                                              \
+    case 4: CINEMA_LAUNCH(KERNEL<4>, GRID, dim3(256), 0, (hipStream_t)stream, p); break;                    \
+    case 8: CINEMA_LAUNCH(KERNEL<8>, GRID, dim3(256), 0, (hipStream_t)stream, p); break;                    \
+    case 16: CINEMA_LAUNCH(KERNEL<16>, GRID, dim3(256), 0, (hipStream_t)stream, p); break;                  \
+    case 32: CINEMA_LAUNCH(KERNEL<32>, GRID, dim3(256), 0, (hipStream_t)stream, p); break;                  \
+    default: CINEMA_LAUNCH(KERNEL<64>, GRID, dim3(256), 0, (hipStream_t)stream, p); break;                  \
+  }
+CINEMA_API int cinema_conv1ch_fwd(const uint16_t* x, const float* w, const float* bias, float* y, int b, int X, int Y, int Z, int kx, int ky, int kz, int n, void* stream) {
+  if (!x || !w || !y) return CINEMA_ERR_BAD_ARG;
+  Sten1P p{x, w, bias, y, nullptr, nullptr, nullptr, nullptr, b, X, Y, Z, kx, ky, kz, n};
+  if (!sten1_ok(p) || (((uintptr_t)y) & 15)) return CINEMA_ERR_UNSUPPORTED;
+  const dim3 grid(grid_for((long long)b * X * Y * Z, 256));
+  STEN1_DISPATCH(sten1_fwd_kernel, grid)
+  return launch_status();
+}
+CINEMA_API int cinema_conv1ch_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, int b, int X, int Y, int Z, int kx, int ky,
+                                  int kz, int n, void* stream) {
+  if (!x || !w || !dy) return CINEMA_ERR_BAD_ARG;
+  Sten1P p{x, w, nullptr, nullptr, dy, dx, dw, db, b, X, Y, Z, kx, ky, kz, n};
+  if (!sten1_ok(p) || (((uintptr_t)dy) & 15)) return CINEMA_ERR_UNSUPPORTED;
+  const long long rows = (long long)b * X * Y * Z;
+  if (dw || db) {
+    long long g = (rows + 7) / 8;
+    if (g > 2048) g = 2048;  // every block ends with one global atomic per gradient entry
+    const dim3 grid((unsigned)g);
+    STEN1_DISPATCH(sten1_wgrad_kernel, grid)
+  }
+  if (dx) {
+    const dim3 grid(grid_for(rows, 256));
+    STEN1_DISPATCH(sten1_dgrad_kernel, grid)
+  }
+  return launch_status();
+}
+#undef STEN1_DISPATCH
+
 // y[i] = x[i] * s[0] with the scalar read from device memory (chain rule through scalar losses without a host round trip)
 CINEMA_API int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream) {
   if (!x || !s || !y || n <= 0) return CINEMA_ERR_BAD_ARG;

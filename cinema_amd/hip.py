@@ -143,6 +143,8 @@ _PROTOS = {
     "cinema_thin_linear_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_fanout_linear_fwd": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_fanout_linear_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "cinema_conv1ch_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cinema_conv1ch_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_rng_advance": [_vp, _vp],
     "cinema_dropout_bf16": [_vp, _vp, _ll, _f, _vp, C.c_uint, _vp],
     "cinema_droppath_scale": [_vp, _i, _f, _vp, C.c_uint, _vp],
@@ -799,6 +801,35 @@ def fanout_linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dw: to
     dx = _empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_dx else None
     _check(load().cinema_fanout_linear_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), _p(dw), _p(db), x.shape[0], w.shape[0], w.shape[1], _stream()),
            "fanout_linear_bwd")
+    return dx
+
+
+def _conv1ch_geom(x: torch.Tensor, w: torch.Tensor) -> tuple:
+    if x.dtype != torch.bfloat16 or w.dtype != torch.float32 or not x.is_contiguous() or not w.is_contiguous() or w.dim() != x.dim() + 1 or w.shape[1] != 1:
+        raise HipLibraryError("conv1ch: contiguous bf16 volume [b, *spatial] and fp32 weight (n, 1, *k)")
+    sp = (1,) * (3 - (x.dim() - 1)) + tuple(x.shape[1:])
+    ks = (1,) * (3 - (w.dim() - 2)) + tuple(w.shape[2:])
+    return (x.shape[0], *sp, *ks, w.shape[0])
+
+
+def conv1ch_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """"Same" convolution of a one-channel volume x bf16 [b, *spatial] with the fp32 weight (n, 1, *k) (extents 1 or 3, n in {4, 8, 16, 32, 64}) + bias ->
+    fp32 rows [b * prod(spatial), n]; direct stencil kernel."""
+    _dev(x, w, bias)
+    geom = _conv1ch_geom(x, w)
+    y = _empty((x.numel(), w.shape[0]), dtype=torch.float32, device=x.device)
+    _check(load().cinema_conv1ch_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), *geom, _stream()), "conv1ch_fwd")
+    return y
+
+
+def conv1ch_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor | None, db: torch.Tensor | None, want_dx: bool) -> torch.Tensor | None:
+    """Backward of :func:`conv1ch_fwd`: dy fp32 [rows, n]; dw (n, 1, *k) / db (n) fp32 accumulated in place; returns dx bf16 [rows, 1] when asked."""
+    _dev(x, w, dy, dw, db)
+    geom = _conv1ch_geom(x, w)
+    if dy.dtype != torch.float32 or not dy.is_contiguous() or tuple(dy.shape) != (x.numel(), w.shape[0]) or (dw is not None and (dw.dtype != torch.float32 or not dw.is_contiguous() or dw.numel() != w.numel())):
+        raise HipLibraryError("conv1ch_bwd: contiguous fp32 dy [rows, n], dw of the weight's size")
+    dx = _empty((x.numel(), 1), dtype=torch.bfloat16, device=x.device) if want_dx else None
+    _check(load().cinema_conv1ch_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx), _p(dw), _p(db), *geom, _stream()), "conv1ch_bwd")
     return dx
 
 

@@ -312,6 +312,12 @@ int cinema_thin_linear_bwd(const uint16_t* x, const float* w, const float* dy, u
  * cinema/conv.py:322-327): k <= 8, n in {4, 8, 16, 32, 64}; x bf16 [rows][k], w fp32 [n][k], y / dy fp32 [rows][n] (16-byte aligned); same contract as the thin pair. */
 int cinema_fanout_linear_fwd(const uint16_t* x, const float* w, const float* bias, float* y, long long rows, int n, int k, void* stream);
 int cinema_fanout_linear_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, long long rows, int n, int k, void* stream);
+/* "Same" convolution of a ONE-channel channels-last volume x bf16 [b*X*Y*Z] with the fp32 master weight w [n][kx*ky*kz] (torch layout (n, 1, kx, ky, kz); extents 1 or 3,
+ * n in {4, 8, 16, 32, 64}) as direct stencil kernels - the first conv of the raw-image ConvResBlock (cinema/conv.py:320-345, in_chans = 1), too thin for the MFMA
+ * path: y fp32 [rows][n] = conv(x, w) + bias.  bwd: dy fp32 [rows][n]; dw [n][taps] / db [n] accumulated (NULL: skipped), dx bf16 [rows] written (NULL: skipped). */
+int cinema_conv1ch_fwd(const uint16_t* x, const float* w, const float* bias, float* y, int b, int X, int Y, int Z, int kx, int ky, int kz, int n, void* stream);
+int cinema_conv1ch_bwd(const uint16_t* x, const float* w, const float* dy, uint16_t* dx, float* dw, float* db, int b, int X, int Y, int Z, int kx, int ky, int kz, int n,
+                       void* stream);
 /* dst[0 .. n_words) = word (32-bit pattern; torch.zeros / torch.full of the reference's host code as a launch of this library). */
 int cinema_fill_u32(void* dst, unsigned int word, long long n_words, void* stream);
 

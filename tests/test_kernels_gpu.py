@@ -816,3 +816,30 @@ def test_fanout_linear_kernels(rows: int, n: int, k: int) -> None:
     close(db - 0.25, want_db, 2e-4, 2e-4 * float(want_db.abs().max()) + 1e-3, "fanout db")
     close(dx, want_dx, 1e-2, 1e-2 * float(want_dx.abs().max()), "fanout dx (bf16)")
     assert K.fanout_linear_bwd(x, w, dy, dw, None, want_dx=False) is None
+
+
+@pytest.mark.parametrize(("spatial", "ks", "n"), [((9, 10, 6), (3, 3, 3), 32), ((12, 11), (3, 3), 16), ((5, 6, 4), (3, 3, 1), 8), ((7, 5, 3), (1, 1, 1), 64)])
+def test_one_channel_stencil_conv(spatial: tuple, ks: tuple, n: int) -> None:
+    """cinema_conv1ch_fwd / bwd (the first conv of the raw-image ConvResBlock) against torch's conv autograd on the same bf16-rounded input, fp32 weights."""
+    import torch.nn.functional as F  # noqa: N812
+
+    b, nd = 2, len(spatial)
+    x = rnd(b, *spatial, seed=110)
+    w = rnd(n, 1, *ks, dtype=torch.float32, seed=111, scale=0.3)
+    bias = rnd(n, dtype=torch.float32, seed=112)
+    conv = F.conv3d if nd == 3 else F.conv2d
+    xr = x.float().unsqueeze(1).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = conv(xr, wr, br, padding=tuple(k // 2 for k in ks))
+    y = K.conv1ch_fwd(x, w, bias)
+    want = ref.movedim(1, -1).reshape(-1, n)
+    close(y, want, 1e-5, 1e-5 * float(want.abs().max()), "conv1ch fwd")
+    dy = rnd(y.shape[0], n, dtype=torch.float32, seed=113)
+    ref.backward(dy.reshape(b, *spatial, n).movedim(-1, 1))
+    dw = torch.full_like(w, 0.5)
+    db = torch.full_like(bias, 0.25)
+    dx = K.conv1ch_bwd(x, w, dy, dw, db, want_dx=True)
+    close(dw - 0.5, wr.grad, 3e-4, 3e-4 * float(wr.grad.abs().max()) + 1e-3, "conv1ch dW")
+    close(db - 0.25, br.grad, 3e-4, 3e-4 * float(br.grad.abs().max()) + 1e-3, "conv1ch db")
+    close(dx.reshape(b, *spatial), xr.grad[:, 0], 1e-2, 1e-2 * float(xr.grad.abs().max()), "conv1ch dx (bf16)")
+    assert K.conv1ch_bwd(x, w, dy, None, None, want_dx=False) is None
