@@ -187,7 +187,7 @@ def seg_main(args, rank: int, world: int, device: str, sync) -> None:  # noqa: A
     model = ConvUNetR(**kw)
     cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model.to(device).train()
-    step = SegTrainStep(model, ["sax"], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, layer_decay=0.75, clip_grad=5.0, synchronizer=sync)
+    step = SegTrainStep(model, ["sax"], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, layer_decay=0.75, clip_grad=5.0, synchronizer=sync, replay=not args.eager)
     gen = torch.Generator().manual_seed(1234 + rank)
     batches = []
     for _ in range(2):
@@ -214,6 +214,8 @@ def seg_main(args, rank: int, world: int, device: str, sync) -> None:  # noqa: A
         dt = float(t)
     final_loss = float(loss)
     peak_gib = round(torch.cuda.max_memory_reserved() / 2**30, 1)
+    n_launches = next(iter(step._recorded.values())).n_launches if step._recorded else None  # noqa: SLF001
+    step.replay = False  # the per-launch event timing below goes through the module code
     roofline = None
     if args.profile_steps > 0:
         from cinema_amd import tape as T_
@@ -252,7 +254,8 @@ def seg_main(args, rank: int, world: int, device: str, sync) -> None:  # noqa: A
                "config": {"workload": f"ConvUNetR ViT-{args.size.capitalize()} (ACDC decoder recipe), SAX {'x'.join(str(v) for v in sax)}, 4 classes, per-GPU batch "
                                       f"{batch_size}, dropout 0.1 / drop_path 0.1, fwd + CE/Dice + bwd + clip(5.0) + layer-decay(0.75) AdamW, random-init weights",
                           "global_batch": world * batch_size, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5), "peak_mem_gib": peak_gib,
-                          "host": "module code issues every launch (eager)",
+                          "host": ("module code issues every launch (--eager)" if args.eager else
+                                   f"forward + loss + backward re-issued from a recorded list of {n_launches} HIP launches (cinema_amd/replay.py); clip+AdamW eager"),
                           "reference_equiv_tflops_per_gpu": round(samples_per_s / world * SEG_STEP_GFLOP_PER_SAMPLE / 1e3, 1) if sax == (256, 256, 12) and args.size == "base" else None},
                "roofline": roofline}
         if world == 1 and args.cpu_budget > 0:

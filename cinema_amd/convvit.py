@@ -148,7 +148,8 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
             pe = self.pos_embed.detach().float().cpu().reshape(1, *self.patch_embed.grid_size, emb).movedim(-1, 1)
             pe = F.interpolate(pe, size=tuple(grid_size), mode=mode, antialias=False)
             cache.clear()
-            cache[key] = pe.movedim(1, -1).reshape(1, -1, emb).to(device=self.pos_embed.device, dtype=self.pos_embed.dtype)
+            host = pe.movedim(1, -1).reshape(1, -1, emb).contiguous()
+            cache[key] = K.persistent(lambda: host.to(device=self.pos_embed.device, dtype=self.pos_embed.dtype))  # outside a recording's private pool
         return cache[key]
 
     def grid_for(self, image_size: tuple) -> tuple:

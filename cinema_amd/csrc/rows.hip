@@ -614,6 +614,29 @@ CINEMA_API int cinema_conv_weight_dgrad(const float* w, uint16_t* rows, int c_ou
   return launch_status();
 }
 
+// ---- transposed-conv weights (k == s up-sampling, tape.op_conv_transpose): w fp32 (c_in, c_out, kvol) <-> GEMM rows [(kv, co)][ci]
+// direction 0: rows bf16 <- w (and bias_t[kv * c_out + co] = bias[co]); direction 1: w += rows fp32 (the gradient way back)
+__global__ __launch_bounds__(256) void convt_weight_relayout_kernel(float* w, void* rows, int c_in, int c_out, int kvol, int direction, const float* bias,
+                                                                     float* bias_t) {
+  const long long total = (long long)c_in * c_out * kvol;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % c_in);
+    const int r = (int)(i / c_in);  // kv * c_out + co
+    const int kv = r / c_out, co = r - kv * c_out;
+    const long long wi = ((long long)ci * c_out + co) * kvol + kv;
+    if (direction == 0) reinterpret_cast<bf16_t*>(rows)[i] = f2bf(w[wi]);
+    else w[wi] += reinterpret_cast<const float*>(rows)[i];
+  }
+  if (direction == 0 && bias && blockIdx.x == 0)
+    for (int j = threadIdx.x; j < kvol * c_out; j += blockDim.x) bias_t[j] = bias[j % c_out];
+}
+CINEMA_API int cinema_convt_weight_relayout(float* w, void* rows, int c_in, int c_out, int kvol, int direction, const float* bias, float* bias_t, void* stream) {
+  if (!w || !rows || c_in <= 0 || c_out <= 0 || kvol <= 0 || (direction != 0 && direction != 1) || (bias && !bias_t)) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(convt_weight_relayout_kernel, dim3(grid_for((long long)c_in * c_out * kvol, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, c_in, c_out, kvol,
+                direction, bias, bias_t);
+  return launch_status();
+}
+
 // ---- z-blocked implicit convolution (gemm.hip cinema_conv_gemm_bf16, conv_zb > 1): block-banded weights and the fold of their gradient
 __global__ __launch_bounds__(256) void conv_weight_zblock_kernel(const bf16_t* w, int n, int c, int ld_w, int zb, int transpose, bf16_t* out, const float* bias,
                                                                  float* bias_zb) {

@@ -143,6 +143,7 @@ _PROTOS = {
     "cinema_thin_linear_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_fanout_linear_fwd": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_fanout_linear_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "cinema_convt_weight_relayout": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "cinema_conv1ch_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_conv1ch_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_rng_advance": [_vp, _vp],
@@ -708,6 +709,37 @@ def rope_heads(x: torch.Tensor, n_slots: int, heads: int, head_dim: int, cos: to
 _RNG_STATE: dict = {}
 
 
+def persistent(fn):  # noqa: ANN001, ANN201
+    """Run ``fn()`` - which builds a device tensor whose CONTENT must survive for the life of the process (index tables, RNG state) - outside a recording's
+    private memory pool.  While a step is being recorded (cinema_amd/replay.py) the caching allocator hands freed blocks of the pool out again: a table built
+    at first use could land on the address of an earlier temporary, and every replay of the launches that wrote that temporary would overwrite the table
+    (seen as a memory fault of the implicit convolution reading a clobbered tap table).  ``torch.cuda.use_mem_pool`` routes only the CURRENT thread's
+    allocations, so the build runs on a helper thread."""
+    if RECORD is None:
+        return fn()
+    import threading
+
+    box: list = []
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def work() -> None:
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
+            box.append(fn())
+            if dev is not None:
+                torch.cuda.synchronize()  # built on this thread's default stream: complete before any consumer on the recording's streams
+        except BaseException as e:  # noqa: BLE001
+            box.append(e)
+
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    if isinstance(box[0], BaseException):
+        raise box[0]
+    return box[0]
+
+
 def rng_state(device: torch.device) -> torch.Tensor:
     """The per-device Philox state tensor (int64 [2]: step counter, seed); the seed is drawn from torch's generator on first use, so
     ``torch.manual_seed`` makes the dropout / drop-path masks reproducible."""
@@ -715,7 +747,7 @@ def rng_state(device: torch.device) -> torch.Tensor:
     st = _RNG_STATE.get(key)
     if st is None:
         seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
-        st = _RNG_STATE[key] = torch.tensor([0, seed], dtype=torch.int64, device=device)
+        st = _RNG_STATE[key] = persistent(lambda: torch.tensor([0, seed], dtype=torch.int64, device=device))
     return st
 
 
@@ -878,6 +910,29 @@ def patch_weight_grad_accumulate(g_rows: torch.Tensor, w_grad: torch.Tensor, jma
     kvol = w_grad[0, 0].numel()
     _check(load().cinema_patch_weight_relayout(w_grad.data_ptr(), g_rows.data_ptr(), 0, out, c, kvol, _rowmajor(g_rows, "g_rows"), _p(jmap), 1, _stream()),
            "patch_weight_relayout")
+
+
+def convt_weight_rows(w: torch.Tensor, bias: torch.Tensor | None = None) -> tuple:
+    """Transposed-conv weight fp32 (c_in, c_out, *k) -> (bf16 GEMM rows [(kv, c_out), c_in], bias repeated per kernel voxel or None)."""
+    _dev(w, bias)
+    if w.dtype != torch.float32 or not w.is_contiguous() or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != w.shape[1])):
+        raise HipLibraryError("convt_weight_rows: contiguous fp32 weight (c_in, c_out, *k), fp32 bias [c_out]")
+    c_in, c_out = w.shape[0], w.shape[1]
+    kvol = w[0, 0].numel()
+    rows = _empty((kvol * c_out, c_in), dtype=torch.bfloat16, device=w.device)
+    bias_t = None if bias is None else _empty(kvol * c_out, dtype=torch.float32, device=w.device)
+    _check(load().cinema_convt_weight_relayout(w.data_ptr(), rows.data_ptr(), c_in, c_out, kvol, 0, _p(bias), _p(bias_t), _stream()), "convt_weight_relayout")
+    return rows, bias_t
+
+
+def convt_weight_grad_accumulate(g_rows: torch.Tensor, w_grad: torch.Tensor) -> None:
+    """w_grad (c_in, c_out, *k) fp32 += g_rows fp32 [(kv, c_out), c_in]."""
+    _dev(g_rows, w_grad)
+    c_in, c_out = w_grad.shape[0], w_grad.shape[1]
+    kvol = w_grad[0, 0].numel()
+    if g_rows.dtype != torch.float32 or w_grad.dtype != torch.float32 or not w_grad.is_contiguous() or not g_rows.is_contiguous() or tuple(g_rows.shape) != (kvol * c_out, c_in):
+        raise HipLibraryError("convt_weight_grad_accumulate: fp32 rows [(kv, c_out), c_in], contiguous fp32 destination")
+    _check(load().cinema_convt_weight_relayout(w_grad.data_ptr(), g_rows.data_ptr(), c_in, c_out, kvol, 1, None, None, _stream()), "convt_weight_relayout")
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, row_idx: torch.Tensor | None = None) -> torch.Tensor:

@@ -118,3 +118,72 @@ class RecordedStep:
                 if rc != 0:
                     raise K.HipLibraryError(f"replayed launch {fn.__name__} failed: {rc}")
         return self.loss, self.metrics
+
+
+class RecordedSegStep:
+    """forward + CE / Dice loss + backward of the segmentation fine-tuning step for one input signature, as a launch list (see the module docstring).
+    The model is entered through ``forward_rows`` and the loss kernels read / write channels-last rows, so nothing but library launches sits between
+    the inputs and the flat gradient buffer; dropout / drop-path masks change per replay because the launch that advances the device RNG step is part
+    of the list.  ``run(batch)`` -> (loss, metrics) with the keys of ``segmentation_loss`` (static tensors, overwritten by the next run)."""
+
+    def __init__(self, model: torch.nn.Module, views: list, batch: dict, audit: bool = False) -> None:
+        self.model, self.views = model, list(views)
+        dev = next(model.parameters()).device
+        self.images = {v: batch[f"{v}_image"].detach().to(dev).float().contiguous().clone() for v in self.views}
+        self.labels = {v: batch[f"{v}_label"].detach().to(dev).reshape(-1).to(torch.int32).contiguous().clone() for v in self.views}
+        self.batch = next(iter(self.images.values())).shape[0]
+        self.pool = torch.cuda.MemPool()
+        self.unaccounted: list = []
+        T.WEIGHTS.invalidate()
+        calls: list = []
+        K.RECORD = calls
+        try:
+            with torch.cuda.use_mem_pool(self.pool):
+                if audit:
+                    with _Audit(self.unaccounted):
+                        self._eager_step()
+                else:
+                    self._eager_step()
+        finally:
+            K.RECORD, T.REC_CALL = None, None
+        self.calls = calls
+        self.n_launches = sum(1 for fn, _ in calls if fn is not None)
+        self.loss, self.metrics = self._collect()
+
+    def _eager_step(self) -> None:
+        rows = self.model.forward_rows(self.images)
+        up = K.full((1,), 1.0 / len(self.views), torch.float32, self.labels[self.views[0]].device)  # d (mean over views) / d loss_v as a recorded fill
+        self.out4, grads = {}, []
+        for v in self.views:
+            out4, coef = K.seg_loss_fwd(rows[v], self.labels[v], self.batch)
+            grads.append(K.seg_loss_bwd(rows[v], self.labels[v], self.batch, coef, out4, up))
+            self.out4[v] = out4
+        T.REC_CALL.backward(*grads)  # on this thread (inside the memory pool), not through the autograd engine
+
+    def _collect(self) -> tuple:
+        """The metric dict of ``segmentation_loss_tensors`` from the loss kernels' result vectors (a few 0-d ops per step, outside the list)."""
+        with allowed_aten():
+            metrics, n = {}, len(self.views)
+            for v in self.views:
+                o = self.out4[v]
+                metrics.update({f"{v}_cross_entropy": o[1], f"{v}_mean_dice_loss": o[2], f"{v}_loss": o[0], f"{v}_{v}_loss": o[0]})
+            loss = sum(self.out4[v][0] for v in self.views) / n
+            metrics["loss"] = loss
+            for k in ("cross_entropy", "mean_dice_loss", "loss"):
+                if k != "loss":
+                    metrics[k] = sum(metrics[f"{v}_{k}"] for v in self.views) / n
+            return loss, metrics
+
+    def run(self, batch: dict):  # noqa: ANN201
+        for v in self.views:
+            self.images[v].copy_(batch[f"{v}_image"], non_blocking=True)
+            self.labels[v].copy_(batch[f"{v}_label"].reshape(-1), non_blocking=True)
+        for fn, args in self.calls:
+            if fn is None:
+                args()
+            else:
+                rc = fn(*args)
+                if rc != 0:
+                    raise K.HipLibraryError(f"replayed launch {fn.__name__} failed: {rc}")
+        self.loss, self.metrics = self._collect()
+        return self.loss, self.metrics

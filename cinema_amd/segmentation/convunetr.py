@@ -178,6 +178,14 @@ class ConvUNetR(nn.Module):
             self.enc_down_dict[v].set_grad_ckpt(enable)
 
     def forward(self, image_dict: dict) -> dict:
+        """Logits (batch, out_chans, *image_size) per view, channels first like the reference."""
+        rows = self.forward_rows(image_dict)
+        batch = next(iter(image_dict.values())).shape[0]
+        return {v: r.reshape(batch, *image_dict[v].shape[2:], -1).movedim(-1, 1).contiguous() for v, r in rows.items()}
+
+    def forward_rows(self, image_dict: dict) -> dict:
+        """The same forward with the logits left as the kernels produce them: fp32 channels-last rows [batch * prod(image_size), out_chans] per view (what the
+        loss kernels read; the recorded fine-tuning step uses this entry so that no layout copy sits between the model and the loss)."""
         views = list(image_dict.keys())
         if any(v not in self.views for v in views):
             raise ValueError(f"views {views} must be in self.input_keys {self.views}.")
@@ -218,7 +226,7 @@ class ConvUNetR(nn.Module):
             return outs, []
 
         res = T.taped_call(run, [], T.trainable_params(self))
-        return {v: r.reshape(batch, *images[v].shape[2:], -1).movedim(-1, 1).contiguous() for v, r in zip(views, res)}
+        return dict(zip(views, res))
 
     @classmethod
     def from_finetuned(cls, repo_id: str | None = None, model_filename: str | None = None, config_filename: str | None = None, *,

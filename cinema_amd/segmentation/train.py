@@ -103,9 +103,39 @@ class SegTrainStep(FineTuneStep):
     metrics) as device tensors."""
 
     def __init__(self, model, views: list, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, layer_decay: float | None = 0.75,  # noqa: ANN001
-                 clip_grad: float | None = 5.0, synchronizer=None) -> None:  # noqa: ANN001
+                 clip_grad: float | None = 5.0, synchronizer=None, replay: bool = False, audit: bool = False) -> None:  # noqa: ANN001
         super().__init__(model, views, segmentation_loss_tensors, lr=lr, betas=betas, weight_decay=weight_decay, layer_decay=layer_decay,
                          clip_grad=clip_grad, synchronizer=synchronizer)
+        # replay: forward + loss + backward recorded once per input signature as the flat list of this library's launches and re-issued from it
+        # (cinema_amd/replay.py RecordedSegStep): the module code needs ~50 ms of host time for the ~2000 launches of config 4, as long as the GPU needs
+        self.replay, self.audit = replay, audit
+        self._recorded: dict = {}
+
+    def reset_recordings(self) -> None:
+        """Drop the recorded steps (after changing ``requires_grad`` flags, train / eval mode or sub-modules)."""
+        self._recorded.clear()
+
+    def __call__(self, batch: dict, n_accum_steps: int = 1, update_grad: bool = True) -> tuple:
+        if not (self.replay and n_accum_steps == 1 and self.model.training):
+            return super().__call__(batch, n_accum_steps, update_grad)
+        from cinema_amd.replay import RecordedSegStep
+
+        if self.sync is not None:
+            self.sync.arm(update_grad)
+        key = tuple((v, tuple(batch[f"{v}_image"].shape), tuple(batch[f"{v}_label"].shape)) for v in self.views)
+        rec = self._recorded.get(key)
+        if rec is None:  # the recording IS this step
+            rec = self._recorded[key] = RecordedSegStep(self.model, self.views, batch, audit=self.audit)
+            loss, metrics = rec.loss, rec.metrics
+        else:
+            loss, metrics = rec.run(batch)
+        grad_norm = None
+        if update_grad:
+            if self.sync is not None:
+                self.sync.all_reduce()
+            grad_norm = self.optimizer.step(self.clip_grad)
+            self.optimizer.zero_grad()
+        return loss, grad_norm, metrics
 
 
 # ---------------------------------------------------------------------------------------------------------------------

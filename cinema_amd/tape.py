@@ -96,7 +96,7 @@ def const(key: tuple, fn: Callable) -> torch.Tensor:
     t = _CONST.get(key)
     if t is None:
         with _Allowed():
-            t = _CONST[key] = fn()
+            t = _CONST[key] = K.persistent(fn)  # never from a recording's private pool: its content is not rebuilt by the replayed launches
     return t
 
 
@@ -1050,12 +1050,7 @@ def _chan_last_strides(chans: int, spatial: tuple) -> tuple:
 def w_conv_transpose(weight: torch.nn.Parameter) -> torch.Tensor:
     """ConvTranspose weight (c_in, c_out, *k) -> bf16 [(*k, c_out), c_in]: one GEMM gives every output voxel of a k == s up-sampling."""
 
-    def build() -> torch.Tensor:
-        w = weight.detach()
-        perm = (*range(2, w.dim()), 1, 0)
-        return K.cast(w.permute(perm).reshape(-1, w.shape[0]).contiguous(), BF16)
-
-    return WEIGHTS.get((weight,), "conv_transpose", build)
+    return WEIGHTS.get((weight,), "conv_transpose", lambda: K.convt_weight_rows(weight.detach())[0])
 
 
 def conv_transpose_grad_to_param(weight: torch.nn.Parameter) -> Callable:
@@ -1066,6 +1061,7 @@ def conv_transpose_grad_to_param(weight: torch.nn.Parameter) -> Callable:
         g = g.reshape(*shape[2:], shape[1], shape[0])
         return g.permute(nd + 1, nd, *range(nd)).contiguous()
 
+    conv.hip_relayout = ("convt",)  # the flat-buffer path adds the rows with one re-layout kernel (cinema_convt_weight_relayout) instead of this permute
     return conv
 
 
@@ -1078,7 +1074,7 @@ def op_conv_transpose(tape: Tape, x: Var, batch: int, spatial: tuple, weight: to
     c_out = weight.shape[1]
     k_vol = math.prod(ks)
     wt = w_conv_transpose(weight)
-    bias_t = None if bias is None else WEIGHTS.get((bias,), f"tile{k_vol}", lambda: bias.detach().repeat(k_vol).contiguous())
+    bias_t = None if bias is None else WEIGHTS.get((weight, bias), f"tile{k_vol}", lambda: K.convt_weight_rows(weight.detach(), bias.detach())[1])
     rows = K.gemm(x.data, wt, bias=bias_t)
     out_spatial = tuple(s * k for s, k in zip(spatial, ks))
     n_out = batch * math.prod(out_spatial)
@@ -1287,7 +1283,10 @@ class _TapedCall(torch.autograd.Function):
             in_flat = flat is not None and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)()
             tagged = getattr(pv.to_param_layout, "hip_relayout", None) if pv is not None else None
             if tagged is not None and in_flat and pv.grad is not None and not pv.direct and p.requires_grad:
-                K.patch_weight_grad_accumulate(pv.grad.view(p.shape[0], -1), flat.view(p.shape), tagged[0])  # re-layout + add, one kernel
+                if tagged[0] == "convt":  # transposed-conv rows [(kv, c_out), c_in] -> (c_in, c_out, *k)
+                    K.convt_weight_grad_accumulate(pv.grad.contiguous(), flat.view(p.shape))
+                else:
+                    K.patch_weight_grad_accumulate(pv.grad.view(p.shape[0], -1), flat.view(p.shape), tagged[0])  # re-layout + add, one kernel
                 p_grads.append(None)
                 continue
             g = pv.final_grad() if (pv is not None and p.requires_grad) else None

@@ -364,6 +364,10 @@ int cinema_visible_index(const int* keep, int n_rows, int n_dims, const int* gri
  *   jmap[kvol] (optional): row feature block jj holds kernel voxel jmap[jj] (visible-voxel stem ordering). */
 int cinema_patch_weight_relayout(float* w, void* rows, int rows_is_bf16, int outer, int c, int kvol, int ld, const int* jmap, int direction, void* stream);
 
+/* The same for the k == s transposed convolutions of UpsampleDecoder (cinema/segmentation/convunetr.py:62-101): w fp32 (c_in, c_out, kvol) <-> GEMM rows
+ * [(kv, co)][ci]; direction 0: rows bf16 <- w and, with bias, bias_t[kv * c_out + co] = bias[co]; direction 1: w += rows (fp32 gradient rows). */
+int cinema_convt_weight_relayout(float* w, void* rows, int c_in, int c_out, int kvol, int direction, const float* bias, float* bias_t, void* stream);
+
 /* elementwise: dtype codes as above */
 int cinema_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
 /* dst[c][r] = src[r][c] (bf16 out); src fp32 or bf16 */

@@ -283,3 +283,48 @@ def test_metric_module_stability_and_volumes_on_the_device() -> None:
     assert torch.allclose(vol, onehot.sum(dim=(2, 3, 4)) * (1.25 * 1.25 * 10.0) / 1000.0, rtol=1e-6)
     with pytest.raises(NotImplementedError):
         stability_score(logits.to(DEV), threshold_offset=0.5)
+
+
+def test_recorded_seg_step_replays_the_eager_step() -> None:
+    """``SegTrainStep(replay=True)`` (cinema_amd/replay.py RecordedSegStep): with dropout 0 the recorded / replayed trajectory equals the eager one from
+    the same weights (three steps, two views); the audit finds no device work outside the launch list; with dropout 0.1 the replays draw new masks."""
+    import copy
+
+    from cinema_amd.segmentation.train import SegTrainStep
+
+    base, g, _ = mini_unetr()
+    images = {k: v for k, v in split(g, "image/").items()}
+    views = list(images)
+    gen = torch.Generator().manual_seed(4)
+    batches = []
+    for _ in range(3):
+        imgs = {v: torch.rand(images[v].shape, generator=gen) for v in views}
+        batches.append({**{f"{v}_image": imgs[v].to(DEV) for v in views}, **{f"{v}_label": torch.clamp((imgs[v] * 4).long(), 0, 3).to(DEV) for v in views}})
+    eager_model, rec_model = copy.deepcopy(base).to(DEV).train(), copy.deepcopy(base).to(DEV).train()
+    eager = SegTrainStep(eager_model, views, lr=1e-3, layer_decay=0.75)
+    rec = SegTrainStep(rec_model, views, lr=1e-3, layer_decay=0.75, replay=True, audit=True)
+    for i, batch in enumerate(batches):
+        le, ge, me = eager(batch)
+        lr_, gr, mr = rec(batch)
+        assert float(lr_) == pytest.approx(float(le), rel=2e-4), i
+        assert float(gr) == pytest.approx(float(ge), rel=2e-3), i
+        assert set(mr) == set(me)
+        for k in me:
+            assert float(mr[k]) == pytest.approx(float(me[k]), rel=2e-4, abs=1e-6), (i, k)
+    (recording,) = rec._recorded.values()  # noqa: SLF001
+    assert recording.unaccounted == [], recording.unaccounted[:5]
+    assert recording.n_launches > 200
+    diff = (eager.flat.flat_param - rec.flat.flat_param).abs()
+    # three AdamW steps at lr 1e-3: an element whose tiny gradient changes sign with the summation order of the atomic reductions moves by a few lr (Adam's normalised step is O(1) and flips with the sign)
+    assert float(diff.max()) <= 1e-2 and float(diff.mean()) <= 5e-5, (float(diff.max()), float(diff.mean()))  # measured 1.3e-3 .. 4.0e-3 / 1.5e-5
+    # accumulation steps and eval mode fall back to the eager path
+    assert rec(batches[0], n_accum_steps=2, update_grad=False)[1] is None
+    # dropout: the replayed list advances the device RNG step, so two replays of the same batch differ
+    K.rng_seed(torch.device(DEV), 11)
+    drop, _, _ = mini_unetr(dropout=0.1, drop_path=0.1)
+    drop.to(DEV).train()
+    st = SegTrainStep(drop, views, lr=0.0, replay=True)  # lr 0: the weights stay, only the masks change
+    l0 = float(st(batches[0])[0])
+    l1 = float(st(batches[0])[0])
+    l2 = float(st(batches[0])[0])
+    assert len({round(l0, 7), round(l1, 7), round(l2, 7)}) == 3
