@@ -305,3 +305,27 @@ def test_pretrain_one_epoch_loop_follows_the_reference_schedule() -> None:
     assert {"loss", "grad_norm", "lr", "n_samples"} <= set(logs[0]) and any(k.endswith("mse_loss") for k in logs[0])
     assert all(torch.isfinite(lg["grad_norm"]) for lg in logs)
     assert float(logs[-1]["loss"]) < float(logs[0]["loss"])
+
+
+def test_persistent_tables_are_not_allocated_from_a_recording_pool() -> None:
+    """``hip.persistent`` / ``tape.const`` inside a recording: the table must not land on a block of the recording's private pool (the allocator would
+    reuse the address of a freed temporary, and replaying the launches that wrote the temporary would overwrite the table)."""
+    from cinema_amd import tape as T
+
+    pool = torch.cuda.MemPool()
+    K.RECORD = []
+    try:
+        with torch.cuda.use_mem_pool(pool):
+            tmp = torch.empty(1 << 20, dtype=torch.float32, device=DEV)
+            lo, hi = tmp.data_ptr(), tmp.data_ptr() + tmp.numel() * 4
+            del tmp  # back to the pool: the next allocation of this size on this thread gets the same block
+            again = torch.empty(1 << 20, dtype=torch.float32, device=DEV)
+            assert again.data_ptr() == lo  # the hazard the helper avoids
+            del again
+            table = T.const(("test_persistent_table", 1 << 20), lambda: torch.arange(1 << 20, dtype=torch.float32).to(DEV))
+            assert not (lo <= table.data_ptr() < hi)
+            state = K.persistent(lambda: torch.zeros(1 << 20, dtype=torch.float32, device=DEV))
+            assert not (lo <= state.data_ptr() < hi)
+            assert float(table[12345]) == 12345.0
+    finally:
+        K.RECORD = None
