@@ -328,3 +328,33 @@ def test_recorded_seg_step_replays_the_eager_step() -> None:
     l1 = float(st(batches[0])[0])
     l2 = float(st(batches[0])[0])
     assert len({round(l0, 7), round(l1, 7), round(l2, 7)}) == 3
+
+
+def test_config4_shape_recorded_step_matches_the_eager_step() -> None:
+    """The recorded step at the REAL config-4 shape (batch 2, dropout 0 so that both runs are deterministic): two replays after the recording give the eager
+    losses.  This is the size at which index tables built during the recording used to be overwritten on replay (hip.persistent)."""
+    import copy
+
+    from cinema_amd.segmentation.train import SegTrainStep
+    from cinema_amd.vit import get_vit_config
+
+    vit = get_vit_config("base")
+    torch.manual_seed(0)
+    base = ConvUNetR(image_size_dict={"sax": (256, 256, 12)}, in_chans_dict={"sax": 1}, out_chans=4, enc_patch_size_dict={"sax": (4, 4, 1)},
+                     enc_scale_factor_dict={"sax": (2, 2, 1)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2, enc_embed_dim=vit["enc_embed_dim"],
+                     enc_depth=vit["enc_depth"], enc_n_heads=vit["enc_n_heads"], dec_chans=(32, 64, 128, 256, 512), dec_patch_size_dict={"sax": (2, 2, 1)},
+                     dec_scale_factor_dict={"sax": (2, 2, 1)})
+    gen = torch.Generator().manual_seed(2)
+    batches = []
+    for _ in range(2):
+        image = torch.rand(2, 1, 256, 256, 12, generator=gen)
+        batches.append({"sax_image": image.to(DEV), "sax_label": torch.clamp((image * 4).long(), 0, 3).to(torch.int8).to(DEV)})
+    losses = {}
+    for mode in ("eager", "replay"):
+        model = copy.deepcopy(base).to(DEV).train()
+        step = SegTrainStep(model, ["sax"], lr=3e-4, layer_decay=0.75, replay=mode == "replay")
+        losses[mode] = [float(step(batches[i % 2])[0]) for i in range(3)]
+        del step, model
+        torch.cuda.empty_cache()
+    for a, b in zip(losses["eager"], losses["replay"]):
+        assert math.isfinite(b) and b == pytest.approx(a, rel=2e-3), losses
