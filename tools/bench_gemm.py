@@ -18,6 +18,7 @@ SHAPES = [
     ("4096^3", 4096, 4096, 4096),
     ("enc qkv", 10960, 2304, 768), ("enc proj", 10960, 768, 768), ("enc fc1", 10960, 3072, 768), ("enc fc2", 10960, 768, 3072),
     ("dec q/proj", 32848, 512, 512), ("dec kv", 10944, 1024, 512), ("dec fc1", 32848, 2048, 512), ("dec fc2", 32848, 512, 2048),
+    ("X dec kv fused", 10944, 8192, 512), ("X dec kv one", 10944, 1024, 512),
     ("F enc qkv", 10752, 2304, 768), ("F enc proj", 10752, 768, 768), ("F enc fc1", 10752, 3072, 768), ("F enc fc2", 10752, 768, 3072),
     ("F dec proj", 32768, 512, 512), ("F dec fc1", 32768, 2048, 512), ("F dec fc2", 32768, 512, 2048),
     ("stem1 1x1", 589824, 64, 64), ("stem1 fc1", 589824, 256, 64), ("stem1 fc2", 589824, 64, 256),
