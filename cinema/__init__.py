@@ -3,8 +3,8 @@
 ``from cinema import CineMA, ConvViT, ConvUNetR, patchify, unpatchify`` and the sub-module imports the reference's training / inference
 scripts use (``cinema.mae.mae``, ``cinema.convvit``, ``cinema.vit``, ``cinema.conv``, ``cinema.rotary``, ``cinema.optim``, ``cinema.device``, ``cinema.transform``,
 ``cinema.segmentation.convunetr``, ``cinema.segmentation.train``, ``cinema.classification.train``, ``cinema.regression.train``) resolve to the ``cinema_amd`` modules of the same name: one set of
-classes, two import names.  Only the hot path is aliased; data loading, hydra entry points, the landmark heat-map helpers of
-``cinema.metric`` and the ResNet / UNet baselines are not part of this build and are not faked here.
+classes, two import names.  Only the hot path is aliased; data loading, hydra entry points, the landmark models and the ResNet / UNet
+baselines are not part of this build and are not faked here.
 """
 
 import importlib
@@ -39,6 +39,7 @@ for _alias, _target in _ALIASES.items():
         globals()[_leaf] = _mod
 
 from cinema_amd import CineMA, ConvUNetR, ConvViT, patchify, unpatchify  # noqa: E402
+from cinema_amd.metric import heatmap_soft_argmax  # noqa: E402
 
 # dataset constants of the reference package root (cinema/__init__.py:9-21)
 UKB_SPACING = (1.0, 1.0, 10.0)
@@ -51,4 +52,4 @@ MYO_LABEL = 2
 LV_LABEL = 3
 LABEL_TO_NAME = {RV_LABEL: "RV", MYO_LABEL: "MYO", LV_LABEL: "LV"}
 
-__all__ = ["LABEL_TO_NAME", "LV_LABEL", "MYO_LABEL", "RV_LABEL", "CineMA", "ConvUNetR", "ConvViT", "patchify", "unpatchify"]
+__all__ = ["LABEL_TO_NAME", "LV_LABEL", "MYO_LABEL", "RV_LABEL", "CineMA", "ConvUNetR", "ConvViT", "heatmap_soft_argmax", "patchify", "unpatchify"]

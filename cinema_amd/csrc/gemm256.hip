@@ -1,0 +1,500 @@
+// Persistent 256x256x64 bf16 GEMM for gfx950 with the split reduction finished inside the launch.
+//
+// One workgroup of 8 waves (2 x 4, a wave owns 128 x 64 outputs = 4 x 2 MFMA 32x32x16 blocks) per CU, 128 KiB of LDS as two 64 KiB k-tile
+// stages filled by LDS-DMA (the 256-row operand tile is two of gemm_shared.cuh's 128-row sub-tiles, so loaders, swizzles and fragment reads are
+// the 128x128 kernel's).  Half the staged bytes per FLOP of the 128x128 tile - the 128x128 loop is bound by that stream.
+//
+// Work is a list of PIECES: (problem, output tile, k-tile range).  Two schedules:
+//   split   - every tile of problem i is cut into split[i] equal k-slices (the host balances the slice lengths over up to 8 problems: the weight
+//             gradients of one transformer block in one launch); workgroups walk the pieces grid-stride, slice-major so that neighbours share panels
+//   stream  - the (tile, k-tile) units of one problem are dealt to the workgroups as equal contiguous ranges (tile counts like 129 on 256 CUs)
+// A tile cut into n pieces is finished by its LAST ARRIVER: a piece takes a ticket from the tile's arrival counter; tickets 0..n-2 store their
+// accumulators as a fragment-ordered fp32 slot (write-through sc1 stores, 1 KiB per wave-instruction), drain, and bump the tile's publish counter;
+// ticket n-1 keeps its accumulators, waits for n-1 publishes (its partners arrived before it and never wait themselves: no deadlock for any dispatch
+// order or co-residency), adds their slots and runs the fused epilogue.  The last arriver zeroes both counters: no per-launch memset, no reduce
+// launch, no fp32 slab round trip through a second kernel.  Visibility follows the CDNA4 recipe (sc1 payload + per-wave vmcnt(0) + barrier + relaxed
+// agent counter; consumer: relaxed poll, ONE agent acquire, barrier, plain loads) and does not depend on placement.
+#include "gemm_shared.cuh"
+
+namespace {
+
+constexpr int P_TILE = 256;
+constexpr int P_SUB = 16384;                 // one 128-row (or 128-column) operand sub-tile of a k-tile
+constexpr int P_STAGE = 4 * P_SUB;           // A0 A1 B0 B1
+constexpr int P_CTL = 2 * P_STAGE;           // control words behind the two stages
+constexpr int P_SMEM = P_CTL + 64;
+constexpr int P_SLOT_FLOATS = P_TILE * P_TILE;
+constexpr int P_MAX = 8;
+constexpr int P_COUNTER_BYTES = 65536;       // head of the workspace: 2 counters per output tile (zero on entry, left zero)
+
+struct P256 {
+  GemmP p[P_MAX];
+  int count, mode;               // mode 0 = split, 1 = stream
+  int tile_begin[P_MAX + 1];     // prefix sums of the 256x256 tile counts (global tile id = counter index)
+  int piece_begin[P_MAX + 1];    // split: prefix sums of tiles_i * split_i
+  int split[P_MAX], kts[P_MAX];  // split: slices per tile, k-tiles per slice
+  int nkt[P_MAX];
+  long long units;               // stream: tiles_0 * nkt_0
+  int per, rem;                  // stream: units per workgroup; the first `rem` workgroups take one more
+  float* slots;                  // fp32 partial slots [..][P_SLOT_FLOATS]
+  unsigned* counters;
+  unsigned* error;               // set to 1 when a bounded spin gives up (never in a healthy run)
+};
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ long long stream_start(const P256& g, int wg) { return (long long)wg * g.per + min(wg, g.rem); }
+__device__ __forceinline__ int stream_owner_of(const P256& g, long long u) {  // workgroup whose range holds unit u
+  const long long big = (long long)g.rem * (g.per + 1);
+  return u < big ? (int)(u / (g.per + 1)) : g.rem + (int)((u - big) / g.per);
+}
+
+// ---- main loop, form 0: k-tiles of 64, two 64 KiB stages, one barrier per k-tile (every wave: fragment reads, then MFMAs, hipcc's interleave)
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void p256_loop64(const GemmP& p, int m0, int n0, int kt_begin, int kt_end, float16v (&acc)[4][2], float (&rs)[4], bool do_rowsum,
+                                            char* smem) {
+  using AIO = TileIO<A_KMAJ>;
+  using BIO = TileIO<B_KMAJ>;
+  const int lane = threadIdx.x & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wr = wave_u >> 2, wc = wave_u & 3;      // wave grid 2 (m) x 4 (n)
+  const int sub = wave_u >> 2, w4 = wave_u & 3;     // loader role: waves 0-3 fill sub-tile 0 of A and B, waves 4-7 sub-tile 1
+  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const typename AIO::Src4 asrc = AIO::src4(p.a, p.lda, m0 + sub * 128, p.m, lane, w4);
+  const typename BIO::Src4 bsrc = BIO::src4(p.b, p.ldb, n0 + sub * 128, p.n, lane, w4);
+  const size_t astep = AIO::k_step(p.lda), bstep = BIO::k_step(p.ldb);
+  const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  auto load_tile = [&](int stage, int kt) {
+    const uint32_t a_dst = smem_addr + stage * P_STAGE + sub * P_SUB, b_dst = a_dst + 2 * P_SUB;
+    if ((kt + 1) * BK <= p.k) {
+      AIO::glds_at(a_dst, asrc, (size_t)kt * astep, w4);
+      BIO::glds_at(b_dst, bsrc, (size_t)kt * bstep, w4);
+    } else {  // ragged last k-tile: per-element range tests, zero page
+      AIO::glds(smem + stage * P_STAGE + sub * P_SUB, p.a, p.lda, m0 + sub * 128, p.m, kt * BK, p.k, lane, w4, zero_page);
+      BIO::glds(smem + stage * P_STAGE + (2 + sub) * P_SUB, p.b, p.ldb, n0 + sub * 128, p.n, kt * BK, p.k, lane, w4, zero_page);
+    }
+  };
+  load_tile(0, kt_begin);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; kt++) {
+    const int cur = (kt - kt_begin) & 1;
+    const char* sa = smem + cur * P_STAGE + wr * P_SUB;
+    const char* sb = smem + cur * P_STAGE + (2 + (wc >> 1)) * P_SUB;
+    const int bcol = (wc & 1) * 64;
+    const bool more = kt + 1 < kt_end;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      short8v fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[i] = AIO::frag(sa, i * 32, ks, lane);
+      fb[0] = BIO::frag(sb, bcol, ks, lane);
+      fb[1] = BIO::frag(sb, bcol + 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs[i] += frag_sum8(fa[i]);
+      }
+      if (ks == 0 && more) load_tile(cur ^ 1, kt + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// ---- main loop, form 1: PHASES of 32 k, ring of four 32 KiB half-stages, the two waves of a SIMD half a phase apart.
+// A phase of one wave = READ segment (its 12 operand fragments of the phase: 12 ds_read_b128 or 24 ds_read_b64_tr_b16) | barrier | MFMA segment (16 MFMAs at
+// priority 1, the LDS-DMA of the phase three ahead issued between them: its issue slots are free there) | barrier.  Waves 4-7 run one barrier behind
+// waves 0-3, so on every SIMD one wave computes while its partner reads: the matrix pipe sees MFMA segments back to back, the LDS sees one group of
+// four readers at a time.  DMA(p + 3) is issued in MFMA(p) into the half-stage last read in phase p - 1 (two barriers earlier for every wave) and waited
+// for with a COUNTED vmcnt at the end of READ(p + 2) - three intervals of flight - so no wave ever drains its queue inside the loop.
+#define P256_BAR() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+constexpr int P_HS = 32768;   // half-stage: A sub-tiles 0, 1 then B sub-tiles 0, 1, 8 KiB each
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int ph_begin, int ph_end, float16v (&acc)[4][2], float (&rs)[4], bool do_rowsum,
+                                            char* smem) {
+  using AIO = TileIO32<A_KMAJ>;
+  using BIO = TileIO32<B_KMAJ>;
+  const int lane = threadIdx.x & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wr = wave_u >> 2, wc = wave_u & 3;
+  const int sub = wave_u >> 2, w4 = wave_u & 3;
+  const bf16_t* zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const typename AIO::Src2 asrc = AIO::src2(p.a, p.lda, m0 + sub * 128, p.m, lane, w4);
+  const typename BIO::Src2 bsrc = BIO::src2(p.b, p.ldb, n0 + sub * 128, p.n, lane, w4);
+  const size_t astep = AIO::k_step(p.lda), bstep = BIO::k_step(p.ldb);
+  const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  // validity of this lane's pieces in a ragged last phase (k0 + 32 > K): k-major operand: the lane's 16-byte chunk covers 8 k; reduction-strided
+  // operand: piece pss covers k row (pss * 4 + w4) * 4 + lane / 16
+  auto issue = [&](int ph) {
+    const uint32_t dst = smem_addr + (ph & 3) * P_HS + sub * 8192 + w4 * 1024;
+    const size_t ka = (size_t)ph * astep, kb = (size_t)ph * bstep;
+    const bf16_t *a0 = asrc.p[0] + ka, *a1 = asrc.p[1] + ka, *b0 = bsrc.p[0] + kb, *b1 = bsrc.p[1] + kb;
+    if ((ph + 1) * 32 > p.k) {
+      const int k0 = ph * 32;
+      if (A_KMAJ) {
+        const int r0 = w4 * 16 + (lane >> 2), r1 = r0 + 64;
+        if (k0 + (((lane & 3) ^ ((r0 >> 2) & 3)) << 3) >= p.k) a0 = zero_page;
+        if (k0 + (((lane & 3) ^ ((r1 >> 2) & 3)) << 3) >= p.k) a1 = zero_page;
+      } else {
+        if (k0 + w4 * 4 + (lane >> 4) >= p.k) a0 = zero_page;
+        if (k0 + (4 + w4) * 4 + (lane >> 4) >= p.k) a1 = zero_page;
+      }
+      if (B_KMAJ) {
+        const int r0 = w4 * 16 + (lane >> 2), r1 = r0 + 64;
+        if (k0 + (((lane & 3) ^ ((r0 >> 2) & 3)) << 3) >= p.k) b0 = zero_page;
+        if (k0 + (((lane & 3) ^ ((r1 >> 2) & 3)) << 3) >= p.k) b1 = zero_page;
+      } else {
+        if (k0 + w4 * 4 + (lane >> 4) >= p.k) b0 = zero_page;
+        if (k0 + (4 + w4) * 4 + (lane >> 4) >= p.k) b1 = zero_page;
+      }
+    }
+    glds16x4(dst, dst + 4096, dst + 16384, dst + 16384 + 4096, a0, a1, b0, b1);
+  };
+  const int nph = ph_end - ph_begin;
+  // prologue: phases 0..2 in flight, phase 0 landed
+  issue(ph_begin);
+  if (nph > 1) issue(ph_begin + 1);
+  if (nph > 2) issue(ph_begin + 2);
+  if (nph > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nph > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P256_BAR();
+  if (wr == 1) P256_BAR();   // waves 4-7 run one barrier behind
+  const int bcol = (wc & 1) * 64;
+  for (int q = 0; q < nph; q++) {
+    const int ph = ph_begin + q;
+    const char* hs = smem + (ph & 3) * P_HS;
+    const char* sa = hs + wr * 8192;
+    const char* sb = hs + 16384 + (wc >> 1) * 8192;
+    short8v fa[2][4], fb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      fb[ks][0] = BIO::frag(sb, bcol, ks, lane);
+      fb[ks][1] = BIO::frag(sb, bcol + 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[ks][i] = AIO::frag(sa, i * 32, ks, lane);
+    }
+    // DMA(ph + 1) must have landed before the barrier that lets anyone read it; DMA(ph + 2) (the youngest, if issued) stays in flight
+    if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P256_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+      if (ks == 0 && q + 3 < nph) issue(ph + 3);
+      if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs[i] += frag_sum8(fa[ks][i]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    P256_BAR();
+  }
+  if (wr == 0) P256_BAR();
+}
+
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int LOOP>
+__device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gtile, int tile, int kt_begin, int kt_end, int n_pieces,
+                                           float* my_slot, int first_other, int n_other, long long tile_unit0, int me, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wr = wave_u >> 2, wc = wave_u & 3;      // wave grid 2 (m) x 4 (n)
+  const int tiles_n = (p.n + P_TILE - 1) / P_TILE, tiles_m = (p.m + P_TILE - 1) / P_TILE;
+  int tm, tn;
+  tile_of(tile, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * P_TILE, n0 = tn * P_TILE;
+
+  float16v acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_rowsum = !A_KMAJ && p.a_rowsum != nullptr && wc == 0 && n0 == 0;
+  if (LOOP == 0) p256_loop64<A_KMAJ, B_KMAJ>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
+  else p256_loop32<A_KMAJ, B_KMAJ>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
+
+  if (do_rowsum) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float t = rs[i] + __shfl_xor(rs[i], 32, 64);
+      const int m = m0 + wr * 128 + i * 32 + lane;
+      if (lane < 32 && m < p.m) unsafeAtomicAdd(p.a_rowsum + m, t);
+    }
+  }
+
+  // ---- split reduction: last arriver finishes the tile
+  if (n_pieces > 1) {
+    unsigned* cnt = g.counters + 2 * gtile;
+    volatile unsigned* ctl = reinterpret_cast<volatile unsigned*>(smem + P_CTL);
+    if (tid == 0) ctl[0] = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = ctl[0];
+    __syncthreads();
+    if (ticket != (unsigned)(n_pieces - 1)) {
+      // publish: fragment order, wave w / register quad q / lane l -> float4 index (w * 32 + q) * 64 + l
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(my_slot, 0, P_SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int idx = (wave_u * 32 + (i * 2 + j) * 4 + q) * 64 + lane;
+            u32x4v v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
+                        __float_as_uint(acc[i][j][4 * q + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, idx * 16, 0, 16 /* sc1: write-through */);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(n_pieces - 1)) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 26)) { *g.error = 1u; break; }
+      }
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // left zero for the next launch on this workspace
+      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    for (int o = 0; o < n_other; o++) {
+      const float* src;
+      if (g.mode == 0) {
+        const int s = first_other + o + ((first_other + o >= me) ? 1 : 0);  // slices 0..n-1 except mine
+        src = my_slot + ((long long)s - me) * tiles_m * tiles_n * (long long)P_SLOT_FLOATS;   // slice-major piece order: same tile, slice s
+      } else {
+        int w = first_other + o;
+        if (w >= me) w++;
+        const int which = stream_start(g, w) >= tile_unit0 ? 0 : 1;
+        src = g.slots + ((long long)w * 2 + which) * P_SLOT_FLOATS;
+      }
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float4 t[8];
+#pragma unroll
+        for (int jq = 0; jq < 8; jq++) t[jq] = s4[(wave_u * 32 + i * 8 + jq) * 64 + lane];
+#pragma unroll
+        for (int jq = 0; jq < 8; jq++) {
+          const int j = jq >> 2, q = jq & 3;
+          acc[i][j][4 * q] += t[jq].x; acc[i][j][4 * q + 1] += t[jq].y; acc[i][j][4 * q + 2] += t[jq].z; acc[i][j][4 * q + 3] += t[jq].w;
+        }
+      }
+    }
+  }
+
+  // ---- fused epilogue, one 32 x 64 block row of the wave tile at a time through 8 KiB of LDS per wave (both stages are free)
+  float* stg = reinterpret_cast<float*>(smem + wave * 8192);
+  GemmP q = p;
+  q.ws = nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; i++) half_epilogue<EPI>(q, acc[i], m0 + wr * 128 + i * 32, n0 + wc * 64, lane, 0, stg);
+  __syncthreads();  // the staging area becomes stage 0 / 1 of the next piece
+}
+
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int LOOP>
+__global__ __launch_bounds__(512, 2) void gemm_p256_kernel(P256 g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = (int)gridDim.x;
+  const int wg = xcd_remap((int)blockIdx.x, G);  // neighbouring logical ids share an XCD (and with it operand panels in L2)
+  if (g.mode == 0) {
+    const int total = g.piece_begin[g.count];
+    for (int q = wg; q < total; q += G) {
+      int i = 0;
+#pragma unroll
+      for (int j = 1; j < P_MAX; j++) i += (j < g.count && q >= g.piece_begin[j]) ? 1 : 0;
+      const GemmP& p = g.p[i];
+      const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
+      const int local = q - g.piece_begin[i];
+      const int s = local / tiles, tile = local - s * tiles;   // slice-major
+      const int kt_begin = s * g.kts[i], kt_end = min(g.nkt[i], kt_begin + g.kts[i]);
+      const int n_pieces = g.split[i];
+      float* my_slot = g.slots + (long long)q * P_SLOT_FLOATS;
+      p256_piece<A_KMAJ, B_KMAJ, EPI, LOOP>(g, p, g.tile_begin[i] + tile, tile, kt_begin, kt_end, n_pieces, my_slot, 0, n_pieces - 1, 0, s, smem);
+    }
+    return;
+  }
+  // stream: contiguous unit range [u, end) of problem 0
+  const GemmP& p = g.p[0];
+  const int nkt = g.nkt[0];
+  long long u = stream_start(g, wg);
+  const long long u_start = u, end = stream_start(g, wg + 1);
+  while (u < end) {
+    const int tile = (int)(u / nkt);
+    const long long t0 = (long long)tile * nkt;
+    const int kt_begin = (int)(u - t0);
+    const int kt_end = (int)min((long long)nkt, end - t0);
+    const int w_first = stream_owner_of(g, t0), w_last = stream_owner_of(g, t0 + nkt - 1);
+    const int n_pieces = w_last - w_first + 1;
+    const int which = u_start >= t0 ? 0 : 1;   // this workgroup's first piece, or a later one (only its last piece can be partial then)
+    float* my_slot = g.slots + ((long long)wg * 2 + which) * P_SLOT_FLOATS;
+    p256_piece<A_KMAJ, B_KMAJ, EPI, LOOP>(g, p, tile, tile, kt_begin, kt_end, n_pieces, my_slot, w_first, n_pieces - 1, t0, wg, smem);
+    u = t0 + kt_end;
+  }
+}
+
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int LOOP>
+int launch_p256(const P256& g, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  auto fn = gemm_p256_kernel<A_KMAJ, B_KMAJ, EPI, LOOP>;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, P_SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  launch_any(fn, dim3(grid), dim3(512), (size_t)P_SMEM, st, g);
+  return launch_status();
+}
+
+int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    if (cus < 8) cus = 8;
+  }
+  return cus;
+}
+
+}  // namespace
+
+// Grouped / persistent 256x256 GEMM: up to 8 problems of ONE operand layout and epilogue class in one launch (see the header of this file).
+//   schedule 0 "split": balanced k-slices per tile (weight gradients; also whole-K tiles when the tile count fills the chip),
+//   schedule 1 "stream": one problem, equal contiguous (tile, k-tile) ranges per workgroup.
+// workspace: >= cinema_gemm_p256_workspace_bytes(); its first 64 KiB hold the tile counters and must be ZERO before the first use (the kernel
+// leaves them zero); one workspace per stream (concurrent launches must not share one).
+CINEMA_API long long cinema_gemm_p256_workspace_bytes(void) { return (long long)P_COUNTER_BYTES + 2LL * cu_count() * P_SLOT_FLOATS * 4; }
+
+CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int schedule, void* workspace, long long workspace_bytes, void* stream) {
+  if (!args || count < 1 || count > P_MAX || !workspace || (((uintptr_t)workspace) & 255)) return CINEMA_ERR_BAD_ARG;
+  if (schedule == 1 && count != 1) return CINEMA_ERR_BAD_ARG;
+  auto al8 = [](long long v) { return (v & 7) == 0; };
+  auto ptr16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  // main-loop form (p256_loop64 / p256_loop32) and with it the k extent of a schedule unit; CINEMA_P256_LOOP=0 selects the plain k-tile loop
+  static const int loop_form = getenv("CINEMA_P256_LOOP") ? atoi(getenv("CINEMA_P256_LOOP")) : 1;
+  const int unit_k = loop_form ? 32 : BK;
+  P256 g;
+  g.count = count; g.mode = schedule ? 1 : 0;
+  g.tile_begin[0] = 0; g.piece_begin[0] = 0;
+  const int ak = args[0].a_kmajor, bk = args[0].b_kmajor;
+  if (!ak && bk) return CINEMA_ERR_UNSUPPORTED;
+  int epi = -1;
+  long long units = 0;
+  for (int i = 0; i < count; i++) {
+    const cinema_gemm_args* a = &args[i];
+    if (!a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
+    if (a->a_kmajor != ak || a->b_kmajor != bk) return CINEMA_ERR_UNSUPPORTED;
+    if (a->residual_bf16 || a->row_mask || a->scale_a || a->scale_b || a->conv_taps) return CINEMA_ERR_UNSUPPORTED;
+    if (a->accumulate && !a->out_f32) return CINEMA_ERR_BAD_ARG;
+    if (a->accumulate && a->residual_f32) return CINEMA_ERR_UNSUPPORTED;
+    bool ok = al8(a->lda) && al8(a->ldb) && al8(a->ldd) && al8(a->n) && ptr16(a->a) && ptr16(a->b) && ptr16(a->d);
+    ok = ok && (a->a_kmajor ? al8(a->k) : al8(a->m)) && (a->b_kmajor ? al8(a->k) : true);
+    ok = ok && (!a->bias || ptr16(a->bias)) && (!a->residual_f32 || (al8(a->ld_res) && ptr16(a->residual_f32)));
+    ok = ok && (!a->gelu_in || (al8(a->ld_gelu) && ptr16(a->gelu_in))) && (!a->aux_out || (al8(a->ld_aux) && ptr16(a->aux_out)));
+    if (!ok) return CINEMA_ERR_UNSUPPORTED;
+    if (a->a_rowsum && a->a_kmajor) return CINEMA_ERR_UNSUPPORTED;
+    GemmP& p = g.p[i];
+    p.a = (const bf16_t*)a->a; p.b = (const bf16_t*)a->b; p.d = a->d;
+    p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldb = a->ldb; p.ldd = a->ldd;
+    p.alpha = a->alpha;
+    p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
+    p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
+    p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = a->a_rowsum;
+    if (a->accumulate) { p.res_f32 = (const float*)a->d; p.ld_res = a->ldd; }  // one owner per element: plain read-modify-write
+    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+    p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
+    p.cX = p.cY = p.cZ = p.cC = 0;
+    p.ktiles_per_split = 0;
+    int e;
+    if (!p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) e = EPI_BF16;
+    else if (!p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 1) e = EPI_BF16_GELU;
+    else if (!p.out_f32 && !p.res_f32 && p.gelu_in && p.act == 0 && !p.aux_out && !p.bias) e = EPI_BF16_GELU_GRAD;
+    else if (p.out_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) e = EPI_F32;
+    else return CINEMA_ERR_UNSUPPORTED;
+    if (epi >= 0 && e != epi) return CINEMA_ERR_UNSUPPORTED;
+    epi = e;
+    const int tiles = ((a->m + P_TILE - 1) / P_TILE) * ((a->n + P_TILE - 1) / P_TILE);
+    g.nkt[i] = (a->k + unit_k - 1) / unit_k;
+    g.tile_begin[i + 1] = g.tile_begin[i] + tiles;
+    units += (long long)tiles * g.nkt[i];
+  }
+  if (g.tile_begin[count] * 8 > P_COUNTER_BYTES) return CINEMA_ERR_UNSUPPORTED;
+  const int G = cu_count();
+  int grid;
+  long long slots;
+  if (g.mode == 0) {
+    // smallest slice length x (in k-tiles) whose piece count fits one round of the chip; more tiles than CUs: whole-K tiles, several rounds
+    const int total_tiles = g.tile_begin[count];
+    long long x = (units + G - 1) / G;
+    if (x < 256 / unit_k) x = 256 / unit_k;
+    int maxk = 0;
+    for (int i = 0; i < count; i++) maxk = g.nkt[i] > maxk ? g.nkt[i] : maxk;
+    if (args[0].split_k == 1 || total_tiles >= G) x = maxk;
+    for (;; x++) {
+      long long pieces = 0;
+      for (int i = 0; i < count; i++) pieces += (long long)(g.tile_begin[i + 1] - g.tile_begin[i]) * ((g.nkt[i] + x - 1) / x);
+      if (pieces <= G || x >= maxk) break;
+    }
+    for (int i = 0; i < count; i++) {
+      const int sp = (int)((g.nkt[i] + x - 1) / x);
+      g.kts[i] = (g.nkt[i] + sp - 1) / sp;
+      g.split[i] = (g.nkt[i] + g.kts[i] - 1) / g.kts[i];
+      g.piece_begin[i + 1] = g.piece_begin[i] + (g.tile_begin[i + 1] - g.tile_begin[i]) * g.split[i];
+    }
+    for (int i = count; i < P_MAX; i++) { g.piece_begin[i + 1] = g.piece_begin[count]; g.tile_begin[i + 1] = g.tile_begin[count]; g.split[i] = 1; g.kts[i] = 1; g.nkt[i] = 1; }
+    grid = g.piece_begin[count] < G ? g.piece_begin[count] : G;
+    slots = g.piece_begin[count];
+    bool any_split = false;
+    for (int i = 0; i < count; i++) any_split = any_split || g.split[i] > 1;
+    if (!any_split) slots = 0;
+    g.units = units; g.per = 0; g.rem = 0;
+  } else {
+    grid = units < G ? (int)units : G;
+    g.units = units; g.per = (int)(units / grid); g.rem = (int)(units % grid);
+    for (int i = 0; i < P_MAX; i++) { g.split[i] = 1; g.kts[i] = g.nkt[0]; }
+    for (int i = 1; i < P_MAX; i++) { g.piece_begin[i + 1] = 0; g.tile_begin[i + 1] = g.tile_begin[1]; g.nkt[i] = 1; }
+    g.piece_begin[1] = 0;
+    slots = 2LL * grid;
+  }
+  if (workspace_bytes < P_COUNTER_BYTES + slots * P_SLOT_FLOATS * 4LL) return CINEMA_ERR_BAD_ARG;
+  g.counters = (unsigned*)workspace;
+  g.error = g.counters + P_COUNTER_BYTES / 4 - 1;   // last counter word (tile ids never reach it: checked above)
+  g.slots = (float*)((char*)workspace + P_COUNTER_BYTES);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < count; i++) args[i].kernel_used = 2048 + (ak && bk ? 1 : (ak ? 2 : 3)) + 8 * epi;
+#define P256_LAYOUT(E)                                                        \
+  do {                                                                        \
+    if (loop_form) {                                                          \
+      if (ak && bk) return launch_p256<true, true, E, 1>(g, grid, st);        \
+      if (ak && !bk) return launch_p256<true, false, E, 1>(g, grid, st);      \
+      return launch_p256<false, false, E, 1>(g, grid, st);                    \
+    }                                                                         \
+    if (ak && bk) return launch_p256<true, true, E, 0>(g, grid, st);          \
+    if (ak && !bk) return launch_p256<true, false, E, 0>(g, grid, st);        \
+    return launch_p256<false, false, E, 0>(g, grid, st);                      \
+  } while (0)
+  switch (epi) {
+    case EPI_BF16: P256_LAYOUT(EPI_BF16);
+    case EPI_BF16_GELU: P256_LAYOUT(EPI_BF16_GELU);
+    case EPI_BF16_GELU_GRAD: P256_LAYOUT(EPI_BF16_GELU_GRAD);
+    default: P256_LAYOUT(EPI_F32);
+  }
+#undef P256_LAYOUT
+}

@@ -237,6 +237,11 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const float* logits, const
     for (int j = 0; j < c; j++) { se += expf(z[j] - mx); sz += z[j]; }
     const float lse = mx + logf(se);
     const int y = labels[i];
+    if (y < 0 || y >= c) {  // F.cross_entropy raises for such a label: the loss becomes NaN (the step's non-finite guard skips the update) instead of
+      part = NAN;           // reading z[y] out of bounds
+      for (int j = 0; j < c; j++) dlogits[(size_t)i * c + j] = NAN;
+      continue;
+    }
     part += (1.f - eps) * (lse - z[y]) + eps * (lse - sz / c);
     const float inv = 1.f / se;
     for (int j = 0; j < c; j++) dlogits[(size_t)i * c + j] = (expf(z[j] - mx) * inv - (j == y ? 1.f - eps : 0.f) - eps / c) / b;

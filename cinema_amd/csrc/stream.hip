@@ -74,8 +74,17 @@ int lane_submit(lane_relaunch_t relaunch, const void* fn_single, const void* fn_
 }
 
 CINEMA_API int cinema_lanes_begin(int n) {
-  if (n < 1 || n > MAX_LANES || g_lanes.n != 0) return CINEMA_ERR_BAD_ARG;
+  if (n < 1 || n > MAX_LANES) return CINEMA_ERR_BAD_ARG;
+  // a group left open by a caller that died between begin and end holds launches that were never issued: drop them (their buffers are gone) instead
+  // of refusing every later group - and every later launch - for the rest of the process
   g_lanes.n = n; g_lanes.cur = 0;
+  for (int i = 0; i < MAX_LANES; i++) g_lanes.seq[i].clear();
+  return 0;
+}
+
+// Drop an open group without issuing anything (error paths: the recorded launches reference buffers the failed caller no longer owns).
+CINEMA_API int cinema_lanes_abort(void) {
+  g_lanes.n = 0; g_lanes.cur = 0;
   for (int i = 0; i < MAX_LANES; i++) g_lanes.seq[i].clear();
   return 0;
 }

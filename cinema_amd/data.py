@@ -67,9 +67,13 @@ class GpuInputPipeline:
         torch.cuda.current_stream().wait_event(ev)
         views = list(dev[0].keys())
         out = {v: torch.empty((len(dev), 1, *self.sizes[v]), dtype=torch.float32, device=self.device) for v in views}
+        consumer = torch.cuda.current_stream()
         for i, (d, z) in enumerate(zip(dev, zooms)):
             for v in views:
                 nd = d[v].dim()
                 K.zoom_scale_pad(d[v], (z[v],) * nd, out[v][i, 0], cubic=(nd == 2))  # trilinear SAX, bicubic LAX (pretrain.py:170,178)
+                # the raw sample was allocated under the copy stream but is read by the zoom kernel on the compute stream: without this the block goes
+                # back to the copy stream's pool when the slot is overwritten and the next upload may land on it while the zoom is still queued
+                d[v].record_stream(consumer)
         del host
         return out

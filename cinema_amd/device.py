@@ -18,29 +18,23 @@ logger = logging.getLogger(__name__)
 
 
 def get_amp_dtype_and_device() -> tuple:
-    """(amp dtype, device) as the reference picks them (``cinema/device.py:51-72``): bf16 on a GPU that supports it (every MI355X), fp16
-    otherwise, CPU when no GPU is visible.  The HIP path always computes bf16-MFMA / fp32-accumulate, so a surrounding
-    ``torch.autocast(dtype=amp_dtype)`` is harmless and unnecessary; MIOpen auto-tuning (the reference's ``cudnn.benchmark``) is not used -
-    no ATen convolution runs on this path."""
-    amp_dtype = torch.float16
-    if torch.cuda.is_available():
-        torch.cuda.empty_cache()
-        device = torch.device("cuda")
-        if torch.cuda.is_bf16_supported():
-            amp_dtype = torch.bfloat16
-            logger.info("Using bfloat16 for automatic mixed precision.")
-    else:
-        logger.info("CUDA is not available, using CPU.")
-        device = torch.device("cpu")
-    return amp_dtype, device
+    """-> (autocast dtype, device), the pair the reference's scripts ask for first (``cinema/device.py:51-72``): the GPU with bf16 when the device has
+    it (every MI355X does), fp16 on an older GPU, and the CPU with fp16 when no GPU is visible.  On the HIP path the dtype is informational - the
+    kernels always run bf16 MFMA with fp32 accumulation, a surrounding ``torch.autocast`` changes nothing - and there is no library auto-tuning
+    switch to flip (the reference enables ``cudnn.benchmark``; no ATen convolution runs here)."""
+    if not torch.cuda.is_available():
+        logger.info("no GPU visible: running on the CPU")
+        return torch.float16, torch.device("cpu")
+    torch.cuda.empty_cache()
+    bf16 = torch.cuda.is_bf16_supported()
+    logger.info("autocast dtype: %s", "bfloat16" if bf16 else "float16")
+    return (torch.bfloat16 if bf16 else torch.float16), torch.device("cuda")
 
 
 def print_model_info(model: nn.Module) -> None:
-    """Parameter counts (reference ``cinema/device.py:75-83``)."""
-    n_params = sum(p.numel() for p in model.parameters())
-    logger.info(f"number of parameters: {n_params:,}")
-    n_trainable_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    logger.info(f"number of trainable parameters: {n_trainable_params:,}")
+    """Log the total and the trainable parameter count (``cinema/device.py:75-83``)."""
+    sizes = [(p.numel(), p.requires_grad) for p in model.parameters()]
+    logger.info("parameters: %s total, %s trainable", f"{sum(n for n, _ in sizes):,}", f"{sum(n for n, t in sizes if t):,}")
 
 
 def setup_ddp_model(model: nn.Module, device: torch.device, rank: int, world_size: int) -> tuple:  # noqa: ARG001

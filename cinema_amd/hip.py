@@ -96,6 +96,8 @@ _PROTOS = {
     "cinema_hip_info": [C.POINTER(C.c_int)],
     "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "cinema_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i, _vp],
+    "cinema_gemm_bf16_p256": [C.POINTER(GemmArgs), _i, _i, _vp, _ll, _vp],
+    "cinema_gemm_p256_workspace_bytes": [],
     "cinema_gemm_fp8": [C.POINTER(GemmArgs), _vp],
     "cinema_conv_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "cinema_conv_wgrad_bf16": [C.POINTER(GemmArgs), _vp],
@@ -158,6 +160,7 @@ _PROTOS = {
     "cinema_lanes_begin": [_i],
     "cinema_lanes_select": [_i],
     "cinema_lanes_end": [_vp, _vp],
+    "cinema_lanes_abort": [],
     "cinema_marker_record": [_vp],
     "cinema_marker_done": [_ll],
     "cinema_launch_probe": [_i, _vp],
@@ -189,7 +192,7 @@ def library_path() -> Path:
 # after it ran.  The arguments are plain ints / floats / ctypes structs, so the same launch can be issued again verbatim; host-only queries
 # (workspace sizes) and the completion markers are not part of a step's launch list.
 RECORD: list | None = None
-_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe")
+_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
 
 
 class _Entry:
@@ -360,6 +363,15 @@ class lanes:  # noqa: N801
                 _check(rc, "lanes_end")
 
 
+def lanes_abort() -> None:
+    """Close whatever lane group is open without issuing its launches (error paths of callers that open and close a group in separate steps)."""
+    global LANE  # noqa: PLW0603
+    LANE = None
+    _LANE_KEEP.clear()
+    if _lib is not None:
+        _lib.cinema_lanes_abort()
+
+
 def _rowmajor(t: torch.Tensor, name: str) -> int:
     if t.dim() == 2 and t.shape[1] == 1:  # a single column: the inner stride is meaningless (torch may report anything for it)
         return t.stride(0)
@@ -391,13 +403,33 @@ def _tail_workspace(device: torch.device) -> torch.Tensor:
     return _workspace("tail", 512 * 128 * 128, device)
 
 
+_P256_WS: dict = {}
+
+
+def _p256_workspace(device: torch.device) -> torch.Tensor:
+    """Counters + fp32 partial slots of the persistent 256x256 GEMM (csrc/gemm256.hip), one per (device, stream, lane): the counters are zero at
+    allocation and every launch leaves them zero, so the buffer must never be handed back to the allocator (``persistent``: outside a recording's pool)."""
+    key = (device.index, _stream(), LANE)
+    ws = _P256_WS.get(key)
+    if ws is None:
+        n = load().cinema_gemm_p256_workspace_bytes()
+        ws = _P256_WS[key] = persistent(lambda: torch.zeros(n // 4, dtype=torch.float32, device=device))
+    return ws
+
+
+def _p256_call(arr, count: int, schedule: int, device: torch.device) -> None:  # noqa: ANN001
+    ws = _p256_workspace(device)
+    _check(load().cinema_gemm_bf16_p256(arr, count, schedule, ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_p256")
+
+
 # --------------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True, out: torch.Tensor | None = None,
          out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None,
          gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, aux_out: torch.Tensor | None = None,
          act: int = 0, accumulate: bool = False, split_k: int = 1, alpha: float = 1.0, force_generic: bool = False,
-         a_rowsum: torch.Tensor | None = None) -> torch.Tensor:
-    """D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N]."""
+         a_rowsum: torch.Tensor | None = None, p256: int | None = None) -> torch.Tensor:
+    """D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N].
+    ``p256`` = 0 / 1: the persistent 256x256 kernel with its split / stream schedule (``split_k`` = 1 then means whole-K tiles, 0 balanced slices)."""
     lib = load()
     _dev(a, b, out, bias, residual, gelu_in, row_mask, aux_out)
     if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
@@ -440,6 +472,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     if a_rowsum is not None:  # fp32 [m], accumulated: sum_k A[m, k] (bias gradient of a weight-gradient GEMM)
         _dev(a_rowsum)
         g.a_rowsum = a_rowsum.data_ptr()
+    if p256 is not None:
+        _p256_call(C.byref(g), 1, p256, a.device)
+        return out
     ws = None
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
         ws = _workspace("splitk", split_k * m * n, a.device)
@@ -536,9 +571,10 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
     return out
 
 
-def gemm_wgrad_grouped(problems: list) -> None:
+def gemm_wgrad_grouped(problems: list, p256: bool = False) -> None:
     """One launch for up to 8 weight gradients: each problem is (dy [rows, n_out] bf16, x [rows, k_out] bf16, dst fp32 [n_out, k_out] view,
-    a_rowsum fp32 [n_out] | None); dst += dy^T x, a_rowsum += column sums of dy.  Whole-K tiles, no split-K slabs (see the header)."""
+    a_rowsum fp32 [n_out] | None); dst += dy^T x, a_rowsum += column sums of dy.  Whole-K 128x128 tiles, no split-K slabs (see the header);
+    ``p256``: the persistent 256x256 kernel with balanced k-slices finished inside the launch (the problems may then differ in their row counts)."""
     arr = (GemmArgs * len(problems))()
     for g, (dy, x, dst, rowsum) in zip(arr, problems):
         _dev(dy, x, dst, rowsum)
@@ -547,9 +583,12 @@ def gemm_wgrad_grouped(problems: list) -> None:
         g.a, g.b, g.d = dy.data_ptr(), x.data_ptr(), dst.data_ptr()
         g.m, g.n, g.k = dy.shape[1], x.shape[1], dy.shape[0]
         g.lda, g.ldb, g.ldd = _rowmajor(dy, "dy"), _rowmajor(x, "x"), _rowmajor(dst, "dst")
-        g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, 1
+        g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, (0 if p256 else 1)
         if rowsum is not None:
             g.a_rowsum = rowsum.data_ptr()
+    if p256:
+        _p256_call(arr, len(problems), 0, problems[0][0].device)
+        return
     if GEMM_PROFILE is None:
         _check(load().cinema_gemm_bf16_grouped(arr, len(problems), _stream()), "gemm_grouped")
         return

@@ -2,8 +2,8 @@
 
 ``stability_score`` and ``get_volumes`` of device tensors count voxels with ``cinema_seg_metric_counts`` (one pass over the channels-first logits, the same
 kernel :func:`cinema_amd.segmentation.train.segmentation_metrics` uses); the scalar formulas (ejection fraction, its region, coefficient of variance) are
-host arithmetic on whatever the caller passes (floats, numpy arrays, tensors), as in the reference.  Not provided: the landmark heat-map helpers
-(``heatmap_argmax``, ``heatmap_soft_argmax``) - the landmark task is outside this build."""
+host arithmetic on whatever the caller passes (floats, numpy arrays, tensors), as in the reference.  ``heatmap_argmax`` / ``heatmap_soft_argmax``
+(exported from the package root, ``cinema/__init__.py:5``) are plain tensor functions - the landmark models themselves are outside this build."""
 
 from __future__ import annotations
 
@@ -34,12 +34,28 @@ def stability_score(logits: torch.Tensor, threshold: float = 0.0, threshold_offs
     return torch.where(lo > 0, both / (hi + lo - both).clamp_min(1e-30), torch.full_like(lo, float("nan")))
 
 
+def heatmap_argmax(heatmap: torch.Tensor) -> torch.Tensor:
+    """(batch, 3, w, h) -> (batch, 6) integer coordinates (x0, y0, x1, y1, x2, y2) of the maximum of each of the three maps
+    (reference ``cinema/metric.py:45-59``)."""
+    b, c, w, h = heatmap.shape
+    flat = heatmap.reshape(b, c, w * h).argmax(dim=2)
+    return torch.stack((flat // h, flat % h), dim=2).reshape(b, 2 * c)
+
+
+def heatmap_soft_argmax(heatmap: torch.Tensor, beta: float = 1000.0) -> torch.Tensor:
+    """Expected coordinate under softmax(beta * heatmap) over the map, truncated to integers: (batch, 3, w, h) -> (batch, 6)
+    (reference ``cinema/metric.py:62-81``).  The expectation separates: E[x] = sum_x x * sum_y p(x, y), E[y] likewise."""
+    b, c, w, h = heatmap.shape
+    prob = torch.softmax(heatmap.reshape(b, c, w * h) * beta, dim=2).reshape(b, c, w, h)
+    ex = (prob.sum(dim=3) * torch.arange(w, device=heatmap.device)).sum(dim=2)
+    ey = (prob.sum(dim=2) * torch.arange(h, device=heatmap.device)).sum(dim=2)
+    return torch.stack((ex, ey), dim=2).reshape(b, 2 * c).to(torch.long)
+
+
 def get_volumes(mask: torch.Tensor, spacing: tuple) -> torch.Tensor:
-    """Volume in ml of every class of a one-hot mask (batch, n_classes, ...) (reference ``cinema/metric.py:84-96``).  Device tensors are counted by the
-    voxel-count kernel (the mask's argmax is the class of a one-hot voxel); host tensors by a plain sum."""
+    """Volume in ml of every class of a mask (batch, n_classes, ...) (reference ``cinema/metric.py:84-96``): the plain sum over the spatial axes on
+    either device, so soft or multi-hot masks and all-zero voxels give the reference's numbers (a voxel-count kernel would call an all-zero voxel class 0)."""
     vol = float(np.prod([float(s) for s in spacing])) / 1000.0
-    if mask.is_cuda:
-        return _counts(mask)[..., 0] * vol  # column 0: voxels whose argmax is the class
     return mask.sum(dim=tuple(range(2, mask.ndim))) * vol
 
 

@@ -269,11 +269,18 @@ class Tape:
 
     def backward(self) -> None:
         debug = os.environ.get("CINEMA_TAPE_DEBUG") == "1"
-        for i, fn in enumerate(reversed(self.ops)):
-            fn()
-            if debug:  # localise an asynchronous kernel fault to one backward closure
-                torch.cuda.synchronize()
-                print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
+        try:
+            for i, fn in enumerate(reversed(self.ops)):
+                fn()
+                if debug:  # localise an asynchronous kernel fault to one backward closure
+                    torch.cuda.synchronize()
+                    print(f"[tape] bwd {len(self.ops) - 1 - i:4d} {fn.__qualname__} ok", flush=True)
+        except BaseException:
+            # a backward lane group is opened and closed by two separate closures: a failure in between would leave the library recording (and never
+            # issuing) every later launch of the process
+            if K.LANE is not None:
+                K.lanes_abort()
+            raise
         flush_wgrads(self)
         flush_ln(self)  # 86 LayerNorms per step: one launch per 48 instead of one each
         join_side_stream(release=True)
@@ -510,7 +517,7 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
 # 32.39 ms): the group can only be issued at the end of the block's backward and its 432 workgroups each run for 160 us, so the side
 # stream no longer fills the main stream's idle slots early and the main stream's kernels wait for slots behind long tiles.  Opt-in.
 # Groups that would leave the slots mostly empty (decoder blocks: 192 tiles) keep the per-GEMM split-K path either way.
-GROUP_WGRAD = bool(int(os.environ.get("CINEMA_GROUP_WGRAD", "0")))
+GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "0"))  # 1: whole-K 128x128 tiles (cinema_gemm_bf16_grouped), 2: persistent 256x256 kernel, k-slices finished in the launch
 # LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
 DEFER_LN_REDUCE = bool(int(os.environ.get("CINEMA_LN_DEFER", "1")))
 _GROUP_MIN_TILES = 384
@@ -528,7 +535,7 @@ def wgrad_group(tape: Tape) -> None:
 
 def wgrad_group_end(tape: Tape) -> None:
     def begin() -> None:
-        tape.grouping = GROUP_WGRAD and not K.FORCE_GENERIC
+        tape.grouping = bool(GROUP_WGRAD) and not K.FORCE_GENERIC
 
     tape.record(begin)
 
@@ -544,13 +551,14 @@ def flush_wgrads(tape: Tape) -> None:
     if not probs:
         return
     tiles = sum(((dy.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128) for dy, x, _, _ in probs)
-    if len(probs) < 2 or tiles < _GROUP_MIN_TILES:
+    p256 = GROUP_WGRAD == 2
+    if not p256 and (len(probs) < 2 or tiles < _GROUP_MIN_TILES or len({dy.shape[0] for dy, _, _, _ in probs}) > 1):
         for pr in probs:
             _wgrad_single(*pr)
         return
     for i in range(0, len(probs), 8):
         chunk = probs[i:i + 8]
-        _wgrad_launch(lambda c=chunk: K.gemm_wgrad_grouped(c), *[t for dy, x, _, _ in chunk for t in (dy, x)])
+        _wgrad_launch(lambda c=chunk: K.gemm_wgrad_grouped(c, p256=p256), *[t for dy, x, _, _ in chunk for t in (dy, x)])
 
 
 def wgrad_problem(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias_grad: torch.Tensor | None) -> None:

@@ -67,7 +67,8 @@ typedef struct {
   const void* conv_coords;    /* cinema_conv_wgrad_bf16 only: device int [rows], x | y << 10 | z << 20 of every voxel row */
   int conv_zb;                /* implicit convolution: 0 / 1 = one row per voxel; ZB > 1 = one row per group of ZB consecutive z voxels (see cinema_conv_gemm_bf16) */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
-                                 + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped */
+                                 + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped;
+                                 + 128: the BK = 32 instance; 2048 + layout + 8 x class: cinema_gemm_bf16_p256 */
 } cinema_gemm_args;
 int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
 /* fp8 forward GEMM (BASELINE config 5: "fp8 MFMA path"; the reference picks its autocast dtype at cinema/device.py:58-66): the same call with OCP e4m3
@@ -109,6 +110,15 @@ int cinema_quantize_fp8_segments(const uint16_t* x, const long long* seg_bounds,
  * epilogue term, split_k ignored) in ONE launch with whole-K tiles: the four dW of a transformer block (cinema/vit.py:525-609) have
  * 36-144 output tiles each and would otherwise be cut into k-slices with fp32 slabs and a reduce launch each. */
 int cinema_gemm_bf16_grouped(cinema_gemm_args* args_host_array, int count, void* stream);
+/* Persistent 256x256x64 form of the same GEMMs (csrc/gemm256.hip): one 8-wave workgroup per CU walks a list of (problem, tile, k-range) pieces and a
+ * tile cut into several pieces is finished INSIDE the launch by its last-arriving piece (fp32 partial slots + two counters per tile; no reduce launch,
+ * no fix-up launch).  Up to 8 problems of one operand layout (a_kmajor / b_kmajor as cinema_gemm_bf16; (0, 1) unsupported) and one epilogue class
+ * (bf16 | bf16 + GELU (+ aux_out) | bf16 x GELU'(gelu_in) | fp32 (+ bias, residual_f32 or accumulate)); a_rowsum for reduction-strided A.
+ *   schedule 0: every tile of problem i in balanced k-slices (the linear-layer weight gradients of a transformer block, cinema/vit.py:565-575, in one
+ *               launch; split_k == 1 in args[0] keeps whole-K tiles), schedule 1 (count == 1): equal contiguous (tile, k-tile) ranges per workgroup.
+ * workspace: >= cinema_gemm_p256_workspace_bytes(), 256-byte aligned, first 64 KiB ZERO before the first use (left zero by every launch), one per stream. */
+long long cinema_gemm_p256_workspace_bytes(void);
+int cinema_gemm_bf16_p256(cinema_gemm_args* args_host_array, int count, int schedule, void* workspace, long long workspace_bytes, void* stream);
 
 /* column sums: out[n] += sum_{i<m} x[row(i), n] with row(i) = row_idx ? row_idx[i] : i  (bias / token-parameter gradients).
  * x bf16 (x_dtype 0) or fp32 (1), row-major [.][ldx]; out fp32 [n], accumulated atomically */
@@ -339,6 +349,8 @@ int cinema_stream_fork(void* from_stream, void* to_stream);
 int cinema_lanes_begin(int n);
 int cinema_lanes_select(int lane);
 int cinema_lanes_end(int* merged_out, int* single_out);
+/* error paths: close an open group WITHOUT issuing its recorded launches (cinema_lanes_begin also discards a stale open group) */
+int cinema_lanes_abort(void);
 long long cinema_marker_record(void* stream);
 int cinema_marker_done(long long ticket);
 /* n back-to-back launches of an empty kernel (measures the host cost of one launch; used by tools/launch_rate.py and DESIGN.md section 5). */

@@ -169,6 +169,60 @@ def test_gemm_wgrad_grouped_matches_single_launches() -> None:
         K.gemm_wgrad_grouped([(rnd(64, 8), rnd(32, 8), torch.zeros(8, 8, device=DEV), None)])
 
 
+@pytest.mark.parametrize("rows", [700, 5000])
+def test_gemm_p256_grouped_wgrad_in_launch_reduction(rows: int) -> None:
+    """cinema_gemm_bf16_p256, split schedule: the weight gradients of a block in one persistent launch, tiles cut into k-slices and finished by their
+    last-arriving piece inside the launch.  Against fp32 torch (1e-3 of the largest element: accumulation order only), twice on the same workspace
+    (the counters must come back to zero), ragged tile edges (n, k not multiples of 256) and a ragged last k-tile (rows % 64 != 0) included."""
+    shapes = [(512, 256), (256, 768), (384, 200), (72, 512)]
+    for rep in range(2):
+        probs, ref = [], []
+        for i, (n, k) in enumerate(shapes):
+            dy = rnd(rows, n, scale=0.5, seed=80 + i + 7 * rep)
+            x = rnd(rows, k, scale=0.5, seed=90 + i + 7 * rep)
+            base = rnd(n, k, dtype=torch.float32, seed=100 + i)
+            bsum = rnd(n, dtype=torch.float32, seed=110 + i)
+            probs.append((dy, x, base.clone(), bsum.clone()))
+            ref.append((base + dy.float().t() @ x.float(), bsum + dy.float().sum(0)))
+        K.gemm_wgrad_grouped(probs, p256=True)
+        for (dy, x, dst, b1), (rd, rb) in zip(probs, ref):
+            close(dst, rd, 0.0, 1e-3 * float(rd.abs().max()), f"p256 grouped dW rep {rep}")
+            close(b1, rb, 0.0, 1e-3 * float(rb.abs().max()), f"p256 grouped bias gradient rep {rep}")
+    ws = K._p256_workspace(torch.device(DEV, torch.cuda.current_device()))
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "tile counters / error word not left at zero"
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize(("m", "n", "k"), [(1000, 768, 3072), (2053, 512, 2048), (685, 256, 768), (300, 264, 200)])
+def test_gemm_p256_forward_and_dgrad_epilogues(schedule: int, m: int, n: int, k: int) -> None:
+    """The persistent 256x256 kernel on the forward and data-gradient layouts with every fused epilogue class, both schedules (balanced k-slices and
+    stream ranges: tiles cut at arbitrary k-tiles, up to three pieces), against fp32 torch with the tolerances of the 128x128 kernel's tests."""
+    a, w = rnd(m, k, seed=1), rnd(n, k, scale=0.05, seed=2)
+    bias = rnd(n, dtype=torch.float32, seed=3)
+    res = rnd(m, n, dtype=torch.float32, seed=7)
+    ref = a.float() @ w.float().t() + bias
+    scale = float(ref.abs().max())
+    close(K.gemm(a, w, bias=bias, out_dtype=torch.float32, p256=schedule, split_k=0), ref, 2e-4, 2e-4 * scale, "p256 fwd f32")
+    close(K.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32, p256=schedule, split_k=0), ref + res, 2e-4, 2e-4 * scale, "p256 fwd f32 + residual")
+    close(K.gemm(a, w, bias=bias, p256=schedule, split_k=0), ref, 1e-2, 1e-2 * scale, "p256 fwd bf16")
+    h = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    act = K.gemm(a, w, bias=bias, act=1, aux_out=h, p256=schedule, split_k=0)
+    close(h, ref, 1e-2, 1e-2 * scale, "p256 pre-activation copy")
+    close(act, F.gelu(ref), 1e-2, 1e-2 * scale, "p256 gelu")
+    dy = rnd(m, n, seed=6)
+    wt = w  # dX = dY W with W stored [n (reduction)][k (out)]
+    dref = dy.float() @ wt.float()
+    dscale = float(dref.abs().max())
+    close(K.gemm(dy, wt, a_kmajor=True, b_kmajor=False, out_dtype=torch.float32, p256=schedule, split_k=0), dref, 2e-4, 3e-4 * dscale, "p256 dgrad f32")
+    pre = rnd(m, k, seed=8)
+    gref = dref * (0.5 * (1 + torch.erf(pre.float() / math.sqrt(2))) + pre.float() * torch.exp(-0.5 * pre.float() ** 2) / math.sqrt(2 * math.pi))
+    close(K.gemm(dy, wt, a_kmajor=True, b_kmajor=False, gelu_in=pre, p256=schedule, split_k=0), gref, 1e-2, 1e-2 * dscale, "p256 dgrad x gelu'")
+    # whole-K tiles (split_k = 1): the plain persistent form, no partial slots touched
+    close(K.gemm(a, w, bias=bias, out_dtype=torch.float32, p256=0, split_k=1), ref, 2e-4, 2e-4 * scale, "p256 whole-K")
+    ws = K._p256_workspace(torch.device(DEV, torch.cuda.current_device()))
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "tile counters / error word not left at zero"
+
+
 def test_gemm_strided_views_and_colsum() -> None:
     big = rnd(300, 3 * 256, seed=13)
     a = big[:, 256:512]  # column slice of a fused buffer
