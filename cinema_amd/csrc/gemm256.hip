@@ -5,7 +5,7 @@
 // the 128x128 kernel's).  Half the staged bytes per FLOP of the 128x128 tile - the 128x128 loop is bound by that stream.
 //
 // Work is a list of PIECES: (problem, output tile, k-tile range).  Two schedules:
-//   split   - every tile of problem i is cut into split[i] equal k-slices (the host balances the slice lengths over up to 8 problems: the weight
+//   split   - every tile of problem i is cut into split[i] equal k-slices (the host balances the slice lengths over up to 12 problems: the weight
 //             gradients of one transformer block in one launch); workgroups walk the pieces grid-stride, slice-major so that neighbours share panels
 //   stream  - the (tile, k-tile) units of one problem are dealt to the workgroups as equal contiguous ranges (tile counts like 129 on 256 CUs)
 // A tile cut into n pieces is finished by its LAST ARRIVER: a piece takes a ticket from the tile's arrival counter; tickets 0..n-2 store their
@@ -24,11 +24,29 @@ constexpr int P_STAGE = 4 * P_SUB;           // A0 A1 B0 B1
 constexpr int P_CTL = 2 * P_STAGE;           // control words behind the two stages
 constexpr int P_SMEM = P_CTL + 64;
 constexpr int P_SLOT_FLOATS = P_TILE * P_TILE;
-constexpr int P_MAX = 8;
+constexpr int P_MAX = 12;
 constexpr int P_COUNTER_BYTES = 65536;       // head of the workspace: 2 counters per output tile (zero on entry, left zero)
 
+// what a piece needs of a problem (GemmP carries the fields of every other GEMM mode as well: 12 of them would not fit the kernel-argument segment)
+struct SlimP {
+  const bf16_t* a; const bf16_t* b; void* d;
+  int m, n, k, lda, ldb, ldd;
+  const float* bias; const float* res_f32; const bf16_t* gelu_in; bf16_t* aux_out; float* a_rowsum;
+  int ld_res, ld_gelu, ld_aux, act, out_f32;
+  float alpha;
+};
+__device__ __forceinline__ GemmP expand(const SlimP& s) {
+  GemmP p;
+  p.a = s.a; p.b = s.b; p.d = s.d; p.m = s.m; p.n = s.n; p.k = s.k; p.lda = s.lda; p.ldb = s.ldb; p.ldd = s.ldd; p.alpha = s.alpha;
+  p.bias = s.bias; p.res_f32 = s.res_f32; p.res_bf16 = nullptr; p.ld_res = s.ld_res; p.gelu_in = s.gelu_in; p.ld_gelu = s.ld_gelu;
+  p.row_mask = nullptr; p.aux_out = s.aux_out; p.ld_aux = s.ld_aux; p.act = s.act; p.out_f32 = s.out_f32; p.accumulate = 0;
+  p.ktiles_per_split = 0; p.ws = nullptr; p.a_rowsum = s.a_rowsum; p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.cX = p.cY = p.cZ = p.cC = 0; p.cZB = 1; p.conv_coords = nullptr;
+  return p;
+}
+
 struct P256 {
-  GemmP p[P_MAX];
+  SlimP p[P_MAX];
   int count, mode;               // mode 0 = split, 1 = stream
   int tile_begin[P_MAX + 1];     // prefix sums of the 256x256 tile counts (global tile id = counter index)
   int piece_begin[P_MAX + 1];    // split: prefix sums of tiles_i * split_i
@@ -47,6 +65,17 @@ __device__ __forceinline__ long long stream_start(const P256& g, int wg) { retur
 __device__ __forceinline__ int stream_owner_of(const P256& g, long long u) {  // workgroup whose range holds unit u
   const long long big = (long long)g.rem * (g.per + 1);
   return u < big ? (int)(u / (g.per + 1)) : g.rem + (int)((u - big) / g.per);
+}
+
+// acc + the 8 bf16 of a fragment: four v_dot2c_f32_bf16 against (1, 1) instead of eight shift / mask + add pairs (the bias-gradient row sums of the
+// weight-gradient pieces ran ~100 VALU instructions per phase on two of the eight waves, and everyone waits for them at the phase barriers)
+__device__ __forceinline__ float frag_sum8_dot(const short8v& f, float acc) {
+  typedef uint32_t u32x4f __attribute__((ext_vector_type(4)));
+  const u32x4f w = __builtin_bit_cast(u32x4f, f);
+  const uint32_t ones = 0x3f803f80u;
+#pragma unroll
+  for (int e = 0; e < 4; e++) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w[e]), "v"(ones));
+  return acc;
 }
 
 // ---- main loop, form 0: k-tiles of 64, two 64 KiB stages, one barrier per k-tile (every wave: fragment reads, then MFMAs, hipcc's interleave)
@@ -154,6 +183,26 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
     }
     glds16x4(dst, dst + 4096, dst + 16384, dst + 16384 + 4096, a0, a1, b0, b1);
   };
+  // Transpose reads of a reduction-strided [32 k][128] sub-tile (TileIO32<false>::frag) with the address split into a per-lane, per-fragment base
+  // (computed here, once per piece) and immediates: byte = kr * 256 + ((col / 8) ^ (kr & 3) * 4) * 16 + (col & 7) * 2 with kr = 16 ks + 8 (q4 / 2) + t / 4
+  // (+ 4 for the second half), col = 32 f + 16 (q4 & 1) + 4 (t & 3): kr & 3 = t / 4 is a lane constant, so the swizzle turns fragment f into
+  // 64 * (f ^ t / 4) and everything else is lane part + ks * 4096 + half * 1024 (as one function of (kr, col) the compiler rebuilt ~25 adds per phase).
+  int tr_a[4], tr_b[2];
+  {
+    const int q4 = lane >> 4, t = lane & 15, mm = t >> 2;
+    const int lane_part = (q4 >> 1) * 2048 + mm * 256 + (2 * (q4 & 1) + ((t & 3) >> 1)) * 16 + (t & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) tr_a[i] = wr * 8192 + lane_part + 64 * (i ^ mm);
+#pragma unroll
+    for (int j = 0; j < 2; j++) tr_b[j] = 16384 + (wc >> 1) * 8192 + lane_part + 64 * ((2 * (wc & 1) + j) ^ mm);
+  }
+  auto tr_frag = [&](const char* base, int ks) {
+    const short4v lo = lds_tr16_b64(base + ks * 4096), hi = lds_tr16_b64(base + ks * 4096 + 1024);
+    short8v out;
+    out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+    out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+    return out;
+  };
   const int nph = ph_end - ph_begin;
   // prologue: phases 0..2 in flight, phase 0 landed
   issue(ph_begin);
@@ -173,10 +222,10 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
     short8v fa[2][4], fb[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      fb[ks][0] = BIO::frag(sb, bcol, ks, lane);
-      fb[ks][1] = BIO::frag(sb, bcol + 32, ks, lane);
 #pragma unroll
-      for (int i = 0; i < 4; i++) fa[ks][i] = AIO::frag(sa, i * 32, ks, lane);
+      for (int j = 0; j < 2; j++) fb[ks][j] = B_KMAJ ? BIO::frag(sb, bcol + j * 32, ks, lane) : tr_frag(hs + tr_b[j], ks);
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[ks][i] = A_KMAJ ? AIO::frag(sa, i * 32, ks, lane) : tr_frag(hs + tr_a[i], ks);
     }
     // DMA(ph + 1) must have landed before the barrier that lets anyone read it; DMA(ph + 2) (the youngest, if issued) stays in flight
     if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -194,7 +243,7 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
       if (ks == 0 && q + 3 < nph) issue(ph + 3);
       if (do_rowsum) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) rs[i] += frag_sum8(fa[ks][i]);
+        for (int i = 0; i < 4; i++) rs[i] = frag_sum8_dot(fa[ks][i], rs[i]);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -320,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(P256 g) {
       int i = 0;
 #pragma unroll
       for (int j = 1; j < P_MAX; j++) i += (j < g.count && q >= g.piece_begin[j]) ? 1 : 0;
-      const GemmP& p = g.p[i];
+      const GemmP p = expand(g.p[i]);
       const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
       const int local = q - g.piece_begin[i];
       const int s = local / tiles, tile = local - s * tiles;   // slice-major
@@ -332,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(P256 g) {
     return;
   }
   // stream: contiguous unit range [u, end) of problem 0
-  const GemmP& p = g.p[0];
+  const GemmP p = expand(g.p[0]);
   const int nkt = g.nkt[0];
   long long u = stream_start(g, wg);
   const long long u_start = u, end = stream_start(g, wg + 1);
@@ -375,7 +424,7 @@ int cu_count() {
 
 }  // namespace
 
-// Grouped / persistent 256x256 GEMM: up to 8 problems of ONE operand layout and epilogue class in one launch (see the header of this file).
+// Grouped / persistent 256x256 GEMM: up to 12 problems of ONE operand layout and epilogue class in one launch (see the header of this file).
 //   schedule 0 "split": balanced k-slices per tile (weight gradients; also whole-K tiles when the tile count fills the chip),
 //   schedule 1 "stream": one problem, equal contiguous (tile, k-tile) ranges per workgroup.
 // workspace: >= cinema_gemm_p256_workspace_bytes(); its first 64 KiB hold the tile counters and must be ZERO before the first use (the kernel
@@ -410,18 +459,14 @@ CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int sche
     ok = ok && (!a->gelu_in || (al8(a->ld_gelu) && ptr16(a->gelu_in))) && (!a->aux_out || (al8(a->ld_aux) && ptr16(a->aux_out)));
     if (!ok) return CINEMA_ERR_UNSUPPORTED;
     if (a->a_rowsum && a->a_kmajor) return CINEMA_ERR_UNSUPPORTED;
-    GemmP& p = g.p[i];
+    SlimP& p = g.p[i];
     p.a = (const bf16_t*)a->a; p.b = (const bf16_t*)a->b; p.d = a->d;
     p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldb = a->ldb; p.ldd = a->ldd;
     p.alpha = a->alpha;
-    p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
-    p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
-    p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = a->a_rowsum;
+    p.bias = a->bias; p.res_f32 = a->residual_f32; p.ld_res = a->ld_res;
+    p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
+    p.act = a->act; p.out_f32 = a->out_f32; p.a_rowsum = a->a_rowsum;
     if (a->accumulate) { p.res_f32 = (const float*)a->d; p.ld_res = a->ldd; }  // one owner per element: plain read-modify-write
-    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
-    p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
-    p.cX = p.cY = p.cZ = p.cC = 0;
-    p.ktiles_per_split = 0;
     int e;
     if (!p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) e = EPI_BF16;
     else if (!p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 1) e = EPI_BF16_GELU;

@@ -517,17 +517,22 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
 # 32.39 ms): the group can only be issued at the end of the block's backward and its 432 workgroups each run for 160 us, so the side
 # stream no longer fills the main stream's idle slots early and the main stream's kernels wait for slots behind long tiles.  Opt-in.
 # Groups that would leave the slots mostly empty (decoder blocks: 192 tiles) keep the per-GEMM split-K path either way.
-GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "0"))  # 1: whole-K 128x128 tiles (cinema_gemm_bf16_grouped), 2: persistent 256x256 kernel, k-slices finished in the launch
+GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "2"))  # 1: whole-K 128x128 tiles (cinema_gemm_bf16_grouped), 2: persistent 256x256 kernel, k-slices finished in the launch
 # LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
 DEFER_LN_REDUCE = bool(int(os.environ.get("CINEMA_LN_DEFER", "1")))
 _GROUP_MIN_TILES = 384
+GROUP_FLUSH_MIN = int(os.environ.get("CINEMA_GROUP_FLUSH_MIN", "1"))  # measured: 1 (per block) 28.67, 8 (two encoder blocks) 28.81, 10 29.44 ms/step on one box
+P256_MAX_PROBLEMS = 12
 
 
 def wgrad_group(tape: Tape) -> None:
     """Bracket the forward ops of a module whose weight gradients should be launched together: call at the START of its forward ops (the
     flush runs at the end of its backward) ... and :func:`wgrad_group_end` at the end of them (grouping switches on when the backward enters)."""
     def flush() -> None:
-        flush_wgrads(tape)
+        # the persistent kernel balances better and writes fewer partial tiles with more problems per launch: without a gradient exchange waiting for
+        # this block's range, the launch is held back until GROUP_FLUSH_MIN problems (two transformer blocks) are pending
+        if GROUP_WGRAD != 2 or PARAMS_DONE_HOOK is not None or len(tape.pending_wgrads) >= GROUP_FLUSH_MIN:
+            flush_wgrads(tape)
         tape.grouping = False
 
     tape.record(flush)
@@ -556,8 +561,9 @@ def flush_wgrads(tape: Tape) -> None:
         for pr in probs:
             _wgrad_single(*pr)
         return
-    for i in range(0, len(probs), 8):
-        chunk = probs[i:i + 8]
+    step = P256_MAX_PROBLEMS if p256 else 8
+    for i in range(0, len(probs), step):
+        chunk = probs[i:i + step]
         _wgrad_launch(lambda c=chunk: K.gemm_wgrad_grouped(c, p256=p256), *[t for dy, x, _, _ in chunk for t in (dy, x)])
 
 

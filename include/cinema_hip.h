@@ -112,7 +112,7 @@ int cinema_quantize_fp8_segments(const uint16_t* x, const long long* seg_bounds,
 int cinema_gemm_bf16_grouped(cinema_gemm_args* args_host_array, int count, void* stream);
 /* Persistent 256x256x64 form of the same GEMMs (csrc/gemm256.hip): one 8-wave workgroup per CU walks a list of (problem, tile, k-range) pieces and a
  * tile cut into several pieces is finished INSIDE the launch by its last-arriving piece (fp32 partial slots + two counters per tile; no reduce launch,
- * no fix-up launch).  Up to 8 problems of one operand layout (a_kmajor / b_kmajor as cinema_gemm_bf16; (0, 1) unsupported) and one epilogue class
+ * no fix-up launch).  Up to 12 problems of one operand layout (a_kmajor / b_kmajor as cinema_gemm_bf16; (0, 1) unsupported) and one epilogue class
  * (bf16 | bf16 + GELU (+ aux_out) | bf16 x GELU'(gelu_in) | fp32 (+ bias, residual_f32 or accumulate)); a_rowsum for reduction-strided A.
  *   schedule 0: every tile of problem i in balanced k-slices (the linear-layer weight gradients of a transformer block, cinema/vit.py:565-575, in one
  *               launch; split_k == 1 in args[0] keeps whole-K tiles), schedule 1 (count == 1): equal contiguous (tile, k-tile) ranges per workgroup.
