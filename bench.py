@@ -88,8 +88,8 @@ def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float, device
                       f"see `parity` for the like-for-like comparison); {cores} intra-op threads of the host's {host_cores} cores (more threads are slower on this graph)"}, parity
 
 
-PMC_TRAFFIC_FILE = "profiles/pmc_hbm_traffic.json"
-PMC_MFMA_FILE = "profiles/r02_mfma_util.json"
+PMC_TRAFFIC_FILE = "profiles/r03_pmc_hbm_traffic.json"
+PMC_MFMA_FILE = "profiles/r03_mfma_util.json"
 
 
 def _committed(rel: str, kernel: str):  # noqa: ANN202
@@ -97,6 +97,22 @@ def _committed(rel: str, kernel: str):  # noqa: ANN202
         return json.loads((ROOT / rel).read_text())["kernels"].get(kernel)
     except (OSError, ValueError, KeyError):
         return None
+
+
+def pmc_binding(rel: str) -> dict:
+    """Ties a committed counter file to the binary that is being timed: the file carries the sha256 of the library its passes ran
+    (tools/gpu_pmc_r03.sh); ``stale`` says whether that is NOT the library loaded by this process."""
+    import hashlib
+
+    from cinema_amd import hip as K
+
+    try:
+        meta = json.loads((ROOT / rel).read_text())
+    except (OSError, ValueError):
+        return {"file": rel, "stale": None}
+    loaded = hashlib.sha256(Path(K.library_path()).read_bytes()).hexdigest()
+    return {"file": rel, "so_sha256": meta.get("so_sha256"), "git_head": meta.get("git_head"), "loaded_so_sha256": loaded,
+            "stale": meta.get("so_sha256") != loaded}
 
 
 def pmc_traffic(kernel: str):  # noqa: ANN201
@@ -129,42 +145,22 @@ def seg_kwargs(size: str = "base", sax=(256, 256, 12)) -> dict:  # noqa: ANN001
 
 def seg_cpu_baseline(kw: dict, state_dict: dict, device: str, budget_s: float) -> tuple:
     """(cpu_baseline, parity) for the segmentation task: the fp32 CPU oracle's ConvUNetR forward + loss + backward on ONE sample of the same
-    shape (the sample of the baseline), and - the config-4 acceptance - the HIP path's eval-mode logits against the oracle's on that sample:
-    argmax agreement and the Dice of the two argmax segmentations (oracle/cinema_oracle.py, checker only)."""
+    shape (the sample of the baseline), and - the config-4 acceptance - the HIP path against the oracle on that sample (oracle/parity.py,
+    checker only): argmax agreement, the Dice of the two argmax segmentations, loss and gradient-norm errors."""
     sys.path.insert(0, str(ROOT / "oracle"))
-    import cinema_oracle as O  # noqa: N812
-
-    from cinema_amd.segmentation.convunetr import ConvUNetR
-    from cinema_amd.segmentation.train import segmentation_metrics
+    from parity import seg_step_parity
 
     host_cores = os.cpu_count() or 1
     cores = min(host_cores, 16)
-    torch.set_num_threads(cores)
-    cfg = O.MAEConfig(image_size_dict=kw["image_size_dict"], in_chans_dict=kw["in_chans_dict"], enc_patch_size_dict=kw["enc_patch_size_dict"],
-                      enc_scale_factor_dict=kw["enc_scale_factor_dict"], enc_conv_chans=kw["enc_conv_chans"], enc_conv_n_blocks=kw["enc_conv_n_blocks"],
-                      enc_embed_dim=kw["enc_embed_dim"], enc_depth=kw["enc_depth"], enc_n_heads=kw["enc_n_heads"], dec_embed_dim=16, dec_depth=1, dec_n_heads=2)
-    gen = torch.Generator().manual_seed(99)
-    image = torch.rand(1, 1, *kw["image_size_dict"]["sax"], generator=gen)
-    labels = torch.clamp((image * 4).long(), 0, 3)
-    p = {k: v.detach().float().cpu().clone().requires_grad_(not k.endswith("pos_embed")) for k, v in state_dict.items()}
-    t0 = time.perf_counter()
-    logits = O.convunetr_forward(p, cfg, tuple(kw["dec_chans"]), 1, 1, {"sax": image})["sax"]
-    loss, _ = O.segmentation_loss_one_view(logits, labels)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    model = ConvUNetR(**kw)
-    model.load_state_dict({k: v.detach().float().cpu() for k, v in state_dict.items()})
-    model.to(device).eval()
-    with torch.no_grad():
-        got = model({"sax": image.to(device)})["sax"].float()
-    ref = logits.detach()
-    agree = float((got.argmax(1).cpu() == ref.argmax(1)).float().mean())
-    m = segmentation_metrics(got, ref.argmax(1, keepdim=True).to(device), (1.0, 1.0, 10.0))
-    dice = float(torch.nanmean(torch.stack([m[f"class_{k}_dice_score"] for k in (1, 2, 3)])))
-    parity = {"argmax_agreement": round(agree, 5), "dice_gpu_vs_cpu_segmentation": round(dice, 5), "logits_max_abs": round(float((got.cpu() - ref).abs().max()), 4),
-              "logits_abs_max_ref": round(float(ref.abs().max()), 3),
-              "what": "eval-mode logits of the HIP path vs the fp32 CPU oracle on one identical sample and identical weights (random init): fraction of voxels "
-                      "with the same argmax class, and the foreground Dice between the two argmax segmentations (acceptance: >= 0.995, |1 - Dice| <= 0.01)"}
+    par = seg_step_parity(kw, state_dict, device=device, threads=cores)
+    dt = par["oracle_seconds"]
+    parity = {"argmax_agreement": round(par["argmax_agreement"], 5), "dice_gpu_vs_cpu_segmentation": round(par["dice_gpu_vs_cpu_segmentation"], 5),
+              "logits_max_abs": round(par["logits_max_abs"], 4), "logits_abs_max_ref": round(par["logits_abs_max_ref"], 3),
+              "loss_rel": round(par["loss_rel"], 6), "grad_norm_rel": round(par["grad_norm_rel"], 5),
+              "worst_grad_rel_l2": {"name": par["worst_grad_rel_l2"]["name"], "value": round(par["worst_grad_rel_l2"]["value"], 4)},
+              "what": "HIP path (dropout / drop_path off) vs the fp32 CPU oracle on one identical sample and identical weights (random init): fraction of voxels "
+                      "with the same argmax class and the foreground Dice between the two argmax segmentations of the eval-mode logits (acceptance: >= 0.995, "
+                      "|1 - Dice| <= 0.01); CE + Dice loss, global gradient norm and worst per-tensor gradient of the training-mode step"}
     del budget_s
     return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"1 forward + CE/Dice loss + backward of the same ConvUNetR config at batch 1 (fp32 torch-CPU oracle, no optimiser update), {dt:.1f} s, "
@@ -263,6 +259,89 @@ def seg_main(args, rank: int, world: int, device: str, sync) -> None:  # noqa: A
         print(json.dumps(out), flush=True)
 
 
+def secondary_configs(device: str, with_parity: bool) -> dict:
+    """BASELINE configs 4 and 5 in the same process, short (a few seconds of GPU time each), so that the driver's one run times them too:
+    config4 = ConvUNetR fine-tuning step (SAX 256x256x12, batch 4, recorded step); config5_fp8 = ViT-Large MAE step at 256x256x24 + 3 LAX 256x256,
+    batch 8, e4m3 forward projections, with the bf16 time of the same shape beside it.  Parity objects from oracle/parity.py (checker only)."""
+    import gc
+
+    from cinema_amd import CineMA
+    from cinema_amd import tape as T_
+    from cinema_amd.optim import TrainStep
+    from cinema_amd.segmentation.convunetr import ConvUNetR
+    from cinema_amd.segmentation.train import SegTrainStep
+
+    sys.path.insert(0, str(ROOT / "oracle"))
+    out: dict = {}
+
+    def timed(fn, warm: int, n: int) -> float:  # noqa: ANN001
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    # ---- config 4
+    kw = seg_kwargs("base", (256, 256, 12))
+    torch.manual_seed(0)
+    model = ConvUNetR(**kw)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(device).train()
+    step = SegTrainStep(model, ["sax"], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, layer_decay=0.75, clip_grad=5.0, replay=True)
+    gen = torch.Generator().manual_seed(1234)
+    image = torch.rand(4, 1, 256, 256, 12, generator=gen)
+    batch = {"sax_image": image.to(device), "sax_label": torch.clamp((image * 4).long(), 0, 3).to(torch.int8).to(device)}
+    ms = timed(lambda: step(batch), 6, 12)
+    out["config4"] = {"workload": "ConvUNetR ViT-Base (ACDC decoder recipe), SAX 256x256x12, 4 classes, per-GPU batch 4, dropout / drop_path 0.1, fwd + CE/Dice + bwd + "
+                                  "clip + layer-decay AdamW, recorded step", "ms_per_step": round(ms, 3), "samples_per_s": round(4e3 / ms, 2), "steps": 12, "warmup": 6,
+                      "dtype": "bf16", "reference_equiv_tflops_per_gpu": round(4e3 / ms * SEG_STEP_GFLOP_PER_SAMPLE / 1e3, 1)}
+    del step, model
+    gc.collect()
+    torch.cuda.empty_cache()
+    if with_parity:
+        from parity import seg_step_parity
+
+        par = seg_step_parity(kw, sd, device=device, threads=min(os.cpu_count() or 1, 16))
+        out["config4"]["parity"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in par.items()}
+        out["config4"]["parity"]["what"] = "HIP path vs fp32 CPU oracle, one identical sample: argmax agreement / Dice of the argmax segmentations (>= 0.995, |1 - Dice| <= 0.01), loss and gradients"
+    # ---- config 5 shape: bf16 and fp8 forward
+    kw5 = base_kwargs("large", (256, 256, 24), (256, 256))
+    torch.manual_seed(0)
+    model = CineMA(**kw5)
+    sd5 = {k: v.detach().clone() for k, v in model.state_dict().items()} if with_parity else None
+    model.to(device)
+    b5 = synthetic_batch(kw5, 8, 4321, device)
+    res = {}
+    prev = T_.FP8_FORWARD
+    try:
+        for name, fp8 in (("bf16", False), ("fp8", True)):
+            T_.FP8_FORWARD = fp8
+            st = TrainStep(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0, replay=True)
+            res[name] = timed(lambda: st(b5, 0.75), 4, 6)  # noqa: B023
+            del st
+            gc.collect()
+    finally:
+        T_.FP8_FORWARD = prev
+    out["config5_fp8"] = {"workload": "CineMA ViT-Large MAE, 4 views (SAX 256x256x24 + 3 LAX 256x256), mask 0.75, per-GPU batch 8, fwd+bwd+clip+AdamW, recorded step",
+                          "dtype": "fp8 (e4m3 forward projections, per-row activation / per-tensor weight scales; bf16 backward)", "ms_per_step": round(res["fp8"], 3),
+                          "samples_per_s": round(8e3 / res["fp8"], 2), "bf16_ms_per_step": round(res["bf16"], 3), "fp8_speedup_over_bf16": round(res["bf16"] / res["fp8"], 4),
+                          "steps": 6, "warmup": 4, "reference_equiv_tflops_per_gpu": round(8e3 / res["fp8"] * 3 * 1806.7 / 1e3, 1)}
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+    if with_parity:
+        from parity import mae_loss_parity
+
+        par = mae_loss_parity(kw5, sd5, batch=1, device=device, fp8=True, threads=min(os.cpu_count() or 1, 16))
+        out["config5_fp8"]["parity"] = {"loss_rel": round(par["loss_rel"], 6), "loss": round(par["loss"], 6), "oracle_loss": round(par["oracle_loss"], 6),
+                                        "view_loss_rel": {k: round(v, 6) for k, v in par["view_loss_rel"].items()},
+                                        "what": "first-step loss (forward) of the fp8 path vs the fp32 CPU oracle at this shape, batch 1, identical weights / inputs / masks (stated: <= 5e-2)"}
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +360,7 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the transformer blocks' forward projections on e4m3 operands (BASELINE config 5, "
                     "with --size large --sax 256,256,24 --lax 256,256 --batch 8); backward GEMMs stay bf16.  The BASELINE metric (config 2) is bf16")
     ap.add_argument("--eager", action="store_true", help="issue every launch from the module code instead of the recorded launch list (A/B)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short config-4 / config-5 measurements appended to the default one-GPU line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -406,10 +486,12 @@ def main() -> None:
         roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(alg_bytes / n), "traffic_over_algorithmic": round(traffic / (alg_bytes / n), 2) if traffic else None,
-                    "traffic_source": f"committed {PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc_bench.sh); not collected live",
+                    "traffic_source": f"committed {PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc_r03.sh); not collected live",
+                    "traffic_stale": pmc_binding(PMC_TRAFFIC_FILE)["stale"], "traffic_binding": pmc_binding(PMC_TRAFFIC_FILE),
                     "mfma_util": pmc_mfma_util(K.GEMM_KERNEL_NAMES[kind]),
-                    "mfma_util_source": f"committed {PMC_MFMA_FILE} (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes, tools/gpu_pmc_mfma.sh); not collected live",
-                    "timing": "HIP events on the launch stream around every launch of this kernel, live in this process (the events also cover the split-K reduce that follows each launch)",
+                    "mfma_util_source": f"committed {PMC_MFMA_FILE} (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes, tools/gpu_pmc_r03.sh); not collected live",
+                    "mfma_util_stale": pmc_binding(PMC_MFMA_FILE)["stale"],
+                    "timing": "HIP events on the launch stream around every launch of this kernel, live in this process (a grouped persistent launch finishes its split reduction inside the kernel; for the 128x128 split-K kernel the events also cover the reduce launch behind it)",
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(secs / n * 1e6, 2),
                     "gflop_per_launch": round(flops / n / 1e9, 3),
                     "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
@@ -435,6 +517,17 @@ def main() -> None:
         }
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(kw, cpu_state, 2, args.cpu_budget, device)
+        default_workload = (args.size, args.sax, args.lax, args.dtype, args.batch) == ("base", "192,192,16", "192,192", "bf16", 16)
+        if world == 1 and default_workload and not args.no_secondary and not args.force_sync and args.profile_steps > 0:
+            import gc
+
+            del step, model, batches
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                out["secondary"] = secondary_configs(device, with_parity=args.cpu_budget > 0)
+            except Exception as e:  # noqa: BLE001  (the headline line must not depend on the information-only runs)
+                out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_sync:
         dist.destroy_process_group()

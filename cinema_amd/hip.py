@@ -53,6 +53,7 @@ GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel"}
 GEMM_KERNEL_NAMES[64] = "gemm_mfma_grouped_kernel<false, false, 4>"
 GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
+GEMM_KERNEL_NAMES.update({2048 + lay + 8 * epi: f"gemm_p256_kernel<{txt}, {epi}, 1>" for lay, txt in _LAYOUTS.items() for epi in range(5)})  # csrc/gemm256.hip
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (kernel_used, algorithmic_flops, start_event, end_event)
 GEMM_PROFILE: list | None = None
@@ -473,7 +474,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         _dev(a_rowsum)
         g.a_rowsum = a_rowsum.data_ptr()
     if p256 is not None:
+        if GEMM_PROFILE is None or LANE is not None:
+            _p256_call(C.byref(g), 1, p256, a.device)
+            return out
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         _p256_call(C.byref(g), 1, p256, a.device)
+        ev1.record()
+        extra = sum(t.numel() * t.element_size() for t in (residual, gelu_in, aux_out) if t is not None)
+        alg_bytes = 2.0 * (m * k + k * n) + out.element_size() * m * n * (2 if accumulate else 1) + extra
+        GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), 0, alg_bytes)))
         return out
     ws = None
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
@@ -587,7 +597,16 @@ def gemm_wgrad_grouped(problems: list, p256: bool = False) -> None:
         if rowsum is not None:
             g.a_rowsum = rowsum.data_ptr()
     if p256:
+        if GEMM_PROFILE is None or LANE is not None:
+            _p256_call(arr, len(problems), 0, problems[0][0].device)
+            return
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         _p256_call(arr, len(problems), 0, problems[0][0].device)
+        ev1.record()
+        flops = sum(2.0 * g.m * g.n * g.k for g in arr)
+        alg = sum(2.0 * (g.m * g.k + g.k * g.n) + 8.0 * g.m * g.n for g in arr)  # every operand once, the fp32 gradient read + written once
+        GEMM_PROFILE.append((arr[0].kernel_used, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg)))
         return
     if GEMM_PROFILE is None:
         _check(load().cinema_gemm_bf16_grouped(arr, len(problems), _stream()), "gemm_grouped")

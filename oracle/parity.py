@@ -1,7 +1,7 @@
 """First-step parity of the HIP path against the CPU oracle on identical weights, inputs and masks -- TEST INFRASTRUCTURE ONLY.
 
-Used by ``tests/test_model_gpu.py`` (the real BASELINE config-2 shape) and by ``bench.py``'s ``cpu_baseline`` leg, which prints the
-result as the ``parity`` object of its JSON line.  The product package never imports this file.
+Used by ``tests/test_model_gpu.py`` / ``tests/test_seg_gpu.py`` (the real BASELINE config-2, config-4 and config-5 shapes) and by ``bench.py``'s
+``cpu_baseline`` leg, which prints the results as the ``parity`` objects of its JSON line.  The product package never imports this file.
 """
 
 from __future__ import annotations
@@ -87,3 +87,90 @@ def mae_step_parity(kw: dict, state_dict: dict, batch: int = 2, seed: int = 7, d
     out["worst_grad_max_abs_over_max"] = {"name": worst_max[0], "value": worst_max[1]}
     out["grad_rel"] = max(v["rel_l2"] for v in per_name.values()) if per_name else worst[1]
     return out
+
+
+def seg_step_parity(kw: dict, state_dict: dict, device: str = "cuda", seed: int = 99, threads: int | None = None) -> dict:
+    """BASELINE config 4 acceptance on ONE sample: ``cinema_amd`` ConvUNetR(**kw) with dropout / drop_path switched off against the oracle on the
+    same ``state_dict`` and the same U[0,1) volume (labels = the intensity quantised into the classes): eval-mode logits -> argmax agreement and the
+    foreground Dice between the two argmax segmentations (>= 0.995, |1 - Dice| <= 0.01), and train-mode CE + Dice loss / global gradient
+    norm / worst per-tensor gradient against ``O.segmentation_loss_one_view`` + autograd."""
+    from cinema_amd.segmentation.convunetr import ConvUNetR
+    from cinema_amd.segmentation.train import segmentation_loss_tensors, segmentation_metrics
+
+    if threads:
+        torch.set_num_threads(threads)
+    kw = dict(kw, dropout=0.0, drop_path=0.0)
+    n_cls = kw["out_chans"]
+    cfg = O.MAEConfig(image_size_dict=kw["image_size_dict"], in_chans_dict=kw["in_chans_dict"], enc_patch_size_dict=kw["enc_patch_size_dict"],
+                      enc_scale_factor_dict=kw["enc_scale_factor_dict"], enc_conv_chans=kw["enc_conv_chans"], enc_conv_n_blocks=kw["enc_conv_n_blocks"],
+                      enc_embed_dim=kw["enc_embed_dim"], enc_depth=kw["enc_depth"], enc_n_heads=kw["enc_n_heads"], dec_embed_dim=16, dec_depth=1, dec_n_heads=2)
+    gen = torch.Generator().manual_seed(seed)
+    image = torch.rand(1, 1, *kw["image_size_dict"]["sax"], generator=gen)
+    labels = torch.clamp((image * n_cls).long(), 0, n_cls - 1)
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+    p = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+    t0 = time.perf_counter()
+    ref = O.convunetr_forward(p, cfg, tuple(kw["dec_chans"]), 1, 1, {"sax": image})["sax"]
+    ref_loss, _ = O.segmentation_loss_one_view(ref, labels)
+    ref_loss.backward()
+    cpu_s = time.perf_counter() - t0
+
+    model = ConvUNetR(**kw)
+    model.load_state_dict(sd)
+    model.to(device).eval()
+    with torch.no_grad():
+        got = model({"sax": image.to(device)})["sax"].float()
+    ref_d = ref.detach()
+    agree = float((got.argmax(1).cpu() == ref_d.argmax(1)).float().mean())
+    m = segmentation_metrics(got, ref_d.argmax(1, keepdim=True).to(device), (1.0, 1.0, 10.0))
+    dice = float(torch.nanmean(torch.stack([m[f"class_{k}_dice_score"] for k in range(1, n_cls)])))
+    model.train()
+    loss, _ = segmentation_loss_tensors(model, {"sax_image": image.to(device), "sax_label": labels.to(torch.int8).to(device)}, ["sax"], torch.device(device))
+    loss.backward()
+    sq_g = sq_r = 0.0
+    worst = ("", 0.0)
+    for k, q in model.named_parameters():
+        r = p[k].grad
+        if r is None or q.grad is None:
+            continue
+        g = q.grad.float().cpu()
+        sq_g += float(g.double().pow(2).sum())
+        sq_r += float(r.double().pow(2).sum())
+        l2 = float((g - r).norm() / r.norm().clamp_min(1e-30))
+        if l2 > worst[1]:
+            worst = (k, l2)
+    return {"argmax_agreement": agree, "dice_gpu_vs_cpu_segmentation": dice, "logits_max_abs": float((got.cpu() - ref_d).abs().max()),
+            "logits_abs_max_ref": float(ref_d.abs().max()), "loss": float(loss), "oracle_loss": float(ref_loss),
+            "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "grad_norm_rel": abs(math.sqrt(sq_g) - math.sqrt(sq_r)) / math.sqrt(sq_r),
+            "worst_grad_rel_l2": {"name": worst[0], "value": worst[1]}, "oracle_seconds": round(cpu_s, 2)}
+
+
+def mae_loss_parity(kw: dict, state_dict: dict, batch: int = 1, seed: int = 7, device: str = "cuda", fp8: bool = False, threads: int | None = None) -> dict:
+    """Forward-only first-step loss of the HIP path (optionally with the e4m3 forward projections) against the oracle: the check that fits the Large
+    256 x 256 x 24 shape of BASELINE config 5 into a test (the oracle's backward at that shape takes minutes, its forward seconds)."""
+    from cinema_amd import CineMA
+    from cinema_amd import tape as T
+
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = O.MAEConfig(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
+    gen = torch.Generator().manual_seed(seed)
+    images = {v: torch.rand(batch, 1, *s, generator=gen) for v, s in kw["image_size_dict"].items()}
+    masks = {v: O.random_patch_mask(batch, math.prod(cfg.grid_size(v)), 0.75, gen) for v in images}
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref_loss, _, ref_metrics = O.mae_forward(sd, cfg, images, masks)
+    cpu_s = time.perf_counter() - t0
+    model = CineMA(**kw)
+    model.load_state_dict(sd)
+    model.to(device)
+    prev, T.FP8_FORWARD = T.FP8_FORWARD, fp8
+    try:
+        with torch.no_grad():
+            loss, _, _, metrics = model({k: v.to(device) for k, v in images.items()}, 0.75, enc_mask_dict={k: v.to(device) for k, v in masks.items()})
+    finally:
+        T.FP8_FORWARD = prev
+    return {"loss": float(loss), "oracle_loss": float(ref_loss), "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
+            "view_loss_rel": {v: abs(float(metrics[f"{v}_mse_loss"]) - float(ref_metrics[f"{v}_mse_loss"])) / abs(float(ref_metrics[f"{v}_mse_loss"])) for v in images},
+            "fp8": fp8, "oracle_seconds": round(cpu_s, 2)}

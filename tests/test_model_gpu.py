@@ -316,10 +316,38 @@ def test_fp8_forward_path_vs_oracle_and_bf16() -> None:
         T.FP8_FORWARD = False
 
 
+def test_large_config_256_fp8_first_step_loss_vs_oracle() -> None:
+    """BASELINE config 5 at its OWN shape (ViT-Large, SAX 256 x 256 x 24 + 3 LAX 256 x 256, batch 1): first-step loss of the fp8 path (e4m3 forward
+    projections) and of the bf16 path against the fp32 CPU oracle's forward on identical weights, inputs and masks (oracle/parity.py::mae_loss_parity).
+    Stated tolerance: fp8 loss rel <= 5e-2, bf16 <= 2e-2; the fp8 loss must differ from the bf16 one (the e4m3 kernels really ran)."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "oracle"))
+    from parity import mae_loss_parity
+
+    from cinema_amd.vit import get_vit_config
+
+    views = ["sax", "lax_2c", "lax_3c", "lax_4c"]
+    kw = dict(image_size_dict={v: (256, 256, 24) if v == "sax" else (256, 256) for v in views}, in_chans_dict=dict.fromkeys(views, 1),
+              enc_patch_size_dict={v: (4, 4, 1) if v == "sax" else (4, 4) for v in views},
+              enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2,
+              **get_vit_config("large"))
+    torch.manual_seed(3)
+    sd = {k: v.detach().clone() for k, v in CineMA(**kw).state_dict().items()}
+    p8 = mae_loss_parity(kw, sd, batch=1, device=DEV, fp8=True, threads=16)
+    p16 = mae_loss_parity(kw, sd, batch=1, device=DEV, fp8=False, threads=16)
+    print("config-5 shape, first-step loss vs oracle:", p8, p16)
+    assert p8["loss_rel"] <= 5e-2 and max(p8["view_loss_rel"].values()) <= 5e-2, p8
+    assert p16["loss_rel"] <= 2e-2, p16
+    assert p8["loss"] != p16["loss"]
+
+
 def test_large_config_256_step_properties() -> None:
     """BASELINE config 5 shape (ViT-Large, 4 views, SAX 256x256x24 + LAX 256x256, 6144 + 3 x 256 tokens) at batch 1: too large for the CPU
     oracle inside a test, so size-independent properties are checked instead: mask counts, finite loss / gradient norm, a loss that falls on
-    a fixed batch, and the recorded (replayed) steps continuing the eager trajectory (bf16 compute; the fp8 variant of that config is not built)."""
+    a fixed batch, and the recorded (replayed) steps continuing the eager trajectory (bf16 compute; the fp8 path at this shape is checked against the
+    oracle by ``test_large_config_256_fp8_first_step_loss_vs_oracle``)."""
     from cinema_amd.optim import TrainStep
     from cinema_amd.vit import get_vit_config
 
