@@ -158,6 +158,7 @@ def seg_cpu_baseline(kw: dict, state_dict: dict, device: str, budget_s: float) -
               "logits_max_abs": round(par["logits_max_abs"], 4), "logits_abs_max_ref": round(par["logits_abs_max_ref"], 3),
               "loss_rel": round(par["loss_rel"], 6), "grad_norm_rel": round(par["grad_norm_rel"], 5),
               "worst_grad_rel_l2": {"name": par["worst_grad_rel_l2"]["name"], "value": round(par["worst_grad_rel_l2"]["value"], 4)},
+              "worst_grad_err_over_global_norm": {"name": par["worst_grad_err_over_global_norm"]["name"], "value": round(par["worst_grad_err_over_global_norm"]["value"], 6)},
               "what": "HIP path (dropout / drop_path off) vs the fp32 CPU oracle on one identical sample and identical weights (random init): fraction of voxels "
                       "with the same argmax class and the foreground Dice between the two argmax segmentations of the eval-mode logits (acceptance: >= 0.995, "
                       "|1 - Dice| <= 0.01); CE + Dice loss, global gradient norm and worst per-tensor gradient of the training-mode step"}

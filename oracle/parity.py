@@ -128,21 +128,32 @@ def seg_step_parity(kw: dict, state_dict: dict, device: str = "cuda", seed: int 
     loss, _ = segmentation_loss_tensors(model, {"sax_image": image.to(device), "sax_label": labels.to(torch.int8).to(device)}, ["sax"], torch.device(device))
     loss.backward()
     sq_g = sq_r = 0.0
-    worst = ("", 0.0)
-    for k, q in model.named_parameters():
-        r = p[k].grad
-        if r is None or q.grad is None:
-            continue
-        g = q.grad.float().cpu()
+    worst, worst_small, worst_global = ("", 0.0), ("", 0.0, 0.0), ("", 0.0)
+    pairs = [(k, q.grad.float().cpu(), p[k].grad) for k, q in model.named_parameters() if p[k].grad is not None and q.grad is not None]
+    ref_norm = math.sqrt(sum(float(r.double().pow(2).sum()) for _, _, r in pairs))
+    for k, g, r in pairs:
         sq_g += float(g.double().pow(2).sum())
         sq_r += float(r.double().pow(2).sum())
-        l2 = float((g - r).norm() / r.norm().clamp_min(1e-30))
-        if l2 > worst[1]:
-            worst = (k, l2)
+        share = float(r.norm()) / ref_norm
+        err = float((g - r).norm())
+        if err / ref_norm > worst_global[1]:
+            worst_global = (k, err / ref_norm)
+        if share < 1e-6:  # e.g. the weight of a LayerNorm over ONE channel (the raw-image block): its input is identically zero after the mean is
+            continue      # removed, the gradient is rounding noise on both sides
+        l2 = err / float(r.norm())
+        # tensors that carry less than 1e-3 of the gradient norm (at random init: the q / k projections of the T = 3073 attention, whose softmax is
+        # nearly uniform) are dominated by bf16 rounding of much larger intermediate terms: reported, bounded relative to the GLOBAL norm
+        if share >= 1e-3:
+            if l2 > worst[1]:
+                worst = (k, l2)
+        elif l2 > worst_small[1]:
+            worst_small = (k, l2, share)
     return {"argmax_agreement": agree, "dice_gpu_vs_cpu_segmentation": dice, "logits_max_abs": float((got.cpu() - ref_d).abs().max()),
             "logits_abs_max_ref": float(ref_d.abs().max()), "loss": float(loss), "oracle_loss": float(ref_loss),
             "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "grad_norm_rel": abs(math.sqrt(sq_g) - math.sqrt(sq_r)) / math.sqrt(sq_r),
-            "worst_grad_rel_l2": {"name": worst[0], "value": worst[1]}, "oracle_seconds": round(cpu_s, 2)}
+            "worst_grad_rel_l2": {"name": worst[0], "value": worst[1]},
+            "worst_small_grad_rel_l2": {"name": worst_small[0], "value": worst_small[1], "share_of_grad_norm": worst_small[2]},
+            "worst_grad_err_over_global_norm": {"name": worst_global[0], "value": worst_global[1]}, "oracle_seconds": round(cpu_s, 2)}
 
 
 def mae_loss_parity(kw: dict, state_dict: dict, batch: int = 1, seed: int = 7, device: str = "cuda", fp8: bool = False, threads: int | None = None) -> dict:
