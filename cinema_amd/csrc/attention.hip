@@ -6,6 +6,7 @@
 //   acc reg r of lane l  <->  row (r&3)+8*(r>>2)+4*(l>>5), col l&31;   regs 8s..8s+7 = the 8 k-slots of MFMA step s.
 // The operand that is strided along the reduction index (V^T, K^T, dO^T, Q^T) is read from its row-major LDS tile
 // with ds_read_b64_tr_b16.  Tiles are staged through registers into XOR-swizzled LDS, double buffered.
+#include <cstdlib>
 #include "common.cuh"
 #include <initializer_list>
 #include <type_traits>
@@ -24,6 +25,8 @@ struct AttnP {
 };
 
 constexpr float NEG_INF = -1e30f;
+__device__ __forceinline__ float bf_lo32(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 // ---- stage a [ROWS][HD] bf16 tile (rows = tokens row0.., this head's HD columns) global -> regs -> swizzled LDS
 template <int HD, int ROWS>
@@ -450,6 +453,221 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
   }
 }
 
+// ================================================================================================
+// backward, ONE pass (head_dim 32, tk <= 768): one workgroup of 8 waves per (batch, head); P and dS are computed once.
+// ================================================================================================
+// The two-kernel backward above evaluates exp(S - lse) twice per score (once with the query in the lane for dQ, once with the key in the lane
+// for dK / dV) and reads Q, K, V, dO twice.  Here the keys of one (batch, head) are dealt to the 8 waves in blocks of 32 (wave w owns blocks
+// w, w + 8, w + 16): dK / dV of those keys live in the wave's accumulators for the whole kernel, K sits in LDS, and the workgroup walks the
+// queries in tiles of 64 (Q / dO tiles by LDS-DMA, double buffered).  Per (key block, 32 queries) a wave runs S = Q K^T and dP = dO V^T
+// (key in the lane, queries in the registers), P = exp2(S c2 - lse), dS = P (dP - delta), dV += P^T dO and dK += dS^T Q with the
+// accumulator registers as the k-slot operand - and dQ, whose reduction runs over the KEYS, i.e. over the lanes of dS: the 32 x 32 bf16
+// block dS goes through 2 KiB of wave-private LDS (four ds_write_b64 per lane, [key][query] rows) and comes back query-in-the-lane through
+// ds_read_b64_tr_b16, the same transpose read that feeds K^T.  The waves' partial dQ^T tiles (fp32) are summed through LDS in a fixed order
+// (deterministic, no atomics) and written once.  delta = rowsum(dO * O) is computed per query tile from the rows themselves.
+constexpr int FUSED_MAXKB = 3;
+template <int HD>
+struct FusedGeom {
+  static constexpr int RB = HD * 2;                         // bytes per Q / K / dO row
+  static constexpr int KS_BYTES = 8 * FUSED_MAXKB * 32 * RB;
+  static constexpr int TB = 64 * RB;
+  static constexpr int ST = 2 * TB + 512;                   // Q | dO | lse[64] | delta[64]
+  static constexpr int DST_BYTES = 8 * 32 * 64;             // per wave: one 32 x 32 bf16 dS tile
+  static constexpr int RED_BYTES = 8 * 64 * HD * 4;
+  static constexpr int SMEM = KS_BYTES + 2 * ST + DST_BYTES + RED_BYTES;
+};
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
+  static_assert(HD == 32, "one 32-wide head-dim block per accumulator");
+  using G = FusedGeom<HD>;
+  using Stage = TileStage<HD, 64>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks_ = smem;
+  char* stage0 = smem + G::KS_BYTES;
+  char* dst_all = stage0 + 2 * G::ST;
+  float* red = reinterpret_cast<float*>(dst_all + G::DST_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int b = blockIdx.x / p.h, h = blockIdx.x % p.h;
+  const int nkb = (p.tk + 31) / 32;
+  const bf16_t* qbase = p.q + (size_t)b * p.tq * p.ldq + h * HD;
+  const bf16_t* dobase = p.d_o + (size_t)b * p.tq * p.lddo + h * HD;
+  const bf16_t* obase = p.o + (size_t)b * p.tq * p.ldo + h * HD;
+  const bf16_t* kbase = p.k + (size_t)b * p.tk * p.ldk + h * HD;
+  const bf16_t* vbase = p.v + (size_t)b * p.tk * p.ldv + h * HD;
+  const float* lsebase = p.lse + ((size_t)b * p.h + h) * p.tq;
+  char* dstw = dst_all + wave_u * 2048;
+
+  // K -> LDS (16 rows per 1 KiB piece, swizzle on the source chunk), V rows of this wave's keys -> registers
+  {
+    const uint32_t a0 = __builtin_amdgcn_readfirstlane(lds_address(ks_));
+    for (int blk = wave_u; blk < nkb * 2; blk += 8) {
+      const int row = blk * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      const int rr = min(row, p.tk - 1);
+      glds16(__builtin_amdgcn_readfirstlane(a0 + blk * 1024), kbase + (size_t)rr * p.ldk + c * 8);
+    }
+  }
+  short8v vf[FUSED_MAXKB][HD / 16];
+#pragma unroll
+  for (int kb = 0; kb < FUSED_MAXKB; kb++) {
+    const int key = min(32 * (wave_u + 8 * kb) + (lane & 31), p.tk - 1);
+    load_row_frags<HD>(vf[kb], vbase + (size_t)key * p.ldv, lane);
+  }
+  float16v dk[FUSED_MAXKB], dv[FUSED_MAXKB];
+#pragma unroll
+  for (int kb = 0; kb < FUSED_MAXKB; kb++) { zero16(dk[kb]); zero16(dv[kb]); }
+
+  const int nqt = (p.tq + 63) / 64;
+  float st_l = 0.f;  // threads 0..63: lse, 64..127: delta of the next tile's queries
+  auto load_stats = [&](int q0) {
+    if (tid < 64) {
+      const int qi = q0 + tid;
+      st_l = qi < p.tq ? lsebase[qi] : 1e30f;  // lse = +big -> P = 0 for padded queries
+    } else if (tid < 128) {
+      const int qi = q0 + tid - 64;
+      float s = 0.f;
+      if (qi < p.tq) {
+        const uint4* op = reinterpret_cast<const uint4*>(obase + (size_t)qi * p.ldo);
+        const uint4* dp = reinterpret_cast<const uint4*>(dobase + (size_t)qi * p.lddo);
+#pragma unroll
+        for (int c = 0; c < HD / 8; c++) {
+          const uint4 a = op[c], d = dp[c];
+          s += bf_lo32(a.x) * bf_lo32(d.x) + bf_hi32(a.x) * bf_hi32(d.x) + bf_lo32(a.y) * bf_lo32(d.y) + bf_hi32(a.y) * bf_hi32(d.y) +
+               bf_lo32(a.z) * bf_lo32(d.z) + bf_hi32(a.z) * bf_hi32(d.z) + bf_lo32(a.w) * bf_lo32(d.w) + bf_hi32(a.w) * bf_hi32(d.w);
+        }
+      }
+      st_l = s;
+    }
+  };
+  auto store_stats = [&](char* base) {
+    if (tid < 128) reinterpret_cast<float*>(base + 2 * G::TB)[tid] = st_l;
+  };
+  auto load_tiles = [&](char* base, int q0) {  // waves 0-3: the four pieces of the Q tile, waves 4-7: of the dO tile
+    if (wave_u < 4) Stage::glds(base, qbase, p.ldq, q0, p.tq, lane, wave_u);
+    else Stage::glds(base + G::TB, dobase, p.lddo, q0, p.tq, lane, wave_u - 4);
+  };
+  load_tiles(stage0, 0);
+  load_stats(0);
+  store_stats(stage0);
+
+  for (int qt = 0; qt < nqt; qt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile qt (and, first time, K) landed; everyone is done with the other stage and with `red`
+    const char* qs_ = stage0 + (qt & 1) * G::ST;
+    const char* dos_ = qs_ + G::TB;
+    const float* stats = reinterpret_cast<const float*>(qs_ + 2 * G::TB);
+    const bool more = qt + 1 < nqt;
+    if (more) {
+      load_tiles(stage0 + ((qt + 1) & 1) * G::ST, (qt + 1) * 64);
+      load_stats((qt + 1) * 64);
+    }
+    const int nu = qt * 64 + 32 < p.tq ? 2 : 1;  // empty 32-query half of the last tile (workgroup-uniform)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      float16v dq;
+      zero16(dq);
+      if (u < nu) {
+        // Q / dO row fragments of these 32 queries: once per half tile, not once per key block
+        short8v qf[HD / 16], dof[HD / 16];
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ks++) { qf[ks] = frag_km<HD>(qs_, 32 * u, ks, lane); dof[ks] = frag_km<HD>(dos_, 32 * u, ks, lane); }
+#pragma unroll
+        for (int kb = 0; kb < FUSED_MAXKB; kb++) {
+          const int blk = wave_u + 8 * kb;
+          if (blk < nkb) {
+            const char* kt_ = ks_ + blk * 32 * G::RB;
+            float16v s, dp;
+            zero16(s); zero16(dp);
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ks++) {
+              s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], frag_km<HD>(kt_, 0, ks, lane), s, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[kb][ks], dp, 0, 0, 0);
+            }
+            // row statistics straight from LDS (broadcast reads; held in registers across the key blocks they cost 32 VGPRs and spilled):
+            // acc reg r <-> query 32u + (r&3) + 8*(r>>2) + 4g
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float4 l4 = *reinterpret_cast<const float4*>(stats + 32 * u + 8 * j + 4 * g);
+              const float4 d4 = *reinterpret_cast<const float4*>(stats + 64 + 32 * u + 8 * j + 4 * g);
+              const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                const float pr = fast_exp2(fmaf(s[4 * j + i], p.c2, -lv[i]));
+                s[4 * j + i] = pr;
+                dp[4 * j + i] = pr * (dp[4 * j + i] - dl[i]);
+              }
+            }
+            if (blk * 32 + 32 > p.tk) {  // ragged last key block (wave-uniform): keys past the end contribute nothing
+              const bool key_ok = blk * 32 + (lane & 31) < p.tk;
+#pragma unroll
+              for (int r = 0; r < 16; r++) { s[r] = key_ok ? s[r] : 0.f; dp[r] = key_ok ? dp[r] : 0.f; }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+              const short8v pf = pack_slots(s, st);
+              union { short8v v; uint32_t u32[4]; } dsf;
+              dsf.v = pack_slots(dp, st);
+              dv[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(dos_, 32 * u + 16 * st, 0, lane), pf, dv[kb], 0, 0, 0);
+              dk[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(qs_, 32 * u + 16 * st, 0, lane), dsf.v, dk[kb], 0, 0, 0);
+              // dS -> [key][query] rows of the wave's scratch tile: this lane's key, queries 8c + 4g .. + 3 (c = 2 st, 2 st + 1)
+              const int j = lane & 31;
+              *reinterpret_cast<uint2*>(dstw + swz_off<64>(j, 2 * st) + 8 * g) = make_uint2(dsf.u32[0], dsf.u32[1]);
+              *reinterpret_cast<uint2*>(dstw + swz_off<64>(j, 2 * st + 1) + 8 * g) = make_uint2(dsf.u32[2], dsf.u32[3]);
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: both operands by transpose reads (K tile rows = keys; scratch tile rows = keys)
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+              dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(kt_, 16 * st, 0, lane), frag_tr<32>(dstw, 16 * st, 0, lane), dq, 0, 0, 0);
+          }
+        }
+      }
+      // partial dQ^T of this wave -> red[wave][q][d] (16-byte chunk index XORed with q & 7: a ds_write_b128 lane group covers consecutive q)
+      const int q = 32 * u + (lane & 31);
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        *reinterpret_cast<float4*>(red + ((size_t)(wave_u * 64 + q) * 8 + ((2 * c + g) ^ (q & 7))) * 4) =
+            make_float4(dq[4 * c], dq[4 * c + 1], dq[4 * c + 2], dq[4 * c + 3]);
+    }
+    if (more) store_stats(stage0 + ((qt + 1) & 1) * G::ST);
+    __syncthreads();
+    {  // fixed-order sum over the 8 waves: wave w finishes queries 8w .. 8w + 7 of the tile, a lane 4 head-dim values of one query
+      const int row = wave_u * 8 + (lane >> 3), chunk = lane & 7;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ww = 0; ww < 8; ww++) {
+        const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)(ww * 64 + row) * 8 + (chunk ^ (row & 7))) * 4);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      const int qg = qt * 64 + row;
+      if (qg < p.tq) {
+        uint2 pk;
+        pk.x = pack_bf2(acc.x * p.scale, acc.y * p.scale);
+        pk.y = pack_bf2(acc.z * p.scale, acc.w * p.scale);
+        *reinterpret_cast<uint2*>(p.dq + ((size_t)b * p.tq + qg) * p.lddq + h * HD + chunk * 4) = pk;
+      }
+    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < FUSED_MAXKB; kb++) {
+    const int krow = 32 * (wave_u + 8 * kb) + (lane & 31);
+    if (krow < p.tk) {
+      bf16_t* kp = p.dk + ((size_t)b * p.tk + krow) * p.lddk + h * HD;
+      bf16_t* vp = p.dv + ((size_t)b * p.tk + krow) * p.lddv + h * HD;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint2 pk;
+        pk.x = pack_bf2(dk[kb][4 * j] * p.scale, dk[kb][4 * j + 1] * p.scale);
+        pk.y = pack_bf2(dk[kb][4 * j + 2] * p.scale, dk[kb][4 * j + 3] * p.scale);
+        *reinterpret_cast<uint2*>(kp + 8 * j + 4 * g) = pk;
+        pk.x = pack_bf2(dv[kb][4 * j], dv[kb][4 * j + 1]);
+        pk.y = pack_bf2(dv[kb][4 * j + 2], dv[kb][4 * j + 3]);
+        *reinterpret_cast<uint2*>(vp + 8 * j + 4 * g) = pk;
+      }
+    }
+  }
+}
+
 // delta[b,h,q] = sum_d dO*O
 __global__ void attn_delta_kernel(AttnP p) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -642,6 +860,19 @@ CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* 
     CINEMA_LAUNCH(attn_delta_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, p);
   }
   if (mfma && mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv})) {
+    // one-pass backward (hd 32, at most 3 key blocks of 32 per wave): CINEMA_ATTN_FUSED=0 keeps the two-kernel form
+    const char* fused_txt = getenv("CINEMA_ATTN_FUSED");  // read per call: tests switch between the two forms
+    const int fused_env = fused_txt ? atoi(fused_txt) : 1;
+    if (fused_env && hd == 32 && tk <= 8 * FUSED_MAXKB * 32 && !(ldo & 7)) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_mfma<32>), hipFuncAttributeMaxDynamicSharedMemorySize, FusedGeom<32>::SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+      }
+      CINEMA_LAUNCH(attn_bwd_fused_mfma<32>, dim3((unsigned)(b * h)), dim3(512), (size_t)FusedGeom<32>::SMEM, st, p);
+      return launch_status();
+    }
     dim3 gq((tq + 127) / 128, h, b), gk((tk + 127) / 128, h, b);
     if (hd == 64) {
       CINEMA_LAUNCH(attn_bwd_dq_mfma<64>, gq, dim3(256), 0, st, p);

@@ -340,6 +340,35 @@ def test_attention_forward_backward(hd: int, heads: int, tq: int, tk: int, gener
         close(got, want, 2e-2, tol, f"attention {name}")
 
 
+@pytest.mark.parametrize(("heads", "tq", "tk"), [(16, 2053, 684), (4, 70, 33), (2, 130, 768), (3, 64, 97)])
+def test_attention_backward_one_pass_equals_two_kernel_form(heads: int, tq: int, tk: int, monkeypatch) -> None:  # noqa: ANN001
+    """attn_bwd_fused_mfma<32> (one workgroup per (batch, head), P and dS computed once, dQ through the in-LDS transpose of dS and a fixed-order
+    cross-wave sum) against fp32 autograd (2 % of the tensor scale: bf16 P / dS and outputs) and against the two-kernel form (same arithmetic up to
+    the summation order of dQ and the bf16 rounding points: 1 % of the tensor scale), ragged key / query tails included; run twice (determinism)."""
+    b, hd = 2, 32
+    c = hd * heads
+    q, kv = rnd(b, tq, c, seed=31), rnd(b, tk, 2 * c, seed=32)
+    k, v = kv[..., :c], kv[..., c:]
+    scale = hd**-0.5
+    qr, kr, vr = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qr, kr, vr, heads)
+    o, lse = K.attention_fwd(q, k, v, heads, scale)
+    d_o = rnd(b, tq, c, seed=33)
+    ref.backward(d_o.float())
+    outs = {}
+    for form in ("1", "0", "1"):
+        monkeypatch.setenv("CINEMA_ATTN_FUSED", form)
+        dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+        K.attention_bwd(q, k, v, o, d_o, lse, heads, scale, dq, dkv[..., :c], dkv[..., c:])
+        if form == "1" and "1" in outs:
+            assert torch.equal(dq, outs["1"][0]) and torch.equal(dkv, outs["1"][1]), "one-pass backward is not deterministic"
+        outs[form] = (dq, dkv)
+    for name, i, sl, want in (("dq", 0, slice(None), qr.grad), ("dk", 1, slice(0, c), kr.grad), ("dv", 1, slice(c, 2 * c), vr.grad)):
+        tol = float(want.abs().max())
+        close(outs["1"][i][..., sl], want, 2e-2, 2e-2 * tol, f"one-pass {name} vs autograd")
+        close(outs["1"][i][..., sl], outs["0"][i][..., sl], 0.0, 1e-2 * tol, f"one-pass {name} vs two-kernel form")
+
+
 def test_attention_rescale_branch() -> None:
     """Force large running-max jumps between key tiles (guide rule 26): one spiked key per tile, increasing."""
     b, heads, hd, t = 1, 1, 64, 256
