@@ -762,11 +762,74 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
     return y
 
 
-def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, fp8: bool = False) -> Var:  # noqa: ANN001
-    """q from xq (bf16 [b*tq, c]), k|v from xk (bf16 [b*tk, c], shared by every decoder block, not normed)."""
+class SharedKV:
+    """k|v projections of ALL decoder blocks from one GEMM (:func:`op_shared_kv`): ``data`` [b*tk, n_blocks * 2c] bf16, ``grad`` the same shape,
+    filled block by block in the backward pass and consumed by one data-gradient GEMM + one grouped weight-gradient launch."""
+
+    def __init__(self, data: torch.Tensor, width: int) -> None:
+        self.data, self.width, self.grad = data, width, None
+
+    def part(self, i: int) -> torch.Tensor:
+        return self.data[:, i * self.width:(i + 1) * self.width]
+
+    def grad_part(self, i: int) -> torch.Tensor:
+        if self.grad is None:
+            self.grad = K.empty_like(self.data)
+        return self.grad[:, i * self.width:(i + 1) * self.width]
+
+
+# The decoder blocks all project the SAME un-normed encoder output to their keys / values (reference cinema/mae/mae.py:580-582, cinema/vit.py:472-477):
+# one GEMM with the concatenated weights (N = n_blocks * 2c: 10.75 rounds of tiles instead of 8 x 1.34), one data-gradient GEMM with K = n_blocks * 2c
+# and one grouped weight-gradient launch instead of 8 of each: 423 vs 610 us per step measured in isolation (tools/bench_gemm.py "X dec").  Off under a
+# gradient exchange (the blocks' collectives start when their own backward ops are launched; these weight gradients come later) and with fp8 forward.
+SHARE_DECODER_KV = bool(int(os.environ.get("CINEMA_SHARE_KV", "1")))
+
+
+def share_kv_ok(xk: Var, attns: list) -> bool:
+    return (SHARE_DECODER_KV and len(attns) > 1 and PARAMS_DONE_HOOK is None and not FP8_FORWARD and xk.data.is_cuda and not K.FORCE_GENERIC
+            and all(a.kv.weight.shape == attns[0].kv.weight.shape and (a.kv.bias is None) == (attns[0].kv.bias is None) for a in attns)
+            and attns[0].kv.weight.shape[0] % 16 == 0 and xk.data.shape[1] % 8 == 0)
+
+
+def op_shared_kv(tape: Tape, xk: Var, attns: list) -> SharedKV:
+    """k|v of every block in ``attns`` (modules with ``kv`` Linear layers) from xk bf16 [b*tk, c]."""
+    n, (two_c, c) = len(attns), attns[0].kv.weight.shape
+    rows = xk.data.shape[0]
+    wcat = K.empty((n * two_c, c), dtype=BF16, device=xk.data.device)
+    K.row_copy_multi([dict(dst=wcat[i * two_c:(i + 1) * two_c], src=w_plain(a.kv.weight)) for i, a in enumerate(attns)])
+    bcat = None
+    if attns[0].kv.bias is not None:
+        bcat = K.empty((n * two_c,), dtype=F32, device=xk.data.device)
+        K.row_copy_multi([dict(dst=bcat[i * two_c:(i + 1) * two_c].view(1, two_c), src=a.kv.bias.detach().view(1, two_c)) for i, a in enumerate(attns)])
+    shared = SharedKV(K.gemm(xk.data, wcat, bias=bcat), two_c)
+    pvs = [(tape.pvar(a.kv.weight), tape.pvar(a.kv.bias)) for a in attns]
+
+    def bwd() -> None:  # recorded before the blocks: runs after all of them in the backward pass
+        if shared.grad is None:
+            return
+        prev, tape.grouping = tape.grouping, GROUP_WGRAD == 2
+        for i, (a, (wv, bv)) in enumerate(zip(attns, pvs)):
+            if a.kv.weight.requires_grad:
+                wgrad(tape, shared.grad_part(i), xk.data, wv, bv if (a.kv.bias is not None and a.kv.bias.requires_grad) else None, (two_c, c))
+        flush_wgrads(tape)
+        tape.grouping = prev
+        if xk.needs_grad:
+            xk.add_grad(K.gemm(shared.grad, wcat, a_kmajor=True, b_kmajor=False))
+        assert rows == shared.grad.shape[0]
+
+    tape.record(bwd)
+    return shared
+
+
+def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, fp8: bool = False, shared: tuple | None = None) -> Var:  # noqa: ANN001
+    """q from xq (bf16 [b*tq, c]), k|v from xk (bf16 [b*tk, c], shared by every decoder block, not normed).  ``shared`` = (SharedKV, block index):
+    the k|v projection (and its gradients) are handled by :func:`op_shared_kv` for all blocks at once."""
     c = xq.data.shape[1]
     wq, wkv = w_plain(q_w), w_plain(kv_w)
-    if fp8 and _fp8_ok(xq.data, q_w) and _fp8_ok(xk.data, kv_w):
+    if shared is not None:
+        q = K.gemm(xq.data, wq, bias=None if q_b is None else q_b.detach())
+        kv = shared[0].part(shared[1])
+    elif fp8 and _fp8_ok(xq.data, q_w) and _fp8_ok(xk.data, kv_w):
         q = K.gemm_fp8(*a_fp8(xq), *w_fp8(q_w), bias=None if q_b is None else q_b.detach())
         if xk.fp8 is None:  # the keys are the same tensor for every decoder block: quantise once
             xk.fp8 = K.quantize_fp8_rows(xk.data)
@@ -784,15 +847,17 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
     def bwd() -> None:
         if y.grad is None:
             return
-        dq, dkv = K.empty_like(q), K.empty_like(kv)
+        dq = K.empty_like(q)
+        dkv = K.empty_like(kv) if shared is None else shared[0].grad_part(shared[1])
         dkv3 = dkv.view(batch, tk, 2 * c)
         K.attention_bwd(q3, kv3[..., :c], kv3[..., c:], o, y.grad.view(batch, tq, c), lse, heads, scale, dq.view(batch, tq, c), dkv3[..., :c],
                         dkv3[..., c:])
         wgrad(tape, dq, xq.data, pv[0], pv[1], (c, c))
-        wgrad(tape, dkv, xk.data, pv[2], pv[3], (2 * c, c))
+        if shared is None:
+            wgrad(tape, dkv, xk.data, pv[2], pv[3], (2 * c, c))
         if xq.needs_grad:
             xq.add_grad(K.gemm(dq, wq, a_kmajor=True, b_kmajor=False))
-        if xk.needs_grad:
+        if shared is None and xk.needs_grad:
             xk.add_grad(K.gemm(dkv, wkv, a_kmajor=True, b_kmajor=False))
 
     tape.record(bwd)

@@ -180,8 +180,9 @@ class Attention(nn.Module):
         # "rotary/out_plain" to 6e-8).  The HIP path applies that same head-indexed rotation (cinema_rope_heads) to the fused q|k rows.
         self.rotary = RotaryEmbedding(self.head_dim) if rotary else None
 
-    def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int) -> T.Var:
-        """xq: bf16 [b*tq, c] (normed queries); xk: bf16 [b*tk, c] or None for self-attention.  Returns bf16 [b*tq, c]."""
+    def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int, shared_kv: tuple | None = None) -> T.Var:
+        """xq: bf16 [b*tq, c] (normed queries); xk: bf16 [b*tk, c] or None for self-attention.  Returns bf16 [b*tq, c].
+        ``shared_kv`` = (tape.SharedKV, index): k|v of this block were projected together with the other decoder blocks'."""
         if xk is not None and self.rotary:
             raise ValueError("Rotary positional embedding is not supported with different query and key.")
         if xk is None:
@@ -191,7 +192,8 @@ class Attention(nn.Module):
                 rope = T.const(("rope_tables", self.n_heads, self.head_dim, self.rotary.base, self.rotary.scaling_factor, str(dev)),
                                lambda: self.rotary.head_tables(self.n_heads, dev))
             return T.op_self_attention(tp, xq, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, rope=rope, fp8=T.FP8_FORWARD)
-        return T.op_cross_attention(tp, xq, xk, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, fp8=T.FP8_FORWARD)
+        return T.op_cross_attention(tp, xq, xk, batch, self.n_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, fp8=T.FP8_FORWARD,
+                                    shared=shared_kv)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor | None = None) -> torch.Tensor:
         b, tq, c = q.shape
@@ -284,13 +286,13 @@ class Block(nn.Module, _CkptFlag):
             pl = self.__dict__["_plist"] = [p for p in self.parameters() if p.requires_grad]
         return pl
 
-    def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int) -> T.Var:
+    def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int, shared_kv: tuple | None = None) -> T.Var:
         """xq: fp32 residual stream [b*tq, c]; xk: bf16 un-normed keys [b*tk, c] or None (``vit.py:589``)."""
         drop = self.drop_path_rate if self.training else 0.0
         T.mark_params(tp, self._param_list())  # gradient all-reduce of this block may start once its backward ops are launched
         T.wgrad_group(tp)                      # ... which includes the grouped weight-gradient launch: its flush runs before that marker fires
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps, fp8=True)
-        att = self.attn.tape_forward(tp, qn, xk, batch)
+        att = self.attn.tape_forward(tp, qn, xk, batch, shared_kv=shared_kv)
         if drop > 0.0:  # q + drop_path1(path1(q)), q + drop_path2(path2(q)) (vit.py:606-609): the residual adds leave the GEMM epilogues
             h1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, out_f32=True, fp8=T.FP8_FORWARD)
             x1 = T.op_droppath_add(tp, h1, xq, batch, drop)
@@ -395,8 +397,10 @@ class ViTDecoder(nn.Module, _CkptFlag):
     def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int) -> T.Var:
         """Runs the blocks and the final LayerNorm on every query row (the callers slice the masked rows; the norm is
         row-wise so normalising the extra cls/visible rows changes nothing).  Output bf16 [b*tq, c]."""
-        for blk in self.blocks:
-            xq = blk.tape_forward(tp, xq, xk, batch)
+        attns = [blk.attn for blk in self.blocks]
+        shared = T.op_shared_kv(tp, xk, attns) if (xk is not None and T.share_kv_ok(xk, attns)) else None
+        for i, blk in enumerate(self.blocks):
+            xq = blk.tape_forward(tp, xq, xk, batch, shared_kv=None if shared is None else (shared, i))
         return T.op_layernorm(tp, xq, self.norm.weight, self.norm.bias, self.norm.eps)
 
     def forward(self, x_q: torch.Tensor, x_k: torch.Tensor | None, n_enc_masked: int) -> torch.Tensor:
