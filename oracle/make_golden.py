@@ -76,7 +76,52 @@ def model_kwargs(name: str) -> dict:
             enc_scale_factor_dict={v: (2, 2, 1) if v == "sax" else (2, 2) for v in views},
             enc_conv_chans=[16, 32], enc_conv_n_blocks=1, enc_embed_dim=64, enc_depth=2, enc_n_heads=4,
             dec_embed_dim=32, dec_depth=2, dec_n_heads=4)
+    if name == "midsize_2view":  # MFMA-sized channels: E = 256 / head_dim 64, decoder 128 / head_dim 32, 64- / 128-channel stem
+        views = ["sax", "lax_2c"]
+        return dict(
+            image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1),
+            enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)}, enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)},
+            enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=2, enc_n_heads=4, dec_embed_dim=128, dec_depth=2, dec_n_heads=4)
     raise KeyError(name)
+
+
+def gen_midsize() -> None:
+    """Reference outputs at MFMA-sized channel counts WITHOUT the weights: the seeded construction is bit-identical between the reference and the
+    build (fingerprint stored and checked), so the fixture holds the seed, inputs, masks, loss, predictions, metrics, the squared gradient norm and the
+    gradients of a dozen tensors (every 4th row of the large matrices)."""
+    name, batch, seed_init, seed_data = "midsize_2view", 3, 0, 21
+    kw = model_kwargs(name)
+    torch.manual_seed(seed_init)
+    model = CineMA(**kw)
+    model.train()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(seed_data)
+    images = {v: torch.rand(batch, 1, *kw["image_size_dict"][v], generator=g) for v in kw["image_size_dict"]}
+    masks = {v: fixed_masks(batch, model.enc_down_dict[v].patch_embed.n_patches, 0.75, 300 + i) for i, v in enumerate(images)}
+    with InjectMasks([masks[v] for v in images]):
+        loss, pred, _, metrics = model(images, 0.75)
+    loss.backward()
+    t = {f"image/{v}": x for v, x in images.items()}
+    t.update({f"mask/{v}": x.to(torch.uint8) for v, x in masks.items()})
+    t.update({f"pred/{v}": x.detach() for v, x in pred.items()})
+    t.update({f"metric/{k}": x.detach().reshape(1) for k, x in metrics.items()})
+    t["loss"] = loss.detach().reshape(1)
+    t["grad_sq_norm"] = sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None).float().reshape(1)
+    keys = ["enc_down_dict.sax.conv_blocks.0.conv.0.dw_conv.weight", "enc_down_dict.sax.conv_blocks.1.conv.0.mlp.fc1.weight",
+            "enc_down_dict.sax.conv_blocks.1.patch_embed.conv.weight", "enc_down_dict.sax.patch_embed.proj.weight", "enc_down_dict.lax_2c.linear.weight",
+            "encoder.blocks.0.attn.q.weight", "encoder.blocks.0.attn.kv.weight", "encoder.blocks.1.attn.proj.weight", "encoder.blocks.1.mlp.fc1.weight",
+            "encoder.blocks.0.mlp.fc2.weight", "encoder.blocks.0.norm1.weight", "encoder.blocks.1.mlp.fc1.bias", "encoder.norm.bias", "encoder.cls_token",
+            "enc_fusion_dict.sax.down_convs.0.weight", "dec_linear.weight", "decoder.blocks.0.attn.q.weight", "decoder.blocks.1.attn.kv.weight",
+            "decoder.blocks.1.mlp.fc2.weight", "decoder.blocks.0.norm2.bias", "dec_embed_dict.sax.mask_token", "pred_head_dict.lax_2c.weight",
+            "pred_head_dict.sax.bias"]
+    named = dict(model.named_parameters())
+    for k in keys:
+        gk = named[k].grad.detach().reshape(named[k].shape[0], -1) if named[k].dim() > 1 else named[k].grad.detach()
+        t[f"grad/{k}"] = gk[::4].clone() if gk.numel() >= 65536 else gk.clone()
+    save_file({k: v.detach().clone().contiguous() for k, v in t.items()}, str(OUT / f"{name}.safetensors"))
+    (OUT / f"{name}_meta.json").write_text(json.dumps({"seed_init": seed_init, "seed_data": seed_data, "batch": batch, "grad_row_stride_large": 4,
+                                                         "large_numel": 65536, "params": fingerprint(sd)}, indent=0))
+    print(name, "loss", float(loss), "tensors", len(t), "MB", sum(v.numel() * v.element_size() for v in t.values()) / 1e6)
 
 
 GRAD_KEYS = {
@@ -280,3 +325,4 @@ if __name__ == "__main__":
     gen_trajectory()
     gen_layers()
     gen_manifests()
+    gen_midsize()

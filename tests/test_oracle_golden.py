@@ -404,3 +404,63 @@ def test_segmentation_metrics_oracle_known_answers_and_independent_dice() -> Non
                     den += float(prob[b, c, i, j]) + t
             terms.append(1.0 - (2.0 * inter + 1e-5) / (den + 1e-5))
     assert float(mm["mean_dice_loss"]) == pytest.approx(sum(terms) / len(terms), rel=1e-5)
+
+
+def test_oracle_at_mfma_sized_channels_vs_reference_golden() -> None:
+    """The oracle pinned at the channel counts the MFMA kernels use (E = 256 / head_dim 64, decoder 128 / head_dim 32, 64- / 128-channel stem, batch 3):
+    tests/golden/midsize_2view.safetensors (oracle/make_golden.py::gen_midsize, written by the upstream reference).  Weights = the seeded
+    construction of the build, whose fingerprint must equal the reference's."""
+    from cinema_amd import CineMA
+
+    g = load_golden("midsize_2view.safetensors")
+    meta = json.loads((GOLDEN / "midsize_2view_meta.json").read_text())
+    views = ["sax", "lax_2c"]
+    kw = dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1),
+              enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)}, enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)},
+              enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=2, enc_n_heads=4, dec_embed_dim=128, dec_depth=2, dec_n_heads=4)
+    torch.manual_seed(meta["seed_init"])
+    sd = {k: v.detach().clone() for k, v in CineMA(**kw).state_dict().items()}
+    for k, v in sd.items():
+        f = meta["params"][k]
+        assert list(v.shape) == f["shape"] and [float(x) for x in v.flatten()[:4]] == f["head"], k
+        assert abs(float(v.double().sum()) - f["sum"]) <= 1e-6 * max(1.0, f["abs"]), k
+    p = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+    loss, preds, metrics = O.mae_forward(p, O.MAEConfig(**kw), split(g, "image/"), {k: v.bool() for k, v in split(g, "mask/").items()})
+    assert torch.allclose(loss, g["loss"][0], rtol=2e-5, atol=2e-5)
+    for v, t in split(g, "pred/").items():
+        assert torch.allclose(preds[v], t, rtol=1e-4, atol=5e-5), v
+    loss.backward()
+    sq = sum(float(q.grad.double().pow(2).sum()) for q in p.values() if q.grad is not None)
+    assert abs(sq - float(g["grad_sq_norm"][0])) <= 1e-4 * float(g["grad_sq_norm"][0])
+    for k, t in split(g, "grad/").items():
+        gk = p[k].grad.reshape(p[k].shape[0], -1) if p[k].dim() > 1 else p[k].grad
+        gk = gk[::meta["grad_row_stride_large"]] if gk.numel() >= meta["large_numel"] else gk
+        assert torch.allclose(gk, t, rtol=2e-3, atol=2e-5 * float(t.abs().max()) + 1e-8), (k, float((gk - t).abs().max()), float(t.abs().max()))
+
+
+def test_convunetr_oracle_at_mfma_sized_channels_vs_reference_golden() -> None:
+    """``O.convunetr_forward`` with the ACDC decoder widths (32 .. 512 channels) against tests/golden/convunetr_mid.safetensors (upstream reference,
+    oracle/make_golden_convunetr.py::gen_mid); weights from the seeded construction, fingerprint checked."""
+    from cinema_amd.segmentation.convunetr import ConvUNetR
+
+    g = load_golden("convunetr_mid.safetensors")
+    meta = json.loads((GOLDEN / "convunetr_mid_meta.json").read_text())
+    kw = dict(image_size_dict={"sax": (64, 64, 4)}, in_chans_dict={"sax": 1}, out_chans=4, enc_patch_size_dict={"sax": (4, 4, 1)},
+              enc_scale_factor_dict={"sax": (2, 2, 1)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=2, enc_n_heads=4,
+              dec_chans=(32, 64, 128, 256, 512), dec_patch_size_dict={"sax": (2, 2, 1)}, dec_scale_factor_dict={"sax": (2, 2, 1)})
+    torch.manual_seed(meta["seed_init"])
+    sd = {k: v.detach().clone() for k, v in ConvUNetR(**kw).state_dict().items()}
+    for k, v in sd.items():
+        f = meta["params"][k]
+        assert list(v.shape) == f["shape"] and [float(x) for x in v.flatten()[:4]] == f["head"], k
+    cfg = O.MAEConfig(image_size_dict=kw["image_size_dict"], in_chans_dict=kw["in_chans_dict"], enc_patch_size_dict=kw["enc_patch_size_dict"],
+                      enc_scale_factor_dict=kw["enc_scale_factor_dict"], enc_conv_chans=kw["enc_conv_chans"], enc_conv_n_blocks=kw["enc_conv_n_blocks"],
+                      enc_embed_dim=kw["enc_embed_dim"], enc_depth=kw["enc_depth"], enc_n_heads=kw["enc_n_heads"], dec_embed_dim=16, dec_depth=1, dec_n_heads=2)
+    p = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+    logits = O.convunetr_forward(p, cfg, kw["dec_chans"], 1, 1, {"sax": g["image/sax"]})["sax"]
+    assert torch.allclose(logits, g["logits/sax"], rtol=1e-4, atol=1e-4 * float(g["logits/sax"].abs().max()))
+    (logits * g["coef/sax"]).sum().backward()
+    for k, t in split(g, "grad/").items():
+        gk = p[k].grad.reshape(p[k].shape[0], -1) if p[k].dim() > 1 else p[k].grad
+        gk = gk[::meta["grad_row_stride_large"]] if gk.numel() >= meta["large_numel"] else gk
+        assert torch.allclose(gk, t, rtol=5e-3, atol=5e-5 * float(t.abs().max()) + 1e-8), (k, float((gk - t).abs().max()), float(t.abs().max()))
