@@ -361,6 +361,7 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the transformer blocks' forward projections on e4m3 operands (BASELINE config 5, "
                     "with --size large --sax 256,256,24 --lax 256,256 --batch 8); backward GEMMs stay bf16.  The BASELINE metric (config 2) is bf16")
     ap.add_argument("--eager", action="store_true", help="issue every launch from the module code instead of the recorded launch list (A/B)")
+    ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce payload (N > 1): bf16 halves the xGMI bytes")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short config-4 / config-5 measurements appended to the default one-GPU line")
     args = ap.parse_args()
 
@@ -392,7 +393,7 @@ def main() -> None:
     sync = None
     if world > 1:
         ddp_setup(rank, world, backend=backend)
-        sync = GradientSynchronizer(world)
+        sync = GradientSynchronizer(world, exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32)
     elif args.force_sync:  # one-process RCCL group: runs the overlapped all-reduce schedule on one GPU (path check, not a metric)
         os.environ.setdefault("MASTER_PORT", "29533")
         ddp_setup(0, 1, backend="nccl")
@@ -439,6 +440,38 @@ def main() -> None:
     final_loss = float(loss)
     n_launches = next(iter(step._recorded.values())).n_launches if step._recorded else None  # noqa: SLF001
     peak_gib = round(torch.cuda.max_memory_reserved() / 2**30, 1)  # of 288: parameters + optimiser state + the recorded step's private pool
+    # ---- N > 1: how much of the gradient exchange hides behind the backward pass (every rank runs the same extra steps; the replicas diverge
+    # in the "no exchange" mode, which is why this comes after the timed region).  exposed = overlapped step - step without exchange;
+    # unoverlapped = step with every collective after the backward - step without exchange
+    ddp_info = None
+    if world > 1 and sync is not None and args.profile_steps > 0:
+        def mode_ms(n: int = 8) -> float:
+            for i in range(2):
+                step(batches[i % 2], 0.75)
+            barrier()
+            t0m = time.perf_counter()
+            for i in range(n):
+                step(batches[i % 2], 0.75)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0m], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t) / n * 1e3
+
+        ranks = [None] * world
+        dist.all_gather_object(ranks, (rank, torch.cuda.get_device_name(local_rank), local_rank))
+        overlapped = mode_ms()
+        sync.defer_all = True
+        at_end = mode_ms()
+        sync.defer_all, sync.disabled = False, True
+        none = mode_ms()
+        sync.disabled = False
+        total_comm, exposed = max(at_end - none, 0.0), max(overlapped - none, 0.0)
+        ddp_info = {"n_ranks_seen": len({r[0] for r in ranks}), "devices": sorted({r[1] for r in ranks}), "backend": dist.get_backend(), "exchange_dtype": args.grad_exchange,
+                    "payload_bytes_per_step": sync.bytes_last, "early_collectives_per_step": sync.n_early_last,
+                    "ms_per_step_overlapped": round(overlapped, 3), "ms_per_step_exchange_after_backward": round(at_end, 3), "ms_per_step_no_exchange": round(none, 3),
+                    "exposed_comm_ms": round(exposed, 3), "unoverlapped_comm_ms": round(total_comm, 3),
+                    "hidden_fraction": (round(1.0 - exposed / total_comm, 3) if total_comm > 0 else None),
+                    "how": "8 steps per mode after the timed region, max over ranks; per-collective kernel overlap: tools/rccl_overlap.py on a rocprofv3 kernel trace"}
     # forward GFLOP of the reference graph x 3 (SURVEY appendix A probes): config 2 and config 5 shapes only
     ref_gflop = {("base", "192,192,16", "192,192"): STEP_GFLOP_PER_SAMPLE, ("large", "256,256,24", "256,256"): 3 * 1806.7}.get((args.size, args.sax, args.lax))
     step.replay = False  # the information-only runs below (dense stem, per-launch events) go through the module code
@@ -516,6 +549,8 @@ def main() -> None:
                        "reference_equiv_tflops_per_gpu": (None if ref_gflop is None else round(samples_per_s / world * ref_gflop / 1e3, 1))},
             "roofline": roofline,
         }
+        if ddp_info is not None:
+            out["ddp"] = ddp_info
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(kw, cpu_state, 2, args.cpu_budget, device)
         default_workload = (args.size, args.sax, args.lax, args.dtype, args.batch) == ("base", "192,192,16", "192,192", "bf16", 16)

@@ -49,7 +49,7 @@ class GradientSynchronizer:
     """
 
     def __init__(self, world_size: int | None = None, bucket_bytes: int = 128 << 20, group=None, overlap: bool = True,
-                 force_collectives: bool = False) -> None:  # noqa: ANN001
+                 force_collectives: bool = False, exchange_dtype: torch.dtype = torch.float32, min_early_bytes: int = 1 << 20) -> None:  # noqa: ANN001
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.bucket_bytes = bucket_bytes
         self.group = group
@@ -58,10 +58,24 @@ class GradientSynchronizer:
         self.overlap = overlap
         self.force = force_collectives  # issue the collectives even in a one-process group (exercises the RCCL path on one GPU)
         self.armed = False
-        self.min_early = 1 << 18  # elements (1 MiB)
+        # a block's range goes out early only if it is worth a collective of its own: below ~1 MiB an all-reduce over xGMI is latency-bound
+        # (launch + 7 point-to-point hops), so biases / LayerNorm vectors ride in the final buckets
+        self.min_early = max(1, min_early_bytes // 4)  # elements
+        # bf16 exchange (optional): each rank's fp32 range is rounded to bf16 into a staging buffer, the collective moves and sums bf16 (half the
+        # xGMI bytes: 487 -> 244 MB per step for ViT-Base), and the mean is widened back into the fp32 gradient buffer.  Every rank receives the
+        # same bf16 result, so the replicas stay bit-identical; the rounding error is bounded by the tests (rel-L2 <= 1e-2 against the fp32 exchange)
+        if exchange_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("exchange_dtype: torch.float32 or torch.bfloat16")
+        self.exchange_dtype = exchange_dtype
         self._early: list = []   # (begin, end) ranges already handed to a collective in this backward pass
         self._works: list = []
+        self._bytes = 0
+        self._staged: list = []  # bf16 exchange: (fp32 range view, bf16 staging tensor) pairs to widen back after the wait
         self.n_early_last = 0    # early (overlapped) collectives of the last completed exchange (diagnostics / tests)
+        self.disabled = False    # measurement switches (bench.py, N > 1): no exchange at all / everything at the end of the backward pass
+        self.defer_all = False
+        self.n_collectives_total = 0  # collectives issued since construction (tests: accumulation micro-steps must not communicate)
+        self.bytes_last = 0      # payload bytes of the last completed exchange
 
     def attach(self, flat) -> None:  # noqa: ANN001
         self.flat = flat
@@ -83,17 +97,32 @@ class GradientSynchronizer:
 
     def _launch(self, t: torch.Tensor) -> None:
         op = dist.ReduceOp.AVG if dist.get_backend(self.group) == "nccl" else dist.ReduceOp.SUM  # gloo (CPU tests) has no AVG
+        if self.exchange_dtype == torch.bfloat16:
+            if t.is_cuda:
+                from cinema_amd import hip as K
+
+                rec, K.RECORD = K.RECORD, None  # inside a recorded step this runs as a HOST entry (re-run on every replay): its launches are not list entries
+                try:
+                    stage = K.cast(t, torch.bfloat16)
+                finally:
+                    K.RECORD = rec
+            else:
+                stage = t.to(torch.bfloat16)
+            self._staged.append((t, stage))
+            t = stage
         self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+        self.n_collectives_total += 1
+        self._bytes += t.numel() * t.element_size()
 
     def arm(self, on: bool) -> None:
         """Called before ``backward()``: only the micro-step that ends with the optimiser update all-reduces."""
-        self.armed = bool(on) and (self.world_size > 1 or self.force) and self.flat is not None
-        self._early, self._works = [], []
+        self.armed = bool(on) and (self.world_size > 1 or self.force) and self.flat is not None and not self.disabled
+        self._early, self._works, self._staged, self._bytes = [], [], [], 0
 
     def params_done(self, tape, params: list) -> None:  # noqa: ANN001
         """Backward-pass hook: all gradient kernels of ``params`` are in the stream -> start their all-reduce.  Every rank
         takes the same decisions (they depend on the model only), so the collectives stay matched."""
-        if not self.armed:
+        if not self.armed or self.defer_all:
             return
         ranges = []
         for p in params:
@@ -116,7 +145,7 @@ class GradientSynchronizer:
             self._early.append((a, b))
 
     def all_reduce(self) -> None:
-        if self.world_size <= 1 and not self.force:
+        if (self.world_size <= 1 and not self.force) or self.disabled:
             return
         n = self.flat.flat_grad.numel()
         per = max(1, self.bucket_bytes // 4)
@@ -129,10 +158,18 @@ class GradientSynchronizer:
             pos = max(pos, b)
         for w in self._works:
             w.wait()
+        for dst, stage in self._staged:  # bf16 exchange: widen the reduced values back into the fp32 gradient buffer
+            if dst.is_cuda:
+                from cinema_amd import hip as K
+
+                K.cast(stage, torch.float32, out=dst)
+            else:
+                dst.copy_(stage)
         if dist.get_backend(self.group) != "nccl":
             self.flat.flat_grad.div_(self.world_size)
         self.n_early_last = len(self._early)
-        self._early, self._works, self.armed = [], [], False
+        self.bytes_last = self._bytes
+        self._early, self._works, self._staged, self.armed = [], [], [], False
 
     def all_finite(self, loss: torch.Tensor) -> torch.Tensor:
         """Collective NaN decision (a rank-local ``continue`` as in ``pretrain.py:255-257`` would dead-lock DDP)."""

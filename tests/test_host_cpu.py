@@ -269,6 +269,65 @@ def test_gradient_synchronizer_world_size_2_gloo(tmp_path: Path) -> None:
     assert float(torch.load(tmp_path / "finite0.pt")) == 0.0 and float(torch.load(tmp_path / "finite1.pt")) == 0.0  # collective NaN decision
 
 
+def _ddp_bf16_worker(rank: int, world: int, port: int, tmp: str) -> None:
+    sys.path.insert(0, str(ROOT))
+    from cinema_amd.ddp import GradientSynchronizer, ddp_setup
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    ddp_setup(rank, world, port=port, backend="gloo")
+    torch.manual_seed(0)
+    model = CineMA(**mini_kwargs())
+    flat = FlatModel(model, 0.05)
+    gen = torch.Generator().manual_seed(50 + rank)
+    grad = torch.randn(flat.numel, generator=gen) * torch.logspace(-4, 0, flat.numel)  # four decades of magnitudes, different per rank
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        sync = GradientSynchronizer(world, bucket_bytes=64 << 10, exchange_dtype=dt, overlap=False)
+        sync.attach(flat)
+        flat.flat_grad.copy_(grad)
+        sync.arm(True)
+        sync.all_reduce()
+        out[name] = (flat.flat_grad.clone(), sync.bytes_last)
+    # gradient accumulation: n_accum_steps = 2 -> the first micro-step must not communicate (reference pretrain.py:259-269 all-reduces on every
+    # micro-step through DDP; here only the boundary step does), the second one must
+    sync = GradientSynchronizer(world, bucket_bytes=64 << 10, overlap=True, min_early_bytes=256)
+    sync.attach(flat)
+    from types import SimpleNamespace
+
+    blocks = [list(model.encoder.blocks[i].parameters()) for i in (1, 0)]
+    fake_tape = SimpleNamespace(pvars={id(p): SimpleNamespace(direct=True) for b in blocks for p in b})
+    counts = []
+    for micro in range(4):
+        update = (micro + 1) % 2 == 0
+        flat.flat_grad.add_(grad) if micro % 2 else flat.flat_grad.copy_(grad)
+        sync.arm(update)
+        for b in blocks:  # the backward pass reports the blocks on every micro-step
+            sync.params_done(fake_tape, b)
+        if update:
+            sync.all_reduce()
+        counts.append(sync.n_collectives_total)
+    torch.save({"f32": out["f32"][0], "bf16": out["bf16"][0], "bytes": (out["f32"][1], out["bf16"][1]), "counts": counts, "accum": flat.flat_grad.clone()},
+               f"{tmp}/bf16_{rank}.pt")
+    torch.distributed.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_and_accumulation_window_world_size_2_gloo(tmp_path: Path) -> None:
+    """(a) The optional bf16 exchange: half the payload bytes, every rank ends with bit-identical gradients, relative L2 error against the fp32
+    exchange <= 1e-2 (two roundings to bf16: 2^-9 each).  (b) With n_accum_steps = 2 only the boundary micro-step communicates: the collective counter
+    stands still on the accumulation micro-step although the backward hooks fire, and the exchanged buffer holds the mean of the accumulated gradients."""
+    from cinema_amd.ddp import get_free_port
+
+    mp.spawn(_ddp_bf16_worker, args=(2, get_free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "bf16_0.pt"), torch.load(tmp_path / "bf16_1.pt")
+    assert torch.equal(r0["f32"], r1["f32"]) and torch.equal(r0["bf16"], r1["bf16"])  # replicas bit-identical in both modes
+    rel = float((r0["bf16"] - r0["f32"]).norm() / r0["f32"].norm())
+    assert 0.0 < rel <= 1e-2, rel
+    assert r0["bytes"][1] * 2 == r0["bytes"][0] > 0
+    c = r0["counts"]
+    assert c[0] == 0 and c[1] > 0 and c[2] == c[1] and c[3] == 2 * c[1], c  # micro-steps 0 and 2 accumulate silently
+    assert r0["counts"] == r1["counts"] and torch.equal(r0["accum"], r1["accum"])
+
+
 def test_oracle_two_rank_average_equals_full_batch_gradient() -> None:
     """Data-parallel semantics the synchroniser implements: mean over ranks of per-rank mean-loss gradients == full-batch gradient
     (equal per-rank batch sizes, same masks), checked with the CPU oracle on the mini config."""
