@@ -327,7 +327,7 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
     finally:
         T_.FP8_FORWARD = prev
     out["config5_fp8"] = {"workload": "CineMA ViT-Large MAE, 4 views (SAX 256x256x24 + 3 LAX 256x256), mask 0.75, per-GPU batch 8, fwd+bwd+clip+AdamW, recorded step",
-                          "dtype": "fp8 (e4m3 forward projections, per-row activation / per-tensor weight scales; bf16 backward)", "ms_per_step": round(res["fp8"], 3),
+                          "dtype": "fp8 (e4m3 forward projections and data gradients, per-row activation / gradient and per-tensor weight scales; bf16 weight gradients)", "ms_per_step": round(res["fp8"], 3),
                           "samples_per_s": round(8e3 / res["fp8"], 2), "bf16_ms_per_step": round(res["bf16"], 3), "fp8_speedup_over_bf16": round(res["bf16"] / res["fp8"], 4),
                           "steps": 6, "warmup": 4, "reference_equiv_tflops_per_gpu": round(8e3 / res["fp8"] * 3 * 1806.7 / 1e3, 1)}
     del model
@@ -358,8 +358,8 @@ def main() -> None:
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the per-kernel roofline")
     ap.add_argument("--task", default="mae", choices=["mae", "seg"], help="mae: the BASELINE metric (config 2 / 3 / 5 shapes); seg: BASELINE config 4, the "
                     "ConvUNetR segmentation fine-tuning step (SAX 256x256x12, 4 classes, per-GPU batch 4, dropout / drop_path 0.1)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the transformer blocks' forward projections on e4m3 operands (BASELINE config 5, "
-                    "with --size large --sax 256,256,24 --lax 256,256 --batch 8); backward GEMMs stay bf16.  The BASELINE metric (config 2) is bf16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the transformer blocks' forward projections and data gradients on e4m3 operands (BASELINE config 5, "
+                    "with --size large --sax 256,256,24 --lax 256,256 --batch 8); weight gradients stay bf16.  The BASELINE metric (config 2) is bf16")
     ap.add_argument("--eager", action="store_true", help="issue every launch from the module code instead of the recorded launch list (A/B)")
     ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce payload (N > 1): bf16 halves the xGMI bytes")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short config-4 / config-5 measurements appended to the default one-GPU line")
@@ -536,7 +536,7 @@ def main() -> None:
         out = {
             "metric": "MAE-pretrain samples/sec (4-view cine, 75% mask)", "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "untimed_steps": extra_untimed + args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("bf16" if args.dtype == "bf16" else "fp8 (e4m3 forward projections, per-tensor current scaling; bf16 backward)"), "data": "synthetic",
+            "vs_baseline": None, "dtype": ("bf16" if args.dtype == "bf16" else "fp8 (e4m3 forward projections and data gradients: weights per tensor, activations / gradients per row, current scaling; bf16 weight gradients)"), "data": "synthetic",
             "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX {args.sax.replace(',', 'x')} + LAX 2C/3C/4C {args.lax.replace(',', 'x')}), mask 0.75, "
                                    f"per-GPU batch {args.batch}, fwd+bwd+clip(5.0)+AdamW, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),

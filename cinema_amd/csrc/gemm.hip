@@ -709,7 +709,8 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
 // bf16 pre-activation copy (aux_out), fp32 residual; bf16 or fp32 output.  No split-K / split tail.
 CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0 || !a->scale_a || !a->scale_b) return CINEMA_ERR_BAD_ARG;
-  if (!a->a_kmajor || !a->b_kmajor || a->accumulate || a->split_k > 1 || a->gelu_in || a->row_mask || a->residual_bf16 || a->a_rowsum) return CINEMA_ERR_UNSUPPORTED;
+  if (!a->a_kmajor || !a->b_kmajor || a->accumulate || a->split_k > 1 || a->row_mask || a->residual_bf16 || a->a_rowsum) return CINEMA_ERR_UNSUPPORTED;
+  if (a->gelu_in && ((a->ld_gelu & 7) || (((uintptr_t)a->gelu_in) & 15))) return CINEMA_ERR_UNSUPPORTED;
   auto al = [](long long v, int q) { return (v % q) == 0; };
   if (!al(a->k, 16) || !al(a->lda, 16) || !al(a->ldb, 16) || !al(a->ldd, 8) || !al(a->n, 8) || !al((uintptr_t)a->a, 16) || !al((uintptr_t)a->b, 16) ||
       !al((uintptr_t)a->d, 16) || (a->bias && !al((uintptr_t)a->bias, 16)) || (a->residual_f32 && (!al(a->ld_res, 8) || !al((uintptr_t)a->residual_f32, 16))) ||
@@ -720,7 +721,7 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.m = a->m; p.n = a->n; p.k = a->k / 2; p.lda = a->lda / 2; p.ldb = a->ldb / 2; p.ldd = a->ldd;  // byte pairs: see gemm_tile<.., FP8>
   p.alpha = a->alpha;
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
-  p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
+  p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
   p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
@@ -728,7 +729,11 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.ktiles_per_split = nkt;
   dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);
   hipStream_t st = (hipStream_t)stream;
-  if (!p.out_f32 && !p.res_f32 && p.act == 0 && !p.aux_out) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16; }
+  if (p.gelu_in) {
+    if (p.out_f32 || p.res_f32 || p.act || p.aux_out || p.bias) return CINEMA_ERR_UNSUPPORTED;
+    CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16_GELU_GRAD>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16_GELU_GRAD;
+  }
+  else if (!p.out_f32 && !p.res_f32 && p.act == 0 && !p.aux_out) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16; }
   else if (!p.out_f32 && !p.res_f32 && p.act == 1) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_BF16_GELU>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_BF16_GELU; }
   else if (p.out_f32 && p.act == 0 && !p.aux_out) { CINEMA_LAUNCH(gemm_fp8_kernel<EPI_F32>, grid, dim3(256), 0, st, p); a->kernel_used = 256 + EPI_F32; }
   else return CINEMA_ERR_UNSUPPORTED;

@@ -581,6 +581,48 @@ CINEMA_API int cinema_quantize_fp8_segments(const uint16_t* x, const long long* 
   return launch_status();
 }
 
+// TRANSPOSED e4m3 shadows of the 2-D weights of a flat bf16 buffer (fp8 data-gradient GEMMs: dX = dY W needs W with the OUTPUT features contiguous):
+// segment s = matrix [rows][cols] at element offset desc[3s], written as [cols][rows] bytes at the same offset of yt with the segment's scale from
+// cinema_quantize_fp8_segments (same amax).  blockIdx.y = segment, the blocks of a segment walk its 64 x 64 tiles; desc[3s + 1] = rows, + 2 = cols.
+__global__ __launch_bounds__(256) void quantize_fp8_seg_t_kernel(const bf16_t* x, const long long* desc, const float* scales, uint8_t* yt) {
+  __shared__ float tile[64][65];
+  const long long off = desc[3 * blockIdx.y];
+  const int rows = (int)desc[3 * blockIdx.y + 1], cols = (int)desc[3 * blockIdx.y + 2];
+  const float inv = 1.0f / scales[blockIdx.y];
+  const int tr = (rows + 63) / 64, tc = (cols + 63) / 64;
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {  // 64 rows x 8 chunks of 8 columns
+      const int r = i >> 3, c8 = (i & 7) * 8;
+      if (r0 + r < rows && c0 + c8 < cols) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + off + (long long)(r0 + r) * cols + c0 + c8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) tile[r][c8 + j] = bf2f(v.v[j]) * inv;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {  // 64 output rows (= source columns) x 8 chunks of 8 source rows
+      const int c = i >> 3, r8 = (i & 7) * 8;
+      if (c0 + c < cols && r0 + r8 < rows) {
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(tile[r8][c], tile[r8 + 1][c], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(tile[r8 + 2][c], tile[r8 + 3][c], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(tile[r8 + 4][c], tile[r8 + 5][c], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(tile[r8 + 6][c], tile[r8 + 7][c], hi, true);
+        *reinterpret_cast<int2*>(yt + off + (long long)(c0 + c) * rows + r0 + r8) = make_int2(lo, hi);
+      }
+    }
+  }
+}
+
+CINEMA_API int cinema_quantize_fp8_segments_t(const uint16_t* x, const long long* seg_desc, int n_seg, const float* scales, uint8_t* yt, void* stream) {
+  if (!x || !seg_desc || !scales || !yt || n_seg <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)yt) & 7)) return CINEMA_ERR_UNSUPPORTED;
+  CINEMA_LAUNCH(quantize_fp8_seg_t_kernel, dim3(48, n_seg), dim3(256), 0, (hipStream_t)stream, x, seg_desc, scales, yt);
+  return launch_status();
+}
+
 CINEMA_API int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, float* scale_out, unsigned int* amax_ws, void* stream) {
   if (!x || !y || !scale_out || !amax_ws || n <= 0) return CINEMA_ERR_BAD_ARG;
   if ((n & 7) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CINEMA_ERR_UNSUPPORTED;

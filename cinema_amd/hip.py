@@ -107,6 +107,7 @@ _PROTOS = {
     "cinema_quantize_fp8_rows": [_vp, _i, _i, _vp, _vp, _vp],
     "cinema_layernorm_fwd_fp8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_quantize_fp8_segments": [_vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "cinema_quantize_fp8_segments_t": [_vp, _vp, _i, _vp, _vp, _vp],
     "cinema_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "cinema_layernorm_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cinema_layernorm_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, _vp],
@@ -545,9 +546,19 @@ def quantize_fp8_segments(x: torch.Tensor, seg_bounds: torch.Tensor, y: torch.Te
            "quantize_fp8_segments")
 
 
+def quantize_fp8_segments_t(x: torch.Tensor, seg_desc: torch.Tensor, scales: torch.Tensor, yt: torch.Tensor) -> None:
+    """Transposed e4m3 copies of the 2-D segments of the flat bf16 buffer ``x``: seg_desc int64 [n, 3] = (offset, rows, cols); yt uint8, [cols][rows] per segment
+    at the same offsets, scaled with ``scales`` (from :func:`quantize_fp8_segments` on the same buffer)."""
+    _dev(x, seg_desc, scales, yt)
+    if x.dtype != torch.bfloat16 or yt.dtype != torch.uint8 or seg_desc.dtype != torch.int64 or not seg_desc.is_contiguous() or scales.dtype != torch.float32:
+        raise HipLibraryError("quantize_fp8_segments_t: bf16 source, uint8 destination, int64 [n, 3] descriptors, fp32 scales")
+    _check(load().cinema_quantize_fp8_segments_t(x.data_ptr(), seg_desc.data_ptr(), seg_desc.shape[0], scales.data_ptr(), yt.data_ptr(), _stream()),
+           "quantize_fp8_segments_t")
+
+
 def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16,
              bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, aux_out: torch.Tensor | None = None, act: int = 0,
-             alpha: float = 1.0, out: torch.Tensor | None = None) -> torch.Tensor:
+             alpha: float = 1.0, out: torch.Tensor | None = None, gelu_in: torch.Tensor | None = None) -> torch.Tensor:
     """D = epilogue(alpha * scale_a * scale_b * A8 @ B8^T): e4m3 operands a8 [M, K], b8 [N, K] (uint8 storage, k-major), per-tensor fp32 [1] scales;
     bias / exact GELU (+ bf16 pre-activation copy) / fp32 residual epilogue like :func:`gemm`."""
     _dev(a8, scale_a, b8, scale_b, bias, residual, aux_out)
@@ -576,6 +587,9 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
         g.residual_f32, g.ld_res = residual.data_ptr(), _rowmajor(residual, "residual")
     if aux_out is not None:
         g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
+    if gelu_in is not None:  # D = (A8 B8^T) x GELU'(gelu_in): the data gradient through fc1's activation
+        _dev(gelu_in)
+        g.gelu_in, g.ld_gelu = gelu_in.data_ptr(), _rowmajor(gelu_in, "gelu_in")
     g.act, g.out_f32 = act, int(out.dtype == torch.float32)
     _check(load().cinema_gemm_fp8(C.byref(g), _stream()), "gemm_fp8")
     return out

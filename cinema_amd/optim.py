@@ -105,9 +105,10 @@ class FlatModel:
 
     # ---- e4m3 weight shadows for the fp8 forward GEMMs (BASELINE config 5): one scale per matrix parameter, all of them re-quantised from the
     # bf16 shadows in three launches whenever the weights changed (cinema_quantize_fp8_segments); created on first use
-    def fp8_shadow(self, p: nn.Parameter):  # noqa: ANN201
+    def fp8_shadow(self, p: nn.Parameter, transposed: bool = False):  # noqa: ANN201
         """-> (uint8 view of p's e4m3 shadow [numel], fp32 [1] scale) in sync with the current bf16 shadow, or None for a parameter outside the
-        flat buffers / without a fresh bf16 shadow."""
+        flat buffers / without a fresh bf16 shadow.  ``transposed``: the [in][out] copy (operand of the fp8 data-gradient GEMM), built for all
+        2-D weights in one more launch behind the plain copies."""
         rng = self.offsets.get(id(p))
         if rng is None or self.flat_shadow is None or getattr(p, "_cinema_shadow_version", -1) != p._version or p.dim() < 2:  # noqa: SLF001
             return None
@@ -126,6 +127,19 @@ class FlatModel:
             st["epoch"] = T.WEIGHTS.epoch
         i = st["index"][id(p)]
         a = rng[0]
+        if transposed:
+            if p.dim() != 2 or p.shape[0] % 8 or p.shape[1] % 8:
+                return None
+            if "data_t" not in st:
+                mats = [q for q in self.params if q.dim() >= 2]
+                st["desc_t"] = torch.tensor([[self.offsets[id(q)][0], q.shape[0], q.numel() // q.shape[0]] if (q.dim() == 2 and q.shape[0] % 8 == 0 and q.shape[1] % 8 == 0)
+                                             else [self.offsets[id(q)][0], 0, 0] for q in mats], dtype=torch.int64, device=self.flat_param.device)
+                st["data_t"] = torch.zeros(self.numel, dtype=torch.uint8, device=self.flat_param.device)
+                st["epoch_t"] = None
+            if st["epoch_t"] != T.WEIGHTS.epoch:
+                K.quantize_fp8_segments_t(self.flat_shadow, st["desc_t"], st["scales"], st["data_t"])
+                st["epoch_t"] = T.WEIGHTS.epoch
+            return st["data_t"][a:a + p.numel()], st["scales"][i:i + 1]
         return st["data"][a:a + p.numel()], st["scales"][i:i + 1]
 
     def refresh_shadows(self) -> None:

@@ -384,6 +384,40 @@ def w_plain(weight: torch.nn.Parameter) -> torch.Tensor:
 FP8_FORWARD = bool(int(os.environ.get("CINEMA_FP8", "0")))
 
 
+# The DATA-gradient GEMMs of those projections in e4m3 as well (follows FP8_FORWARD unless CINEMA_FP8_DGRAD=0): dX = dY W with dY quantised per row
+# (one launch per gradient tensor) and W from the TRANSPOSED e4m3 shadows (all 2-D weights in one launch per optimiser step).  Weight gradients stay
+# bf16: their reduction runs over the tokens, so neither per-row activation scales nor the token-major layouts fit the e4m3 MFMA without transposed,
+# re-scaled copies of every activation - measured not to pay at these sequence lengths.
+FP8_DGRAD = bool(int(os.environ.get("CINEMA_FP8_DGRAD", "1")))
+
+
+def w_fp8_t(weight: torch.nn.Parameter) -> tuple | None:
+    """(uint8 [in, out] transposed e4m3 shadow, fp32 [1] scale) of a 2-D Linear weight, or None."""
+    flat = getattr(weight, "_cinema_flat", None)
+    if flat is None or weight.dim() != 2:
+        return None
+    off = flat.offsets.get(id(weight))
+    if off is None or off[0] % 8:
+        return None
+    hit = flat.fp8_shadow(weight, transposed=True)
+    return None if hit is None else (hit[0].view(weight.shape[1], weight.shape[0]), hit[1])
+
+
+def dgrad(dy16: torch.Tensor, weight: torch.nn.Parameter, w16: torch.Tensor, *, gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None,
+          fp8: bool = False, dy8: tuple | None = None, out_f32_residual: torch.Tensor | None = None) -> torch.Tensor:
+    """dX = dY W (x GELU'(gelu_in)): bf16 MFMA GEMM, or - ``fp8`` and the shapes allow it - the e4m3 GEMM on per-row quantised dY (``dy8`` = an already
+    quantised (bytes, row scales) pair of the same rows, e.g. a column slice of a fused gradient) and the transposed weight shadow.
+    ``out_f32_residual``: fp8 path only, adds an fp32 tensor and returns fp32 (two weights fed by column blocks of one gradient)."""
+    if fp8 and FP8_FORWARD and FP8_DGRAD and row_mask is None and dy16.is_cuda and weight.shape[0] % 16 == 0 and weight.shape[1] % 8 == 0 and (dy8 is not None or dy16.is_contiguous()):
+        wt = w_fp8_t(weight)
+        if wt is not None:
+            a8, sa = dy8 if dy8 is not None else K.quantize_fp8_rows(dy16)
+            return K.gemm_fp8(a8, sa, wt[0], wt[1], gelu_in=gelu_in, residual=out_f32_residual, out_dtype=F32 if out_f32_residual is not None else BF16)
+    if out_f32_residual is not None:
+        raise RuntimeError("dgrad: the fp32-residual form exists on the fp8 path only")
+    return K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False, gelu_in=gelu_in, row_mask=row_mask)
+
+
 def w_fp8(weight: torch.nn.Parameter) -> tuple:
     """(uint8 [out, in] e4m3 shadow, fp32 [1] scale) of a Linear weight."""
     flat = getattr(weight, "_cinema_flat", None)
@@ -653,7 +687,7 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
         if weight.requires_grad:
             wgrad(tape, dy16, x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
         if x.needs_grad:
-            x.add_grad(K.gemm(dy16, w, a_kmajor=True, b_kmajor=False, row_mask=row_mask))
+            x.add_grad(dgrad(dy16, weight, w, row_mask=row_mask, fp8=fp8 and w16 is None))
 
     tape.record(bwd)
     return y
@@ -704,10 +738,10 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
             residual.add_grad(y.grad, y.grad16)
         dy16 = y.grad_bf16()
         wgrad(tape, dy16, a, pv[2], pv[3], tuple(w2.shape))
-        dh = K.gemm(dy16, w2, a_kmajor=True, b_kmajor=False, gelu_in=h)
+        dh = dgrad(dy16, fc2_w, w2, gelu_in=h, fp8=fp8)
         wgrad(tape, dh, x.data, pv[0], pv[1], tuple(w1.shape))
         if x.needs_grad:
-            x.add_grad(K.gemm(dh, w1, a_kmajor=True, b_kmajor=False))
+            x.add_grad(dgrad(dh, fc1_w, w1, fp8=fp8))
 
     tape.record(bwd)
     return y
@@ -856,9 +890,9 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
         if shared is None:
             wgrad(tape, dkv, xk.data, pv[2], pv[3], (2 * c, c))
         if xq.needs_grad:
-            xq.add_grad(K.gemm(dq, wq, a_kmajor=True, b_kmajor=False))
+            xq.add_grad(dgrad(dq, q_w, wq, fp8=fp8))
         if shared is None and xk.needs_grad:
-            xk.add_grad(K.gemm(dkv, wkv, a_kmajor=True, b_kmajor=False))
+            xk.add_grad(dgrad(dkv, kv_w, wkv, fp8=fp8))
 
     tape.record(bwd)
     return y

@@ -74,7 +74,8 @@ int cinema_gemm_bf16(cinema_gemm_args* args_host, void* stream);
 /* fp8 forward GEMM (BASELINE config 5: "fp8 MFMA path"; the reference picks its autocast dtype at cinema/device.py:58-66): the same call with OCP e4m3
  * operands a [M][lda] / b [N][ldb] (bytes, k-major: a_kmajor = b_kmajor = 1), per-tensor scales scale_a / scale_b, K % 16 == 0:
  * D = epilogue(alpha * scale_a * scale_b * A8 B8^T) on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales).  Epilogue: bias, exact GELU (+ bf16
- * pre-activation copy), fp32 residual; bf16 or fp32 D.  Backward GEMMs stay bf16. */
+ * pre-activation copy), fp32 residual, or x GELU'(gelu_in) (the data gradient through fc1's activation); bf16 or fp32 D.  Data gradients run through the
+ * same call with A = per-row quantised dY and B = the transposed weight shadow (cinema_quantize_fp8_segments_t); weight gradients stay bf16. */
 int cinema_gemm_fp8(cinema_gemm_args* args_host, void* stream);
 /* Implicit-GEMM "same" convolution (dense 3^n convs of ConvResBlock, cinema/conv.py:320-345, forward and data gradient): args->a = channels-last bf16
  * volume x [batch*X*Y*Z][C] (C % 8 == 0), m = batch*X*Y*Z, b = weights [n][ldb] with features (tap, channel) zero-padded to k = ldb (k % 8 == 0),
@@ -106,6 +107,10 @@ int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, float* scale
 /* Per-row form: x dense bf16 [rows][c] (c % 8 == 0) -> y e4m3 [rows][c], row_scale[rows] = amax(row) / 448; one launch (the row maximum is local). */
 int cinema_quantize_fp8_rows(const uint16_t* x, int rows, int c, uint8_t* y, float* row_scale, void* stream);
 int cinema_quantize_fp8_segments(const uint16_t* x, const long long* seg_bounds, int n_seg, uint8_t* y, float* scales, unsigned int* amax_ws, void* stream);
+/* Transposed e4m3 copies of the 2-D segments (weights [rows][cols], rows and cols multiples of 8, offsets multiples of 8): seg_desc[3 s] = element offset,
+ * [3 s + 1] = rows, [3 s + 2] = cols (device int64); yt holds [cols][rows] bytes at the same offset, scaled with scales[s] of the call above.  The operand
+ * of the fp8 DATA-GRADIENT GEMM dX = dY W (reduction over the weight's output features, which must be contiguous for the e4m3 MFMA). */
+int cinema_quantize_fp8_segments_t(const uint16_t* x, const long long* seg_desc, int n_seg, const float* scales, uint8_t* yt, void* stream);
 /* The tiles of up to 8 independent weight-gradient GEMMs (a_kmajor = b_kmajor = 0, fp32 D, optional accumulate and a_rowsum, no other
  * epilogue term, split_k ignored) in ONE launch with whole-K tiles: the four dW of a transformer block (cinema/vit.py:525-609) have
  * 36-144 output tiles each and would otherwise be cut into k-slices with fp32 slabs and a reduce launch each. */

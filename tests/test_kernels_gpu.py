@@ -763,6 +763,39 @@ def test_fp8_per_row_scales_and_layernorm_fused_quantisation() -> None:
     assert float(((dq - yf.cpu()).norm(dim=1) / yf.cpu().norm(dim=1)).max()) <= 0.04
 
 
+def test_fp8_data_gradient_operands_transposed_shadows_and_gelu_grad_epilogue() -> None:
+    """The fp8 data-gradient GEMM dX = dY W: cinema_quantize_fp8_segments_t writes, for every 2-D segment, exactly the transpose of the bytes
+    cinema_quantize_fp8_segments wrote (same scale); cinema_gemm_fp8 on (per-row quantised dY, transposed shadow) == fp32 matmul of the dequantised
+    operands, plain and through the x GELU'(pre-activation) epilogue of fc2's data gradient."""
+    shapes = [(256, 128), (384, 264), (64, 512)]  # [out][in] weights; 264: a 64-wide tile edge in both directions
+    flat = torch.cat([rnd(n, k, seed=120 + i, scale=0.3 + 0.2 * i).reshape(-1) for i, (n, k) in enumerate(shapes)])
+    offs = [0]
+    for n, k in shapes:
+        offs.append(offs[-1] + n * k)
+    bounds = torch.tensor([[offs[i], offs[i + 1]] for i in range(len(shapes))], dtype=torch.int64, device=DEV)
+    desc = torch.tensor([[offs[i], n, k] for i, (n, k) in enumerate(shapes)], dtype=torch.int64, device=DEV)
+    y, yt = torch.zeros(flat.numel(), dtype=torch.uint8, device=DEV), torch.zeros(flat.numel(), dtype=torch.uint8, device=DEV)
+    scales = torch.ones(len(shapes), dtype=torch.float32, device=DEV)
+    K.quantize_fp8_segments(flat, bounds, y, scales)
+    K.quantize_fp8_segments_t(flat, desc, scales, yt)
+    for i, (n, k) in enumerate(shapes):
+        assert torch.equal(yt[offs[i]:offs[i + 1]].view(k, n), y[offs[i]:offs[i + 1]].view(n, k).t()), f"segment {i}"
+    n, k = shapes[1]
+    m = 333
+    dy = rnd(m, n, seed=130) * (torch.arange(m, device=DEV).float()[:, None] * 0.01 + 0.05).bfloat16()
+    d8, srow = K.quantize_fp8_rows(dy.contiguous())
+    wt8 = yt[offs[1]:offs[2]].view(k, n)
+    ddy = _e4m3_decode(d8.cpu()) * srow.cpu()[:, None]
+    dwt = _e4m3_decode(wt8.cpu()) * float(scales[1])
+    ref = (ddy @ dwt.t()).to(DEV)  # [m, k] = dY W
+    close(K.gemm_fp8(d8, srow, wt8, scales[1:2], out_dtype=torch.float32), ref, 1e-3, 2e-5 * float(ref.abs().max()), "fp8 dgrad")
+    pre = rnd(m, k, seed=131)
+    gp = 0.5 * (1 + torch.erf(pre.float() / math.sqrt(2))) + pre.float() * torch.exp(-0.5 * pre.float() ** 2) / math.sqrt(2 * math.pi)
+    close(K.gemm_fp8(d8, srow, wt8, scales[1:2], gelu_in=pre), ref * gp, 1e-2, 1e-2 * float(ref.abs().max()), "fp8 dgrad x gelu'")
+    exact = dy.float() @ flat[offs[1]:offs[2]].view(n, k).float()
+    assert float((ref - exact).norm() / exact.norm()) <= 6e-2  # what the two e4m3 roundings cost against the bf16 operands
+
+
 # ------------------------------------------------------------------------------------------------ implicit-GEMM convolution (ConvResBlock convs, config 4)
 @pytest.mark.parametrize(("spatial", "c_in", "c_out", "ks"), [((10, 9, 5), 32, 64, (3, 3, 3)), ((12, 11), 64, 32, (3, 3)), ((6, 7, 4), 8, 16, (3, 3, 3)),
                                                               ((9, 8, 3), 128, 40, (3, 3, 1))])

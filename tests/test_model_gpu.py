@@ -342,8 +342,8 @@ def test_base_4view_192_first_step_vs_oracle() -> None:
 
 
 def test_fp8_forward_path_vs_oracle_and_bf16() -> None:
-    """BASELINE config 5's arithmetic ("fp8 MFMA path") on an MFMA-sized 2-view model: the transformer blocks' forward projections on e4m3 operands
-    (per-tensor current scaling), everything else and the whole backward in bf16.  Stated tolerance: loss rel <= 5e-2 against the fp32
+    """BASELINE config 5's arithmetic ("fp8 MFMA path") on an MFMA-sized 2-view model: the transformer blocks' forward projections AND their data gradients on
+    e4m3 operands (weights per tensor, activations / gradients per row, current scaling), weight gradients and everything else in bf16.  Stated tolerance: loss rel <= 5e-2 against the fp32
     CPU oracle; measured on an MI355X: loss rel 1.3e-3 (bf16 path: 1.5e-4), worst matrix-gradient rel-L2 vs the bf16 path 11 % (printed).  Also: 4 recorded training steps with the
     flat optimiser (weights re-quantised from the bf16 shadows each step in three launches) reduce the loss."""
     from cinema_amd import tape as T
