@@ -595,10 +595,11 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
     return out
 
 
-def gemm_wgrad_grouped(problems: list, p256: bool = False) -> None:
+def gemm_wgrad_grouped(problems: list, p256: bool = False, split_k: int = 0) -> None:
     """One launch for up to 8 weight gradients: each problem is (dy [rows, n_out] bf16, x [rows, k_out] bf16, dst fp32 [n_out, k_out] view,
     a_rowsum fp32 [n_out] | None); dst += dy^T x, a_rowsum += column sums of dy.  Whole-K 128x128 tiles, no split-K slabs (see the header);
-    ``p256``: the persistent 256x256 kernel with balanced k-slices finished inside the launch (the problems may then differ in their row counts)."""
+    ``p256``: the persistent 256x256 kernel with balanced k-slices finished inside the launch (the problems may then differ in their row counts;
+    ``split_k = 1`` keeps whole-K tiles there, for A/B measurements)."""
     arr = (GemmArgs * len(problems))()
     for g, (dy, x, dst, rowsum) in zip(arr, problems):
         _dev(dy, x, dst, rowsum)
@@ -607,7 +608,7 @@ def gemm_wgrad_grouped(problems: list, p256: bool = False) -> None:
         g.a, g.b, g.d = dy.data_ptr(), x.data_ptr(), dst.data_ptr()
         g.m, g.n, g.k = dy.shape[1], x.shape[1], dy.shape[0]
         g.lda, g.ldb, g.ldd = _rowmajor(dy, "dy"), _rowmajor(x, "x"), _rowmajor(dst, "dst")
-        g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, (0 if p256 else 1)
+        g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, (split_k if p256 else 1)
         if rowsum is not None:
             g.a_rowsum = rowsum.data_ptr()
     if p256:

@@ -67,6 +67,8 @@ def main() -> None:
         blocks = {
             "enc block": [(10960, 2304, 768), (10960, 768, 768), (10960, 3072, 768), (10960, 768, 3072)],
             "dec block": [(32848, 512, 512), (10944, 1024, 512), (32848, 512, 512), (32848, 2048, 512), (32848, 512, 2048)],
+            "dec no kv": [(32848, 512, 512), (32848, 512, 512), (32848, 2048, 512), (32848, 512, 2048)],
+            "shared kv": [(10944, 8192, 512)],
             "4096^3": [(4096, 4096, 4096)], "8192^3": [(8192, 8192, 8192)],
         }
         print(f"{'block':12s} | {'128x128 split-K + reduce':>26s} {'128x128 grouped whole-K':>26s} {'p256 grouped':>22s}")
