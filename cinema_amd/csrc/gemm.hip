@@ -299,6 +299,79 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
     return;
   }
   // fp32 partial of a split-tail k-slice: plain [128][128] rows (address = base + m * 128 + n with the tile origin folded into base)
+  if (EPI != EPI_GENERAL && tail_dst && p.tail_cnt) {  // (the general class keeps the fix-up launch: its epilogue has no registers to spare)
+    // finished inside the launch by the tile's LAST ARRIVER (the protocol of gemm256.hip): a k-slice takes a ticket; tickets 0..n-2 store their
+    // accumulators fragment-ordered with write-through (sc1) stores, drain, and bump the publish counter; ticket n-1 waits for n-1 publishes (its partners
+    // took their tickets before it and never wait: no deadlock for any dispatch order), sums the slices in slice order - its own at its own position, so the
+    // rounding does not depend on who came last - and runs the fused epilogue.  Both counters are left zero.
+    const int t_local = tile - p.tail_begin, n_pieces = p.tail_split;
+    unsigned* cnt = p.tail_cnt + 2 * t_local;
+    volatile unsigned* ctl = reinterpret_cast<volatile unsigned*>(smem);  // both stages are free after the loop's last barrier
+    if (tid == 0) ctl[0] = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = ctl[0];
+    __syncthreads();
+    if (ticket != (unsigned)(n_pieces - 1)) {
+      typedef unsigned int u32x4t __attribute__((ext_vector_type(4)));
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(tail_dst, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int idx = (wave_u * 16 + (i * 2 + j) * 4 + q) * 64 + lane;
+            u32x4t v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
+                        __float_as_uint(acc[i][j][4 * q + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, idx * 16, 0, 16 /* sc1: write-through */);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(n_pieces - 1)) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 26)) { p.tail_cnt[TAIL_ERROR_WORD] = 1u; break; }  // never in a healthy run
+      }
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const float4* base = reinterpret_cast<const float4*>(p.tail_ws + (size_t)t_local * n_pieces * (BM * BN));
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      float4 r[8];
+#pragma unroll
+      for (int jq = 0; jq < 8; jq++) r[jq] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s2 = 0; s2 < n_pieces; s2++) {
+        if (s2 == zsplit) {
+#pragma unroll
+          for (int jq = 0; jq < 8; jq++) {
+            const int j = jq >> 2, q = jq & 3;
+            r[jq].x += acc[i][j][4 * q]; r[jq].y += acc[i][j][4 * q + 1]; r[jq].z += acc[i][j][4 * q + 2]; r[jq].w += acc[i][j][4 * q + 3];
+          }
+        } else {
+          const float4* s4 = base + (size_t)s2 * (BM * BN / 4);
+          float4 t[8];
+#pragma unroll
+          for (int jq = 0; jq < 8; jq++) t[jq] = s4[(wave_u * 16 + i * 8 + jq) * 64 + lane];
+#pragma unroll
+          for (int jq = 0; jq < 8; jq++) { r[jq].x += t[jq].x; r[jq].y += t[jq].y; r[jq].z += t[jq].z; r[jq].w += t[jq].w; }
+        }
+      }
+#pragma unroll
+      for (int jq = 0; jq < 8; jq++) {
+        const int j = jq >> 2, q = jq & 3;
+        acc[i][j][4 * q] = r[jq].x; acc[i][j][4 * q + 1] = r[jq].y; acc[i][j][4 * q + 2] = r[jq].z; acc[i][j][4 * q + 3] = r[jq].w;
+      }
+    }
+    tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, 0, stg);
+    return;
+  }
   if (tail_dst) tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, 0, stg, tail_dst - ((long long)m0 * BN + n0), BN);
   else tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, zsplit, stg);
 #ifdef CINEMA_GEMM_TIMING
@@ -597,7 +670,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     a->kernel_used = (a->a_kmajor && a->b_kmajor) ? 1 : (a->a_kmajor ? 2 : 3);
     // split tail (measured: 516 tiles on 512 slots cost 1.64 rounds, the 4 left-over tiles run alone at the end): worth a second
     // launch only when the reduction has >= 12 k-tiles and the left-over tiles can be cut at least in two
-    p.tail_split = 0; p.tail_begin = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+    p.tail_split = 0; p.tail_begin = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
     bool tail = false;
     if (gz == 1 && a->force_generic == 0 && !p.accumulate && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= 12) {  // K >= 768 (tools/tail_ab.py: 10960x768x768 38 -> 34 us, x1024 42 -> 35 us; at K = 512 the fix-up launch costs what it saves)
       static int slots = 0;
@@ -610,10 +683,15 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
         int sp2 = slots / rem;
         if (sp2 > nkt / 4) sp2 = nkt / 4;  // >= 4 k-tiles per slice
         if (sp2 > 16) sp2 = 16;
+        static const int cap_env = getenv("CINEMA_TAIL_MAX_SPLIT") ? atoi(getenv("CINEMA_TAIL_MAX_SPLIT")) : 0;
+        const bool in_launch = a->tail_counters != nullptr && !(((uintptr_t)a->tail_counters) & 15);
+        // finished in the launch, ONE workgroup reads the partners' partial tiles (64 KiB each at ~64 B/clk): cap the fan-in
+        if (in_launch && cap_env > 1 && sp2 > cap_env) sp2 = cap_env;
         const int kts = (nkt + sp2 - 1) / sp2;
         sp2 = (nkt + kts - 1) / kts;
         if (sp2 >= 2 && a->workspace_bytes >= (long long)rem * sp2 * BM * BN * 4) {
           p.tail_begin = tiles - rem; p.tail_split = sp2; p.tail_ktiles = kts; p.tail_ws = (float*)a->workspace;
+          if (a->tail_counters && !(((uintptr_t)a->tail_counters) & 15) && 2 * rem <= TAIL_ERROR_WORD) p.tail_cnt = (unsigned*)a->tail_counters;
           grid.x = p.tail_begin + rem * sp2;
           tail = true;
         }
@@ -629,6 +707,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       else if (common && !p.out_f32 && !p.res_f32 && p.gelu_in && p.act == 0 && !p.aux_out && !p.bias) epi = EPI_BF16_GELU_GRAD;
       else if (common && p.out_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) epi = EPI_F32;
       a->kernel_used += 8 * epi;  // 1..3 = operand layout, + 8 x epilogue class
+      if (epi == EPI_GENERAL) p.tail_cnt = nullptr;
       // short reductions go to the BK = 32 kernel (3-4 workgroups per CU): in the step 32.47 vs 32.79 ms with the threshold at 512, 32.52 at 768
       // (above that the BK = 64 loop and its split tail win); CINEMA_GEMM_K32 overrides the threshold (0 = never)
       static const int k32_env = getenv("CINEMA_GEMM_K32") ? atoi(getenv("CINEMA_GEMM_K32")) : 512;
@@ -665,7 +744,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
 #undef LAUNCH_LAYOUT
       }
     }
-    if (tail) {
+    if (tail && !p.tail_cnt) {
       const int rem = ((int)grid.x - p.tail_begin) / p.tail_split;
       const TailFixP tf{p, (a->m + BM - 1) / BM, (a->n + BN - 1) / BN};
       launch_lanes(tail_fixup_kernel, tail_fixup_lanes_kernel, 1, dim3(rem * 8), dim3(256), 0, st, tf);
@@ -723,7 +802,7 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
-  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
   const int nkt = (p.k + BK - 1) / BK;
   p.ktiles_per_split = nkt;
@@ -768,7 +847,7 @@ CINEMA_API int cinema_conv_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
   p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
   p.act = 0; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
-  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
   p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c; p.conv_coords = nullptr;
   p.cZB = zb;
@@ -798,7 +877,7 @@ CINEMA_API int cinema_conv_wgrad_bf16(cinema_gemm_args* a, void* stream) {
   p.alpha = a->alpha;
   p.bias = nullptr; p.res_f32 = nullptr; p.res_bf16 = nullptr; p.ld_res = 0; p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
   p.act = 0; p.out_f32 = 1; p.accumulate = a->accumulate; p.a_rowsum = a->a_rowsum;
-  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
   p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c; p.conv_coords = (const int*)a->conv_coords;
   p.cZB = a->conv_zb > 1 ? a->conv_zb : 1;
@@ -850,7 +929,7 @@ CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void*
     p.ld_res = a->ldd;
     p.ktiles_per_split = (a->k + BK - 1) / BK;
     p.ws = nullptr; p.a_rowsum = a->a_rowsum;
-    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1; p.scale_a_rows = 0;
+    p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr; p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1; p.scale_a_rows = 0;
     g.tile_begin[i + 1] = g.tile_begin[i] + ((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN);
     args[i].kernel_used = 64;  // the grouped kernel
   }

@@ -40,7 +40,7 @@ __device__ __forceinline__ GemmP expand(const SlimP& s) {
   p.a = s.a; p.b = s.b; p.d = s.d; p.m = s.m; p.n = s.n; p.k = s.k; p.lda = s.lda; p.ldb = s.ldb; p.ldd = s.ldd; p.alpha = s.alpha;
   p.bias = s.bias; p.res_f32 = s.res_f32; p.res_bf16 = nullptr; p.ld_res = s.ld_res; p.gelu_in = s.gelu_in; p.ld_gelu = s.ld_gelu;
   p.row_mask = nullptr; p.aux_out = s.aux_out; p.ld_aux = s.ld_aux; p.act = s.act; p.out_f32 = s.out_f32; p.accumulate = 0;
-  p.ktiles_per_split = 0; p.ws = nullptr; p.a_rowsum = s.a_rowsum; p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr;
+  p.ktiles_per_split = 0; p.ws = nullptr; p.a_rowsum = s.a_rowsum; p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.cX = p.cY = p.cZ = p.cC = 0; p.cZB = 1; p.conv_coords = nullptr;
   return p;
 }
@@ -323,29 +323,37 @@ __device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gt
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    for (int o = 0; o < n_other; o++) {
-      const float* src;
-      if (g.mode == 0) {
-        const int s = first_other + o + ((first_other + o >= me) ? 1 : 0);  // slices 0..n-1 except mine
-        src = my_slot + ((long long)s - me) * tiles_m * tiles_n * (long long)P_SLOT_FLOATS;   // slice-major piece order: same tile, slice s
-      } else {
-        int w = first_other + o;
-        if (w >= me) w++;
-        const int which = stream_start(g, w) >= tile_unit0 ? 0 : 1;
-        src = g.slots + ((long long)w * 2 + which) * P_SLOT_FLOATS;
-      }
-      const float4* s4 = reinterpret_cast<const float4*>(src);
+    // the pieces are summed in piece order with this workgroup's registers at their own position: the rounding does not depend on who arrived last
+    // (one 32x32 block = 4 float4 per lane at a time: a second copy of more accumulators than that spills)
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float4 t[8];
+    for (int ij = 0; ij < 8; ij++) {
+      const int i = ij >> 1, j = ij & 1;
+      float4 r[4];
 #pragma unroll
-        for (int jq = 0; jq < 8; jq++) t[jq] = s4[(wave_u * 32 + i * 8 + jq) * 64 + lane];
+      for (int q = 0; q < 4; q++) r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = 0; o <= n_other; o++) {
+        const int s = first_other + o;   // slice (split) / workgroup (stream) of piece o
+        if (s == me) {
 #pragma unroll
-        for (int jq = 0; jq < 8; jq++) {
-          const int j = jq >> 2, q = jq & 3;
-          acc[i][j][4 * q] += t[jq].x; acc[i][j][4 * q + 1] += t[jq].y; acc[i][j][4 * q + 2] += t[jq].z; acc[i][j][4 * q + 3] += t[jq].w;
+          for (int q = 0; q < 4; q++) { r[q].x += acc[i][j][4 * q]; r[q].y += acc[i][j][4 * q + 1]; r[q].z += acc[i][j][4 * q + 2]; r[q].w += acc[i][j][4 * q + 3]; }
+          continue;
         }
+        const float* src;
+        if (g.mode == 0) {
+          src = my_slot + ((long long)s - me) * tiles_m * tiles_n * (long long)P_SLOT_FLOATS;   // slice-major piece order: same tile, slice s
+        } else {
+          const int which = stream_start(g, s) >= tile_unit0 ? 0 : 1;
+          src = g.slots + ((long long)s * 2 + which) * P_SLOT_FLOATS;
+        }
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[q] = s4[(wave_u * 32 + ij * 4 + q) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { r[q].x += t[q].x; r[q].y += t[q].y; r[q].z += t[q].z; r[q].w += t[q].w; }
       }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { acc[i][j][4 * q] = r[q].x; acc[i][j][4 * q + 1] = r[q].y; acc[i][j][4 * q + 2] = r[q].z; acc[i][j][4 * q + 3] = r[q].w; }
     }
   }
 

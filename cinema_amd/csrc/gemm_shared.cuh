@@ -8,6 +8,7 @@
 
 namespace {
 
+constexpr int TAIL_ERROR_WORD = 2047;  // GemmP::tail_cnt: 8 KiB = 2 counters per tail tile (<= 1023 tiles) + this word, set when a bounded spin gives up
 struct GemmP {
   const bf16_t* a; const bf16_t* b; void* d;
   int m, n, k, lda, ldb, ldd;
@@ -24,8 +25,11 @@ struct GemmP {
   // split tail (128x128 kernel, gridDim.z == 1): logical tiles >= tail_begin do not fill the last round of workgroup slots, so each
   // is cut into tail_split k-slices (tail_ktiles k-tiles each) whose fp32 partial tiles go to tail_ws[(tile - tail_begin) * tail_split
   // + slice][128][128]; tail_fixup_kernel sums the slices and runs the fused epilogue.  tail_split == 0: off.
+  // tail_cnt != NULL: the slices are finished INSIDE the launch by the tile's last arriver (two counters per tail tile, zero on entry, left zero;
+  // the partial tiles are then fragment-ordered) and no fix-up launch follows.
   int tail_begin, tail_split, tail_ktiles;
   float* tail_ws;
+  unsigned* tail_cnt;
   // fp8 (e4m3) operands: per-tensor dequantisation scales in device memory (the product multiplies alpha); NULL for bf16 operands
   const float* scale_a; const float* scale_b;
   int scale_a_rows;  // 1: scale_a holds one scale per row of A (per-token activation scaling), 0: one scalar

@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
         ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int), ("conv_coords", C.c_void_p), ("conv_zb", C.c_int),
+        ("tail_counters", C.c_void_p),
         ("kernel_used", C.c_int),
     ]
 
@@ -405,6 +406,23 @@ def _tail_workspace(device: torch.device) -> torch.Tensor:
     return _workspace("tail", 512 * 128 * 128, device)
 
 
+_TAIL_COUNTERS: dict = {}
+# 1: the split tail of the 128x128 GEMM is finished inside the launch by each tile's last k-slice instead of the fix-up launch.  Bit-identical results;
+# measured slower in the step (same box, 2 rounds: 28.58-28.80 ms with fan-in caps 2..16 vs 28.54 with the fix-up launch): ONE workgroup reads its partners'
+# partial tiles (up to 15 x 64 KiB at ~64 B/clk) at the very end of the launch, the fix-up kernel spreads the same reads over 8 workgroups per tile
+TAIL_IN_LAUNCH = bool(int(os.environ.get("CINEMA_TAIL_IN_LAUNCH", "0")))
+
+
+def _tail_counters(device: torch.device) -> torch.Tensor:
+    """Arrival / publish counters of the split-tail tiles (csrc/gemm.hip), one buffer per (device, stream, lane): zero at allocation, left zero by every
+    launch, never handed back to the allocator (``persistent``)."""
+    key = (device.index, _stream(), LANE)
+    t = _TAIL_COUNTERS.get(key)
+    if t is None:
+        t = _TAIL_COUNTERS[key] = persistent(lambda: torch.zeros(2048, dtype=torch.int32, device=device))
+    return t
+
+
 _P256_WS: dict = {}
 
 
@@ -493,6 +511,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     elif split_k == 1 and k >= 768:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
         ws = _tail_workspace(a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        if TAIL_IN_LAUNCH:
+            g.tail_counters = _tail_counters(a.device).data_ptr()
     if GEMM_PROFILE is None or LANE is not None:
         _check(lib.cinema_gemm_bf16(C.byref(g), _stream()), "gemm")
         if g.kernel_used == 0 and not g.force_generic and 2.0 * m * n * k > 1e9:

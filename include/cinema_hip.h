@@ -56,7 +56,9 @@ typedef struct {
   int force_generic;
   void* workspace;            /* optional fp32 scratch. split_k > 1: >= split_k*m*n*4 bytes -> deterministic two-pass reduction instead of atomics.
                                  split_k == 1: >= 32 MiB lets the library cut the tiles left over after the last full round of workgroup slots
-                                 into k-slices (partial tiles here, a fix-up launch applies the epilogue); contents are scratch, use is stream-ordered */
+                                 into k-slices (partial tiles here; a fix-up launch applies the epilogue, or - with tail_counters - the last k-slice
+                                 to arrive at a tile sums its partners' partial tiles and runs the epilogue inside the launch); contents are scratch,
+                                 use is stream-ordered */
   long long workspace_bytes;
   float* a_rowsum;            /* optional (a_kmajor=0 only): a_rowsum[m] += sum_k A[m][k], i.e. the bias gradient of a weight-gradient GEMM, fused */
   const float* scale_a;       /* cinema_gemm_fp8 only: per-tensor dequantisation scales of the e4m3 operands (device scalars); NULL for cinema_gemm_bf16 */
@@ -66,6 +68,8 @@ typedef struct {
   int conv_x, conv_y, conv_z, conv_c;
   const void* conv_coords;    /* cinema_conv_wgrad_bf16 only: device int [rows], x | y << 10 | z << 20 of every voxel row */
   int conv_zb;                /* implicit convolution: 0 / 1 = one row per voxel; ZB > 1 = one row per group of ZB consecutive z voxels (see cinema_conv_gemm_bf16) */
+  void* tail_counters;        /* optional, with `workspace` at split_k == 1: >= 8 KiB of device memory (16-byte aligned), ZERO before the first use (its last word is set if a bounded wait ever gives up) and left zero by every launch,
+                                 one per stream: the split tail is finished inside the GEMM launch (no fix-up launch); NULL = fix-up launch */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
                                  + 8 x epilogue class (0 general, 1 bf16, 2 bf16+GELU, 3 bf16 x GELU', 4 fp32); 64: cinema_gemm_bf16_grouped;
                                  + 128: the BK = 32 instance; 2048 + layout + 8 x class: cinema_gemm_bf16_p256 */

@@ -35,5 +35,5 @@ rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for v in agg.values()) / N * 1e3
 print(f"all GEMM launches: {tot:.2f} ms/step")
 print(f"{'kernel':38s} {'m':>6s} {'n':>5s} {'k':>6s} aK bK sk  n/step  us/launch    TF   ms/step")
-for (kind, (m, n, k, ak, bk, sk)), (fl, secs, cnt) in rows[:int(sys.argv[1]) if len(sys.argv) > 1 else 40]:
+for (kind, (m, n, k, ak, bk, sk, *_)), (fl, secs, cnt) in rows[:int(sys.argv[1]) if len(sys.argv) > 1 else 60]:
     print(f"{K.GEMM_KERNEL_NAMES[kind]:38s} {m:6d} {n:5d} {k:6d} {ak:2d} {bk:2d} {sk:2d} {cnt // N:7d} {secs / cnt * 1e6:10.1f} {fl / secs / 1e12:6.0f} {secs / N * 1e3:8.3f}")
