@@ -135,6 +135,14 @@ __device__ __forceinline__ void gelu2(float& a, float& b) {
   x = x * cdf;
   a = x.x; b = x.y;
 }
+// (a, b) <- gelu(a), gelu(b) and (da, db) = gelu'(a), gelu'(b) from one evaluation of the erf terms
+__device__ __forceinline__ void gelu_both2(float& a, float& b, float& da, float& db) {
+  f32x2 x = {a, b}, cdf, g;
+  gelu_terms2(x, cdf, g);
+  const f32x2 d = x * 0.39894228040143268f * g + cdf;
+  x = x * cdf;
+  a = x.x; b = x.y; da = d.x; db = d.y;
+}
 // (ga, gb) = gelu'(a), gelu'(b)
 __device__ __forceinline__ void gelu_grad2(float a, float b, float& ga, float& gb) {
   f32x2 x = {a, b}, cdf, g;

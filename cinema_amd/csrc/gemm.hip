@@ -640,7 +640,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.alpha = a->alpha;
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = a->residual_bf16; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
-  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
+  p.act = a->act; p.gelu_deriv = a->gelu_deriv; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
   hipStream_t st = (hipStream_t)stream;
 
@@ -801,7 +801,7 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.alpha = a->alpha;
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = nullptr; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
-  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
+  p.act = a->act; p.gelu_deriv = a->gelu_deriv; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
   const int nkt = (p.k + BK - 1) / BK;
@@ -846,7 +846,7 @@ CINEMA_API int cinema_conv_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.alpha = a->alpha;
   p.bias = a->bias; p.res_f32 = a->residual_f32; p.res_bf16 = nullptr; p.ld_res = a->ld_res;
   p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
-  p.act = 0; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
+  p.act = 0; p.gelu_deriv = 0; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
   p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c; p.conv_coords = nullptr;
@@ -876,7 +876,7 @@ CINEMA_API int cinema_conv_wgrad_bf16(cinema_gemm_args* a, void* stream) {
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldb = 0; p.ldd = a->ldd;
   p.alpha = a->alpha;
   p.bias = nullptr; p.res_f32 = nullptr; p.res_bf16 = nullptr; p.ld_res = 0; p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
-  p.act = 0; p.out_f32 = 1; p.accumulate = a->accumulate; p.a_rowsum = a->a_rowsum;
+  p.act = 0; p.gelu_deriv = 0; p.out_f32 = 1; p.accumulate = a->accumulate; p.a_rowsum = a->a_rowsum;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0;
   p.conv_taps = (const int4*)a->conv_taps; p.cX = a->conv_x; p.cY = a->conv_y; p.cZ = a->conv_z; p.cC = a->conv_c; p.conv_coords = (const int*)a->conv_coords;
@@ -924,7 +924,7 @@ CINEMA_API int cinema_gemm_bf16_grouped(cinema_gemm_args* args, int count, void*
     p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldb = a->ldb; p.ldd = a->ldd;
     p.alpha = a->alpha;
     p.bias = nullptr; p.res_bf16 = nullptr; p.gelu_in = nullptr; p.ld_gelu = 0; p.row_mask = nullptr; p.aux_out = nullptr; p.ld_aux = 0;
-    p.act = 0; p.out_f32 = 1; p.accumulate = 0;
+    p.act = 0; p.gelu_deriv = 0; p.out_f32 = 1; p.accumulate = 0;
     p.res_f32 = a->accumulate ? (const float*)a->d : nullptr;  // one owner per element: plain read-modify-write
     p.ld_res = a->ldd;
     p.ktiles_per_split = (a->k + BK - 1) / BK;

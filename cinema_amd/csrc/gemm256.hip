@@ -32,14 +32,14 @@ struct SlimP {
   const bf16_t* a; const bf16_t* b; void* d;
   int m, n, k, lda, ldb, ldd;
   const float* bias; const float* res_f32; const bf16_t* gelu_in; bf16_t* aux_out; float* a_rowsum;
-  int ld_res, ld_gelu, ld_aux, act, out_f32;
+  int ld_res, ld_gelu, ld_aux, act, out_f32, gelu_deriv;
   float alpha;
 };
 __device__ __forceinline__ GemmP expand(const SlimP& s) {
   GemmP p;
   p.a = s.a; p.b = s.b; p.d = s.d; p.m = s.m; p.n = s.n; p.k = s.k; p.lda = s.lda; p.ldb = s.ldb; p.ldd = s.ldd; p.alpha = s.alpha;
   p.bias = s.bias; p.res_f32 = s.res_f32; p.res_bf16 = nullptr; p.ld_res = s.ld_res; p.gelu_in = s.gelu_in; p.ld_gelu = s.ld_gelu;
-  p.row_mask = nullptr; p.aux_out = s.aux_out; p.ld_aux = s.ld_aux; p.act = s.act; p.out_f32 = s.out_f32; p.accumulate = 0;
+  p.row_mask = nullptr; p.aux_out = s.aux_out; p.ld_aux = s.ld_aux; p.act = s.act; p.gelu_deriv = s.gelu_deriv; p.out_f32 = s.out_f32; p.accumulate = 0;
   p.ktiles_per_split = 0; p.ws = nullptr; p.a_rowsum = s.a_rowsum; p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.cX = p.cY = p.cZ = p.cC = 0; p.cZB = 1; p.conv_coords = nullptr;
   return p;
@@ -473,7 +473,7 @@ CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int sche
     p.alpha = a->alpha;
     p.bias = a->bias; p.res_f32 = a->residual_f32; p.ld_res = a->ld_res;
     p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
-    p.act = a->act; p.out_f32 = a->out_f32; p.a_rowsum = a->a_rowsum;
+    p.act = a->act; p.gelu_deriv = a->gelu_deriv; p.out_f32 = a->out_f32; p.a_rowsum = a->a_rowsum;
     if (a->accumulate) { p.res_f32 = (const float*)a->d; p.ld_res = a->ldd; }  // one owner per element: plain read-modify-write
     int e;
     if (!p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) e = EPI_BF16;

@@ -19,6 +19,7 @@ struct GemmP {
   const uint8_t* row_mask;
   bf16_t* aux_out; int ld_aux;
   int act, out_f32, accumulate;
+  int gelu_deriv;  // 1: the auxiliary GELU tensor holds GELU'(pre-activation), not the pre-activation: act == 1 writes it to aux_out, gelu_in is multiplied in as it is
   int ktiles_per_split;
   float* ws;  // split-K partial slabs [gridDim.z][m][n] (fp32) or nullptr
   float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m][k] (the bias gradient of a weight-gradient GEMM), fused into the MFMA loop
@@ -59,7 +60,10 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   }
   if (p.aux_out) {
-    uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+    const bool dv = p.act == 1 && p.gelu_deriv;  // the derivative instead of the pre-activation (see GemmP::gelu_deriv)
+    uint2 pk;
+    pk.x = dv ? pack_bf2(gelu_grad_f(v[0]), gelu_grad_f(v[1])) : pack_bf2(v[0], v[1]);
+    pk.y = dv ? pack_bf2(gelu_grad_f(v[2]), gelu_grad_f(v[3])) : pack_bf2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ld_aux + n0) = pk;
   }
   if (p.act == 1) {
@@ -68,8 +72,9 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
   }
   if (p.gelu_in) {
     const uint2 gi = *reinterpret_cast<const uint2*>(p.gelu_in + (size_t)m * p.ld_gelu + n0);
-    v[0] *= gelu_grad_f(bf2f((bf16_t)(gi.x & 0xffff))); v[1] *= gelu_grad_f(bf2f((bf16_t)(gi.x >> 16)));
-    v[2] *= gelu_grad_f(bf2f((bf16_t)(gi.y & 0xffff))); v[3] *= gelu_grad_f(bf2f((bf16_t)(gi.y >> 16)));
+    const float g0 = bf2f((bf16_t)(gi.x & 0xffff)), g1 = bf2f((bf16_t)(gi.x >> 16)), g2 = bf2f((bf16_t)(gi.y & 0xffff)), g3 = bf2f((bf16_t)(gi.y >> 16));
+    v[0] *= p.gelu_deriv ? g0 : gelu_grad_f(g0); v[1] *= p.gelu_deriv ? g1 : gelu_grad_f(g1);
+    v[2] *= p.gelu_deriv ? g2 : gelu_grad_f(g2); v[3] *= p.gelu_deriv ? g3 : gelu_grad_f(g3);
   }
   if (p.row_mask) {
     const float s = p.row_mask[m] ? 1.f : 0.f;
@@ -166,17 +171,38 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
       *reinterpret_cast<uint2*>(dst) = pk;
     }
   };
-  if (p.aux_out) store_bf16(p.aux_out + (size_t)m * p.ld_aux + n0);
-  if (p.act == 1) {
+  if (p.act == 1 && p.aux_out && p.gelu_deriv) {
+    // GELU and its derivative from ONE evaluation of the erf terms; the derivative (bf16) is what the data gradient of this layer multiplies in later
+    float dv[W];
 #pragma unroll
-    for (int i = 0; i < W; i += 2) gelu2(v[i], v[i + 1]);
+    for (int i = 0; i < W; i += 2) gelu_both2(v[i], v[i + 1], dv[i], dv[i + 1]);
+    bf16_t* dst = p.aux_out + (size_t)m * p.ld_aux + n0;
+    if (W == 8) {
+      u32x4 pk = {pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3]), pack_bf2(dv[W - 4], dv[W - 3]), pack_bf2(dv[W - 2], dv[W - 1])};
+      if (NT_STORES) __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(dst));
+      else *reinterpret_cast<u32x4*>(dst) = pk;
+    } else {
+      uint2 pk; pk.x = pack_bf2(dv[0], dv[1]); pk.y = pack_bf2(dv[2], dv[3]);
+      *reinterpret_cast<uint2*>(dst) = pk;
+    }
+  } else {
+    if (p.aux_out) store_bf16(p.aux_out + (size_t)m * p.ld_aux + n0);
+    if (p.act == 1) {
+#pragma unroll
+      for (int i = 0; i < W; i += 2) gelu2(v[i], v[i + 1]);
+    }
   }
   if (p.gelu_in) {
+    if (p.gelu_deriv) {
 #pragma unroll
-    for (int i = 0; i < W / 2; i++) {
-      float ga, gb;
-      gelu_grad2(bf_lo(e.g[i]), bf_hi(e.g[i]), ga, gb);
-      v[2 * i] *= ga; v[2 * i + 1] *= gb;
+      for (int i = 0; i < W / 2; i++) { v[2 * i] *= bf_lo(e.g[i]); v[2 * i + 1] *= bf_hi(e.g[i]); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < W / 2; i++) {
+        float ga, gb;
+        gelu_grad2(bf_lo(e.g[i]), bf_hi(e.g[i]), ga, gb);
+        v[2 * i] *= ga; v[2 * i + 1] *= gb;
+      }
     }
   }
   if (p.row_mask) {
@@ -301,9 +327,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const float16v (&a
 __device__ __forceinline__ void epilogue1(const GemmP& p, int m, int n, float acc, bool add_bias) {
   float v = acc * p.alpha;
   if (p.bias && add_bias) v += p.bias[n];
-  if (p.aux_out) p.aux_out[(size_t)m * p.ld_aux + n] = f2bf(v);
+  if (p.aux_out) p.aux_out[(size_t)m * p.ld_aux + n] = f2bf((p.act == 1 && p.gelu_deriv) ? gelu_grad_f(v) : v);
   if (p.act == 1) v = gelu_f(v);
-  if (p.gelu_in) v *= gelu_grad_f(bf2f(p.gelu_in[(size_t)m * p.ld_gelu + n]));
+  if (p.gelu_in) v *= p.gelu_deriv ? bf2f(p.gelu_in[(size_t)m * p.ld_gelu + n]) : gelu_grad_f(bf2f(p.gelu_in[(size_t)m * p.ld_gelu + n]));
   if (p.row_mask) v *= p.row_mask[m] ? 1.f : 0.f;
   if (p.res_f32) v += p.res_f32[(size_t)m * p.ld_res + n];
   else if (p.res_bf16) v += bf2f(p.res_bf16[(size_t)m * p.ld_res + n]);

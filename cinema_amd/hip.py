@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("gelu_in", C.c_void_p), ("ld_gelu", C.c_int),
         ("row_mask", C.c_void_p),
         ("aux_out", C.c_void_p), ("ld_aux", C.c_int),
-        ("act", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
+        ("act", C.c_int), ("gelu_deriv", C.c_int), ("out_f32", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int), ("force_generic", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
         ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int), ("conv_coords", C.c_void_p), ("conv_zb", C.c_int),
@@ -447,8 +447,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
          out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None,
          gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, aux_out: torch.Tensor | None = None,
          act: int = 0, accumulate: bool = False, split_k: int = 1, alpha: float = 1.0, force_generic: bool = False,
-         a_rowsum: torch.Tensor | None = None, p256: int | None = None) -> torch.Tensor:
+         a_rowsum: torch.Tensor | None = None, p256: int | None = None, gelu_deriv: bool = False) -> torch.Tensor:
     """D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N].
+    ``gelu_deriv``: the auxiliary GELU tensor holds GELU'(pre-activation) - written to ``aux_out`` by an ``act=1`` launch, multiplied in from ``gelu_in``.
     ``p256`` = 0 / 1: the persistent 256x256 kernel with its split / stream schedule (``split_k`` = 1 then means whole-K tiles, 0 balanced slices)."""
     lib = load()
     _dev(a, b, out, bias, residual, gelu_in, row_mask, aux_out)
@@ -488,6 +489,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     if aux_out is not None:
         g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
     g.act, g.out_f32, g.accumulate = act, int(out.dtype == torch.float32), int(accumulate)
+    g.gelu_deriv = int(gelu_deriv)
     g.split_k, g.force_generic = split_k, int(force_generic or FORCE_GENERIC)
     if a_rowsum is not None:  # fp32 [m], accumulated: sum_k A[m, k] (bias gradient of a weight-gradient GEMM)
         _dev(a_rowsum)
@@ -578,7 +580,7 @@ def quantize_fp8_segments_t(x: torch.Tensor, seg_desc: torch.Tensor, scales: tor
 
 def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16,
              bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, aux_out: torch.Tensor | None = None, act: int = 0,
-             alpha: float = 1.0, out: torch.Tensor | None = None, gelu_in: torch.Tensor | None = None) -> torch.Tensor:
+             alpha: float = 1.0, out: torch.Tensor | None = None, gelu_in: torch.Tensor | None = None, gelu_deriv: bool = False) -> torch.Tensor:
     """D = epilogue(alpha * scale_a * scale_b * A8 @ B8^T): e4m3 operands a8 [M, K], b8 [N, K] (uint8 storage, k-major), per-tensor fp32 [1] scales;
     bias / exact GELU (+ bf16 pre-activation copy) / fp32 residual epilogue like :func:`gemm`."""
     _dev(a8, scale_a, b8, scale_b, bias, residual, aux_out)
@@ -610,7 +612,7 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
     if gelu_in is not None:  # D = (A8 B8^T) x GELU'(gelu_in): the data gradient through fc1's activation
         _dev(gelu_in)
         g.gelu_in, g.ld_gelu = gelu_in.data_ptr(), _rowmajor(gelu_in, "gelu_in")
-    g.act, g.out_f32 = act, int(out.dtype == torch.float32)
+    g.act, g.out_f32, g.gelu_deriv = act, int(out.dtype == torch.float32), int(gelu_deriv)
     _check(load().cinema_gemm_fp8(C.byref(g), _stream()), "gemm_fp8")
     return out
 

@@ -50,6 +50,9 @@ typedef struct {
   uint16_t* aux_out;          /* [m][ld_aux] bf16 pre-activation copy or NULL */
   int ld_aux;
   int act;                    /* 0 none, 1 exact GELU */
+  int gelu_deriv;             /* 1: the auxiliary GELU tensor holds GELU'(pre-activation) instead of the pre-activation: with act = 1 aux_out receives the
+                                 derivative (computed from the same erf terms as the activation), and gelu_in is multiplied in as it is - the data gradient
+                                 through the activation then costs one multiply per element instead of an erf evaluation */
   int out_f32;                /* 1: D is fp32, 0: D is bf16 */
   int accumulate;             /* 1: D += result with fp32 atomics (out_f32 must be 1) */
   int split_k;                /* >=1 */

@@ -122,6 +122,20 @@ def test_gemm_bf16_epilogue_classes_on_both_tile_depths(k: int) -> None:
     dh = K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=aux)
     assert dh.dtype == torch.bfloat16
     close(dh, (dy.float() @ w2.float()) * hx.grad, 1e-2, 2e-2, "gelu' on the data-gradient layout")
+    # stored-derivative form (gelu_deriv): the forward epilogue writes GELU'(pre-activation) from the same erf terms, the data gradient multiplies it in
+    dv = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    assert torch.equal(K.gemm(a, w, bias=bias, act=1, aux_out=dv, gelu_deriv=True), out)
+    px = pre.clone().requires_grad_(True)
+    F.gelu(px).backward(torch.ones_like(px))
+    close(dv, px.grad, 1e-2, 1e-2, "stored GELU derivative")
+    dh2 = K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv, gelu_deriv=True)
+    close(dh2, (dy.float() @ w2.float()) * dv.float(), 1e-2, 2e-2, "data gradient x stored derivative")
+    for sched in (0, 1):  # the same two epilogues on the persistent 256x256 kernel
+        dv3 = torch.empty_like(dv)
+        close(K.gemm(a, w, bias=bias, act=1, aux_out=dv3, gelu_deriv=True, p256=sched, split_k=0), F.gelu(pre), 1e-2, 2e-2, "p256 gelu")
+        close(dv3, px.grad, 1e-2, 1e-2, "p256 stored derivative")
+        close(K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv, gelu_deriv=True, p256=sched, split_k=0), (dy.float() @ w2.float()) * dv.float(), 1e-2, 2e-2,
+              "p256 x stored derivative")
 
 
 @pytest.mark.parametrize(("m", "n", "k"), [(10960, 768, 3072), (8300, 512, 2048), (10960, 768, 2304)])
