@@ -8,6 +8,10 @@
 //   split   - every tile of problem i is cut into split[i] equal k-slices (the host balances the slice lengths over up to 12 problems: the weight
 //             gradients of one transformer block in one launch); workgroups walk the pieces grid-stride, slice-major so that neighbours share panels
 //   stream  - the (tile, k-tile) units of one problem are dealt to the workgroups as equal contiguous ranges (tile counts like 129 on 256 CUs)
+//   split + remainder (chosen by the host when it is shorter than the equal slices) - every tile is cut into slices of the SAME length L ~ units / CUs, one
+//             per workgroup, and the rest of the tile's reduction (shorter than L) goes to workgroups that take several such rests one after the other: the
+//             weight gradients of an encoder block are 108 tiles x 343 units = 144.7 units per CU; equal slices give 216 pieces of 172 units on 256 CUs,
+//             this schedule 216 slices of 147 + 108 rests of 49 packed three to a workgroup (252 CUs, 147 units each)
 // A tile cut into n pieces is finished by its LAST ARRIVER: a piece takes a ticket from the tile's arrival counter; tickets 0..n-2 store their
 // accumulators as a fragment-ordered fp32 slot (write-through sc1 stores, 1 KiB per wave-instruction), drain, and bump the tile's publish counter;
 // ticket n-1 keeps its accumulators, waits for n-1 publishes (its partners arrived before it and never wait themselves: no deadlock for any dispatch
@@ -47,11 +51,15 @@ __device__ __forceinline__ GemmP expand(const SlimP& s) {
 
 struct P256 {
   SlimP p[P_MAX];
-  int count, mode;               // mode 0 = split, 1 = stream
+  int count, mode;               // mode 0 = split, 1 = stream, 2 = split + remainder
   int tile_begin[P_MAX + 1];     // prefix sums of the 256x256 tile counts (global tile id = counter index)
   int piece_begin[P_MAX + 1];    // split: prefix sums of tiles_i * split_i
   int split[P_MAX], kts[P_MAX];  // split: slices per tile, k-tiles per slice
   int nkt[P_MAX];
+  int nbig[P_MAX];               // split + remainder: full slices per tile (kts[i] units each); the rest [nbig * kts, nkt) is the tile's remainder piece (none: rem_per = 0)
+  int big_begin[P_MAX + 1];      //   prefix sums of tiles_i * nbig_i: logical workgroup ids of the full slices (= their slot ids); the remainder of global tile t uses slot n_big + t
+  int rem_begin[P_MAX + 1];      //   prefix sums of the remainder workgroups per problem
+  int rem_per[P_MAX];            //   remainder pieces (consecutive tiles) per remainder workgroup
   long long units;               // stream: tiles_0 * nkt_0
   int per, rem;                  // stream: units per workgroup; the first `rem` workgroups take one more
   float* slots;                  // fp32 partial slots [..][P_SLOT_FLOATS]
@@ -252,9 +260,20 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
   if (wr == 0) P256_BAR();
 }
 
+// where the pieces of this piece's tile publish: pieces first .. first + n_pieces - 1 in summation order, `me` among them
+struct PieceRed {
+  float* my_slot;
+  const float* slot0; long long stride; int n_big;   // split: pieces 0 .. n_big - 1 at slot0 + piece * stride,
+  const float* rem_slot;                             //        piece n_big (the remainder, if any) here
+  int first; long long tile_unit0;                   // stream: pieces = workgroups first .., slot by stream_start
+  int me;
+};
+
 template <bool A_KMAJ, bool B_KMAJ, int EPI, int LOOP>
-__device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gtile, int tile, int kt_begin, int kt_end, int n_pieces,
-                                           float* my_slot, int first_other, int n_other, long long tile_unit0, int me, char* smem) {
+__device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gtile, int tile, int kt_begin, int kt_end, int n_pieces, const PieceRed& rd, char* smem) {
+  float* my_slot = rd.my_slot;
+  const int first_other = rd.first, n_other = n_pieces - 1, me = rd.me;
+  const long long tile_unit0 = rd.tile_unit0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wr = wave_u >> 2, wc = wave_u & 3;      // wave grid 2 (m) x 4 (n)
@@ -339,8 +358,8 @@ __device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gt
           continue;
         }
         const float* src;
-        if (g.mode == 0) {
-          src = my_slot + ((long long)s - me) * tiles_m * tiles_n * (long long)P_SLOT_FLOATS;   // slice-major piece order: same tile, slice s
+        if (g.mode != 1) {
+          src = s < rd.n_big ? rd.slot0 + (long long)s * rd.stride : rd.rem_slot;   // slice-major piece order: same tile, slice s
         } else {
           const int which = stream_start(g, s) >= tile_unit0 ? 0 : 1;
           src = g.slots + ((long long)s * 2 + which) * P_SLOT_FLOATS;
@@ -366,44 +385,84 @@ __device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gt
   __syncthreads();  // the staging area becomes stage 0 / 1 of the next piece
 }
 
+// The next piece of logical workgroup `wg` (it = how many it has taken, u = stream position): problem, tile, k range, fan-in and where the tile's pieces
+// publish.  One function for the three schedules so that the kernel has ONE inlined copy of the piece body (four copies spilled 60-280 registers).
+struct PieceSel { int i, gtile, tile, kt_begin, kt_end, n_pieces; PieceRed rd; };
+__device__ __forceinline__ bool next_piece(const P256& g, int wg, int G, int it, long long& u, long long u_end, PieceSel& o) {
+  o.rd.first = 0; o.rd.tile_unit0 = 0; o.rd.rem_slot = nullptr; o.rd.slot0 = nullptr; o.rd.stride = 0; o.rd.n_big = 0;
+  if (g.mode == 0) {
+    const int q = wg + it * G;
+    if (q >= g.piece_begin[g.count]) return false;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < P_MAX; j++) i += (j < g.count && q >= g.piece_begin[j]) ? 1 : 0;
+    const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
+    const int local = q - g.piece_begin[i];
+    const int s = local / tiles, tile = local - s * tiles;   // slice-major
+    o.i = i; o.tile = tile; o.gtile = g.tile_begin[i] + tile;
+    o.kt_begin = s * g.kts[i]; o.kt_end = min(g.nkt[i], o.kt_begin + g.kts[i]); o.n_pieces = g.split[i];
+    o.rd.my_slot = g.slots + (long long)q * P_SLOT_FLOATS;
+    o.rd.stride = (long long)tiles * P_SLOT_FLOATS; o.rd.slot0 = o.rd.my_slot - (long long)s * o.rd.stride; o.rd.n_big = o.n_pieces; o.rd.me = s;
+    return true;
+  }
+  if (g.mode == 2) {
+    const int n_big = g.big_begin[g.count];
+    if (wg < n_big) {  // one full slice
+      if (it > 0) return false;
+      int i = 0;
+#pragma unroll
+      for (int j = 1; j < P_MAX; j++) i += (j < g.count && wg >= g.big_begin[j]) ? 1 : 0;
+      const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
+      const int local = wg - g.big_begin[i];
+      const int s = local / tiles, tile = local - s * tiles;   // slice-major
+      o.i = i; o.tile = tile; o.gtile = g.tile_begin[i] + tile;
+      o.kt_begin = s * g.kts[i]; o.kt_end = min(g.nkt[i], o.kt_begin + g.kts[i]); o.n_pieces = g.nbig[i] + (g.rem_per[i] > 0 ? 1 : 0);
+      o.rd.my_slot = g.slots + (long long)wg * P_SLOT_FLOATS;
+      o.rd.stride = (long long)tiles * P_SLOT_FLOATS; o.rd.slot0 = o.rd.my_slot - (long long)s * o.rd.stride; o.rd.n_big = g.nbig[i];
+      o.rd.rem_slot = g.slots + (long long)(n_big + o.gtile) * P_SLOT_FLOATS; o.rd.me = s;
+      return true;
+    }
+    const int rc = wg - n_big;  // the remainders of rem_per consecutive tiles, one after the other
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < P_MAX; j++) i += (j < g.count && rc >= g.rem_begin[j]) ? 1 : 0;
+    const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
+    const int tile = (rc - g.rem_begin[i]) * g.rem_per[i] + it;
+    if (it >= g.rem_per[i] || tile >= tiles) return false;
+    o.i = i; o.tile = tile; o.gtile = g.tile_begin[i] + tile;
+    o.kt_begin = g.nbig[i] * g.kts[i]; o.kt_end = g.nkt[i]; o.n_pieces = g.nbig[i] + 1;
+    o.rd.my_slot = g.slots + (long long)(n_big + o.gtile) * P_SLOT_FLOATS;
+    o.rd.stride = (long long)tiles * P_SLOT_FLOATS; o.rd.slot0 = g.slots + (long long)(g.big_begin[i] + tile) * P_SLOT_FLOATS; o.rd.n_big = g.nbig[i];
+    o.rd.rem_slot = o.rd.my_slot; o.rd.me = g.nbig[i];
+    return true;
+  }
+  // stream: contiguous unit range [u, u_end) of problem 0
+  if (u >= u_end) return false;
+  const int nkt = g.nkt[0];
+  const int tile = (int)(u / nkt);
+  const long long t0 = (long long)tile * nkt;
+  o.i = 0; o.tile = tile; o.gtile = tile;
+  o.kt_begin = (int)(u - t0); o.kt_end = (int)min((long long)nkt, u_end - t0);
+  const int w_first = stream_owner_of(g, t0), w_last = stream_owner_of(g, t0 + nkt - 1);
+  o.n_pieces = w_last - w_first + 1;
+  const int which = stream_start(g, wg) >= t0 ? 0 : 1;   // this workgroup's first piece, or a later one (only its last piece can be partial then)
+  o.rd.my_slot = g.slots + ((long long)wg * 2 + which) * P_SLOT_FLOATS;
+  o.rd.first = w_first; o.rd.tile_unit0 = t0; o.rd.me = wg;
+  u = t0 + o.kt_end;
+  return true;
+}
+
 template <bool A_KMAJ, bool B_KMAJ, int EPI, int LOOP>
 __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(P256 g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = (int)gridDim.x;
   const int wg = xcd_remap((int)blockIdx.x, G);  // neighbouring logical ids share an XCD (and with it operand panels in L2)
-  if (g.mode == 0) {
-    const int total = g.piece_begin[g.count];
-    for (int q = wg; q < total; q += G) {
-      int i = 0;
-#pragma unroll
-      for (int j = 1; j < P_MAX; j++) i += (j < g.count && q >= g.piece_begin[j]) ? 1 : 0;
-      const GemmP p = expand(g.p[i]);
-      const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
-      const int local = q - g.piece_begin[i];
-      const int s = local / tiles, tile = local - s * tiles;   // slice-major
-      const int kt_begin = s * g.kts[i], kt_end = min(g.nkt[i], kt_begin + g.kts[i]);
-      const int n_pieces = g.split[i];
-      float* my_slot = g.slots + (long long)q * P_SLOT_FLOATS;
-      p256_piece<A_KMAJ, B_KMAJ, EPI, LOOP>(g, p, g.tile_begin[i] + tile, tile, kt_begin, kt_end, n_pieces, my_slot, 0, n_pieces - 1, 0, s, smem);
-    }
-    return;
-  }
-  // stream: contiguous unit range [u, end) of problem 0
-  const GemmP p = expand(g.p[0]);
-  const int nkt = g.nkt[0];
-  long long u = stream_start(g, wg);
-  const long long u_start = u, end = stream_start(g, wg + 1);
-  while (u < end) {
-    const int tile = (int)(u / nkt);
-    const long long t0 = (long long)tile * nkt;
-    const int kt_begin = (int)(u - t0);
-    const int kt_end = (int)min((long long)nkt, end - t0);
-    const int w_first = stream_owner_of(g, t0), w_last = stream_owner_of(g, t0 + nkt - 1);
-    const int n_pieces = w_last - w_first + 1;
-    const int which = u_start >= t0 ? 0 : 1;   // this workgroup's first piece, or a later one (only its last piece can be partial then)
-    float* my_slot = g.slots + ((long long)wg * 2 + which) * P_SLOT_FLOATS;
-    p256_piece<A_KMAJ, B_KMAJ, EPI, LOOP>(g, p, tile, tile, kt_begin, kt_end, n_pieces, my_slot, w_first, n_pieces - 1, t0, wg, smem);
-    u = t0 + kt_end;
+  long long u = 0, u_end = 0;
+  if (g.mode == 1) { u = stream_start(g, wg); u_end = stream_start(g, wg + 1); }
+  PieceSel o;
+  for (int it = 0; next_piece(g, wg, G, it, u, u_end, o); it++) {
+    const GemmP p = expand(g.p[o.i]);
+    p256_piece<A_KMAJ, B_KMAJ, EPI, LOOP>(g, p, o.gtile, o.tile, o.kt_begin, o.kt_end, o.n_pieces, o.rd, smem);
   }
 }
 
@@ -515,9 +574,43 @@ CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int sche
     grid = g.piece_begin[count] < G ? g.piece_begin[count] : G;
     slots = g.piece_begin[count];
     bool any_split = false;
-    for (int i = 0; i < count; i++) any_split = any_split || g.split[i] > 1;
+    int longest = 0;
+    for (int i = 0; i < count; i++) { any_split = any_split || g.split[i] > 1; longest = g.kts[i] > longest ? g.kts[i] : longest; }
     if (!any_split) slots = 0;
     g.units = units; g.per = 0; g.rem = 0;
+    for (int i = 0; i < P_MAX; i++) { g.nbig[i] = 0; g.rem_per[i] = 0; g.big_begin[i + 1] = 0; g.rem_begin[i + 1] = 0; }
+    g.big_begin[0] = 0; g.rem_begin[0] = 0;
+    // split + remainder: slices of one length L >= units / CUs and the rests packed several to a workgroup; taken when its longest workgroup is
+    // >= 4 % shorter than the equal slices' (CINEMA_P256_REMAINDER=0: never)
+    static const int rem_env = getenv("CINEMA_P256_REMAINDER") ? atoi(getenv("CINEMA_P256_REMAINDER")) : 1;
+    const int min_rest = 256 / unit_k;  // a shorter rest is not worth a piece of its own: the slices of that problem are stretched instead
+    if (rem_env && any_split && args[0].split_k != 1 && total_tiles < G) {
+      for (long long L = (units + G - 1) / G; L < longest; L++) {
+        int nb[P_MAX], len[P_MAX], per[P_MAX], used = 0, worst = 0;
+        for (int i = 0; i < count; i++) {
+          const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
+          nb[i] = (int)(g.nkt[i] / L); len[i] = (int)L; per[i] = 0;
+          int rest = g.nkt[i] - nb[i] * (int)L;
+          if (nb[i] > 0 && rest < min_rest) { len[i] = (g.nkt[i] + nb[i] - 1) / nb[i]; nb[i] = (g.nkt[i] + len[i] - 1) / len[i]; rest = 0; }
+          if (rest > 0) { per[i] = (int)(L / rest) > 0 ? (int)(L / rest) : 1; used += (tiles + per[i] - 1) / per[i]; worst = per[i] * rest > worst ? per[i] * rest : worst; }
+          used += tiles * nb[i];
+          if (nb[i] > 0 && len[i] > worst) worst = len[i];
+        }
+        if (used > G) continue;
+        if (worst * 100 > longest * 96) break;  // the first fit is the shortest; not enough of a gain
+        for (int i = 0; i < count; i++) {
+          const int tiles = g.tile_begin[i + 1] - g.tile_begin[i];
+          g.nbig[i] = nb[i]; g.kts[i] = len[i]; g.rem_per[i] = per[i];
+          g.big_begin[i + 1] = g.big_begin[i] + tiles * nb[i];
+          g.rem_begin[i + 1] = g.rem_begin[i] + (per[i] > 0 ? (tiles + per[i] - 1) / per[i] : 0);
+        }
+        for (int i = count; i < P_MAX; i++) { g.big_begin[i + 1] = g.big_begin[count]; g.rem_begin[i + 1] = g.rem_begin[count]; }
+        g.mode = 2;
+        grid = g.big_begin[count] + g.rem_begin[count];
+        slots = g.big_begin[count] + total_tiles;
+        break;
+      }
+    }
   } else {
     grid = units < G ? (int)units : G;
     g.units = units; g.per = (int)(units / grid); g.rem = (int)(units % grid);
