@@ -580,9 +580,11 @@ CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int sche
     g.units = units; g.per = 0; g.rem = 0;
     for (int i = 0; i < P_MAX; i++) { g.nbig[i] = 0; g.rem_per[i] = 0; g.big_begin[i + 1] = 0; g.rem_begin[i + 1] = 0; }
     g.big_begin[0] = 0; g.rem_begin[0] = 0;
-    // split + remainder: slices of one length L >= units / CUs and the rests packed several to a workgroup; taken when its longest workgroup is
-    // >= 4 % shorter than the equal slices' (CINEMA_P256_REMAINDER=0: never)
-    static const int rem_env = getenv("CINEMA_P256_REMAINDER") ? atoi(getenv("CINEMA_P256_REMAINDER")) : 1;
+    // split + remainder: slices of one length L >= units / CUs and the rests packed several to a workgroup; taken (CINEMA_P256_REMAINDER=1) when its longest
+    // workgroup is >= 4 % shorter than the equal slices'.  OFF by default - measured on the encoder block's weight gradients (216 equal slices of 172 units vs
+    // 216 x 147 + 108 rests of 49): 210.7 -> 206.5 us only (the launch is not bound by its longest workgroup: with 252 instead of 216 busy CUs the per-CU rate
+    // drops), for 9 % more HBM traffic (three partial tiles per output tile instead of two).
+    const int rem_env = getenv("CINEMA_P256_REMAINDER") ? atoi(getenv("CINEMA_P256_REMAINDER")) : 0;  // read per call (tests toggle it)
     const int min_rest = 256 / unit_k;  // a shorter rest is not worth a piece of its own: the slices of that problem are stretched instead
     if (rem_env && any_split && args[0].split_k != 1 && total_tiles < G) {
       for (long long L = (units + G - 1) / G; L < longest; L++) {

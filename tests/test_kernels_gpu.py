@@ -196,12 +196,15 @@ def test_gemm_wgrad_grouped_matches_single_launches() -> None:
         K.gemm_wgrad_grouped([(rnd(64, 8), rnd(32, 8), torch.zeros(8, 8, device=DEV), None)])
 
 
-@pytest.mark.parametrize("rows", [700, 5000])
-def test_gemm_p256_grouped_wgrad_in_launch_reduction(rows: int) -> None:
+@pytest.mark.parametrize("remainder", [0, 1])
+@pytest.mark.parametrize("rows", [700, 5000, 10960])
+def test_gemm_p256_grouped_wgrad_in_launch_reduction(rows: int, remainder: int, monkeypatch: pytest.MonkeyPatch) -> None:
     """cinema_gemm_bf16_p256, split schedule: the weight gradients of a block in one persistent launch, tiles cut into k-slices and finished by their
     last-arriving piece inside the launch.  Against fp32 torch (1e-3 of the largest element: accumulation order only), twice on the same workspace
-    (the counters must come back to zero), ragged tile edges (n, k not multiples of 256) and a ragged last k-tile (rows % 64 != 0) included."""
-    shapes = [(512, 256), (256, 768), (384, 200), (72, 512)]
+    (the counters must come back to zero), ragged tile edges (n, k not multiples of 256) and a ragged last k-tile (rows % 64 != 0) included.
+    ``remainder`` = 1: the split + remainder schedule (equal-length slices, the rests of several tiles on one workgroup: fan-in 3, pieces of two lengths)."""
+    monkeypatch.setenv("CINEMA_P256_REMAINDER", str(remainder))
+    shapes = [(512, 256), (256, 768), (384, 200), (72, 512)] if rows < 10000 else [(2304, 768), (768, 768), (3072, 768), (768, 3072)]  # an encoder block
     for rep in range(2):
         probs, ref = [], []
         for i, (n, k) in enumerate(shapes):
