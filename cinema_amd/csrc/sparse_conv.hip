@@ -282,6 +282,162 @@ template <int KZ>
 __global__ __launch_bounds__(256) void sparse_dwconv_wgrad_kernel(SpP p) { sparse_dwconv_wgrad_body<KZ>(p); }
 template <int KZ>
 __global__ __launch_bounds__(256) void sparse_dwconv_wgrad_lanes_kernel(Lanes<SpP> L) { sparse_dwconv_wgrad_body<KZ>(L.p[blockIdx.z]); }
+// ---- halo source rows of every kept token, once per mask / stage / kernel extent: hidx[r][hv] = compact row of halo voxel hv of token r, -1 = masked /
+// outside the volume.  The weight-gradient kernel below reads them as one coalesced row per token instead of chasing keep -> rank -> pos per token.
+__device__ __forceinline__ void sparse_halo_index_body(const SpP& p, int* hidx) {
+  __shared__ int cell_rank[128];
+  __shared__ int pos_l[512];
+  const Halo h = make_halo(p);
+  const int Bv = p.bx * p.by * p.bz, tid = threadIdx.x;
+  for (int i = tid; i < Bv; i += 256) pos_l[i] = p.pos[i];
+  const int r = blockIdx.x;
+  const TokCoord tc = token_coord(p, r);
+  load_cells(p, h, tc, cell_rank, tid);
+  __syncthreads();
+  index_halo(p, h, pos_l, cell_rank, hidx + (size_t)r * h.Hvox, tid);
+}
+struct SpHaloP { SpP p; int* hidx; };
+__global__ __launch_bounds__(256) void sparse_halo_index_kernel(SpHaloP q) { sparse_halo_index_body(q.p, q.hidx); }
+__global__ __launch_bounds__(256) void sparse_halo_index_lanes_kernel(Lanes<SpHaloP> L) { const SpHaloP& q = L.p[blockIdx.y]; sparse_halo_index_body(q.p, q.hidx); }
+
+// Weight gradient, pipelined over the tokens of a workgroup (the first form above spends ~6 us per token in three dependent global round trips - keep ->
+// rank -> rows - and four barriers, for ~1.3 us of FMAs): the halo source rows come from the table above, and while token r is accumulated from LDS the
+// rows of token r + 1 are already in flight into registers (<= NG 16-byte loads per thread) and the index row of token r + 2 into one more register pair;
+// two barriers per token.  Same arithmetic, same slab layout, same reduce kernel.
+template <int KZ, int NG>
+__device__ __forceinline__ void sparse_dwconv_wgrad_pipe_body(const SpP& p, const int* hidx) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  const int Bv = p.bx * p.by * p.bz, nxy = p.kx * p.ky, taps = nxy * KZ;
+  const Halo h = make_halo(p);
+  const int Hy = h.Hy, Hz = h.Hz, Hvox = h.Hvox;
+  char* tile = dyn_smem;
+  char* dyb = tile + (size_t)Hvox * 128;
+  int* src_row = reinterpret_cast<int*>(dyb + (size_t)Bv * 128);
+  int* pos_l = src_row + Hvox;
+  const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+  for (int i = tid; i < Bv; i += 256) pos_l[i] = p.pos[i];
+  const int cg = tid & 7, txy = tid >> 3;
+  const bool worker = txy < nxy && c0 + cg * 8 < p.c;
+  const int ti = txy / p.ky, tj = txy % p.ky;
+  const bool center = worker && ti == (p.kx >> 1) && tj == (p.ky >> 1);
+  float acc[KZ][8];
+  float accb[8];
+#pragma unroll
+  for (int k = 0; k < KZ; k++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[k][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) accb[i] = 0.f;
+  const int r_begin = blockIdx.x * p.tok_per_block, r_end = min(p.n_tok, r_begin + p.tok_per_block);
+  const int n_chunks = Hvox * 8, n_dy = Bv * 8;
+  const bool ch_ok = c0 + cg * 8 < p.c;  // (chunk & 7) == cg for every chunk of this thread: 256 is a multiple of 8
+
+  int idx_reg[2];                        // index row of a later token: halo voxels tid and tid + 256 (Hvox <= 512)
+  uint4 hv[NG], dv[2];                   // rows in flight: halo chunks tid + 256 q, dy chunks tid + 256 q
+  auto load_idx = [&](int r) {
+    const int* row = hidx + (size_t)r * Hvox;
+    idx_reg[0] = tid < Hvox ? row[tid] : -1;
+    idx_reg[1] = tid + 256 < Hvox ? row[tid + 256] : -1;
+  };
+  auto store_idx = [&]() {
+    if (tid < Hvox) src_row[tid] = idx_reg[0];
+    if (tid + 256 < Hvox) src_row[tid + 256] = idx_reg[1];
+  };
+  auto gather = [&](int r) {             // needs src_row (LDS) of token r
+#pragma unroll
+    for (int q = 0; q < NG; q++) {
+      const int chk = tid + q * 256;
+      hv[q] = make_uint4(0u, 0u, 0u, 0u);
+      if (chk < n_chunks && ch_ok) {
+        const int row = src_row[chk >> 3];
+        if (row >= 0) hv[q] = *reinterpret_cast<const uint4*>(p.x + (size_t)row * p.c + c0 + cg * 8);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int chk = tid + q * 256;
+      dv[q] = make_uint4(0u, 0u, 0u, 0u);
+      if (chk < n_dy && ch_ok) dv[q] = *reinterpret_cast<const uint4*>(p.dy + ((size_t)r * Bv + pos_l[chk >> 3]) * p.c + c0 + cg * 8);
+    }
+  };
+  auto store_rows = [&]() {
+#pragma unroll
+    for (int q = 0; q < NG; q++) {
+      const int chk = tid + q * 256;
+      if (chk < n_chunks) *reinterpret_cast<uint4*>(tile + (size_t)(chk >> 3) * 128 + cg * 16) = hv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int chk = tid + q * 256;
+      if (chk < n_dy) *reinterpret_cast<uint4*>(dyb + (size_t)(chk >> 3) * 128 + cg * 16) = dv[q];
+    }
+  };
+
+  if (r_begin >= r_end) return;
+  load_idx(r_begin);
+  store_idx();
+  __syncthreads();                       // pos_l and the first index row
+  gather(r_begin);
+  if (r_begin + 1 < r_end) load_idx(r_begin + 1);
+  store_rows();
+  __syncthreads();                       // everyone has read src_row(r_begin)
+  store_idx();
+  __syncthreads();
+  for (int r = r_begin; r < r_end; r++) {
+    const bool more = r + 1 < r_end;
+    if (more) gather(r + 1);             // in flight while token r is accumulated
+    if (r + 2 < r_end) load_idx(r + 2);
+    if (worker) {
+      for (int v = 0; v < Bv; v++) {
+        const int uz = v % p.bz, uy = (v / p.bz) % p.by, ux = v / (p.bz * p.by);
+        const uint4 dq = *reinterpret_cast<const uint4*>(dyb + (size_t)v * 128 + cg * 16);
+        if (center) {
+          float d[8];
+          unpack8(dq, d);
+#pragma unroll
+          for (int i = 0; i < 8; i++) accb[i] += d[i];
+        }
+        // acc[c] += x[c] * dy[c] per channel as v_dot2c_f32_bf16 on the packed pairs with the OTHER half of the dy pair zeroed: the bf16 products are exact in
+        // fp32 and the zero term adds nothing, so this is the same fp32 FMA chain - without the 16 shift / mask instructions per 8 FMAs of the unpacked form
+        const uint32_t dw_[4] = {dq.x, dq.y, dq.z, dq.w};
+        uint32_t dlo[4], dhi[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { dlo[j] = dw_[j] & 0xffffu; dhi[j] = dw_[j] & 0xffff0000u; }
+        const int hbase = ((ux + ti) * Hy + (uy + tj)) * Hz + uz;
+#pragma unroll
+        for (int k = 0; k < KZ; k++) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(tile + (size_t)(hbase + k) * 128 + cg * 16);
+          const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[k][2 * j]) : "v"(xw[j]), "v"(dlo[j]));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[k][2 * j + 1]) : "v"(xw[j]), "v"(dhi[j]));
+          }
+        }
+      }
+    }
+    __syncthreads();                     // tile / dyb / src_row of token r (and r + 1's index row) are no longer read
+    if (more) { store_rows(); store_idx(); }
+    __syncthreads();
+  }
+  if (!worker) return;
+  const int ch = c0 + cg * 8;
+  float* slab = p.ws + (size_t)blockIdx.x * p.c * (taps + 1);
+#pragma unroll
+  for (int k = 0; k < KZ; k++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) slab[(size_t)(ch + i) * taps + txy * KZ + k] = acc[k][i];
+  if (center) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) slab[(size_t)p.c * taps + ch + i] = accb[i];
+  }
+}
+struct SpPipeP { SpP p; const int* hidx; };
+template <int KZ, int NG>
+__global__ __launch_bounds__(256) void sparse_dwconv_wgrad_pipe_kernel(SpPipeP q) { sparse_dwconv_wgrad_pipe_body<KZ, NG>(q.p, q.hidx); }
+template <int KZ, int NG>
+__global__ __launch_bounds__(256) void sparse_dwconv_wgrad_pipe_lanes_kernel(Lanes<SpPipeP> L) { const SpPipeP& q = L.p[blockIdx.z]; sparse_dwconv_wgrad_pipe_body<KZ, NG>(q.p, q.hidx); }
+
 // dw[i] += sum_blocks slab[block][i]  (i < c*taps), dbias[j] += sum_blocks slab[block][c*taps + j]
 __device__ __forceinline__ void sparse_wgrad_reduce_body(const float* ws, int nblocks, int n_w, int n_b, float* dw, float* dbias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,26 +496,70 @@ CINEMA_API int cinema_sparse_dwconv_fwd(const uint16_t* x, const float* w, const
   return launch_status();
 }
 
+CINEMA_API long long cinema_sparse_halo_ints(const cinema_sparse_geom* geom, int kx, int ky, int kz) {
+  if (!geom) return 0;
+  return (long long)geom->n_tok * (geom->bx + kx - 1) * (geom->by + ky - 1) * (geom->bz + kz - 1);
+}
+
+CINEMA_API int cinema_sparse_halo_index(const cinema_sparse_geom* geom, int kx, int ky, int kz, int* halo_idx, void* stream) {
+  if (!halo_idx) return CINEMA_ERR_BAD_ARG;
+  SpP p{};
+  if (int e = fill(p, geom, 8, kx, ky, kz)) return e;
+  const int ncells = (2 * ((kx / 2 + p.bx - 1) / p.bx) + 1) * (2 * ((ky / 2 + p.by - 1) / p.by) + 1) * (2 * ((kz / 2 + p.bz - 1) / p.bz) + 1);
+  if (ncells > 128 || p.bx * p.by * p.bz > 512) return CINEMA_ERR_UNSUPPORTED;
+  launch_lanes(sparse_halo_index_kernel, sparse_halo_index_lanes_kernel, 1, dim3((unsigned)p.n_tok), dim3(256), 0, (hipStream_t)stream, SpHaloP{p, halo_idx});
+  return launch_status();
+}
+
 CINEMA_API int cinema_sparse_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes,
-                                               const cinema_sparse_geom* geom, int c, int kx, int ky, int kz, void* stream) {
+                                               const cinema_sparse_geom* geom, int c, int kx, int ky, int kz, const int* halo_idx, void* stream) {
   if (!x || !dy || !dw || !workspace) return CINEMA_ERR_BAD_ARG;
   SpP p{};
   if (int e = fill(p, geom, c, kx, ky, kz)) return e;
   if (kz != 5 || kx * ky > 32) return CINEMA_ERR_UNSUPPORTED;
   p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias; p.ws = workspace;
   const int taps = kx * ky * kz, Bv = p.bx * p.by * p.bz;
+  const size_t hv = (size_t)(p.bx + kx - 1) * (p.by + ky - 1) * (p.bz + kz - 1);
+  const int ncells = (2 * ((kx / 2 + p.bx - 1) / p.bx) + 1) * (2 * ((ky / 2 + p.by - 1) / p.by) + 1) * (2 * ((kz / 2 + p.bz - 1) / p.bz) + 1);
+  hipStream_t st = (hipStream_t)stream;
+  const bool pipe = halo_idx != nullptr && hv <= 512 && Bv <= 64;
+  const size_t smem = pipe ? hv * 128 + (size_t)Bv * 128 + (hv + Bv) * 4 : hv * 128 + (size_t)Bv * 128 + (hv + ncells + Bv) * 4;
+  if (smem > 160 * 1024) return CINEMA_ERR_UNSUPPORTED;
   int blocks = p.n_tok < 1024 ? p.n_tok : 1024;
+  if (pipe) {  // one round of the resident workgroups (LDS and ~140 VGPRs: at most 3 per CU), a whole number of tokens each
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    int per_cu = (int)((160 * 1024) / smem);
+    per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
+    const int slots = per_cu * cus;
+    if (blocks > slots) blocks = slots;
+  }
   p.tok_per_block = (p.n_tok + blocks - 1) / blocks;
   blocks = (p.n_tok + p.tok_per_block - 1) / p.tok_per_block;
   if (workspace_bytes < (long long)blocks * c * (taps + 1) * 4) return CINEMA_ERR_BAD_ARG;
-  const size_t hv = (size_t)(p.bx + kx - 1) * (p.by + ky - 1) * (p.bz + kz - 1);
-  const int ncells = (2 * ((kx / 2 + p.bx - 1) / p.bx) + 1) * (2 * ((ky / 2 + p.by - 1) / p.by) + 1) * (2 * ((kz / 2 + p.bz - 1) / p.bz) + 1);
-  const size_t smem = hv * 128 + (size_t)Bv * 128 + (hv + ncells + Bv) * 4;
-  if (smem > 160 * 1024) return CINEMA_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)sparse_dwconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-  hipStream_t st = (hipStream_t)stream;
-  launch_lanes(sparse_dwconv_wgrad_kernel<5>, sparse_dwconv_wgrad_lanes_kernel<5>, 2, dim3(blocks, (c + 63) / 64), dim3(256), smem, st, p);
+  if (pipe) {
+    const SpPipeP q{p, halo_idx};
+    const dim3 grid(blocks, (c + 63) / 64);
+#define PIPE_LAUNCH(NG)                                                                                                                      \
+  do {                                                                                                                                       \
+    static bool attr = false;                                                                                                                \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)sparse_dwconv_wgrad_pipe_kernel<5, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                 (void)hipFuncSetAttribute((const void*)sparse_dwconv_wgrad_pipe_lanes_kernel<5, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    launch_lanes(sparse_dwconv_wgrad_pipe_kernel<5, NG>, sparse_dwconv_wgrad_pipe_lanes_kernel<5, NG>, 2, grid, dim3(256), smem, st, q);     \
+  } while (0)
+    if (hv <= 64) PIPE_LAUNCH(2);
+    else if (hv <= 192) PIPE_LAUNCH(6);
+    else if (hv <= 320) PIPE_LAUNCH(10);
+    else PIPE_LAUNCH(16);
+#undef PIPE_LAUNCH
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)sparse_dwconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    launch_lanes(sparse_dwconv_wgrad_kernel<5>, sparse_dwconv_wgrad_lanes_kernel<5>, 2, dim3(blocks, (c + 63) / 64), dim3(256), smem, st, p);
+  }
   const int total = c * (taps + 1);
   launch_lanes(sparse_wgrad_reduce_kernel, sparse_wgrad_reduce_lanes_kernel, 2, dim3((total + 255) / 256, 16), dim3(256), 0, st, SpRedP{(const float*)workspace, blocks, c * taps, c, dw, dbias});
   return launch_status();

@@ -126,7 +126,9 @@ _PROTOS = {
     "cinema_sparse_nbr_ints": [_i],
     "cinema_sparse_nbr_build": [C.POINTER(SparseGeom), _i, _i, _i, _vp, _vp, _vp],
     "cinema_sparse_dwconv_fwd": [_vp, _vp, _vp, _vp, C.POINTER(SparseGeom), _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "cinema_sparse_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, C.POINTER(SparseGeom), _i, _i, _i, _i, _vp],
+    "cinema_sparse_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, C.POINTER(SparseGeom), _i, _i, _i, _i, _vp, _vp],
+    "cinema_sparse_halo_ints": [C.POINTER(SparseGeom), _i, _i, _i],
+    "cinema_sparse_halo_index": [C.POINTER(SparseGeom), _i, _i, _i, _vp, _vp],
     "cinema_sparse_dwconv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i],
     "cinema_patch_gather": [_vp, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_patch_scatter": [_vp, _i, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
@@ -195,7 +197,7 @@ def library_path() -> Path:
 # after it ran.  The arguments are plain ints / floats / ctypes structs, so the same launch can be issued again verbatim; host-only queries
 # (workspace sizes) and the completion markers are not part of a step's launch list.
 RECORD: list | None = None
-_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
+_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "_halo_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
 
 
 class _Entry:
@@ -235,7 +237,7 @@ def load():  # noqa: ANN201
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib.cdll, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints", "_marker_record")) else C.c_int
+        fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints", "_halo_ints", "_marker_record")) else C.c_int
         setattr(lib, name, _Entry(fn, not name.endswith(_NOT_REPLAYED)))
     _lib = lib
     return lib
@@ -1400,6 +1402,7 @@ def sparse_geom(batch: int, tok_grid: tuple, block: tuple, keep: torch.Tensor, r
     g.n_tok, g.keep, g.rank, g.pos = keep.numel(), keep.data_ptr(), rank.data_ptr(), pos.data_ptr()
     g.keepalive = (keep, rank, pos)
     g.nbr_lists = {}  # kernel extent -> (nbr, cnt), built on first use for this mask
+    g.halo_idx = {}   # kernel extent -> halo source rows of every kept token (weight gradient)
     return g
 
 
@@ -1412,6 +1415,9 @@ def _sparse_nbr(geom: SparseGeom, kdims: tuple, device: torch.device) -> tuple:
         _check(load().cinema_sparse_nbr_build(C.byref(geom), *kdims, nbr.data_ptr(), cnt.data_ptr(), _stream()), "sparse_nbr_build")
         hit = geom.nbr_lists[kdims] = (nbr, cnt)
     return hit
+
+
+SPARSE_WGRAD_PIPE = bool(int(os.environ.get("CINEMA_SPARSE_WGRAD_PIPE", "1")))  # 0: the per-token index chase (A/B)
 
 
 def _kernel3(w: torch.Tensor) -> tuple:
@@ -1440,8 +1446,15 @@ def sparse_dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, w_shape: tuple, 
     kx, ky, kz = (1,) * (3 - len(ks)) + ks
     need = load().cinema_sparse_dwconv_wgrad_workspace_bytes(geom.n_tok, c, kx, ky, kz)
     ws = _workspace("sparse_wgrad", (need + 3) // 4, x.device)
+    hidx = None
+    if SPARSE_WGRAD_PIPE:
+        hidx = geom.halo_idx.get((kx, ky, kz))
+        if hidx is None:  # once per mask and kernel extent, on the stream of its first user (the weight-gradient stream: all users are ordered behind it)
+            hidx = _empty(max(load().cinema_sparse_halo_ints(C.byref(geom), kx, ky, kz), 1), dtype=torch.int32, device=x.device)
+            _check(load().cinema_sparse_halo_index(C.byref(geom), kx, ky, kz, hidx.data_ptr(), _stream()), "sparse_halo_index")
+            geom.halo_idx[(kx, ky, kz)] = hidx
     _check(load().cinema_sparse_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), need, C.byref(geom), c, kx, ky, kz,
-                                                  _stream()), "sparse_dwconv_bwd_weight")
+                                                  _p(hidx), _stream()), "sparse_dwconv_bwd_weight")
 
 
 def patch_geom(batch: int, chans: int, grid: tuple, patch: tuple, strides: tuple, token_idx: torch.Tensor | None = None,

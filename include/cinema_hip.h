@@ -233,7 +233,12 @@ int cinema_sparse_dwconv_fwd(const uint16_t* x, const float* w, const float* bia
                              const int* cnt, int c, int kx, int ky, int kz, int flip, void* stream);
 /* dw[c][taps] += sum x*dy, dbias[c] += sum dy over the visible voxels; workspace >= cinema_sparse_dwconv_wgrad_workspace_bytes(...) */
 int cinema_sparse_dwconv_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes,
-                                    const cinema_sparse_geom* geom, int c, int kx, int ky, int kz, void* stream);
+                                    const cinema_sparse_geom* geom, int c, int kx, int ky, int kz, const int* halo_idx, void* stream);
+/* halo_idx (optional, NULL = the per-token index chase): [n_tok][(bx+kx-1)(by+ky-1)(bz+kz-1)] compact row of every halo voxel of every kept token (-1 =
+ * masked / outside), cinema_sparse_halo_ints(...) ints, built once per mask and kernel extent; with it the weight gradient runs as a pipeline over the
+ * tokens of a workgroup (rows of the next token in flight while the current one is accumulated). */
+long long cinema_sparse_halo_ints(const cinema_sparse_geom* geom, int kx, int ky, int kz);
+int cinema_sparse_halo_index(const cinema_sparse_geom* geom, int kx, int ky, int kz, int* halo_idx, void* stream);
 long long cinema_sparse_dwconv_wgrad_workspace_bytes(int n_tok, int c, int kx, int ky, int kz);
 
 /* ---------------------------------------------------------------------------------------------------------

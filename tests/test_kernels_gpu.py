@@ -507,6 +507,17 @@ def test_sparse_dwconv_matches_dense_masked_conv(tok_grid: tuple, block: tuple, 
     K.sparse_dwconv_bwd_weight(xc, dyc, tuple(w.shape), dw, db, geom)
     close(dw, dw_ref, 1e-3, 1e-2 * float(dw_ref.abs().max()), "sparse dwconv wgrad")
     close(db, db_ref, 1e-3, 1e-3 * float(db_ref.abs().max()), "sparse dwconv bias grad")
+    # the default is the token-pipelined kernel on the halo index table; the per-token index chase gives the same sums (same order within a workgroup,
+    # other workgroup chunks: fp32 rounding of the slab reduction only)
+    assert K.SPARSE_WGRAD_PIPE and (5,) * 3 in geom.halo_idx or (1, 5, 5) in geom.halo_idx
+    prev, K.SPARSE_WGRAD_PIPE = K.SPARSE_WGRAD_PIPE, False
+    try:
+        dw2, db2 = torch.zeros_like(w), torch.zeros(c, device=DEV)
+        K.sparse_dwconv_bwd_weight(xc, dyc, tuple(w.shape), dw2, db2, geom)
+    finally:
+        K.SPARSE_WGRAD_PIPE = prev
+    close(dw, dw2, 1e-5, 1e-5 * float(dw_ref.abs().max()), "sparse dwconv wgrad: pipelined vs index chase")
+    close(db, db2, 1e-5, 1e-5 * float(db_ref.abs().max()), "sparse dwconv bias grad: pipelined vs index chase")
 
 
 def test_patch_gather_scatter_channels_first_image() -> None:
