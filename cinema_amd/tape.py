@@ -517,10 +517,17 @@ def trainable_params(module: torch.nn.Module) -> list:
     return [p for p in pl if p.requires_grad]
 
 
+SPLITK_SLOTS = int(os.environ.get("CINEMA_SPLITK_SLOTS", "256"))
+SPLITK_MIN_ROWS = int(os.environ.get("CINEMA_SPLITK_MIN_ROWS", "512"))
+
+
 def _split_k(m_red: int, n_out: int, k_out: int) -> int:
+    """k-slices of a weight gradient on the 128x128 kernel (the stem / fusion / head GEMMs: small outputs, reductions of 9 k - 147 k rows).  Half a round of
+    workgroup slots and at least 512 rows per slice - measured with the slab reduce behind it (tools/bench_skinny_wgrad.py): dW[64x64] over 147456 rows
+    29.4 us at 512 slices, 24.3 at 256; dW[256x64] 39.6 -> 32.4; dW[128x128] over 36864 rows 19.5 at 144, 18.4 at 64; dW[128x512] 30.1 -> 27.4."""
     tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
-    want = max(1, 512 // tiles)
-    return max(1, min(want, (m_red + 255) // 256))
+    want = max(1, SPLITK_SLOTS // tiles)
+    return max(1, min(want, (m_red + SPLITK_MIN_ROWS - 1) // SPLITK_MIN_ROWS))
 
 
 def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:

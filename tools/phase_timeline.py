@@ -31,7 +31,7 @@ i_dec = first(lambda n: n.startswith("attn_fwd_mfma<32>"))
 marks.append(("fusion + decoder fwd + loss", last(lambda n: n.startswith("attn_fwd_mfma<64>")) + 8))
 i_bwd = first(lambda n: n.startswith("attn_bwd") or n.startswith("attn_delta"))
 marks.append(("decoder bwd", i_bwd - 12))
-marks.append(("fusion bwd + encoder bwd", last(lambda n: n.startswith("attn_bwd_dkv_mfma<32>") or n.startswith("attn_bwd_dq_mfma<32>")) + 12))
+marks.append(("fusion bwd + encoder bwd", last(lambda n: n.startswith("attn_bwd_dkv_mfma<32>") or n.startswith("attn_bwd_dq_mfma<32>") or n.startswith("attn_bwd_fused_mfma<32>")) + 12))
 marks.append(("stems bwd", last(lambda n: n.startswith("attn_bwd_dkv_mfma<64>") or n.startswith("attn_bwd_dq_mfma<64>")) + 12))
 marks.append(("clip + AdamW", first(lambda n: n.startswith("sqnorm_kernel"))))
 marks.append(("end", len(step)))
@@ -52,3 +52,20 @@ for (name, a), (_, b) in zip(marks, marks[1:]):
             cur_e = max(cur_e, e)
     busy += cur_e - cur_s
     print(f"  {name:40s} {len(seg):5d} kernels  wall {wall:6.2f} ms  GPU busy {busy / 1e6:6.2f} ms ({100 * busy / 1e6 / wall:3.0f}%)  avg kernel {sum(e - s for _, s, e in seg) / len(seg) / 1e3:6.1f} us")
+
+import os  # noqa: E402
+
+dump = os.environ.get("PHASE_DUMP")  # e.g. "stems": per-kernel totals of every phase whose name contains the string
+if dump:
+    for (name, a), (_, b) in zip(marks, marks[1:]):
+        if dump not in name:
+            continue
+        agg: dict = {}
+        for n, s, e in step[a:b]:
+            k = n.split("(")[0][:70]
+            t = agg.setdefault(k, [0, 0.0])
+            t[0] += 1
+            t[1] += (e - s) / 1e3
+        print(f"--- {name}")
+        for k, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+            print(f"    {cnt:4d} x {us / cnt:7.1f} us = {us:8.1f} us  {k}")
