@@ -482,7 +482,62 @@ __global__ __launch_bounds__(256) void seg_metric_counts_kernel(const float* log
     if (part[i]) atomicAdd(&counts[(size_t)b * c * 6 + i], part[i]);
 }
 
+// Surface voxels of every class of a label map (monai get_mask_edges as compute_hausdorff_distance calls it: mask XOR binary_erosion(mask) with scipy's
+// default cross-shaped structure and border value 0): a voxel of class k is an edge voxel of k unless all of its 2 * ndim face neighbours exist and carry k.
+// label int32 [b][X][Y][Z] (ndim = 2: X == 1 and the x axis does not exist), edges uint8 [b][c][X*Y*Z].
+__global__ __launch_bounds__(256) void mask_edges_kernel(const int* label, int X, int Y, int Z, int c, int ndim, unsigned char* edges) {
+  const int b = blockIdx.y, vox = X * Y * Z;
+  const int* lab = label + (size_t)b * vox;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < vox; v += gridDim.x * 256) {
+    const int z = v % Z, y = (v / Z) % Y, x = v / (Z * Y);
+    const int k = lab[v];
+    bool inner = true;
+    inner = inner && z > 0 && lab[v - 1] == k && z + 1 < Z && lab[v + 1] == k;
+    inner = inner && y > 0 && lab[v - Z] == k && y + 1 < Y && lab[v + Z] == k;
+    if (ndim == 3) inner = inner && x > 0 && lab[v - Z * Y] == k && x + 1 < X && lab[v + Z * Y] == k;
+    for (int j = 0; j < c; j++) edges[((size_t)b * c + j) * vox + v] = (j == k && !inner) ? 1 : 0;
+  }
+}
+
+// out[i] = min_j |a_i - b_j| (Euclidean, coordinates already in physical units): the value scipy's distance_transform_edt of the complement of set B takes at
+// point a_i.  Brute force with B streamed through LDS: surface sets are a few thousand points.
+__global__ __launch_bounds__(256) void min_dist_kernel(const float* a, const float* bpts, int na, int nb, float* out) {
+  __shared__ float sb[256 * 3];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (i < na) { ax = a[3 * i]; ay = a[3 * i + 1]; az = a[3 * i + 2]; }
+  float best = INFINITY;
+  for (int j0 = 0; j0 < nb; j0 += 256) {
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j < nb) { sb[3 * threadIdx.x] = bpts[3 * j]; sb[3 * threadIdx.x + 1] = bpts[3 * j + 1]; sb[3 * threadIdx.x + 2] = bpts[3 * j + 2]; }
+    __syncthreads();
+    const int n = min(256, nb - j0);
+    for (int t = 0; t < n; t++) {
+      const float dx = ax - sb[3 * t], dy = ay - sb[3 * t + 1], dz = az - sb[3 * t + 2];
+      best = fminf(best, dx * dx + dy * dy + dz * dz);
+    }
+  }
+  if (i < na) out[i] = sqrtf(best);
+}
+
 }  // namespace
+
+CINEMA_API int cinema_mask_edges(const int* label, int b, int X, int Y, int Z, int c, int ndim, unsigned char* edges, void* stream) {
+  if (!label || !edges || b <= 0 || X <= 0 || Y <= 0 || Z <= 0 || c < 1 || (ndim != 2 && ndim != 3) || (ndim == 2 && X != 1)) return CINEMA_ERR_BAD_ARG;
+  const long long vox = (long long)X * Y * Z;
+  if (vox >= (1LL << 31)) return CINEMA_ERR_UNSUPPORTED;
+  int gx = (int)((vox + 255) / 256);
+  if (gx > 4096) gx = 4096;
+  CINEMA_LAUNCH(mask_edges_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, label, X, Y, Z, c, ndim, edges);
+  return launch_status();
+}
+
+CINEMA_API int cinema_min_dist(const float* a, const float* bpts, int na, int nb, float* out, void* stream) {
+  if (!a || !bpts || !out || na <= 0 || nb <= 0) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(min_dist_kernel, dim3((na + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, bpts, na, nb, out);
+  return launch_status();
+}
 
 CINEMA_API int cinema_seg_window_accumulate(const float* window_logits, int c, int px, int py, int pz, int sx, int sy, int sz, int X, int Y, int Z,
                                             float* prob_sum, float* count, void* stream) {

@@ -142,6 +142,8 @@ _PROTOS = {
     "cinema_seg_window_accumulate": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "cinema_seg_window_finish": [_vp, _vp, _i, _ll, _vp, _vp],
     "cinema_seg_metric_counts": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "cinema_mask_edges": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "cinema_min_dist": [_vp, _vp, _i, _i, _vp, _vp],
     "cinema_segment_mean_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp],
     "cinema_segment_mean_bwd": [_vp, _i, _i, _i, _f, _vp, _i, _i, _vp],
     "cinema_scale_f32": [_vp, _f, _vp, _ll, _vp],
@@ -747,6 +749,28 @@ def seg_metric_counts(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tenso
     counts = _empty((b, c, 6), dtype=torch.int32, device=logits.device)
     _check(load().cinema_seg_metric_counts(logits.data_ptr(), labels.data_ptr(), b, vox, c, counts.data_ptr(), _stream()), "seg_metric_counts")
     return counts
+
+
+def mask_edges(label: torch.Tensor, n_classes: int) -> torch.Tensor:
+    """label int32 (b, *spatial) with 2 or 3 spatial axes -> uint8 (b, n_classes, *spatial): surface voxels of every class (``cinema_mask_edges``)."""
+    _dev(label)
+    if label.dtype != torch.int32 or not label.is_contiguous() or label.dim() not in (3, 4):
+        raise HipLibraryError("mask_edges: contiguous int32 label map (b, *spatial), 2 or 3 spatial axes")
+    b, sp = label.shape[0], tuple(label.shape[1:])
+    x, y, z = (1,) * (3 - len(sp)) + sp
+    edges = _empty((b, n_classes, *sp), dtype=torch.uint8, device=label.device)
+    _check(load().cinema_mask_edges(label.data_ptr(), b, x, y, z, n_classes, len(sp), edges.data_ptr(), _stream()), "mask_edges")
+    return edges
+
+
+def min_dist(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a fp32 [na, 3], b fp32 [nb, 3] (physical coordinates) -> fp32 [na]: distance of every a_i to the nearest point of b."""
+    _dev(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or not a.is_contiguous() or not b.is_contiguous() or a.shape[1:] != (3,) or b.shape[1:] != (3,):
+        raise HipLibraryError("min_dist: contiguous fp32 [n, 3] point sets")
+    out = _empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    _check(load().cinema_min_dist(a.data_ptr(), b.data_ptr(), a.shape[0], b.shape[0], out.data_ptr(), _stream()), "min_dist")
+    return out
 
 
 def segment_mean(x: torch.Tensor, n_seg: int, scale: float | None = None) -> torch.Tensor:

@@ -59,6 +59,49 @@ def get_volumes(mask: torch.Tensor, spacing: tuple) -> torch.Tensor:
     return mask.sum(dim=tuple(range(2, mask.ndim))) * vol
 
 
+def _quantile(d: torch.Tensor, q: float) -> torch.Tensor:
+    """torch.quantile's default (linear interpolation between the two nearest order statistics) from one sort; no size limit."""
+    s, _ = torch.sort(d)
+    pos = q * (s.numel() - 1)
+    lo = int(pos)
+    hi = min(lo + 1, s.numel() - 1)
+    return s[lo] + (s[hi] - s[lo]) * (pos - lo)
+
+
+def hausdorff_distance_95(pred_label: torch.Tensor, true_label: torch.Tensor, n_classes: int, spacing: tuple, percentile: float = 95.0) -> torch.Tensor:
+    """Symmetric 95th-percentile Hausdorff distance of every foreground class: label maps (batch, *spatial) with 2 or 3 spatial axes -> (batch, n_classes)
+    (reference ``cinema/segmentation/train.py:262-267`` -> monai ``compute_hausdorff_distance(percentile=95, spacing=spacing)``).  monai's algorithm, restated
+    (the package is absent: parity UNPINNED, cross-checked against scipy in the tests): surface = mask XOR binary_erosion(mask); directed distances = Euclidean
+    distance transform of the other surface's complement, read at this surface's voxels; per direction the 95 % quantile (linear interpolation), then the
+    maximum of the two.  Both surfaces empty -> NaN, exactly one empty -> inf (what monai's inf-filled distance maps produce).  Surfaces come from
+    ``cinema_mask_edges``, nearest-surface distances from ``cinema_min_dist``; the variable-length point lists are built with ``torch.nonzero`` (this is the
+    evaluation path: one host round trip per class is fine)."""
+    from cinema_amd import hip as K
+
+    nd = pred_label.dim() - 1
+    c = n_classes + 1
+    ep = K.mask_edges(pred_label.to(torch.int32).contiguous(), c)
+    et = K.mask_edges(true_label.to(torch.int32).contiguous(), c)
+    sp = torch.tensor([float(v) for v in spacing][:nd], dtype=torch.float32, device=pred_label.device)
+    out = torch.full((pred_label.shape[0], n_classes), float("nan"), dtype=torch.float32, device=pred_label.device)
+
+    def points(e: torch.Tensor) -> torch.Tensor:
+        p = torch.nonzero(e).to(torch.float32) * sp
+        return torch.nn.functional.pad(p, (0, 3 - nd)).contiguous()
+
+    for b in range(pred_label.shape[0]):
+        for k in range(1, c):
+            pa, pb = points(ep[b, k]), points(et[b, k])
+            if pa.shape[0] == 0 and pb.shape[0] == 0:
+                continue
+            if pa.shape[0] == 0 or pb.shape[0] == 0:
+                out[b, k - 1] = float("inf")
+                continue
+            q = percentile / 100.0
+            out[b, k - 1] = torch.maximum(_quantile(K.min_dist(pa, pb), q), _quantile(K.min_dist(pb, pa), q))
+    return out
+
+
 def ejection_fraction(edv, esv):  # noqa: ANN001, ANN201
     """(EDV - ESV) / EDV x 100 (reference ``cinema/metric.py:99-112``)."""
     return (edv - esv) / edv * 100.0

@@ -227,8 +227,10 @@ def segmentation_metrics(logits: torch.Tensor, labels: torch.Tensor, spacing: tu
     """Per-sample evaluation metrics (reference ``train.py:224-286``): Dice, IoU, stability score and volumes per foreground class and their
     means, each of shape (batch,).  All voxel counting (argmax prediction, label, intersections, the two stability masks) is ONE pass of
     ``cinema_seg_metric_counts`` over the channels-first logits; the few (batch, n_classes) ratios are formed from those integer counts.
-    ``hausdorff_distance_95`` (monai's surface-distance transform, CPU-side in the reference as well) is not built: its keys are absent."""
+    ``hausdorff_distance_95`` (monai ``compute_hausdorff_distance``, reference ``train.py:262-267``) comes from :func:`cinema_amd.metric.hausdorff_distance_95`
+    (surface extraction + nearest-surface distances on the device; monai's algorithm restated, parity-unpinned)."""
     from cinema_amd import hip as K
+    from cinema_amd.metric import hausdorff_distance_95
 
     n_classes = logits.shape[1] - 1
     lab = labels.squeeze(dim=1).to(torch.int32).contiguous()
@@ -240,17 +242,20 @@ def segmentation_metrics(logits: torch.Tensor, labels: torch.Tensor, spacing: tu
     for s in spacing:
         vol *= float(s)
     true_vol, pred_vol = true * vol / 1000.0, pred * vol / 1000.0  # ml (cinema/metric.py:84-96)
+    hd95 = hausdorff_distance_95(logits.argmax(dim=1), lab, n_classes, spacing)  # (batch, n_classes), foreground classes
     metrics = {}
     for i in range(n_classes):
         k = i + 1
         metrics[f"class_{k}_dice_score"] = dice[:, k]
         metrics[f"class_{k}_iou_score"] = iou[:, k]
         metrics[f"class_{k}_stability_score"] = stability[:, k]
+        metrics[f"class_{k}_hausdorff_distance_95"] = hd95[:, i]
         metrics[f"class_{k}_true_volume"] = true_vol[:, k]
         metrics[f"class_{k}_pred_volume"] = pred_vol[:, k]
     metrics["mean_dice_score"] = torch.mean(dice[:, 1:], dim=-1)
     metrics["mean_iou_score"] = torch.mean(iou[:, 1:], dim=-1)
     metrics["mean_stability_score"] = torch.mean(stability[:, 1:], dim=-1)
+    metrics["mean_hausdorff_distance_95"] = torch.mean(hd95, dim=-1)
     return metrics
 
 

@@ -303,6 +303,13 @@ int cinema_seg_window_accumulate(const float* window_logits, int c, int px, int 
                                  float* prob_sum, float* count, void* stream);
 int cinema_seg_window_finish(const float* prob_sum, const float* count, int c, long long n_voxels, float* logits_out, void* stream);
 int cinema_seg_metric_counts(const float* logits, const int* labels, int b, int vox, int c, unsigned int* counts, void* stream);
+/* The two device pieces of `hausdorff_distance_95` in segmentation_metrics (reference cinema/segmentation/train.py:262-267,277,284 -> monai 1.5.2
+ * compute_hausdorff_distance(percentile=95, spacing), absent from the image; restated from its published algorithm = scipy binary_erosion + distance_transform_edt):
+ *   mask_edges: edges uint8 [b][c][X*Y*Z] = surface voxels of every class of the label map int32 [b][X][Y][Z] (mask XOR erosion with the face-neighbour cross,
+ *       border value 0); ndim = 2: X == 1 and the x axis does not exist.
+ *   min_dist: out[i] = min_j |a_i - b_j| for point sets a [na][3], b [nb][3] in physical units (= the Euclidean distance transform of B's complement at a_i). */
+int cinema_mask_edges(const int* label, int b, int X, int Y, int Z, int c, int ndim, unsigned char* edges, void* stream);
+int cinema_min_dist(const float* a, const float* b_points, int na, int nb, float* out, void* stream);
 
 /* Token pooling of the ConvViT heads (reference cinema/convvit.py:523-547, `x.mean(dim=1, keepdim=True)` and the mean over head outputs):
  * out[s][:] = scale * sum of the seg_rows consecutive rows of segment s of x (fp32 [n_seg*seg_rows][c]); bwd broadcasts scale * dy[s] back. */

@@ -729,8 +729,36 @@ def stability_score(logits: Tensor, threshold: float = 0.0, threshold_offset: fl
     return _iou_ignore_empty((norm >= threshold + threshold_offset).long(), (norm >= threshold - threshold_offset).long())
 
 
+def hausdorff_distance_95(pred_label: Tensor, true_label: Tensor, n_classes: int, spacing: tuple, percentile: float = 95.0) -> Tensor:
+    """monai 1.5.2 ``compute_hausdorff_distance(y_pred, y, include_background=False, percentile=95, spacing=spacing)`` as the reference calls it
+    (``cinema/segmentation/train.py:262-267``), restated from the published algorithm with the scipy functions monai itself uses on CPU (PARITY-UNPINNED:
+    monai is absent and the reference holds no value): per (sample, foreground class) the surfaces are ``mask ^ binary_erosion(mask)``
+    (``get_mask_edges``; scipy's default cross structure, border value 0), the directed distances ``distance_transform_edt(~other_surface, sampling=
+    spacing)[this_surface]`` (``get_surface_distance``), the result the maximum over the two directions of the ``percentile`` quantile (``torch.quantile``,
+    linear interpolation).  An empty surface on exactly one side fills the distance map with inf -> inf; both empty -> NaN.
+    label maps (batch, *spatial) -> (batch, n_classes)."""
+    from scipy import ndimage
+
+    nd = pred_label.dim() - 1
+    sp = [float(v) for v in spacing][:nd]
+    out = torch.full((pred_label.shape[0], n_classes), float("nan"))
+    for b in range(pred_label.shape[0]):
+        for k in range(1, n_classes + 1):
+            p, t = (pred_label[b] == k).numpy(), (true_label[b] == k).numpy()
+            ep, et = ndimage.binary_erosion(p) ^ p, ndimage.binary_erosion(t) ^ t
+            if not ep.any() and not et.any():
+                continue
+            if not ep.any() or not et.any():
+                out[b, k - 1] = float("inf")
+                continue
+            d_pt = torch.from_numpy(ndimage.distance_transform_edt(~et, sampling=sp)[ep]).float()
+            d_tp = torch.from_numpy(ndimage.distance_transform_edt(~ep, sampling=sp)[et]).float()
+            out[b, k - 1] = torch.maximum(torch.quantile(d_pt, percentile / 100.0), torch.quantile(d_tp, percentile / 100.0))
+    return out
+
+
 def segmentation_metrics(logits: Tensor, labels: Tensor, spacing: tuple) -> dict:
-    """``segmentation_metrics`` (``cinema/segmentation/train.py:224-286``) without the Hausdorff distance: argmax one-hot prediction, monai
+    """``segmentation_metrics`` (``cinema/segmentation/train.py:224-286``): argmax one-hot prediction, monai
     ``compute_dice`` (2 |A & B| / (|A| + |B|), NaN where the ground truth is empty: ``ignore_empty=True``) and ``compute_iou``, stability score,
     volumes in ml (``cinema/metric.py:84-96``).  ``compute_dice`` is PARITY-UNPINNED (monai absent, no reference value); it is cross-checked in
     the tests against an independent float64 count-based derivation."""
@@ -752,6 +780,10 @@ def segmentation_metrics(logits: Tensor, labels: Tensor, spacing: tuple) -> dict
         out[f"class_{k}_true_volume"], out[f"class_{k}_pred_volume"] = t_o[:, k] * vox, p_o[:, k] * vox
     out["mean_dice_score"], out["mean_iou_score"] = dice[:, 1:].mean(-1), iou[:, 1:].mean(-1)
     out["mean_stability_score"] = stab[:, 1:].mean(-1)
+    hd = hausdorff_distance_95(torch.argmax(logits, dim=1), lab, n_classes, spacing)
+    for i in range(n_classes):
+        out[f"class_{i + 1}_hausdorff_distance_95"] = hd[:, i]
+    out["mean_hausdorff_distance_95"] = hd.mean(-1)
     return out
 
 

@@ -387,7 +387,36 @@ def test_segmentation_metrics_oracle_known_answers_and_independent_dice() -> Non
                 assert float(m[f"class_{k}_iou_score"][b]) == pytest.approx(inter / (ps + ts - inter), rel=1e-6)
             assert float(m[f"class_{k}_true_volume"][b]) == pytest.approx(ts * 22.5 / 1000.0, rel=1e-6)
             assert float(m[f"class_{k}_pred_volume"][b]) == pytest.approx(ps * 22.5 / 1000.0, rel=1e-6)
-    assert "mean_hausdorff_distance_95" not in m and math.isnan(float(m["mean_dice_score"][0]))
+    assert math.isnan(float(m["mean_dice_score"][0]))
+    # Hausdorff distance (monai absent: unpinned against the reference): known answers of the restatement and an independent brute-force derivation
+    z = torch.zeros(1, 12, 12, 4, dtype=torch.long)
+    a, b_ = z.clone(), z.clone()
+    a[0, 2:6, 2:6, 1:3] = 1
+    b_[0, 5:9, 2:6, 1:3] = 1                      # the same box moved by 3 voxels along x: every surface point is 3 voxels from the other surface or closer
+    hd = O.hausdorff_distance_95(a, b_, 2, (1.5, 1.0, 10.0))
+    assert float(hd[0, 0]) == pytest.approx(4.5, rel=1e-6) and math.isnan(float(hd[0, 1]))   # 3 voxels x 1.5 mm; class 2 absent on both sides
+    assert math.isinf(float(O.hausdorff_distance_95(a, z, 1, (1.0, 1.0, 1.0))[0, 0]))           # one side empty
+    torch.manual_seed(3)
+    pl, tl = torch.randint(0, 3, (2, 9, 8, 5)), torch.randint(0, 3, (2, 9, 8, 5))
+    sp = (1.25, 0.8, 6.0)
+    hd = O.hausdorff_distance_95(pl, tl, 2, sp)
+    for b in range(2):
+        for k in (1, 2):
+            def surface(lab: torch.Tensor) -> torch.Tensor:  # face-neighbour definition, explicit loops
+                m_, pts = lab == k, []
+                for i in range(9):
+                    for j in range(8):
+                        for l_ in range(5):
+                            if not m_[i, j, l_]:
+                                continue
+                            nb = [(i - 1, j, l_), (i + 1, j, l_), (i, j - 1, l_), (i, j + 1, l_), (i, j, l_ - 1), (i, j, l_ + 1)]
+                            if not all(0 <= x < 9 and 0 <= y < 8 and 0 <= w < 5 and bool(m_[x, y, w]) for x, y, w in nb):
+                                pts.append((i * sp[0], j * sp[1], l_ * sp[2]))
+                return torch.tensor(pts, dtype=torch.float64)
+            sa, sb = surface(pl[b]), surface(tl[b])
+            d = torch.cdist(sa, sb)
+            want = max(float(torch.quantile(d.min(1).values, 0.95)), float(torch.quantile(d.min(0).values, 0.95)))
+            assert float(hd[b, k - 1]) == pytest.approx(want, rel=1e-5)
     # Dice loss, second derivation: float64, explicit loops over samples / classes / voxels
     lg = torch.randn(2, 3, 4, 5, dtype=torch.float64)
     lb = torch.randint(-1, 3, (2, 1, 4, 5))

@@ -246,7 +246,25 @@ def test_metric_counts_kernel_vs_oracle_metrics() -> None:
     got = segmentation_metrics(logits.to(DEV), labels.to(DEV), (1.25, 1.25, 10.0))
     assert set(got) == set(want)
     for k, t in want.items():
-        assert torch.allclose(got[k].cpu(), t, rtol=1e-6, atol=1e-7, equal_nan=True), k
+        assert torch.allclose(got[k].cpu(), t, rtol=1e-5 if "hausdorff" in k else 1e-6, atol=1e-7, equal_nan=True), k
+    assert "class_1_hausdorff_distance_95" in got and "mean_hausdorff_distance_95" in got
+    # the surface / nearest-surface kernels on their own: 2-D label maps (the long-axis views), blobs instead of noise, one side empty, both empty
+    from cinema_amd.metric import hausdorff_distance_95
+
+    yy, xx = torch.meshgrid(torch.arange(48.0), torch.arange(40.0), indexing="ij")
+    pl = (((yy - 20) ** 2 + (xx - 18) ** 2) < 90).long() + 2 * (((yy - 34) ** 2 + (xx - 30) ** 2) < 30).long()
+    tl = (((yy - 23) ** 2 + (xx - 17) ** 2) < 70).long()
+    pl2, tl2 = torch.stack([pl, torch.zeros_like(pl)]), torch.stack([tl, torch.zeros_like(tl)])
+    want2 = O.hausdorff_distance_95(pl2, tl2, 3, (1.4, 0.9))
+    got2 = hausdorff_distance_95(pl2.to(DEV), tl2.to(DEV), 3, (1.4, 0.9)).cpu()
+    assert torch.allclose(got2, want2, rtol=1e-5, atol=1e-6, equal_nan=True), (got2, want2)
+    assert math.isfinite(float(got2[0, 0])) and math.isinf(float(got2[0, 1])) and math.isnan(float(got2[0, 2])) and math.isnan(float(got2[1, 0]))
+    edges = K.mask_edges(pl2.to(torch.int32).to(DEV), 4).cpu()
+    from scipy import ndimage
+
+    for k in range(4):
+        m = (pl == k).numpy()
+        assert (edges[0, k].numpy().astype(bool) == (ndimage.binary_erosion(m) ^ m)).all(), k
 
 
 def test_sliding_window_forward_vs_reference_golden() -> None:
