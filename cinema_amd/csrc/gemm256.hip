@@ -4,18 +4,19 @@
 // stages filled by LDS-DMA (the 256-row operand tile is two of gemm_shared.cuh's 128-row sub-tiles, so loaders, swizzles and fragment reads are
 // the 128x128 kernel's).  Half the staged bytes per FLOP of the 128x128 tile - the 128x128 loop is bound by that stream.
 //
-// Work is a list of PIECES: (problem, output tile, k-tile range).  Two schedules:
+// Work is a list of PIECES: (problem, output tile, k-tile range).  Three schedules:
 //   split   - every tile of problem i is cut into split[i] equal k-slices (the host balances the slice lengths over up to 12 problems: the weight
 //             gradients of one transformer block in one launch); workgroups walk the pieces grid-stride, slice-major so that neighbours share panels
 //   stream  - the (tile, k-tile) units of one problem are dealt to the workgroups as equal contiguous ranges (tile counts like 129 on 256 CUs)
-//   split + remainder (chosen by the host when it is shorter than the equal slices) - every tile is cut into slices of the SAME length L ~ units / CUs, one
+//   split + remainder (CINEMA_P256_REMAINDER=1, off by default: 2 % faster for 9 % more traffic) - every tile is cut into slices of the SAME length L ~ units / CUs, one
 //             per workgroup, and the rest of the tile's reduction (shorter than L) goes to workgroups that take several such rests one after the other: the
 //             weight gradients of an encoder block are 108 tiles x 343 units = 144.7 units per CU; equal slices give 216 pieces of 172 units on 256 CUs,
 //             this schedule 216 slices of 147 + 108 rests of 49 packed three to a workgroup (252 CUs, 147 units each)
 // A tile cut into n pieces is finished by its LAST ARRIVER: a piece takes a ticket from the tile's arrival counter; tickets 0..n-2 store their
 // accumulators as a fragment-ordered fp32 slot (write-through sc1 stores, 1 KiB per wave-instruction), drain, and bump the tile's publish counter;
 // ticket n-1 keeps its accumulators, waits for n-1 publishes (its partners arrived before it and never wait themselves: no deadlock for any dispatch
-// order or co-residency), adds their slots and runs the fused epilogue.  The last arriver zeroes both counters: no per-launch memset, no reduce
+// order or co-residency), sums the slots in piece order with its own registers at their position (rounding independent of the arrival order) and runs the
+// fused epilogue.  The last arriver zeroes both counters: no per-launch memset, no reduce
 // launch, no fp32 slab round trip through a second kernel.  Visibility follows the CDNA4 recipe (sc1 payload + per-wave vmcnt(0) + barrier + relaxed
 // agent counter; consumer: relaxed poll, ONE agent acquire, barrier, plain loads) and does not depend on placement.
 #include "gemm_shared.cuh"
