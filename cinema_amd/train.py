@@ -19,7 +19,13 @@ class FineTuneStep:
     ``cinema/train.py:262-268``); None: one group of all trainable parameters (``train.py:269-270``).  ``loss_fn`` returns the loss as a tensor that is
     differentiable through the model (the ``*_loss_tensors`` functions of this build keep the metrics on the device; the reference-shaped
     ``*_loss`` functions, which return floats, work as well).  Gradient accumulation as in the reference: ``loss / n_accum_steps`` is
-    back-propagated every call, the update happens when ``update_grad``."""
+    back-propagated every call, the update happens when ``update_grad``.
+
+    Non-finite losses - a stated difference from the reference: ``train_one_epoch`` / ``pretrain_one_epoch`` there read the loss back and skip only the
+    micro-batch whose loss is NaN (``cinema/train.py:138-140``, ``cinema/mae/pretrain.py:255-257``), keeping the gradients accumulated from the
+    earlier micro-batches of the window.  Here nothing is read back: a NaN loss back-propagates NaN into the shared flat gradient buffer, the clip kernel
+    then zeroes the update and AdamW leaves parameters, moments and the step count untouched - so with ``n_accum_steps > 1`` ONE bad micro-batch drops the
+    whole accumulation window, good micro-batches included.  With ``n_accum_steps == 1`` the two behaviours coincide."""
 
     def __init__(self, model, views: list, loss_fn: Callable, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05,  # noqa: ANN001
                  layer_decay: float | None = 0.75, clip_grad: float | None = 5.0, synchronizer=None) -> None:  # noqa: ANN001
