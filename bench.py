@@ -88,8 +88,14 @@ def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float, device
                       f"see `parity` for the like-for-like comparison); {cores} intra-op threads of the host's {host_cores} cores (more threads are slower on this graph)"}, parity
 
 
-PMC_TRAFFIC_FILE = "profiles/r03_pmc_hbm_traffic.json"
-PMC_MFMA_FILE = "profiles/r03_mfma_util.json"
+def _latest_profile(suffix: str) -> str:
+    """Newest committed counter capture by round prefix (profiles/rNN_<suffix>; tools/gpu_pmc_round.sh writes them, stamped with the library's sha256)."""
+    hits = sorted(p.name for p in (ROOT / "profiles").glob(f"r[0-9][0-9]_{suffix}"))
+    return f"profiles/{hits[-1]}" if hits else f"profiles/{suffix}"
+
+
+PMC_TRAFFIC_FILE = _latest_profile("pmc_hbm_traffic.json")
+PMC_MFMA_FILE = _latest_profile("mfma_util.json")
 
 
 def _committed(rel: str, kernel: str):  # noqa: ANN202
@@ -101,7 +107,7 @@ def _committed(rel: str, kernel: str):  # noqa: ANN202
 
 def pmc_binding(rel: str) -> dict:
     """Ties a committed counter file to the binary that is being timed: the file carries the sha256 of the library its passes ran
-    (tools/gpu_pmc_r03.sh); ``stale`` says whether that is NOT the library loaded by this process."""
+    (tools/gpu_pmc_round.sh); ``stale`` says whether that is NOT the library loaded by this process."""
     import hashlib
 
     from cinema_amd import hip as K
@@ -520,10 +526,10 @@ def main() -> None:
         roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(alg_bytes / n), "traffic_over_algorithmic": round(traffic / (alg_bytes / n), 2) if traffic else None,
-                    "traffic_source": f"committed {PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc_r03.sh); not collected live",
+                    "traffic_source": f"committed {PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc_round.sh); not collected live",
                     "traffic_stale": pmc_binding(PMC_TRAFFIC_FILE)["stale"], "traffic_binding": pmc_binding(PMC_TRAFFIC_FILE),
                     "mfma_util": pmc_mfma_util(K.GEMM_KERNEL_NAMES[kind]),
-                    "mfma_util_source": f"committed {PMC_MFMA_FILE} (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes, tools/gpu_pmc_r03.sh); not collected live",
+                    "mfma_util_source": f"committed {PMC_MFMA_FILE} (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes, tools/gpu_pmc_round.sh); not collected live",
                     "mfma_util_stale": pmc_binding(PMC_MFMA_FILE)["stale"],
                     "timing": "HIP events on the launch stream around every launch of this kernel, live in this process (a grouped persistent launch finishes its split reduction inside the kernel; for the 128x128 split-K kernel the events also cover the reduce launch behind it)",
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(secs / n * 1e6, 2),

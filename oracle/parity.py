@@ -185,3 +185,79 @@ def mae_loss_parity(kw: dict, state_dict: dict, batch: int = 1, seed: int = 7, d
     return {"loss": float(loss), "oracle_loss": float(ref_loss), "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
             "view_loss_rel": {v: abs(float(metrics[f"{v}_mse_loss"]) - float(ref_metrics[f"{v}_mse_loss"])) / abs(float(ref_metrics[f"{v}_mse_loss"])) for v in images},
             "fp8": fp8, "oracle_seconds": round(cpu_s, 2)}
+
+
+def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 5, device: str = "cuda", threads: int | None = None) -> dict:
+    """Gradients of the fp8 path against the ORACLE (not against this repository's bf16 path): one forward + backward of the oracle on the CPU and three
+    of the HIP path on identical weights / inputs / masks - bf16, e4m3 forward only, e4m3 forward + e4m3 data gradients.  The flat parameter buffers
+    (``cinema_amd.optim.FlatModel``) are built BEFORE the comparison: the transposed e4m3 weight shadows the data-gradient GEMM reads exist only there, and
+    the number of GEMMs that really took them is returned (``fp8_dgrad_gemms``; 0 would mean the bf16 fallback was measured).  Per mode: loss rel, gradient-norm
+    rel, worst relative L2 over matrices / conv filters (dim >= 2) and over vectors, and the error of the WHOLE gradient (all tensors concatenated) over
+    the oracle's gradient norm."""
+    from cinema_amd import CineMA
+    from cinema_amd import tape as T
+    from cinema_amd.optim import FlatModel
+
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = O.MAEConfig(**{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
+    gen = torch.Generator().manual_seed(seed)
+    images = {v: torch.rand(batch, 1, *s, generator=gen) for v, s in kw["image_size_dict"].items()}
+    masks = {v: O.random_patch_mask(batch, math.prod(cfg.grid_size(v)), 0.75, gen) for v in images}
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+    train = set(O.trainable_keys(sd))
+    p = {k: v.clone().requires_grad_(k in train) for k, v in sd.items()}
+    t0 = time.perf_counter()
+    ref_loss, _, _ = O.mae_forward(p, cfg, images, masks)
+    ref_loss.backward()
+    cpu_s = time.perf_counter() - t0
+    ref = {k: p[k].grad for k in train if p[k].grad is not None}
+    ref_norm = math.sqrt(sum(float(r.double().pow(2).sum()) for r in ref.values()))
+
+    model = CineMA(**kw)
+    model.load_state_dict(sd)
+    model.to(device)
+    flat = FlatModel(model, 0.05)
+    named = dict(model.named_parameters())
+    dimg, dmask = {k: v.to(device) for k, v in images.items()}, {k: v.to(device) for k, v in masks.items()}
+    calls = {"n": 0}
+    orig_wt = T.w_fp8_t
+
+    def counting_wt(weight):  # noqa: ANN001, ANN202
+        hit = orig_wt(weight)
+        calls["n"] += hit is not None
+        return hit
+
+    prev = (T.FP8_FORWARD, T.FP8_DGRAD)
+    out = {"oracle_loss": float(ref_loss), "oracle_grad_norm": ref_norm, "oracle_seconds": round(cpu_s, 2), "batch": batch}
+    T.w_fp8_t = counting_wt
+    try:
+        for mode, (fwd8, dg8) in {"bf16": (False, False), "fp8_forward": (True, False), "fp8": (True, True)}.items():
+            T.FP8_FORWARD, T.FP8_DGRAD = fwd8, dg8
+            calls["n"] = 0
+            flat.zero_grad()
+            loss, _, _, _ = model(dimg, 0.75, enc_mask_dict=dmask)
+            loss.backward()
+            sq_g = sq_e = 0.0
+            worst_m, worst_v = ("", 0.0), ("", 0.0)
+            for k, r in ref.items():
+                g = named[k].grad.float().cpu()
+                e = float((g - r).double().pow(2).sum())
+                sq_g += float(g.double().pow(2).sum())
+                sq_e += e
+                rn = float(r.norm())
+                if rn < 1e-6 * ref_norm:  # numerically nothing on both sides (LayerNorm over one channel)
+                    continue
+                l2 = math.sqrt(e) / rn
+                if r.dim() >= 2 and l2 > worst_m[1]:
+                    worst_m = (k, l2)
+                if r.dim() < 2 and l2 > worst_v[1]:
+                    worst_v = (k, l2)
+            out[mode] = {"loss": float(loss), "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
+                         "grad_norm_rel": abs(math.sqrt(sq_g) - ref_norm) / ref_norm, "whole_grad_rel_l2": math.sqrt(sq_e) / ref_norm,
+                         "worst_matrix_rel_l2": {"name": worst_m[0], "value": worst_m[1]}, "worst_vector_rel_l2": {"name": worst_v[0], "value": worst_v[1]},
+                         "fp8_dgrad_gemms": calls["n"]}
+    finally:
+        T.w_fp8_t = orig_wt
+        T.FP8_FORWARD, T.FP8_DGRAD = prev
+    return out

@@ -341,11 +341,27 @@ def test_base_4view_192_first_step_vs_oracle() -> None:
     assert par["worst_grad_rel_l2"]["value"] <= CFG2_WORST_GRAD_L2, par["worst_grad_rel_l2"]
 
 
+# fp8 path vs the ORACLE (measured on an MI355X, printed by the test; bounds = ~2 x measured): e4m3 has 3 mantissa bits, so a GEMM on e4m3 operands carries
+# ~3-6 % relative error per output element and the gradients of a 2+2-block model end up ~10 % from the fp32 oracle per matrix
+FP8_LOSS_RTOL = 5e-2
+FP8_GRAD_NORM_RTOL = 5e-2
+FP8_MATRIX_GRAD_L2 = 0.30
+FP8_VECTOR_GRAD_L2 = 0.30
+FP8_WHOLE_GRAD_L2 = 0.20
+
+
 def test_fp8_forward_path_vs_oracle_and_bf16() -> None:
     """BASELINE config 5's arithmetic ("fp8 MFMA path") on an MFMA-sized 2-view model: the transformer blocks' forward projections AND their data gradients on
-    e4m3 operands (weights per tensor, activations / gradients per row, current scaling), weight gradients and everything else in bf16.  Stated tolerance: loss rel <= 5e-2 against the fp32
-    CPU oracle; measured on an MI355X: loss rel 1.3e-3 (bf16 path: 1.5e-4), worst matrix-gradient rel-L2 vs the bf16 path 11 % (printed).  Also: 4 recorded training steps with the
-    flat optimiser (weights re-quantised from the bf16 shadows each step in three launches) reduce the loss."""
+    e4m3 operands (weights per tensor, activations / gradients per row, current scaling), weight gradients and everything else in bf16.  Loss AND GRADIENTS are
+    compared with the fp32 CPU ORACLE (``oracle/parity.py::mae_fp8_grad_parity``; reference graph ``cinema/mae/mae.py:504-612``), in three modes: bf16, e4m3 forward,
+    e4m3 forward + data gradients.  The flat buffers exist before the comparison, and the test asserts that the e4m3 data-gradient GEMMs really ran (their
+    transposed weight shadows live in the flat buffers only).  Also: 5 recorded training steps with the flat optimiser reduce the loss."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "oracle"))
+    from parity import mae_fp8_grad_parity
+
     from cinema_amd import tape as T
     from cinema_amd.optim import TrainStep
 
@@ -357,32 +373,30 @@ def test_fp8_forward_path_vs_oracle_and_bf16() -> None:
     torch.manual_seed(3)
     model = CineMA(**kw)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    cfg = O.MAEConfig(**kw)
-    gen = torch.Generator().manual_seed(5)
-    images = {v: torch.rand(3, 1, *kw["image_size_dict"][v], generator=gen) for v in views}
-    masks = {v: O.random_patch_mask(3, math.prod(cfg.grid_size(v)), 0.75, gen) for v in views}
-    p = {k: v.clone().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
-    ref_loss, _, _ = O.mae_forward(p, cfg, images, masks)
+    par = mae_fp8_grad_parity(kw, sd, batch=3, seed=5, device=DEV)
+    for mode in ("bf16", "fp8_forward", "fp8"):
+        print(f"fp8 parity vs oracle [{mode}]:", par[mode])
+    assert par["bf16"]["fp8_dgrad_gemms"] == 0 and par["fp8_forward"]["fp8_dgrad_gemms"] == 0
+    assert par["fp8"]["fp8_dgrad_gemms"] >= 10, par["fp8"]  # q, kv, proj, fc1, fc2 of 2 + 2 blocks: the e4m3 data-gradient kernels really ran
+    assert par["fp8"]["loss"] != par["bf16"]["loss"]  # ... and so did the e4m3 forward
+    for mode in ("fp8_forward", "fp8"):
+        r = par[mode]
+        assert r["loss_rel"] <= FP8_LOSS_RTOL, r
+        assert r["grad_norm_rel"] <= FP8_GRAD_NORM_RTOL, r
+        assert r["worst_matrix_rel_l2"]["value"] <= FP8_MATRIX_GRAD_L2, r
+        assert r["worst_vector_rel_l2"]["value"] <= FP8_VECTOR_GRAD_L2, r
+        assert r["whole_grad_rel_l2"] <= FP8_WHOLE_GRAD_L2, r
+    assert par["bf16"]["worst_matrix_rel_l2"]["value"] <= 0.055 and par["bf16"]["loss_rel"] <= 2e-3, par["bf16"]
     model.to(DEV)
-    dimg, dmask = {k: v.to(DEV) for k, v in images.items()}, {k: v.to(DEV) for k, v in masks.items()}
-    out = {}
+    g = torch.Generator().manual_seed(5)
+    dimg = {v: torch.rand(3, 1, *kw["image_size_dict"][v], generator=g).to(DEV) for v in views}
     try:
-        for fp8 in (False, True):
-            T.FP8_FORWARD = fp8
-            model.zero_grad(set_to_none=True)
-            loss, _, _, _ = model(dimg, 0.75, enc_mask_dict=dmask)
-            loss.backward()
-            out[fp8] = (float(loss), {k: q.grad.float().cpu().clone() for k, q in model.named_parameters() if q.grad is not None})
-        rel8, rel16 = abs(out[True][0] - float(ref_loss)) / float(ref_loss), abs(out[False][0] - float(ref_loss)) / float(ref_loss)
-        worst = max(float((out[True][1][k] - g).norm() / g.norm().clamp_min(1e-12)) for k, g in out[False][1].items() if g.dim() > 1)
-        print(f"fp8 forward: loss rel vs oracle {rel8:.2e} (bf16 path {rel16:.2e}); worst matrix-gradient rel-L2 vs the bf16 path {worst:.3f}")
-        assert rel8 <= 5e-2 and out[True][0] != out[False][0]  # the fp8 path really ran
-        assert worst <= 0.25
         T.FP8_FORWARD = True
         step = TrainStep(model, lr=1e-3, replay=True)
         losses = [float(step(dimg, 0.75)[0]) for _ in range(5)]
         assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
         assert step.flat._fp8 is not None and step.flat._fp8["epoch"] is not None  # noqa: SLF001  (the segmented weight quantisation ran)
+        assert step.flat._fp8.get("epoch_t") is not None  # noqa: SLF001  (... and the transposed copies for the data gradients)
     finally:
         T.FP8_FORWARD = False
 
