@@ -97,6 +97,110 @@ __device__ __forceinline__ int8v frag_fp8(const char* lds, int base, int ks, int
   return out;
 }
 
+// Split tail finished INSIDE the launch, reduce-scatter form: every k-slice of a tail tile (1) publishes its fp32 accumulators fragment-ordered with
+// write-through (sc1) 16-byte stores (each lane one store per accumulator quad: coalesced, no LDS staging), drains, and bumps the tile's publish counter;
+// (2) waits until all n slices of the tile have published (they are the last workgroups of the grid and n_tiles x n <= the workgroup slots, so they are
+// co-resident or waiting for slots that free themselves: no slice ever waits for a workgroup that cannot start); (3) sums ITS share of the tile - the
+// 32x32 accumulator blocks u = slice, slice + n, ... of the 16, one block per wave at a time - over all slices in slice order (deterministic: the rounding
+// does not depend on arrival order) with sc1 loads and runs the fused epilogue on it.  The serial part per workgroup is 64 KiB written + 64 KiB read
+// whatever n is (the last-arriver form this replaces had ONE workgroup read up to 15 x 64 KiB; the fix-up launch costs a kernel boundary + 5 us).
+// The slice that finishes last (second counter) zeroes both counters for the next launch.
+template <int W>
+__device__ __forceinline__ void block_epilogue_rows(const GemmP& p, const float16v& acc, int mw, int nw, int lane, float* stg) {
+  constexpr int LPR = 32 / W, RPP = 64 / LPR, PASSES = 32 / RPP;  // W = 8: 4 lanes per row, 16 rows per pass; W = 4: 8 lanes per row, 8 rows per pass
+  const int ml = lane & 31, hi = lane >> 5;
+  const int rl = lane / LPR, cl = (lane % LPR) * W;
+  const int n = nw + cl;
+  float bv[W];
+  EpiPre<W> pre[PASSES];
+  epi_load_bias<W>(p, n, true, bv);
+#pragma unroll
+  for (int pss = 0; pss < PASSES; pss++) {
+    const int m = mw + pss * RPP + rl;
+    if (m < p.m && n < p.n) epi_load<W>(p, m, n, pre[pss]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    *reinterpret_cast<float4*>(stg + ml * 32 + (((2 * q + hi) ^ (ml & 7)) << 2)) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+#pragma unroll
+  for (int pss = 0; pss < PASSES; pss++) {
+    const int r = pss * RPP + rl;
+    const int m = mw + r;
+    float v[W];
+#pragma unroll
+    for (int c = 0; c < W / 4; c++) {
+      const float4 t = *reinterpret_cast<const float4*>(stg + r * 32 + ((((cl >> 2) + c) ^ (r & 7)) << 2));
+      v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+    }
+    if (m < p.m && n < p.n) epi_apply<W>(p, m, n, v, bv, pre[pss]);
+  }
+}
+typedef unsigned int tail_u32x4 __attribute__((ext_vector_type(4)));
+template <int EPI, int NI>
+__device__ __forceinline__ void tail_finish_in_launch(const GemmP& p, const float16v (&acc)[NI][2], int tile, int slice, int m0, int n0, float* tail_dst, char* smem) {
+  // NI = 2: the BK = 64 kernel (a wave holds 2x2 blocks of its 64x64 quadrant); the partial tile is 16 blocks x 4 quads x 64 lanes x 16 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_local = tile - p.tail_begin, n_pieces = p.tail_split;
+  unsigned* cnt = p.tail_cnt + 2 * t_local;
+  {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(tail_dst, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int idx = (wave_u * 16 + (i * 2 + j) * 4 + q) * 64 + lane;
+          tail_u32x4 v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
+                          __float_as_uint(acc[i][j][4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, idx * 16, 0, 16 /* sc1: write-through */);
+        }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_pieces) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 26)) { p.tail_cnt[TAIL_ERROR_WORD] = 1u; break; }  // never in a healthy run (the host checks the word in tests / soak runs)
+    }
+  }
+  __syncthreads();
+  const float* tile_base = p.tail_ws + (size_t)t_local * n_pieces * (BM * BN);
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile_base), 0, n_pieces * BM * BN * 4, 0x00020000);
+  float* stg = reinterpret_cast<float*>(smem + wave_u * 4096);  // 4 KiB per wave (operand stages are free after the loop's last barrier)
+  const GemmP q = epi_fold<EPI>(p);
+  for (int u = slice + wave_u * n_pieces; u < 16; u += 4 * n_pieces) {
+    float16v r;
+#pragma unroll
+    for (int e = 0; e < 16; e++) r[e] = 0.f;
+    for (int s2 = 0; s2 < n_pieces; s2++) {
+      tail_u32x4 t[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) t[qq] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((u * 4 + qq) * 64 + lane) * 16, s2 * (BM * BN * 4), 16 /* sc1 */);
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) {
+        r[4 * qq] += __uint_as_float(t[qq][0]); r[4 * qq + 1] += __uint_as_float(t[qq][1]);
+        r[4 * qq + 2] += __uint_as_float(t[qq][2]); r[4 * qq + 3] += __uint_as_float(t[qq][3]);
+      }
+    }
+    const int w_src = u >> 2, ij = u & 3;
+    const int mw = m0 + (w_src >> 1) * 64 + (ij >> 1) * 32, nw = n0 + (w_src & 1) * 64 + (ij & 1) * 32;
+    if (EPI == EPI_F32) block_epilogue_rows<4>(q, r, mw, nw, lane, stg);
+    else block_epilogue_rows<8>(q, r, mw, nw, lane, stg);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned done = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)(n_pieces - 1)) {  // every slice has passed its wait and its reads: leave both counters zero
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 enum { MODE_PLAIN = 0, MODE_FP8 = 1, MODE_CONV = 2, MODE_CONVW = 3 };
 template <bool A_KMAJ, bool B_KMAJ, int EPI, int MODE = MODE_PLAIN>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, int kt_begin, int kt_end, float* tail_dst, char* smem) {
@@ -300,76 +404,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
   }
   // fp32 partial of a split-tail k-slice: plain [128][128] rows (address = base + m * 128 + n with the tile origin folded into base)
   if (EPI != EPI_GENERAL && tail_dst && p.tail_cnt) {  // (the general class keeps the fix-up launch: its epilogue has no registers to spare)
-    // finished inside the launch by the tile's LAST ARRIVER (the protocol of gemm256.hip): a k-slice takes a ticket; tickets 0..n-2 store their
-    // accumulators fragment-ordered with write-through (sc1) stores, drain, and bump the publish counter; ticket n-1 waits for n-1 publishes (its partners
-    // took their tickets before it and never wait: no deadlock for any dispatch order), sums the slices in slice order - its own at its own position, so the
-    // rounding does not depend on who came last - and runs the fused epilogue.  Both counters are left zero.
-    const int t_local = tile - p.tail_begin, n_pieces = p.tail_split;
-    unsigned* cnt = p.tail_cnt + 2 * t_local;
-    volatile unsigned* ctl = reinterpret_cast<volatile unsigned*>(smem);  // both stages are free after the loop's last barrier
-    if (tid == 0) ctl[0] = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned ticket = ctl[0];
-    __syncthreads();
-    if (ticket != (unsigned)(n_pieces - 1)) {
-      typedef unsigned int u32x4t __attribute__((ext_vector_type(4)));
-      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(tail_dst, 0, BM * BN * 4, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int idx = (wave_u * 16 + (i * 2 + j) * 4 + q) * 64 + lane;
-            u32x4t v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
-                        __float_as_uint(acc[i][j][4 * q + 3])};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, idx * 16, 0, 16 /* sc1: write-through */);
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    if (tid == 0) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(n_pieces - 1)) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 26)) { p.tail_cnt[TAIL_ERROR_WORD] = 1u; break; }  // never in a healthy run
-      }
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    const float4* base = reinterpret_cast<const float4*>(p.tail_ws + (size_t)t_local * n_pieces * (BM * BN));
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      float4 r[8];
-#pragma unroll
-      for (int jq = 0; jq < 8; jq++) r[jq] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s2 = 0; s2 < n_pieces; s2++) {
-        if (s2 == zsplit) {
-#pragma unroll
-          for (int jq = 0; jq < 8; jq++) {
-            const int j = jq >> 2, q = jq & 3;
-            r[jq].x += acc[i][j][4 * q]; r[jq].y += acc[i][j][4 * q + 1]; r[jq].z += acc[i][j][4 * q + 2]; r[jq].w += acc[i][j][4 * q + 3];
-          }
-        } else {
-          const float4* s4 = base + (size_t)s2 * (BM * BN / 4);
-          float4 t[8];
-#pragma unroll
-          for (int jq = 0; jq < 8; jq++) t[jq] = s4[(wave_u * 16 + i * 8 + jq) * 64 + lane];
-#pragma unroll
-          for (int jq = 0; jq < 8; jq++) { r[jq].x += t[jq].x; r[jq].y += t[jq].y; r[jq].z += t[jq].z; r[jq].w += t[jq].w; }
-        }
-      }
-#pragma unroll
-      for (int jq = 0; jq < 8; jq++) {
-        const int j = jq >> 2, q = jq & 3;
-        acc[i][j][4 * q] = r[jq].x; acc[i][j][4 * q + 1] = r[jq].y; acc[i][j][4 * q + 2] = r[jq].z; acc[i][j][4 * q + 3] = r[jq].w;
-      }
-    }
-    tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, 0, stg);
+    tail_finish_in_launch<EPI>(p, acc, tile, zsplit, m0, n0, tail_dst, smem);
     return;
   }
   if (tail_dst) tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, 0, stg, tail_dst - ((long long)m0 * BN + n0), BN);
@@ -672,7 +707,14 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     // launch only when the reduction has >= 12 k-tiles and the left-over tiles can be cut at least in two
     p.tail_split = 0; p.tail_begin = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
     bool tail = false;
-    if (gz == 1 && a->force_generic == 0 && !p.accumulate && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= 12) {  // K >= 768 (tools/tail_ab.py: 10960x768x768 38 -> 34 us, x1024 42 -> 35 us; at K = 512 the fix-up launch costs what it saves)
+    const bool in_launch = a->tail_counters != nullptr && !(((uintptr_t)a->tail_counters) & 15);
+    // thresholds: with the fix-up launch a tail pays from 12 k-tiles (K >= 768) and >= 4 k-tiles per slice; finished in the launch (no kernel boundary, the
+    // finish spread over the slices) shorter reductions and slices pay too (CINEMA_TAIL_MIN_NKT / CINEMA_TAIL_MIN_KT override both)
+    static const int min_nkt_env = getenv("CINEMA_TAIL_MIN_NKT") ? atoi(getenv("CINEMA_TAIL_MIN_NKT")) : 0;
+    static const int min_kt_env = getenv("CINEMA_TAIL_MIN_KT") ? atoi(getenv("CINEMA_TAIL_MIN_KT")) : 0;
+    const int min_nkt = min_nkt_env > 0 ? min_nkt_env : 12;
+    const int min_kt = min_kt_env > 0 ? min_kt_env : 4;
+    if (gz == 1 && a->force_generic == 0 && !p.accumulate && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= min_nkt) {  // K >= 768 (tools/tail_ab.py: 10960x768x768 38 -> 34 us, x1024 42 -> 35 us; at K = 512 the fix-up launch costs what it saves)
       static int slots = 0;
       if (slots == 0) {
         int dev = 0; hipDeviceProp_t prop;
@@ -681,11 +723,9 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       const int tiles = (int)grid.x, rem = tiles % slots;
       if (rem > 0 && rem <= slots / 2) {
         int sp2 = slots / rem;
-        if (sp2 > nkt / 4) sp2 = nkt / 4;  // >= 4 k-tiles per slice
-        if (sp2 > 16) sp2 = 16;
+        if (sp2 > nkt / min_kt) sp2 = nkt / min_kt;  // >= min_kt k-tiles per slice
+        if (sp2 > 16) sp2 = 16;  // = the 32x32 accumulator blocks of a tile: every slice finishes at least one of them
         static const int cap_env = getenv("CINEMA_TAIL_MAX_SPLIT") ? atoi(getenv("CINEMA_TAIL_MAX_SPLIT")) : 0;
-        const bool in_launch = a->tail_counters != nullptr && !(((uintptr_t)a->tail_counters) & 15);
-        // finished in the launch, ONE workgroup reads the partners' partial tiles (64 KiB each at ~64 B/clk): cap the fan-in
         if (in_launch && cap_env > 1 && sp2 > cap_env) sp2 = cap_env;
         const int kts = (nkt + sp2 - 1) / sp2;
         sp2 = (nkt + kts - 1) / kts;

@@ -415,6 +415,7 @@ _TAIL_COUNTERS: dict = {}
 # measured slower in the step (same box, 2 rounds: 28.58-28.80 ms with fan-in caps 2..16 vs 28.54 with the fix-up launch): ONE workgroup reads its partners'
 # partial tiles (up to 15 x 64 KiB at ~64 B/clk) at the very end of the launch, the fix-up kernel spreads the same reads over 8 workgroups per tile
 TAIL_IN_LAUNCH = bool(int(os.environ.get("CINEMA_TAIL_IN_LAUNCH", "0")))
+TAIL_MIN_K = int(os.environ.get("CINEMA_TAIL_MIN_K", "768"))  # shortest reduction that gets split-tail scratch (the library decides per shape)
 
 
 def _tail_counters(device: torch.device) -> torch.Tensor:
@@ -514,7 +515,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
         ws = _workspace("splitk", split_k * m * n, a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), split_k * m * n * 4
-    elif split_k == 1 and k >= 768:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
+    elif split_k == 1 and k >= TAIL_MIN_K:  # split-tail scratch (k-slices of the tiles left over after the last full round of workgroup slots)
         ws = _tail_workspace(a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         if TAIL_IN_LAUNCH:

@@ -341,13 +341,18 @@ def test_base_4view_192_first_step_vs_oracle() -> None:
     assert par["worst_grad_rel_l2"]["value"] <= CFG2_WORST_GRAD_L2, par["worst_grad_rel_l2"]
 
 
-# fp8 path vs the ORACLE (measured on an MI355X, printed by the test; bounds = ~2 x measured): e4m3 has 3 mantissa bits, so a GEMM on e4m3 operands carries
-# ~3-6 % relative error per output element and the gradients of a 2+2-block model end up ~10 % from the fp32 oracle per matrix
+# fp8 path vs the ORACLE, measured on an MI355X (printed by the test), midsize 2-view model (2 + 2 blocks), batch 3:
+#   mode                         loss rel   grad-norm rel   whole gradient rel-L2   worst matrix rel-L2                  worst vector rel-L2
+#   bf16                         1.5e-4     1.2e-3          0.6 %                   1.3 % (decoder.blocks.1.attn.q)      1.7 % (decoder.blocks.1.norm1.bias)
+#   e4m3 forward                 2.0e-3     3.3e-3          5.0 %                   12.6 %                               16.8 %
+#   e4m3 forward + data grads    2.0e-3     1.5e-3          6.9 %                   18.1 %                               25.1 %
+# e4m3 has 3 mantissa bits: a GEMM on e4m3 operands carries ~3-6 % relative error per output element; the worst tensors are the decoder's q projection and
+# its LayerNorm (gradients that are sums of small differences of softmax terms).  Bounds = ~1.6 x measured.
 FP8_LOSS_RTOL = 5e-2
-FP8_GRAD_NORM_RTOL = 5e-2
+FP8_GRAD_NORM_RTOL = 1e-2
 FP8_MATRIX_GRAD_L2 = 0.30
-FP8_VECTOR_GRAD_L2 = 0.30
-FP8_WHOLE_GRAD_L2 = 0.20
+FP8_VECTOR_GRAD_L2 = 0.40
+FP8_WHOLE_GRAD_L2 = 0.12
 
 
 def test_fp8_forward_path_vs_oracle_and_bf16() -> None:
