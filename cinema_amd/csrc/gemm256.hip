@@ -39,6 +39,7 @@ struct SlimP {
   const float* bias; const float* res_f32; const bf16_t* gelu_in; bf16_t* aux_out; float* a_rowsum;
   int ld_res, ld_gelu, ld_aux, act, out_f32, gelu_deriv;
   float alpha;
+  const float* scale_a; const float* scale_b;   // fp8 weight-gradient form (LOOP 3): per-tensor dequantisation scales of the 8-bit operands, NULL otherwise
 };
 __device__ __forceinline__ GemmP expand(const SlimP& s) {
   GemmP p;
@@ -46,7 +47,7 @@ __device__ __forceinline__ GemmP expand(const SlimP& s) {
   p.bias = s.bias; p.res_f32 = s.res_f32; p.res_bf16 = nullptr; p.ld_res = s.ld_res; p.gelu_in = s.gelu_in; p.ld_gelu = s.ld_gelu;
   p.row_mask = nullptr; p.aux_out = s.aux_out; p.ld_aux = s.ld_aux; p.act = s.act; p.gelu_deriv = s.gelu_deriv; p.out_f32 = s.out_f32; p.accumulate = 0;
   p.ktiles_per_split = 0; p.ws = nullptr; p.a_rowsum = s.a_rowsum; p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
-  p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.cX = p.cY = p.cZ = p.cC = 0; p.cZB = 1; p.conv_coords = nullptr;
+  p.scale_a = s.scale_a; p.scale_b = s.scale_b; p.scale_a_rows = 0; p.conv_taps = nullptr; p.cX = p.cY = p.cZ = p.cC = 0; p.cZB = 1; p.conv_coords = nullptr;
   return p;
 }
 
@@ -261,6 +262,109 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
   if (wr == 0) P256_BAR();
 }
 
+// ---- main loop, form 3: WEIGHT GRADIENT ON 8-BIT OPERANDS (BASELINE config 5, "fp8 MFMA path"): dW[n][k] = sa * sb * sum_t dY8[t][n] X8[t][k] with both operands
+// stored as the forward / backward passes produce them - row-major [token][feature] bytes (OCP e4m3), per-TENSOR scales - i.e. reduction-strided like the bf16
+// weight gradient.  Same schedule as form 1 (ring of four 32 KiB half-stages, two waves per SIMD half a phase apart, counted vmcnt), but a phase is 64 TOKENS:
+// a 128-feature sub-tile of a phase is [64 token rows][128 B] = 8 KiB, filled by LDS-DMA pieces of 8 rows x 128 B; v_mfma_scale_f32_32x32x64_f8f6f4 (unit
+// block scales) wants 32 consecutive k per lane for one feature, which ds_read_b64_tr_b8 delivers from this layout: a 16-lane group reads an [8 token rows] x
+// [16 features] block, lane t supplies row t / 2, bytes 8 (t & 1) .., and receives feature t at the 8 tokens (tools/probe/probe_tr8.hip, verified on the GPU
+// together with the MFMA operand layout).  Per phase and wave: 24 transpose reads, 8 MFMAs of twice the bf16 instruction's FLOPs per cycle, and HALF the
+// LDS-DMA pieces per FLOP.  Swizzle: 16-byte chunk position = chunk ^ (((row >> 1) & 3) << 1) - the 8 rows x 2 chunk parities of one LDS cycle's two
+// 16-lane groups then cover the 64 banks exactly once; applied to the DMA source address and, as a lane constant, to the read address.
+typedef int i32x2v __attribute__((ext_vector_type(2)));
+typedef int i32x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x2v lds_tr8_b64(const void* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr8_b64_v2i32((i32x2v __attribute__((address_space(3)))*)(lds_ptr));
+}
+__device__ __forceinline__ void p256_loop_fp8w(const GemmP& p, int m0, int n0, int ph_begin, int ph_end, float16v (&acc)[4][2], char* smem) {
+  const int lane = threadIdx.x & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wr = wave_u >> 2, wc = wave_u & 3;
+  const int sub = wave_u >> 2, w4 = wave_u & 3;
+  const uint8_t* zero_page = reinterpret_cast<const uint8_t*>(g_zero_page);
+  const uint8_t* pa = reinterpret_cast<const uint8_t*>(p.a);
+  const uint8_t* pb = reinterpret_cast<const uint8_t*>(p.b);
+  // DMA sources of phase 0: piece pss covers token rows (pss * 4 + w4) * 8 + lane / 8 of the phase, the lane's LDS chunk position lane & 7 holds the
+  // global chunk (lane & 7) ^ swizzle(row); out-of-range features re-read feature 0 (their outputs are never stored)
+  const uint8_t *asrc[2], *bsrc[2];
+  int prow[2];
+#pragma unroll
+  for (int pss = 0; pss < 2; pss++) {
+    const int rr = (pss * 4 + w4) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (((rr >> 1) & 3) << 1);
+    int ca = m0 + sub * 128 + c * 16, cb = n0 + sub * 128 + c * 16;
+    ca = ca < p.m ? ca : 0; cb = cb < p.n ? cb : 0;
+    prow[pss] = rr;
+    asrc[pss] = pa + (size_t)rr * p.lda + ca;
+    bsrc[pss] = pb + (size_t)rr * p.ldb + cb;
+  }
+  const size_t astep = (size_t)64 * p.lda, bstep = (size_t)64 * p.ldb;
+  const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  auto issue = [&](int ph) {
+    const uint32_t dst = smem_addr + (ph & 3) * P_HS + sub * 8192 + w4 * 1024;
+    const size_t ka = (size_t)ph * astep, kb = (size_t)ph * bstep;
+    const uint8_t *a0 = asrc[0] + ka, *a1 = asrc[1] + ka, *b0 = bsrc[0] + kb, *b1 = bsrc[1] + kb;
+    if ((ph + 1) * 64 > p.k) {  // ragged last phase: token rows >= K read the zero page
+      const int k0 = ph * 64;
+      if (k0 + prow[0] >= p.k) { a0 = zero_page; b0 = zero_page; }
+      if (k0 + prow[1] >= p.k) { a1 = zero_page; b1 = zero_page; }
+    }
+    glds16x4(dst, dst + 4096, dst + 16384, dst + 16384 + 4096, a0, a1, b0, b1);
+  };
+  int tr_a[4], tr_b[2];
+  {
+    const int q4 = lane >> 4, t = lane & 15, mm = (t >> 2) & 3;
+    const int lane_part = (32 * (q4 >> 1) + (t >> 1)) * 128 + (q4 & 1) * 16 + (t & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) tr_a[i] = wr * 8192 + lane_part + 32 * (i ^ mm);
+#pragma unroll
+    for (int j = 0; j < 2; j++) tr_b[j] = 16384 + (wc >> 1) * 8192 + lane_part + 32 * ((2 * (wc & 1) + j) ^ mm);
+  }
+  auto tr_frag = [&](const char* base) {
+    i32x8v out;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      const i32x2v v = lds_tr8_b64(base + h * 1024);
+      out[2 * h] = v[0]; out[2 * h + 1] = v[1];
+    }
+    return out;
+  };
+  const int nph = ph_end - ph_begin;
+  issue(ph_begin);
+  if (nph > 1) issue(ph_begin + 1);
+  if (nph > 2) issue(ph_begin + 2);
+  if (nph > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nph > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P256_BAR();
+  if (wr == 1) P256_BAR();   // waves 4-7 run one barrier behind
+  for (int q = 0; q < nph; q++) {
+    const int ph = ph_begin + q;
+    const char* hs = smem + (ph & 3) * P_HS;
+    i32x8v fa[4], fb[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) fb[j] = tr_frag(hs + tr_b[j]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) fa[i] = tr_frag(hs + tr_a[i]);
+    if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P256_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      if (i == 1 && q + 3 < nph) issue(ph + 3);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    P256_BAR();
+  }
+  if (wr == 0) P256_BAR();
+}
+
 // where the pieces of this piece's tile publish: pieces first .. first + n_pieces - 1 in summation order, `me` among them
 struct PieceRed {
   float* my_slot;
@@ -293,7 +397,8 @@ __device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gt
 
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_rowsum = !A_KMAJ && p.a_rowsum != nullptr && wc == 0 && n0 == 0;
-  if (LOOP == 0) p256_loop64<A_KMAJ, B_KMAJ>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
+  if constexpr (LOOP == 0) p256_loop64<A_KMAJ, B_KMAJ>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
+  else if constexpr (LOOP == 3) p256_loop_fp8w(p, m0, n0, kt_begin, kt_end, acc, smem);
   else p256_loop32<A_KMAJ, B_KMAJ>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
 
   if (do_rowsum) {
@@ -381,6 +486,7 @@ __device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gt
   float* stg = reinterpret_cast<float*>(smem + wave * 8192);
   GemmP q = p;
   q.ws = nullptr;
+  if constexpr (LOOP == 3) { q.alpha = p.alpha * p.scale_a[0] * p.scale_b[0]; q.scale_a = nullptr; q.scale_b = nullptr; }  // dequantisation (per-tensor scales in device memory)
 #pragma unroll
   for (int i = 0; i < 4; i++) half_epilogue<EPI>(q, acc[i], m0 + wr * 128 + i * 32, n0 + wc * 64, lane, 0, stg);
   __syncthreads();  // the staging area becomes stage 0 / 1 of the next piece
@@ -499,14 +605,26 @@ int cu_count() {
 // leaves them zero); one workspace per stream (concurrent launches must not share one).
 CINEMA_API long long cinema_gemm_p256_workspace_bytes(void) { return (long long)P_COUNTER_BYTES + 2LL * cu_count() * P_SLOT_FLOATS * 4; }
 
+static int p256_launch_host(cinema_gemm_args* args, int count, int schedule, void* workspace, long long workspace_bytes, void* stream, bool fp8);
 CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int schedule, void* workspace, long long workspace_bytes, void* stream) {
+  return p256_launch_host(args, count, schedule, workspace, workspace_bytes, stream, false);
+}
+// Weight gradients on 8-bit operands (form 3 of the main loop): args[i].a = dY8 [rows = k][lda] bytes, args[i].b = X8 [rows][ldb] bytes (OCP e4m3, row-major
+// [token][feature]: a_kmajor = b_kmajor = 0), m / n = feature counts (multiples of 16, lda / ldb multiples of 16 bytes, 16-byte aligned), scale_a / scale_b =
+// per-tensor dequantisation scales (device scalars); D fp32 [m][ldd] (+)= scale_a * scale_b * dY8^T X8.  No a_rowsum (bias gradients: cinema_colsum), no other
+// epilogue term.  Schedule, workspace and in-launch reduction as cinema_gemm_bf16_p256 (split schedule).
+CINEMA_API int cinema_gemm_fp8_wgrad_p256(cinema_gemm_args* args, int count, void* workspace, long long workspace_bytes, void* stream) {
+  return p256_launch_host(args, count, 0, workspace, workspace_bytes, stream, true);
+}
+static int p256_launch_host(cinema_gemm_args* args, int count, int schedule, void* workspace, long long workspace_bytes, void* stream, bool fp8) {
   if (!args || count < 1 || count > P_MAX || !workspace || (((uintptr_t)workspace) & 255)) return CINEMA_ERR_BAD_ARG;
   if (schedule == 1 && count != 1) return CINEMA_ERR_BAD_ARG;
   auto al8 = [](long long v) { return (v & 7) == 0; };
   auto ptr16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   // main-loop form (p256_loop64 / p256_loop32) and with it the k extent of a schedule unit; CINEMA_P256_LOOP=0 selects the plain k-tile loop
-  static const int loop_form = getenv("CINEMA_P256_LOOP") ? atoi(getenv("CINEMA_P256_LOOP")) : 1;
-  const int unit_k = loop_form ? 32 : BK;
+  static const int loop_env = getenv("CINEMA_P256_LOOP") ? atoi(getenv("CINEMA_P256_LOOP")) : 1;
+  const int loop_form = fp8 ? 3 : loop_env;
+  const int unit_k = fp8 ? 64 : (loop_form ? 32 : BK);
   P256 g;
   g.count = count; g.mode = schedule ? 1 : 0;
   g.tile_begin[0] = 0; g.piece_begin[0] = 0;
@@ -518,7 +636,13 @@ CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int sche
     const cinema_gemm_args* a = &args[i];
     if (!a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
     if (a->a_kmajor != ak || a->b_kmajor != bk) return CINEMA_ERR_UNSUPPORTED;
-    if (a->residual_bf16 || a->row_mask || a->scale_a || a->scale_b || a->conv_taps) return CINEMA_ERR_UNSUPPORTED;
+    if (a->residual_bf16 || a->row_mask || a->conv_taps) return CINEMA_ERR_UNSUPPORTED;
+    if (fp8) {
+      auto al16 = [](long long v) { return (v & 15) == 0; };
+      if (!a->scale_a || !a->scale_b || a->scale_a_rows) return CINEMA_ERR_BAD_ARG;
+      if (a->a_kmajor || a->b_kmajor || !a->out_f32 || a->a_rowsum || a->bias || a->residual_f32 || a->gelu_in || a->aux_out || a->act) return CINEMA_ERR_UNSUPPORTED;
+      if (!al16(a->m) || !al16(a->n) || !al16(a->lda) || !al16(a->ldb)) return CINEMA_ERR_UNSUPPORTED;
+    } else if (a->scale_a || a->scale_b) return CINEMA_ERR_UNSUPPORTED;
     if (a->accumulate && !a->out_f32) return CINEMA_ERR_BAD_ARG;
     if (a->accumulate && a->residual_f32) return CINEMA_ERR_UNSUPPORTED;
     bool ok = al8(a->lda) && al8(a->ldb) && al8(a->ldd) && al8(a->n) && ptr16(a->a) && ptr16(a->b) && ptr16(a->d);
@@ -534,6 +658,7 @@ CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int sche
     p.bias = a->bias; p.res_f32 = a->residual_f32; p.ld_res = a->ld_res;
     p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
     p.act = a->act; p.gelu_deriv = a->gelu_deriv; p.out_f32 = a->out_f32; p.a_rowsum = a->a_rowsum;
+    p.scale_a = fp8 ? a->scale_a : nullptr; p.scale_b = fp8 ? a->scale_b : nullptr;
     if (a->accumulate) { p.res_f32 = (const float*)a->d; p.ld_res = a->ldd; }  // one owner per element: plain read-modify-write
     int e;
     if (!p.out_f32 && !p.res_f32 && !p.gelu_in && p.act == 0 && !p.aux_out) e = EPI_BF16;
@@ -627,7 +752,8 @@ CINEMA_API int cinema_gemm_bf16_p256(cinema_gemm_args* args, int count, int sche
   g.error = g.counters + P_COUNTER_BYTES / 4 - 1;   // last counter word (tile ids never reach it: checked above)
   g.slots = (float*)((char*)workspace + P_COUNTER_BYTES);
   hipStream_t st = (hipStream_t)stream;
-  for (int i = 0; i < count; i++) args[i].kernel_used = 2048 + (ak && bk ? 1 : (ak ? 2 : 3)) + 8 * epi;
+  for (int i = 0; i < count; i++) args[i].kernel_used = (fp8 ? 4096 : 2048) + (ak && bk ? 1 : (ak ? 2 : 3)) + 8 * epi;
+  if (fp8) return launch_p256<false, false, EPI_F32, 3>(g, grid, st);
 #define P256_LAYOUT(E)                                                        \
   do {                                                                        \
     if (loop_form) {                                                          \

@@ -55,6 +55,7 @@ GEMM_KERNEL_NAMES[64] = "gemm_mfma_grouped_kernel<false, false, 4>"
 GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 GEMM_KERNEL_NAMES.update({2048 + lay + 8 * epi: f"gemm_p256_kernel<{txt}, {epi}, 1>" for lay, txt in _LAYOUTS.items() for epi in range(5)})  # csrc/gemm256.hip
+GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4] = "gemm_p256_kernel<false, false, 4, 3>"  # weight gradients on e4m3 operands (cinema_gemm_fp8_wgrad_p256)
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (kernel_used, algorithmic_flops, start_event, end_event)
 GEMM_PROFILE: list | None = None
@@ -99,6 +100,7 @@ _PROTOS = {
     "cinema_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "cinema_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i, _vp],
     "cinema_gemm_bf16_p256": [C.POINTER(GemmArgs), _i, _i, _vp, _ll, _vp],
+    "cinema_gemm_fp8_wgrad_p256": [C.POINTER(GemmArgs), _i, _vp, _ll, _vp],
     "cinema_gemm_p256_workspace_bytes": [],
     "cinema_gemm_fp8": [C.POINTER(GemmArgs), _vp],
     "cinema_conv_gemm_bf16": [C.POINTER(GemmArgs), _vp],
@@ -660,6 +662,34 @@ def gemm_wgrad_grouped(problems: list, p256: bool = False, split_k: int = 0) -> 
     flops = sum(2.0 * g.m * g.n * g.k for g in arr)
     alg = sum(2.0 * (g.m * g.k + g.k * g.n) + 8.0 * g.m * g.n for g in arr)
     GEMM_PROFILE.append((64, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg)))
+
+
+def gemm_fp8_wgrad_grouped(problems: list) -> None:
+    """Weight gradients on 8-bit operands in ONE persistent launch (``cinema_gemm_fp8_wgrad_p256``): each problem is (dy8 uint8 [rows, n_out], scale_dy fp32 [1],
+    x8 uint8 [rows, k_out], scale_x fp32 [1], dst fp32 [n_out, k_out] view); dst += scale_dy * scale_x * dy8^T x8 (e4m3 decode).  The operands are the row-major
+    [token][feature] copies the producing kernels write - no transposed copies; bias gradients are not part of this launch (:func:`colsum`)."""
+    arr = (GemmArgs * len(problems))()
+    for g, (dy, sdy, x, sx, dst) in zip(arr, problems):
+        _dev(dy, sdy, x, sx, dst)
+        if dy.dtype != torch.uint8 or x.dtype != torch.uint8 or dst.dtype != torch.float32 or dy.shape[0] != x.shape[0] or sdy.dtype != torch.float32 or sx.dtype != torch.float32:
+            raise HipLibraryError("gemm_fp8_wgrad_grouped: uint8 (e4m3) operands with a common row count, fp32 [1] scales, fp32 destination")
+        g.a, g.b, g.d = dy.data_ptr(), x.data_ptr(), dst.data_ptr()
+        g.m, g.n, g.k = dy.shape[1], x.shape[1], dy.shape[0]
+        g.lda, g.ldb, g.ldd = _rowmajor(dy, "dy8"), _rowmajor(x, "x8"), _rowmajor(dst, "dst")
+        g.a_kmajor, g.b_kmajor, g.alpha, g.out_f32, g.accumulate, g.split_k = 0, 0, 1.0, 1, 1, 0
+        g.scale_a, g.scale_b = sdy.data_ptr(), sx.data_ptr()
+    dev = problems[0][0].device
+    ws = _p256_workspace(dev)
+    if GEMM_PROFILE is None or LANE is not None:
+        _check(load().cinema_gemm_fp8_wgrad_p256(arr, len(problems), ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_fp8_wgrad_p256")
+        return
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    _check(load().cinema_gemm_fp8_wgrad_p256(arr, len(problems), ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_fp8_wgrad_p256")
+    ev1.record()
+    flops = sum(2.0 * g.m * g.n * g.k for g in arr)
+    alg = sum(1.0 * (g.m * g.k + g.k * g.n) + 8.0 * g.m * g.n for g in arr)  # every 8-bit operand once, the fp32 gradient read + written once
+    GEMM_PROFILE.append((arr[0].kernel_used, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg)))
 
 
 def _warn_generic(m: int, n: int, k: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:

@@ -131,6 +131,14 @@ int cinema_gemm_bf16_grouped(cinema_gemm_args* args_host_array, int count, void*
  * workspace: >= cinema_gemm_p256_workspace_bytes(), 256-byte aligned, first 64 KiB ZERO before the first use (left zero by every launch), one per stream. */
 long long cinema_gemm_p256_workspace_bytes(void);
 int cinema_gemm_bf16_p256(cinema_gemm_args* args_host_array, int count, int schedule, void* workspace, long long workspace_bytes, void* stream);
+/* The same persistent launch for WEIGHT GRADIENTS ON 8-BIT OPERANDS (BASELINE config 5, "fp8 MFMA path"; replaces the bf16 autocast matmuls behind the backward of
+ * the transformer MLP's nn.Linear layers, cinema/vit.py:565-575 via timm Mlp): a = dY8 [rows][lda] and b = X8 [rows][ldb] OCP-e4m3 bytes, row-major
+ * [token][feature] as the producing kernels write them (a_kmajor = b_kmajor = 0), k = rows, m / n = feature counts (multiples of 16; lda, ldb multiples of 16
+ * bytes; 16-byte aligned pointers), scale_a / scale_b = per-tensor dequantisation scales (device scalars), D fp32 [m][ldd], accumulate as cinema_gemm_bf16_p256:
+ *   D (+)= scale_a * scale_b * dY8^T X8   on v_mfma_scale_f32_32x32x64_f8f6f4 with ds_read_b64_tr_b8 fragment reads (no transposed copies of the operands).
+ * No a_rowsum / bias / activation terms (bias gradients: cinema_colsum).  Up to 12 problems, split schedule, workspace as cinema_gemm_bf16_p256.
+ * kernel_used OUT: 4096 + 3 + 8 x 4. */
+int cinema_gemm_fp8_wgrad_p256(cinema_gemm_args* args_host_array, int count, void* workspace, long long workspace_bytes, void* stream);
 
 /* column sums: out[n] += sum_{i<m} x[row(i), n] with row(i) = row_idx ? row_idx[i] : i  (bias / token-parameter gradients).
  * x bf16 (x_dtype 0) or fp32 (1), row-major [.][ldx]; out fp32 [n], accumulated atomically */

@@ -1000,3 +1000,35 @@ def test_one_channel_stencil_conv(spatial: tuple, ks: tuple, n: int) -> None:
     close(db - 0.25, br.grad, 3e-4, 3e-4 * float(br.grad.abs().max()) + 1e-3, "conv1ch db")
     close(dx.reshape(b, *spatial), xr.grad[:, 0], 1e-2, 1e-2 * float(xr.grad.abs().max()), "conv1ch dx (bf16)")
     assert K.conv1ch_bwd(x, w, dy, None, None, want_dx=False) is None
+
+
+@pytest.mark.parametrize("rows", [704, 5000, 13824])
+def test_gemm_fp8_wgrad_p256_vs_independent_e4m3_decoder(rows: int) -> None:
+    """cinema_gemm_fp8_wgrad_p256: weight gradients on ROW-MAJOR [token][feature] e4m3 operands (per-tensor scales), fragments by ds_read_b64_tr_b8, the MX-scaled
+    MFMA with unit block scales, k-slices finished inside the persistent launch.  Reference: fp32 matmul of the operands decoded by an independent e4m3
+    decoder (products of e4m3 values are exact in fp32: only the accumulation order differs -> 1e-3 of the largest element); ragged feature counts (not multiples
+    of 256), a ragged last 64-token phase (rows % 64 != 0), accumulation into an existing gradient, twice on the same workspace (counters back to zero).
+    Also against the bf16 weight gradient of the unquantised operands: relative L2 <= 6e-2 (two e4m3 operands, see test_fp8_quantise_and_gemm)."""
+    shapes = [(512, 256), (256, 768), (80, 208), (272, 512)] if rows < 10000 else [(4096, 1024), (1024, 4096), (1024, 1024)]  # a ViT-Large block's fc1, fc2, proj
+    for rep in range(2):
+        probs, ref, ref16 = [], [], []
+        for i, (n, k) in enumerate(shapes):
+            dy = rnd(rows, n, scale=0.5, seed=180 + i + 7 * rep)
+            x = rnd(rows, k, scale=0.5, seed=190 + i + 7 * rep)
+            dy8, sdy = K.quantize_fp8(dy)
+            x8, sx = K.quantize_fp8(x)
+            base = rnd(n, k, dtype=torch.float32, seed=200 + i)
+            probs.append((dy8, sdy, x8, sx, base.clone()))
+            ddy, dx = _e4m3_decode(dy8.cpu()).to(DEV) * sdy, _e4m3_decode(x8.cpu()).to(DEV) * sx
+            ref.append(base + ddy.t() @ dx)
+            ref16.append(dy.float().t() @ x.float())
+        K.gemm_fp8_wgrad_grouped(probs)
+        for (dy8, sdy, x8, sx, dst), rd, r16, (n, k) in zip(probs, ref, ref16, shapes):
+            close(dst, rd, 0.0, 1e-3 * float(rd.abs().max()), f"fp8 wgrad {n}x{k} rep {rep}")
+            base = rnd(n, k, dtype=torch.float32, seed=200 + shapes.index((n, k)))
+            assert float(((dst - base) - r16).norm() / r16.norm()) <= 6e-2
+    ws = K._p256_workspace(torch.device(DEV, torch.cuda.current_device()))
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "tile counters / error word not left at zero"
+    with pytest.raises(K.HipLibraryError):  # feature counts must be multiples of 16 bytes
+        K.gemm_fp8_wgrad_grouped([(torch.zeros(64, 24, dtype=torch.uint8, device=DEV), torch.ones(1, device=DEV), torch.zeros(64, 32, dtype=torch.uint8, device=DEV),
+                                   torch.ones(1, device=DEV), torch.zeros(24, 32, device=DEV))])

@@ -69,9 +69,10 @@ def main() -> None:
             "dec block": [(32848, 512, 512), (10944, 1024, 512), (32848, 512, 512), (32848, 2048, 512), (32848, 512, 2048)],
             "dec no kv": [(32848, 512, 512), (32848, 512, 512), (32848, 2048, 512), (32848, 512, 2048)],
             "shared kv": [(10944, 8192, 512)],
+            "large enc": [(13824, 3072, 1024), (13824, 1024, 1024), (13824, 4096, 1024), (13824, 1024, 4096)], "large mlp": [(13824, 4096, 1024), (13824, 1024, 4096)],
             "4096^3": [(4096, 4096, 4096)], "8192^3": [(8192, 8192, 8192)],
         }
-        print(f"{'block':12s} | {'128x128 split-K + reduce':>26s} {'128x128 grouped whole-K':>26s} {'p256 grouped':>22s}")
+        print(f"{'block':12s} | {'128x128 split-K + reduce':>26s} {'128x128 grouped whole-K':>26s} {'p256 grouped':>22s} {'p256 e4m3 operands':>22s}")
         for name, gs in blocks.items():
             probs = []
             for rows, n, k in gs:
@@ -84,11 +85,12 @@ def main() -> None:
                 for dy, x, dst, rs in probs:
                     K.gemm(dy, x, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy.shape[0], dy.shape[1], x.shape[1]), a_rowsum=rs)
 
-            fns = {"old": old, "p256": lambda: K.gemm_wgrad_grouped(probs, p256=True)}
+            q8 = [(*K.quantize_fp8(dy), *K.quantize_fp8(x), dst) for dy, x, dst, _ in probs]
+            fns = {"old": old, "p256": lambda: K.gemm_wgrad_grouped(probs, p256=True), "fp8": lambda: K.gemm_fp8_wgrad_grouped(q8)}
             if len({r for r, _, _ in gs}) == 1:
                 fns["grouped"] = lambda: K.gemm_wgrad_grouped(probs)
             r = bench(fns, iters=4)
-            print(f"{name:12s} | {fmt(flops, r['old']):>26s} {(fmt(flops, r['grouped']) if 'grouped' in r else '-'):>26s} {fmt(flops, r['p256']):>22s}", flush=True)
+            print(f"{name:12s} | {fmt(flops, r['old']):>26s} {(fmt(flops, r['grouped']) if 'grouped' in r else '-'):>26s} {fmt(flops, r['p256']):>22s} {fmt(flops, r['fp8']):>22s}", flush=True)
 
 
 if __name__ == "__main__":
