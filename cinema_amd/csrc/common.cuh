@@ -206,6 +206,30 @@ __device__ __forceinline__ void glds16x4(uint32_t a0, uint32_t a1, uint32_t a2, 
       : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(a0), "s"(a1), "s"(a2), "s"(a3)
       : "memory");
 }
+__device__ __forceinline__ float bf_lo16(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// ---- 8-bit output copies with per-tensor delayed scaling (cinema_q8_out): four values -> four e4m3 bytes, saturated (the scale comes from the previous step's
+// maximum, so this step's values may exceed it); the wave's maximum goes into one of Q8_SLOTS slots (device-scope atomics on ONE address serialise: 64 slots still cost 20-40 us per launch of ~14 k waves)
+__device__ __forceinline__ int q8_pack4(float a, float b, float c, float d, float inv) {
+  const float lim = 448.0f;
+  a = fminf(fmaxf(a * inv, -lim), lim); b = fminf(fmaxf(b * inv, -lim), lim); c = fminf(fmaxf(c * inv, -lim), lim); d = fminf(fmaxf(d * inv, -lim), lim);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return w;
+}
+constexpr int Q8_SLOTS = 4096;  // = CINEMA_Q8_SLOTS of include/cinema_hip.h
+__device__ __forceinline__ void q8_amax_commit(unsigned int* slots, float lane_amax, int slot) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lane_amax = fmaxf(lane_amax, __shfl_xor(lane_amax, o, 64));
+  // non-negative floats order like their bit patterns.  A wave first LOOKS at its slot (one L2 load) and only raises it when it has to
+  if ((threadIdx.x & 63) == 0 && lane_amax > 0.f) {
+    unsigned int* s = slots + (slot & (Q8_SLOTS - 1));
+    const unsigned int bits = __float_as_uint(lane_amax);
+    if (__hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(s, bits);
+  }
+}
+
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }  // low 32 bits of a flat LDS pointer = LDS byte address
 
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private 4 MiB L2.  xcd_remap() is a bijection

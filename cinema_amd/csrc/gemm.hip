@@ -112,6 +112,7 @@ __device__ __forceinline__ void block_epilogue_rows(const GemmP& p, const float1
   const int rl = lane / LPR, cl = (lane % LPR) * W;
   const int n = nw + cl;
   float bv[W];
+  float q8max = 0.f;
   EpiPre<W> pre[PASSES];
   epi_load_bias<W>(p, n, true, bv);
 #pragma unroll
@@ -132,8 +133,9 @@ __device__ __forceinline__ void block_epilogue_rows(const GemmP& p, const float1
       const float4 t = *reinterpret_cast<const float4*>(stg + r * 32 + ((((cl >> 2) + c) ^ (r & 7)) << 2));
       v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
     }
-    if (m < p.m && n < p.n) epi_apply<W>(p, m, n, v, bv, pre[pss]);
+    if (m < p.m && n < p.n) epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
   }
+  if (p.out8_amax) q8_amax_commit(p.out8_amax, q8max, (int)blockIdx.x + (int)(threadIdx.x >> 6));
 }
 typedef unsigned int tail_u32x4 __attribute__((ext_vector_type(4)));
 template <int EPI, int NI>
@@ -509,7 +511,15 @@ __device__ __forceinline__ void tail_fixup_body(const GemmP& p, int tiles_m, int
     epilogue_row<4>(p, m, n, lo, true);
     epilogue_row<4>(p, m, n + 4, hi, true);
   } else {
-    epilogue_row<8>(p, m, n, v, true);
+    float bv[8], q8max = 0.f;
+    EpiPre<8> e;
+    epi_load_bias<8>(p, n, true, bv);
+    epi_load<8>(p, m, n, e);
+    epi_apply<8>(p, m, n, v, bv, e, q8max);
+    if (p.out8_amax && q8max > 0.f) {  // a few thousand threads per launch: per-lane, look before raising
+      unsigned int* s8 = p.out8_amax + ((blockIdx.x * 256 + threadIdx.x) & (Q8_SLOTS - 1));
+      if (__hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __float_as_uint(q8max)) atomicMax(s8, __float_as_uint(q8max));
+    }
   }
 }
 __global__ __launch_bounds__(256) void tail_fixup_kernel(TailFixP t) { tail_fixup_body(t.p, t.tiles_m, t.tiles_n); }
@@ -677,6 +687,10 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   p.gelu_in = a->gelu_in; p.ld_gelu = a->ld_gelu; p.row_mask = a->row_mask; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
   p.act = a->act; p.gelu_deriv = a->gelu_deriv; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.ws = nullptr; p.a_rowsum = nullptr;
   p.scale_a = nullptr; p.scale_b = nullptr; p.scale_a_rows = 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
+  if (a->out8_amax) {  // 8-bit output copy / maximum: bf16 outputs only, 8-byte rows
+    if (a->out_f32 || (a->out8 && (!a->out8_inv_scale || (a->ld_out8 & 7) || (((uintptr_t)a->out8) & 7)))) return CINEMA_ERR_BAD_ARG;
+    p.out8 = a->out8; p.ld_out8 = a->ld_out8; p.out8_inv = a->out8_inv_scale; p.out8_amax = a->out8_amax;
+  } else if (a->out8) return CINEMA_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -687,6 +701,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   fast = fast && (!a->residual_bf16 || (al8(a->ld_res) && ptr16(a->residual_bf16))) && (!a->gelu_in || (al8(a->ld_gelu) && ptr16(a->gelu_in)));
   fast = fast && (!a->aux_out || (al8(a->ld_aux) && ptr16(a->aux_out)));
   fast = fast && !(a->a_kmajor == 0 && a->b_kmajor == 1);  // (M-major A, K-major B) is not used by the path
+  if (!fast && p.out8_amax) return CINEMA_ERR_UNSUPPORTED;  // the 8-bit copy is written by the staged MFMA epilogues only
   if (fast) {
     const int nkt = (a->k + BK - 1) / BK;
     const int sp = split > nkt ? nkt : split;
@@ -844,6 +859,10 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
   p.act = a->act; p.gelu_deriv = a->gelu_deriv; p.out_f32 = a->out_f32; p.accumulate = 0; p.ws = nullptr; p.a_rowsum = nullptr;
   p.tail_begin = 0; p.tail_split = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
   p.scale_a = a->scale_a; p.scale_b = a->scale_b; p.scale_a_rows = a->scale_a_rows ? 1 : 0; p.conv_taps = nullptr; p.conv_coords = nullptr; p.cZB = 1;
+  if (a->out8_amax) {
+    if (a->out_f32 || (a->out8 && (!a->out8_inv_scale || (a->ld_out8 & 7) || (((uintptr_t)a->out8) & 7)))) return CINEMA_ERR_BAD_ARG;
+    p.out8 = a->out8; p.ld_out8 = a->ld_out8; p.out8_inv = a->out8_inv_scale; p.out8_amax = a->out8_amax;
+  } else if (a->out8) return CINEMA_ERR_BAD_ARG;
   const int nkt = (p.k + BK - 1) / BK;
   p.ktiles_per_split = nkt;
   dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);

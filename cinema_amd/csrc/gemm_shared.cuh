@@ -43,6 +43,9 @@ struct GemmP {
   // weight gradient of that convolution (MODE_CONVW): dW[co][(tap, ci)] = sum_r dy[r][co] * x[nbr_tap(r)][ci]: the B operand (reduction-strided,
   // [rows][taps * C]) is the virtual im2col matrix; conv_coords[r] = x | y << 10 | z << 20 of voxel r (one int per row, shape-only table)
   const int* conv_coords;
+  // optional 8-bit copy of a bf16 output with per-tensor delayed scaling (cinema_q8_out semantics; the epilogue classes with a bf16 D): out8[m][ld_out8] =
+  // e4m3(sat(D * *out8_inv)); the launch's max|D| goes into out8_amax[64] (also without out8: calibration)
+  uint8_t* out8 = nullptr; int ld_out8 = 0; const float* out8_inv = nullptr; unsigned int* out8_amax = nullptr;
 };
 
 __device__ __forceinline__ float frag_sum8(const short8v& f) {
@@ -157,7 +160,7 @@ __device__ __forceinline__ void epi_load(const GemmP& p, int m, int n0, EpiPre<W
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 template <int W>
-__device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (&v)[W], const float (&bv)[W], const EpiPre<W>& e) {
+__device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (&v)[W], const float (&bv)[W], const EpiPre<W>& e, float& q8max) {
   const float al = p.scale_a_rows ? p.alpha * p.scale_a[m] : p.alpha;  // fp8 operands with per-row activation scales (p.alpha already holds scale_b)
 #pragma unroll
   for (int i = 0; i < W; i++) v[i] = fmaf(v[i], al, bv[i]);
@@ -226,7 +229,22 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
     }
   } else {
     store_bf16(reinterpret_cast<bf16_t*>(p.d) + (size_t)m * p.ldd + n0);
+    if (p.out8_amax) {  // 8-bit copy of the same values (per-tensor delayed scale) + this launch's maximum
+#pragma unroll
+      for (int i = 0; i < W; i++) q8max = fmaxf(q8max, fabsf(v[i]));
+      if (p.out8) {
+        const float inv = *p.out8_inv;
+        uint8_t* dst8 = p.out8 + (size_t)m * p.ld_out8 + n0;
+        if (W == 8) { uint2 pk; pk.x = (uint32_t)q8_pack4(v[0], v[1], v[2], v[3], inv); pk.y = (uint32_t)q8_pack4(v[W - 4], v[W - 3], v[W - 2], v[W - 1], inv); *reinterpret_cast<uint2*>(dst8) = pk; }
+        else *reinterpret_cast<int*>(dst8) = q8_pack4(v[0], v[1], v[2], v[3], inv);
+      }
+    }
   }
+}
+template <int W>
+__device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (&v)[W], const float (&bv)[W], const EpiPre<W>& e) {
+  float unused = 0.f;
+  epi_apply<W>(p, m, n0, v, bv, e, unused);
 }
 template <int W>
 __device__ __forceinline__ void epilogue_row(const GemmP& p, int m, int n0, float (&v)[W], bool add_bias) {
@@ -249,7 +267,7 @@ __device__ __forceinline__ GemmP epi_fold(GemmP p) {  // a by-value copy with th
   if (EPI == EPI_BF16) { p.out_f32 = 0; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; p.res_f32 = nullptr; }
   if (EPI == EPI_BF16_GELU) { p.out_f32 = 0; p.act = 1; p.gelu_in = nullptr; p.res_f32 = nullptr; }                     // bias + GELU, optional pre-activation out
   if (EPI == EPI_BF16_GELU_GRAD) { p.out_f32 = 0; p.act = 0; p.aux_out = nullptr; p.res_f32 = nullptr; p.bias = nullptr; }  // dY * GELU'(pre-activation)
-  if (EPI == EPI_F32) { p.out_f32 = 1; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; }                           // optional bias and fp32 residual
+  if (EPI == EPI_F32) { p.out_f32 = 1; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; p.out8 = nullptr; p.out8_amax = nullptr; }                           // optional bias and fp32 residual
   return p;
 }
 
@@ -269,6 +287,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmP& p, const float16
   const int rl = lane / LPR, cl = (lane % LPR) * W;
   const int n = nw + cl;
   float bv[W];
+  float q8max = 0.f;
   EpiPre<W> pre[PASSES];
   if (!ws_base) {
     epi_load_bias<W>(p, n, add_bias, bv);
@@ -301,10 +320,11 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmP& p, const float16
 #pragma unroll
         for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
       } else {
-        epi_apply<W>(p, m, n, v, bv, pre[pss]);
+        epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
       }
     }
   }
+  if (!ws_base && p.out8_amax) q8_amax_commit(p.out8_amax, q8max, (int)blockIdx.x + (int)(threadIdx.x >> 6));
 }
 
 template <int EPI>
@@ -550,6 +570,7 @@ __device__ __forceinline__ void half_epilogue_rows(const GemmP& p, const float16
   const int rl = lane / LPR, cl = (lane % LPR) * W;
   const int n = nw + cl;
   float bv[W];
+  float q8max = 0.f;
   EpiPre<W> pre[PASSES];
   if (!ws_base) {
     epi_load_bias<W>(p, n, add_bias, bv);
@@ -580,10 +601,11 @@ __device__ __forceinline__ void half_epilogue_rows(const GemmP& p, const float16
 #pragma unroll
         for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
       } else {
-        epi_apply<W>(p, m, n, v, bv, pre[pss]);
+        epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
       }
     }
   }
+  if (!ws_base && p.out8_amax) q8_amax_commit(p.out8_amax, q8max, (int)blockIdx.x + (int)(threadIdx.x >> 6));
 }
 
 template <int EPI>

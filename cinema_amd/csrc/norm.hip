@@ -32,6 +32,7 @@ struct LnFwdP {
   float* mean; float* rstd;
   int lpr;  // lanes per row (power of two, <= 64)
   uint8_t* y_fp8; float* row_scale;  // optional e4m3 copy of y with ONE scale per row (amax(row) / 448): the A operand of cinema_gemm_fp8(row scales)
+  const float* q8_inv; unsigned int* q8_amax;  // per-TENSOR delayed scale instead (cinema_q8_out): y_fp8 = e4m3(sat(y * *q8_inv)), the launch's maximum into q8_amax
 };
 
 template <int CPL>
@@ -43,6 +44,7 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
   const int n_waves = gridDim.x * (blockDim.x >> 6);
   const int nch = p.c >> 2;
   const float inv_c = 1.f / (float)p.c;
+  float tmax = 0.f;
   for (int row0 = wave_global * rows_per_wave; row0 < p.rows; row0 += n_waves * rows_per_wave) {
     const int row = row0 + lane / p.lpr;
     const bool rv = row < p.rows;
@@ -83,9 +85,20 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
       if (p.act == 1) { gelu2(y.x, y.y); gelu2(y.z, y.w); }
       if (p.y_bf16) store4_bf16(p.y_bf16 + (size_t)row * p.ldy + ch * 4, y);
       if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + (size_t)row * p.ldy + ch * 4) = y;
-      if (p.y_fp8) { v[i] = y; amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))); }
+      if (p.y_fp8 || p.q8_amax) { v[i] = y; amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))); }
     }
-    if (p.y_fp8) {  // per-row e4m3 copy: the row's maximum is a reduction over the row's own lanes only, so the quantisation costs no extra pass
+    if (p.q8_amax) {  // per-tensor delayed scale: no reduction at all in the row, the maximum is committed once per wave after the loop
+      tmax = fmaxf(tmax, amax);
+      if (p.y_fp8) {
+        const float inv = *p.q8_inv;
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+          const int ch = sub + i * p.lpr;
+          if (ch >= nch) continue;
+          *reinterpret_cast<int*>(p.y_fp8 + (size_t)row * p.c + ch * 4) = q8_pack4(v[i].x, v[i].y, v[i].z, v[i].w, inv);
+        }
+      }
+    } else if (p.y_fp8) {  // per-row e4m3 copy: the row's maximum is a reduction over the row's own lanes only, so the quantisation costs no extra pass
       for (int o = p.lpr >> 1; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
       const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / scale;
       if (sub == 0) p.row_scale[row] = scale;
@@ -100,6 +113,7 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
       }
     }
   }
+  if (p.q8_amax) q8_amax_commit(p.q8_amax, tmax, wave_global);
 }
 template <int CPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) { ln_fwd_body<CPL>(p); }
@@ -114,6 +128,7 @@ struct LnBwdP {
   float* dgamma; float* dbeta;
   int lpr;
   float* ws;  // per-block partial sums [gridDim.x][2][c] (then ln_param_reduce_kernel) or nullptr: atomics from every block
+  uint8_t* dx_fp8; const float* q8_inv; unsigned int* q8_amax;  // optional 8-bit copy of dx, dense [rows][c] (cinema_q8_out)
 };
 
 // RG = independent row groups per wave iteration: narrow rows (CPL <= 2) carry only 2-4 16-byte loads per lane, too few
@@ -132,6 +147,8 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
   float4 ag[CPL], ab[CPL];
 #pragma unroll
   for (int i = 0; i < CPL; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+  float qmax = 0.f;
+  const float q8inv = (p.q8_amax && p.dx_fp8) ? *p.q8_inv : 1.f;
 
   for (int row0 = wave_global * rows_per_wave * RG; row0 < p.rows; row0 += n_waves * rows_per_wave * RG) {
     float4 xh[RG][CPL], dxh[RG][CPL];
@@ -208,9 +225,14 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
         }
         if (p.dx_f32) *reinterpret_cast<float4*>(p.dx_f32 + off) = dx;
         if (p.dx_bf16) store4_bf16(p.dx_bf16 + off, dx);
+        if (p.q8_amax) {
+          qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(dx.x), fabsf(dx.y)), fmaxf(fabsf(dx.z), fabsf(dx.w))));
+          if (p.dx_fp8) *reinterpret_cast<int*>(p.dx_fp8 + (size_t)row * p.c + ch * 4) = q8_pack4(dx.x, dx.y, dx.z, dx.w, q8inv);
+        }
       }
     }
   }
+  if (p.q8_amax) q8_amax_commit(p.q8_amax, qmax, wave_global);
   if (!p.dgamma && !p.dbeta) return;
   // reduce over the row sub-groups of the wave (lanes that own the same columns), then over the block's waves
 #pragma unroll
@@ -350,7 +372,7 @@ int dispatch_cpl(int cpl, F&& f) {
 }  // namespace
 
 static int layernorm_fwd_impl(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act, uint16_t* y_bf16,
-                              float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream);
+                              float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream, const cinema_q8_out* q8 = nullptr);
 CINEMA_API int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps,
                                     int act, uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, void* stream) {
   return layernorm_fwd_impl(x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, nullptr, nullptr, stream);
@@ -361,12 +383,18 @@ CINEMA_API int cinema_layernorm_fwd_fp8(const void* x, int x_is_bf16, int ldx, c
   if (!y_fp8 || !row_scale || (c & 3)) return CINEMA_ERR_BAD_ARG;
   return layernorm_fwd_impl(x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, y_fp8, row_scale, stream);
 }
+CINEMA_API int cinema_layernorm_fwd_q8(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act,
+                                       uint16_t* y_bf16, float* y_f32, int ldy, float* mean, float* rstd, const cinema_q8_out* q8, void* stream) {
+  if (!q8 || !q8->amax_slots || (q8->data && !q8->inv_scale) || (c & 3)) return CINEMA_ERR_BAD_ARG;
+  return layernorm_fwd_impl(x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, q8->data, nullptr, stream, q8);
+}
 static int layernorm_fwd_impl(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act, uint16_t* y_bf16,
-                              float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream) {
+                              float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream, const cinema_q8_out* q8) {
   if (!x || !gamma || !beta || rows <= 0 || c <= 0 || (!y_bf16 && !y_f32)) return CINEMA_ERR_BAD_ARG;
-  LnFwdP p{x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, pick_lpr(c), y_fp8, row_scale};
+  LnFwdP p{x, x_is_bf16, ldx, gamma, beta, rows, c, eps, act, y_bf16, y_f32, ldy, mean, rstd, pick_lpr(c), y_fp8, row_scale, q8 ? q8->inv_scale : nullptr,
+           q8 ? q8->amax_slots : nullptr};
   if ((c & 3) || (ldx & 3) || (ldy & 3)) {
-    if (c > 64 || y_fp8) return CINEMA_ERR_UNSUPPORTED;
+    if (c > 64 || y_fp8 || q8) return CINEMA_ERR_UNSUPPORTED;
     CINEMA_LAUNCH(ln_fwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
   }
@@ -383,14 +411,14 @@ static int layernorm_fwd_impl(const void* x, int x_is_bf16, int ldx, const float
 static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
                               const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                               const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
-                              float* workspace, long long workspace_bytes, int* deferred_partials, void* stream) {
+                              float* workspace, long long workspace_bytes, int* deferred_partials, void* stream, const cinema_q8_out* q8 = nullptr) {
   if (deferred_partials) *deferred_partials = 0;
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
   if (act == 1 && !beta) return CINEMA_ERR_BAD_ARG;
   LnBwdP p{dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
-           pick_lpr(c), nullptr};
+           pick_lpr(c), nullptr, q8 ? q8->data : nullptr, q8 ? q8->inv_scale : nullptr, q8 ? q8->amax_slots : nullptr};
   if ((c & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) {
-    if (c > 64) return CINEMA_ERR_UNSUPPORTED;
+    if (c > 64 || q8) return CINEMA_ERR_UNSUPPORTED;
     CINEMA_LAUNCH(ln_bwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
   }
@@ -441,6 +469,15 @@ CINEMA_API int cinema_layernorm_bwd_deferred(const void* dy, int dy_is_bf16, int
   if (!n_partials_out) return CINEMA_ERR_BAD_ARG;
   return layernorm_bwd_impl(dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
                             workspace, workspace_bytes, n_partials_out, stream);
+}
+
+CINEMA_API int cinema_layernorm_bwd_deferred_q8(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta,
+                                                const float* mean, const float* rstd, int rows, int c, int act, const float* dx_residual, float* dx_f32,
+                                                uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta, float* workspace, long long workspace_bytes,
+                                                int* n_partials_out, const cinema_q8_out* q8, void* stream) {
+  if (!n_partials_out || !q8 || !q8->amax_slots || (q8->data && !q8->inv_scale)) return CINEMA_ERR_BAD_ARG;
+  return layernorm_bwd_impl(dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
+                            workspace, workspace_bytes, n_partials_out, stream, q8);
 }
 
 namespace {

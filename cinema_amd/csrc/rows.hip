@@ -623,6 +623,55 @@ CINEMA_API int cinema_quantize_fp8_segments_t(const uint16_t* x, const long long
   return launch_status();
 }
 
+// ---- per-tensor DELAYED scaling (cinema_q8_out): maxima -> scales, one wave per site; and the stand-alone producer ------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void fp8_sites_update_kernel(unsigned int* amax, float* scale, float* inv, int n_sites, float margin) {
+  __shared__ float part[4];
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // one workgroup per site
+  unsigned int* slots = amax + (size_t)s * Q8_SLOTS;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < Q8_SLOTS; i += 256) { a = fmaxf(a, __uint_as_float(slots[i])); slots[i] = 0u; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+  if (lane == 0) part[wave] = a;
+  __syncthreads();
+  a = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+  if (threadIdx.x == 0 && a > 0.f && a < 3.0e38f) {  // nothing recorded / a non-finite step: keep the previous scale
+    const float sc = a * margin * (1.0f / 448.0f);
+    scale[s] = sc;
+    inv[s] = 1.0f / sc;
+  }
+}
+__global__ __launch_bounds__(256) void quantize_fp8_site_kernel(const bf16_t* x, long long n8, uint8_t* y, const float* inv_p, unsigned int* amax) {
+  const float inv = y ? *inv_p : 1.f;
+  float mx = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const uint4 u = reinterpret_cast<const uint4*>(x)[i];
+    float f[8] = {bf_lo16(u.x), bf_hi16(u.x), bf_lo16(u.y), bf_hi16(u.y), bf_lo16(u.z), bf_hi16(u.z), bf_lo16(u.w), bf_hi16(u.w)};
+#pragma unroll
+    for (int e = 0; e < 8; e++) mx = fmaxf(mx, fabsf(f[e]));
+    if (y) {
+      uint2 pk;
+      pk.x = (uint32_t)q8_pack4(f[0], f[1], f[2], f[3], inv); pk.y = (uint32_t)q8_pack4(f[4], f[5], f[6], f[7], inv);
+      reinterpret_cast<uint2*>(y)[i] = pk;
+    }
+  }
+  q8_amax_commit(amax, mx, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+}
+}  // namespace
+CINEMA_API int cinema_fp8_sites_update(unsigned int* amax_slots, float* scale, float* inv_scale, int n_sites, float margin, void* stream) {
+  if (!amax_slots || !scale || !inv_scale || n_sites <= 0 || !(margin >= 1.0f)) return CINEMA_ERR_BAD_ARG;
+  CINEMA_LAUNCH(fp8_sites_update_kernel, dim3(n_sites), dim3(256), 0, (hipStream_t)stream, amax_slots, scale, inv_scale, n_sites, margin);
+  return launch_status();
+}
+CINEMA_API int cinema_quantize_fp8_site(const uint16_t* x, long long n, const cinema_q8_out* q8, void* stream) {
+  if (!x || n <= 0 || (n & 7) || !q8 || !q8->amax_slots || (q8->data && !q8->inv_scale) || (((uintptr_t)x) & 15) || (((uintptr_t)q8->data) & 7)) return CINEMA_ERR_BAD_ARG;
+  long long g = (n / 8 + 255) / 256;
+  if (g > 2048) g = 2048;
+  CINEMA_LAUNCH(quantize_fp8_site_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n / 8, q8->data, q8->inv_scale, q8->amax_slots);
+  return launch_status();
+}
+
 CINEMA_API int cinema_quantize_fp8(const uint16_t* x, long long n, uint8_t* y, float* scale_out, unsigned int* amax_ws, void* stream) {
   if (!x || !y || !scale_out || !amax_ws || n <= 0) return CINEMA_ERR_BAD_ARG;
   if ((n & 7) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CINEMA_ERR_UNSUPPORTED;

@@ -41,9 +41,34 @@ class GemmArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("a_rowsum", C.c_void_p),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
         ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int), ("conv_coords", C.c_void_p), ("conv_zb", C.c_int),
+        ("out8", C.c_void_p), ("ld_out8", C.c_int), ("out8_inv_scale", C.c_void_p), ("out8_amax", C.c_void_p),
         ("tail_counters", C.c_void_p),
         ("kernel_used", C.c_int),
     ]
+
+
+class Q8Out(C.Structure):
+    """Mirror of ``cinema_q8_out``."""
+
+    _fields_ = [("data", C.c_void_p), ("inv_scale", C.c_void_p), ("amax_slots", C.c_void_p)]
+
+
+class Q8Site:
+    """One tensor position of the model with an 8-bit copy under per-tensor DELAYED scaling (``cinema_q8_out``): views into the site arrays of
+    ``cinema_amd.tape.Fp8Sites`` - ``scale`` fp32 [1] (dequantisation multiplier, read by the consuming GEMMs), ``inv`` fp32 [1], ``amax`` int32 [CINEMA_Q8_SLOTS] (this step's
+    maximum, float bits).  ``ready``: a scale derived from a recorded maximum exists (one step after the site first ran); until then producers record only."""
+
+    __slots__ = ("scale", "inv", "amax", "owner", "born")
+
+    def __init__(self, scale: torch.Tensor, inv: torch.Tensor, amax: torch.Tensor, owner, born: int) -> None:  # noqa: ANN001
+        self.scale, self.inv, self.amax, self.owner, self.born = scale, inv, amax, owner, born
+
+    @property
+    def ready(self) -> bool:
+        return self.owner.updates > self.born
+
+    def out(self, data: torch.Tensor | None) -> Q8Out:
+        return Q8Out(None if data is None else data.data_ptr(), self.inv.data_ptr(), self.amax.data_ptr())
 
 
 # cinema_gemm_args.kernel_used -> kernel name as rocprofv3 prints it: 0 generic, otherwise
@@ -108,6 +133,10 @@ _PROTOS = {
     "cinema_conv_weight_dgrad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cinema_quantize_fp8": [_vp, _ll, _vp, _vp, _vp, _vp],
     "cinema_quantize_fp8_rows": [_vp, _i, _i, _vp, _vp, _vp],
+    "cinema_fp8_sites_update": [_vp, _vp, _vp, _i, _f, _vp],
+    "cinema_quantize_fp8_site": [_vp, _ll, C.POINTER(Q8Out), _vp],
+    "cinema_layernorm_fwd_q8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(Q8Out), _vp],
+    "cinema_layernorm_bwd_deferred_q8": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, C.POINTER(C.c_int), C.POINTER(Q8Out), _vp],
     "cinema_layernorm_fwd_fp8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_quantize_fp8_segments": [_vp, _vp, _i, _vp, _vp, _vp, _vp],
     "cinema_quantize_fp8_segments_t": [_vp, _vp, _i, _vp, _vp, _vp],
@@ -450,12 +479,23 @@ def _p256_call(arr, count: int, schedule: int, device: torch.device) -> None:  #
 
 
 # --------------------------------------------------------------------------------------------------------
+def _set_out8(g: GemmArgs, out8: tuple, m: int, n: int) -> None:
+    site, data = out8
+    if data is not None:
+        _dev(data)
+        if data.dtype != torch.uint8 or tuple(data.shape) != (m, n):
+            raise HipLibraryError("out8 must be uint8 [M, N]")
+        g.out8, g.ld_out8 = data.data_ptr(), _rowmajor(data, "out8")
+    g.out8_inv_scale, g.out8_amax = site.inv.data_ptr(), site.amax.data_ptr()
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True, out: torch.Tensor | None = None,
          out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None,
          gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, aux_out: torch.Tensor | None = None,
          act: int = 0, accumulate: bool = False, split_k: int = 1, alpha: float = 1.0, force_generic: bool = False,
-         a_rowsum: torch.Tensor | None = None, p256: int | None = None, gelu_deriv: bool = False) -> torch.Tensor:
-    """D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N].
+         a_rowsum: torch.Tensor | None = None, p256: int | None = None, gelu_deriv: bool = False, out8: tuple | None = None) -> torch.Tensor:
+    """``out8`` = (Q8Site, uint8 [M, N] | None): 8-bit copy of a bf16 result with the site's delayed scale (None: record the maximum only).
+    D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N].
     ``gelu_deriv``: the auxiliary GELU tensor holds GELU'(pre-activation) - written to ``aux_out`` by an ``act=1`` launch, multiplied in from ``gelu_in``.
     ``p256`` = 0 / 1: the persistent 256x256 kernel with its split / stream schedule (``split_k`` = 1 then means whole-K tiles, 0 balanced slices)."""
     lib = load()
@@ -501,6 +541,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     if a_rowsum is not None:  # fp32 [m], accumulated: sum_k A[m, k] (bias gradient of a weight-gradient GEMM)
         _dev(a_rowsum)
         g.a_rowsum = a_rowsum.data_ptr()
+    if out8 is not None:
+        _set_out8(g, out8, m, n)
     if p256 is not None:
         if GEMM_PROFILE is None or LANE is not None:
             _p256_call(C.byref(g), 1, p256, a.device)
@@ -553,6 +595,23 @@ def quantize_fp8(x: torch.Tensor) -> tuple:
     return y, scale
 
 
+def quantize_fp8_site(x: torch.Tensor, site: Q8Site) -> tuple | None:
+    """Stand-alone producer of an 8-bit copy under the site's delayed per-tensor scale: -> (uint8 tensor of x's shape, site.scale), or None while the site has
+    no scale yet (this launch then only records max|x|).  One pass, no maximum pre-pass."""
+    _dev(x)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.numel() % 8:
+        raise HipLibraryError("quantize_fp8_site: contiguous bf16 with a multiple of 8 elements")
+    y = _empty(x.shape, dtype=torch.uint8, device=x.device) if site.ready else None
+    q = site.out(y)
+    _check(load().cinema_quantize_fp8_site(x.data_ptr(), x.numel(), C.byref(q), _stream()), "quantize_fp8_site")
+    return None if y is None else (y, site.scale)
+
+
+def fp8_sites_update(amax: torch.Tensor, scale: torch.Tensor, inv: torch.Tensor, n_sites: int, margin: float) -> None:
+    _dev(amax, scale, inv)
+    _check(load().cinema_fp8_sites_update(amax.data_ptr(), scale.data_ptr(), inv.data_ptr(), n_sites, margin, _stream()), "fp8_sites_update")
+
+
 def quantize_fp8_rows(x: torch.Tensor) -> tuple:
     """Per-row e4m3 quantisation of a contiguous bf16 matrix [rows, c]: -> (uint8 [rows, c], fp32 [rows] scales); one launch."""
     _dev(x)
@@ -587,7 +646,8 @@ def quantize_fp8_segments_t(x: torch.Tensor, seg_desc: torch.Tensor, scales: tor
 
 def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16,
              bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, aux_out: torch.Tensor | None = None, act: int = 0,
-             alpha: float = 1.0, out: torch.Tensor | None = None, gelu_in: torch.Tensor | None = None, gelu_deriv: bool = False) -> torch.Tensor:
+             alpha: float = 1.0, out: torch.Tensor | None = None, gelu_in: torch.Tensor | None = None, gelu_deriv: bool = False,
+             out8: tuple | None = None) -> torch.Tensor:
     """D = epilogue(alpha * scale_a * scale_b * A8 @ B8^T): e4m3 operands a8 [M, K], b8 [N, K] (uint8 storage, k-major), per-tensor fp32 [1] scales;
     bias / exact GELU (+ bf16 pre-activation copy) / fp32 residual epilogue like :func:`gemm`."""
     _dev(a8, scale_a, b8, scale_b, bias, residual, aux_out)
@@ -620,6 +680,8 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
         _dev(gelu_in)
         g.gelu_in, g.ld_gelu = gelu_in.data_ptr(), _rowmajor(gelu_in, "gelu_in")
     g.act, g.out_f32, g.gelu_deriv = act, int(out.dtype == torch.float32), int(gelu_deriv)
+    if out8 is not None:
+        _set_out8(g, out8, m, n)
     _check(load().cinema_gemm_fp8(C.byref(g), _stream()), "gemm_fp8")
     return out
 
@@ -1103,14 +1165,26 @@ def colsum(x: torch.Tensor, out: torch.Tensor, row_idx: torch.Tensor | None = No
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, act: int = 0, want_bf16: bool = True,
-                  want_f32: bool = False, want_fp8: bool = False):  # noqa: ANN201
-    """x: [rows, c] fp32/bf16 -> (y_bf16 | None, y_f32 | None, mean, rstd) [+ (y_fp8 uint8 [rows, c], row_scale fp32 [rows]) with ``want_fp8``]."""
+                  want_f32: bool = False, want_fp8: bool = False, q8: Q8Site | None = None):  # noqa: ANN201
+    """x: [rows, c] fp32/bf16 -> (y_bf16 | None, y_f32 | None, mean, rstd) [+ (y_fp8 uint8 [rows, c], row_scale fp32 [rows]) with ``want_fp8``; with ``q8`` (a
+    site with a scale) the copy uses the site's per-tensor delayed scale: (y_fp8, site.scale); a site without a scale yet only records the maximum and the
+    per-row copy is returned]."""
     _dev(x, gamma, beta)
     rows, c = x.shape
     y16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     y32 = _empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None
     mean = _empty(rows, dtype=torch.float32, device=x.device)
     rstd = _empty(rows, dtype=torch.float32, device=x.device)
+    if q8 is not None and q8.ready:
+        y8 = _empty((rows, c), dtype=torch.uint8, device=x.device)
+        q = q8.out(y8)
+        _check(load().cinema_layernorm_fwd_q8(x.data_ptr(), int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), beta.data_ptr(), rows, c, eps, act,
+                                              _p(y16), _p(y32), c, mean.data_ptr(), rstd.data_ptr(), C.byref(q), _stream()), "layernorm_fwd_q8")
+        return y16, y32, mean, rstd, (y8, q8.scale)
+    if q8 is not None:  # calibration: the maximum of y16 through the stand-alone recorder (one extra pass, first step only)
+        out = layernorm_fwd(x, gamma, beta, eps, act=act, want_bf16=True, want_f32=want_f32, want_fp8=want_fp8)
+        quantize_fp8_site(out[0], q8)
+        return out
     if want_fp8:
         y8 = _empty((rows, c), dtype=torch.uint8, device=x.device)
         rscale = _empty(rows, dtype=torch.float32, device=x.device)
@@ -1125,11 +1199,32 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor | None, mean: torch.Tensor, rstd: torch.Tensor, *,
                   act: int = 0, dx_residual: torch.Tensor | None = None, want_f32: bool = True, want_bf16: bool = False,
                   dgamma: torch.Tensor | None = None, dbeta: torch.Tensor | None = None, dx_f32_out: torch.Tensor | None = None,
-                  deferred: list | None = None):  # noqa: ANN201
+                  deferred: list | None = None, q8: Q8Site | None = None):  # noqa: ANN201
     """-> (dx_f32 | None, dx_bf16 | None); dgamma/dbeta (fp32 [c]) are accumulated in place when given - at once, or (``deferred`` list)
-    by a later :func:`ln_param_reduce_batched` over the entries appended to that list."""
+    by a later :func:`ln_param_reduce_batched` over the entries appended to that list.  ``q8``: -> (dx_f32, dx_bf16, (dx8, site.scale) | None), the 8-bit copy of
+    dx under the site's delayed scale (deferred form only)."""
     _dev(dy, x, gamma, mean, rstd, dx_residual, dgamma, dbeta)
     rows, c = x.shape
+    if q8 is not None:
+        if deferred is None or (dgamma is None and dbeta is None) or c % 4:
+            r = layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=act, dx_residual=dx_residual, want_f32=want_f32, want_bf16=True, dgamma=dgamma, dbeta=dbeta,
+                              dx_f32_out=dx_f32_out, deferred=deferred)
+            return r[0], r[1], quantize_fp8_site(r[1], q8)
+        dx32 = dx_f32_out if dx_f32_out is not None else (_empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
+        dx16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+        dx8 = _empty((rows, c), dtype=torch.uint8, device=x.device) if q8.ready else None
+        if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
+            raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
+        ws = _empty(max(load().cinema_layernorm_bwd_workspace_bytes(rows, c) // 4, 4), dtype=torch.float32, device=x.device)
+        n_part = C.c_int(0)
+        q = q8.out(dx8)
+        _check(load().cinema_layernorm_bwd_deferred_q8(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
+                                                       int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
+                                                       rstd.data_ptr(), rows, c, act, _p(dx_residual), _p(dx32), _p(dx16), c, _p(dgamma), _p(dbeta),
+                                                       ws.data_ptr(), ws.numel() * 4, C.byref(n_part), C.byref(q), _stream()), "layernorm_bwd_q8")
+        if n_part.value > 0:
+            deferred.append((ws, n_part.value, c, dgamma, dbeta))
+        return dx32, dx16, (None if dx8 is None else (dx8, q8.scale))
     dx32 = dx_f32_out if dx_f32_out is not None else (_empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
     dx16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):

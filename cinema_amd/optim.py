@@ -245,7 +245,7 @@ class TrainStep:
             raise ValueError("hip_graph=True captures the single-process step; the data-parallel step runs eagerly")
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
-        if self.replay and enc_mask_dict is None and n_accum_steps == 1:
+        if self.replay and enc_mask_dict is None and n_accum_steps == 1 and not T.fp8_calibrating():  # (the first fp8 step records maxima: eager)
             return self._replay_step(image_dict, enc_mask_ratio, update_grad)
         if self.hip_graph and enc_mask_dict is None and n_accum_steps == 1 and update_grad:
             return self._graph_step(image_dict, enc_mask_ratio)
@@ -253,6 +253,7 @@ class TrainStep:
         if self.sync is not None:
             self.sync.arm(update_grad)  # on the micro-step that ends with the optimiser update, blocks all-reduce as their gradients complete
         (loss / n_accum_steps if n_accum_steps > 1 else loss).backward()
+        T.fp8_step_end()  # fp8 weight-gradient path: this step's recorded maxima become the next step's scales (no-op otherwise)
         grad_norm = None
         if update_grad:
             if self.sync is not None:
@@ -281,6 +282,7 @@ class TrainStep:
             loss, metrics = rec.loss, rec.metrics
         else:
             loss, metrics = rec.run(image_dict)
+        T.fp8_step_end()
         grad_norm = None
         if update_grad:
             if self.sync is not None:

@@ -31,14 +31,16 @@ class Var:
     gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
     """
 
-    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8")
+    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = True) -> None:
         self.data = data
         self.grad: torch.Tensor | None = None
         self.grad16: torch.Tensor | None = None
         self.needs_grad = needs_grad
-        self.fp8: tuple | None = None  # (e4m3 copy of data, per-row scales) when the producer emitted one (op_layernorm(fp8=True))
+        self.fp8: tuple | None = None  # (e4m3 copy of data, per-row scales [rows] or per-tensor scale [1]) when the producer emitted one (op_layernorm(fp8=True))
+        self.grad8: tuple | None = None  # (e4m3 copy of the complete gradient, per-tensor scale [1]): written by the LayerNorm backward that produces the gradient
+        self.grad8_site = None  # Q8Site: set by the op that wants that copy (its weight- and data-gradient GEMMs read it)
 
     def add_grad(self, g: torch.Tensor, g16: torch.Tensor | None = None) -> None:
         if not self.needs_grad:
@@ -48,6 +50,7 @@ class Var:
         else:
             K.row_copy(self.grad.view(-1, self.grad.shape[-1]), g.view(-1, g.shape[-1]), accumulate=True)
             self.grad16 = None
+            self.grad8 = None
 
     def grad_bf16(self) -> torch.Tensor:
         """bf16 view of the gradient (GEMM operand)."""
@@ -250,6 +253,7 @@ class Tape:
     def __init__(self, params: dict | None = None, train: bool = True) -> None:
         self.ops: list = []
         self.pending_wgrads: list = []  # (dy, x, dst, bias_grad) deferred to the enclosing weight-gradient group
+        self.pending_wgrads8: list = []  # the same for weight gradients on e4m3 operands (wgrad8_problem)
         self.pending_ln: list = []      # LayerNorm parameter-gradient partials: one batched reduce at the end of the backward pass
         self.grouping = False
         self.pvars: dict = {}
@@ -391,6 +395,103 @@ FP8_FORWARD = bool(int(os.environ.get("CINEMA_FP8", "0")))
 FP8_DGRAD = bool(int(os.environ.get("CINEMA_FP8_DGRAD", "1")))
 
 
+# WEIGHT gradients on e4m3 operands as well (follows FP8_FORWARD unless CINEMA_FP8_WGRAD=0).  dW = dY^T X reduces over the TOKENS, so per-token scales do not
+# factor out: the 8-bit copies of the activations and gradients of the transformer MLP / attention output projection carry ONE scale per tensor, taken from
+# the previous step's maximum (delayed scaling), and are written by the kernels that produce the tensors - LayerNorm forward (the normed rows), fc1's GELU
+# epilogue, fc2's data-gradient epilogue (x GELU'), the LayerNorm backward that completes a residual-stream gradient - or, for attention outputs, by one
+# stand-alone pass; the same copies feed the e4m3 forward and data-gradient GEMMs (no per-row quantisation launches for them).  The weight-gradient kernel
+# reads the row-major copies directly (ds_read_b64_tr_b8), see csrc/gemm256.hip form 3.  A site has no scale in its first step: that step runs the per-row /
+# bf16 forms and records maxima (``Fp8Sites.update`` at the end of every optimisation step turns them into scales).
+FP8_WGRAD = bool(int(os.environ.get("CINEMA_FP8_WGRAD", "1")))
+FP8_MARGIN = float(os.environ.get("CINEMA_FP8_MARGIN", "1.25"))  # scale = margin * amax / 448: headroom for a maximum that grows from one step to the next
+
+
+class Fp8Sites:
+    """Device arrays of the delayed-scaling sites (maxima [cap][4096 slots], scales [cap], inverse scales [cap]) and the key -> site registry."""
+
+    CAP = 1024
+    SLOTS = 4096  # CINEMA_Q8_SLOTS
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.amax = K.persistent(lambda: torch.zeros(self.CAP * self.SLOTS, dtype=torch.int32, device=device))
+        self.scale = K.persistent(lambda: torch.ones(self.CAP, dtype=F32, device=device))
+        self.inv = K.persistent(lambda: torch.ones(self.CAP, dtype=F32, device=device))
+        self.index: dict = {}
+        self.updates = 0
+
+    def site(self, key: tuple) -> K.Q8Site:
+        st = self.index.get(key)
+        if st is None:
+            i = len(self.index)
+            if i >= self.CAP:
+                raise RuntimeError("Fp8Sites: more than CAP delayed-scaling sites")
+            st = self.index[key] = K.Q8Site(self.scale[i:i + 1], self.inv[i:i + 1], self.amax[i * self.SLOTS:(i + 1) * self.SLOTS], self, self.updates)
+        return st
+
+    def update(self) -> None:
+        """Maxima recorded since the last call -> scales (one launch); sites created before this call have a scale afterwards."""
+        if self.index:
+            K.fp8_sites_update(self.amax, self.scale, self.inv, len(self.index), FP8_MARGIN)
+        self.updates += 1
+
+    def all_ready(self) -> bool:
+        return bool(self.index) and all(s.ready for s in self.index.values())
+
+
+_FP8_SITES: dict = {}
+
+
+def fp8_sites(device: torch.device) -> Fp8Sites:
+    st = _FP8_SITES.get(device.index)
+    if st is None:
+        st = _FP8_SITES[device.index] = Fp8Sites(device)
+    return st
+
+
+def fp8_site(t: torch.Tensor, owner: object, kind: str):  # noqa: ANN201
+    """The delayed-scaling site of tensor position ``kind`` at parameter ``owner`` (None when the fp8 weight-gradient path is off / on the CPU)."""
+    if not (FP8_FORWARD and FP8_WGRAD and t.is_cuda):
+        return None
+    return fp8_sites(t.device).site((id(owner), kind))
+
+
+def fp8_step_end() -> None:
+    """End of an optimisation step (``TrainStep`` calls it after the backward pass): recorded maxima become the next step's scales."""
+    for st in _FP8_SITES.values():
+        st.update()
+
+
+def fp8_calibrating() -> bool:
+    """True while a recorded / replayed step must not be taken yet: the fp8 weight-gradient path is on and some site has no scale (first step)."""
+    if not (FP8_FORWARD and FP8_WGRAD):
+        return False
+    return not _FP8_SITES or any(not st.all_ready() for st in _FP8_SITES.values())
+
+
+def _tensor_scaled(q8: tuple | None) -> bool:
+    return q8 is not None and q8[1].numel() == 1
+
+
+def wgrad8_problem(tape: Tape, dy8: tuple, x8: tuple, dst: torch.Tensor, dy16: torch.Tensor, bias_grad: torch.Tensor | None) -> None:
+    """dst[n, k] += dY^T X on the e4m3 copies (per-tensor scales); bias_grad[n] += column sums of the bf16 dY.  Deferred to the enclosing weight-gradient
+    group like the bf16 problems (one persistent launch per block for all of them)."""
+    item = (dy8[0], dy8[1], x8[0], x8[1], dst, dy16, bias_grad)
+    if getattr(tape, "grouping", False):
+        tape.pending_wgrads8.append(item)
+    else:
+        _wgrad8_launch([item])
+
+
+def _wgrad8_launch(items: list) -> None:
+    def run() -> None:
+        K.gemm_fp8_wgrad_grouped([it[:5] for it in items])
+        for it in items:
+            if it[6] is not None:
+                K.colsum(it[5], it[6])
+    _wgrad_launch(run, *[t for it in items for t in (it[0], it[2], it[5])])
+
+
 def w_fp8_t(weight: torch.nn.Parameter) -> tuple | None:
     """(uint8 [in, out] transposed e4m3 shadow, fp32 [1] scale) of a 2-D Linear weight, or None."""
     flat = getattr(weight, "_cinema_flat", None)
@@ -404,7 +505,7 @@ def w_fp8_t(weight: torch.nn.Parameter) -> tuple | None:
 
 
 def dgrad(dy16: torch.Tensor, weight: torch.nn.Parameter, w16: torch.Tensor, *, gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None,
-          fp8: bool = False, dy8: tuple | None = None, out_f32_residual: torch.Tensor | None = None, gelu_deriv: bool = False) -> torch.Tensor:
+          fp8: bool = False, dy8: tuple | None = None, out_f32_residual: torch.Tensor | None = None, gelu_deriv: bool = False, out8: tuple | None = None) -> torch.Tensor:
     """dX = dY W (x GELU'(gelu_in), or x gelu_in itself when it already holds the derivative: ``gelu_deriv``): bf16 MFMA GEMM, or - ``fp8`` and the shapes allow it - the e4m3 GEMM on per-row quantised dY (``dy8`` = an already
     quantised (bytes, row scales) pair of the same rows, e.g. a column slice of a fused gradient) and the transposed weight shadow.
     ``out_f32_residual``: fp8 path only, adds an fp32 tensor and returns fp32 (two weights fed by column blocks of one gradient)."""
@@ -413,10 +514,11 @@ def dgrad(dy16: torch.Tensor, weight: torch.nn.Parameter, w16: torch.Tensor, *, 
         if wt is not None:
             a8, sa = dy8 if dy8 is not None else K.quantize_fp8_rows(dy16)
             return K.gemm_fp8(a8, sa, wt[0], wt[1], gelu_in=gelu_in, residual=out_f32_residual, out_dtype=F32 if out_f32_residual is not None else BF16,
-                              gelu_deriv=gelu_deriv)
+                              gelu_deriv=gelu_deriv, out8=out8 if out_f32_residual is None else None)
     if out_f32_residual is not None:
         raise RuntimeError("dgrad: the fp32-residual form exists on the fp8 path only")
-    return K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False, gelu_in=gelu_in, row_mask=row_mask, gelu_deriv=gelu_deriv)
+    return K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False, gelu_in=gelu_in, row_mask=row_mask, gelu_deriv=gelu_deriv,
+                  out8=out8 if (out8 is not None and row_mask is None and dy16.is_cuda and not K.FORCE_GENERIC) else None)
 
 
 def w_fp8(weight: torch.nn.Parameter) -> tuple:
@@ -573,7 +675,7 @@ def wgrad_group(tape: Tape) -> None:
     def flush() -> None:
         # the persistent kernel balances better and writes fewer partial tiles with more problems per launch: without a gradient exchange waiting for
         # this block's range, the launch is held back until GROUP_FLUSH_MIN problems (two transformer blocks) are pending
-        if GROUP_WGRAD != 2 or PARAMS_DONE_HOOK is not None or len(tape.pending_wgrads) >= GROUP_FLUSH_MIN:
+        if GROUP_WGRAD != 2 or PARAMS_DONE_HOOK is not None or len(tape.pending_wgrads) + len(tape.pending_wgrads8) >= GROUP_FLUSH_MIN:
             flush_wgrads(tape)
         tape.grouping = False
 
@@ -594,6 +696,9 @@ def _wgrad_single(dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias
 
 
 def flush_wgrads(tape: Tape) -> None:
+    probs8, tape.pending_wgrads8 = tape.pending_wgrads8, []
+    for i in range(0, len(probs8), P256_MAX_PROBLEMS):
+        _wgrad8_launch(probs8[i:i + P256_MAX_PROBLEMS])
     probs, tape.pending_wgrads = tape.pending_wgrads, []
     if not probs:
         return
@@ -637,7 +742,8 @@ def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.P
                  fp8: bool = False) -> Var:
     """y = [gelu](LN(x)); x fp32/bf16 [rows, c]; output bf16 (GEMM operand) or fp32 (residual stream)."""
     if fp8 and not out_f32 and FP8_FORWARD and x.data.is_cuda and x.data.shape[1] % 16 == 0:
-        y16, y32, mean, rstd, q8 = K.layernorm_fwd(x.data, gamma.detach(), beta.detach(), eps, act=act, want_bf16=True, want_f32=False, want_fp8=True)
+        y16, y32, mean, rstd, q8 = K.layernorm_fwd(x.data, gamma.detach(), beta.detach(), eps, act=act, want_bf16=True, want_f32=False, want_fp8=True,
+                                                   q8=fp8_site(x.data, gamma, "ln_out"))
         y = Var(y16)
         y.fp8 = q8
     else:
@@ -651,11 +757,14 @@ def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.P
         c = x.data.shape[1]
         want16 = x.data.dtype == F32  # fp32 residual-stream input: also emit the bf16 copy for the upstream GEMMs
         res = x.grad if (x.grad is not None and x.grad.dtype == F32) else None
-        dx32, dx16 = K.layernorm_bwd(y.grad, x.data, gamma.detach(), beta.detach(), mean, rstd, act=act, dx_residual=res,
-                                     want_f32=x.data.dtype == F32, want_bf16=want16 or x.data.dtype == BF16,
-                                     dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln if DEFER_LN_REDUCE else None)
+        site8 = x.grad8_site if (x.data.dtype == F32 and FP8_WGRAD and FP8_FORWARD) else None  # the producer of x wants an 8-bit copy of the complete gradient
+        out = K.layernorm_bwd(y.grad, x.data, gamma.detach(), beta.detach(), mean, rstd, act=act, dx_residual=res,
+                              want_f32=x.data.dtype == F32, want_bf16=want16 or x.data.dtype == BF16,
+                              dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln if DEFER_LN_REDUCE else None, q8=site8)
+        dx32, dx16 = out[0], out[1]
         if x.data.dtype == F32:
             x.grad, x.grad16 = dx32, dx16  # includes the previously accumulated residual gradient
+            x.grad8 = out[2] if site8 is not None else None
         else:
             x.add_grad(dx16)
 
@@ -674,11 +783,22 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
             and math.prod(weight.shape[1:]) == x.data.shape[1] and K.fanout_ok(weight.shape[0], x.data.shape[1])):
         return _op_thin_linear(tape, x, weight, bias, fanout=True)  # few inputs, a few dozen outputs (the 1 -> 32 channel shortcut of the raw-image block)
     w = w16 if w16 is not None else w_plain(weight)
+    x8t = None  # per-tensor e4m3 copy of x (also the X operand of the weight gradient)
+    site_dy = None
     if fp8 and w16 is None and row_mask is None and _fp8_ok(x.data, weight) and (residual is None or residual.data.dtype == F32):
-        x8, sx = a_fp8(x)
+        site_x = fp8_site(x.data, weight, "x")
+        if site_x is not None:
+            if _tensor_scaled(x.fp8):
+                x8t = x.fp8
+            else:
+                x8t = K.quantize_fp8_site(x.data, site_x)  # None in the site's first step (records the maximum)
+            site_dy = fp8_site(x.data, weight, "dy")
+        x8, sx = x8t if x8t is not None else a_fp8(x)
         w8, sw = w_fp8(weight)
         y = Var(K.gemm_fp8(x8, sx, w8, sw, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
                            out_dtype=F32 if (out_f32 or residual is not None) else BF16))
+        if y.data.dtype == F32:
+            y.grad8_site = site_dy  # the LayerNorm backward that completes this residual-stream gradient writes its e4m3 copy
     else:
         y = Var(K.gemm(x.data, w, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
                        out_dtype=F32 if (out_f32 or residual is not None) else BF16, row_mask=row_mask))
@@ -692,10 +812,15 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
         # row_mask contract: y = mask * (xW^T + b) and the consumer (op_dwconv with in_mask) hands back a gradient whose
         # masked rows are already zero, so the weight/bias gradients below need no extra masking pass.
         dy16 = y.grad_bf16()
+        g8 = y.grad8 if (site_dy is not None and _tensor_scaled(y.grad8)) else None
         if weight.requires_grad:
-            wgrad(tape, dy16, x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
+            if g8 is not None and x8t is not None and to_param_layout is None and weight.shape[0] % 16 == 0 and x.data.shape[1] % 16 == 0:
+                wgrad8_problem(tape, g8, x8t, wv.grad_buffer(tuple(w.shape)).view(-1, x.data.shape[1]), dy16,
+                               bv.grad_buffer((weight.shape[0],)) if (bias is not None and bias.requires_grad) else None)
+            else:
+                wgrad(tape, dy16, x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
         if x.needs_grad:
-            x.add_grad(dgrad(dy16, weight, w, row_mask=row_mask, fp8=fp8 and w16 is None))
+            x.add_grad(dgrad(dy16, weight, w, row_mask=row_mask, fp8=fp8 and w16 is None, dy8=g8))
 
     tape.record(bwd)
     return y
@@ -736,11 +861,21 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     m, hidden = x.data.shape[0], w1.shape[0]
     h = K.empty((m, hidden), dtype=BF16, device=x.data.device)  # GELU'(fc1 output) (GELU_DERIV) or the fc1 output itself
     deriv = GELU_DERIV
+    x8t = a8t = None  # per-tensor e4m3 copies of x (LayerNorm output) and of the GELU output: operands of the forward AND weight-gradient GEMMs
+    site_dy = site_dh = None
     if fp8 and _fp8_ok(x.data, fc1_w, fc2_w) and (residual is None or residual.data.dtype == F32):
+        site_a = fp8_site(x.data, fc2_w, "x")
+        if site_a is not None:
+            site_dy, site_dh = fp8_site(x.data, fc2_w, "dy"), fp8_site(x.data, fc1_w, "dy")
+            x8t = x.fp8 if _tensor_scaled(x.fp8) else None
+            a8 = K.empty((m, hidden), dtype=torch.uint8, device=x.data.device) if site_a.ready else None
         x8, sx = a_fp8(x)
-        a = K.gemm_fp8(x8, sx, *w_fp8(fc1_w), bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv)
-        a8, sa = K.quantize_fp8_rows(a)
-        y = Var(K.gemm_fp8(a8, sa, *w_fp8(fc2_w), bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
+        a = K.gemm_fp8(x8, sx, *w_fp8(fc1_w), bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv, out8=None if site_a is None else (site_a, a8))
+        if site_a is not None and a8 is not None:
+            a8t = (a8, site_a.scale)
+        a8r, sa = a8t if a8t is not None else K.quantize_fp8_rows(a)
+        y = Var(K.gemm_fp8(a8r, sa, *w_fp8(fc2_w), bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
+        y.grad8_site = site_dy
     else:
         a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv)
         y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
@@ -752,11 +887,21 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
         if residual is not None:
             residual.add_grad(y.grad, y.grad16)
         dy16 = y.grad_bf16()
-        wgrad(tape, dy16, a, pv[2], pv[3], tuple(w2.shape))
-        dh = dgrad(dy16, fc2_w, w2, gelu_in=h, fp8=fp8, gelu_deriv=deriv)
-        wgrad(tape, dh, x.data, pv[0], pv[1], tuple(w1.shape))
+        g8 = y.grad8 if (site_dy is not None and _tensor_scaled(y.grad8)) else None
+        ok8 = hidden % 16 == 0 and x.data.shape[1] % 16 == 0
+        if g8 is not None and a8t is not None and ok8:
+            wgrad8_problem(tape, g8, a8t, pv[2].grad_buffer(tuple(w2.shape)), dy16, pv[3].grad_buffer((w2.shape[0],)))
+        else:
+            wgrad(tape, dy16, a, pv[2], pv[3], tuple(w2.shape))
+        dh8 = K.empty((m, hidden), dtype=torch.uint8, device=x.data.device) if (site_dh is not None and site_dh.ready) else None
+        dh = dgrad(dy16, fc2_w, w2, gelu_in=h, fp8=fp8, gelu_deriv=deriv, dy8=g8, out8=None if site_dh is None else (site_dh, dh8))
+        dh8t = None if dh8 is None else (dh8, site_dh.scale)
+        if dh8t is not None and x8t is not None and ok8:
+            wgrad8_problem(tape, dh8t, x8t, pv[0].grad_buffer(tuple(w1.shape)), dh, pv[1].grad_buffer((w1.shape[0],)))
+        else:
+            wgrad(tape, dh, x.data, pv[0], pv[1], tuple(w1.shape))
         if x.needs_grad:
-            x.add_grad(dgrad(dh, fc1_w, w1, fp8=fp8))
+            x.add_grad(dgrad(dh, fc1_w, w1, fp8=fp8, dy8=dh8t))
 
     tape.record(bwd)
     return y
@@ -795,13 +940,25 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
         if rope is not None:
             K.rope_heads(dqkv, 2 * heads, heads, c // heads, rope[0], rope[1], inverse=True)
         gq, gkv = pv[0].grad_buffer((c, c)), pv[2].grad_buffer((2 * c, c))
+        # e4m3 weight gradient (FP8_WGRAD): dY = one stand-alone 8-bit copy of dq|dk|dv under a delayed per-tensor scale, X = the LayerNorm's per-tensor copy
+        # (the site is created and fed in EVERY step, whatever the state of the other sites: a site that first appears a step late would miss the recording)
+        site = fp8_site(dqkv, q_w, "dy") if (fp8 and c % 16 == 0) else None
+        d8 = K.quantize_fp8_site(dqkv, site) if site is not None else None
+        if not _tensor_scaled(x.fp8):
+            d8 = None
         if q_b is not None and pv[0].direct and pv[2].direct and _adjacent(gq, gkv):
             bq, bkv = pv[1].grad_buffer((c,)), pv[3].grad_buffer((2 * c,))
             if pv[1].direct and pv[3].direct and _adjacent(bq, bkv):  # one [3c, c] weight-gradient GEMM + one column sum
                 g3, b3 = gq.as_strided((3 * c, c), (c, 1)), bq.as_strided((3 * c,), (1,))
-                wgrad_problem(tape, dqkv, x.data, g3, b3)
+                if d8 is not None:
+                    wgrad8_problem(tape, d8, x.fp8, g3, dqkv, b3)
+                else:
+                    wgrad_problem(tape, dqkv, x.data, g3, b3)
                 gq = None
-        if gq is not None:
+        if gq is not None and d8 is not None:
+            wgrad8_problem(tape, (d8[0][:, :c], d8[1]), x.fp8, gq, dqkv[:, :c], None if q_b is None else pv[1].grad_buffer((c,)))
+            wgrad8_problem(tape, (d8[0][:, c:], d8[1]), x.fp8, gkv, dqkv[:, c:], None if kv_b is None else pv[3].grad_buffer((2 * c,)))
+        elif gq is not None:
             wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))
             wgrad(tape, dqkv[:, c:], x.data, pv[2], pv[3], (2 * c, c))
         if x.needs_grad:

@@ -23,6 +23,23 @@ extern "C" {
 /* library / device info: fills out[0..7] = {abi_version, n_CUs, lds_bytes_per_block, wave_size, 0...} */
 int cinema_hip_info(int* out_host);
 
+/* 8-bit copy of a kernel's output with per-tensor DELAYED scaling (the "fp8 MFMA path" of BASELINE config 5: the copies are the operands of the e4m3 forward,
+ * data-gradient and weight-gradient GEMMs; the reference computes those matmuls in bf16 autocast, cinema/vit.py:472-477,565-575).  The producing kernel
+ * quantises with the scale derived from the PREVIOUS step's maximum and records this step's maximum; cinema_fp8_sites_update turns maxima into scales. */
+#define CINEMA_Q8_SLOTS 4096
+typedef struct cinema_q8_out {
+  uint8_t* data;              /* [rows][c] OCP e4m3 bytes, dense: q = e4m3(sat(value * *inv_scale)); NULL = record the maximum only */
+  const float* inv_scale;     /* device scalar */
+  unsigned int* amax_slots;   /* device [CINEMA_Q8_SLOTS]: float bits of max|value| over this launch, every wave raises slot (wave id mod CINEMA_Q8_SLOTS): thousands of
+                                 device-scope atomics on a handful of addresses serialise (measured: 64 slots cost 20-40 us per launch) */
+} cinema_q8_out;
+/* sites: amax_slots [n_sites][CINEMA_Q8_SLOTS], scale / inv_scale [n_sites].  For every site with a finite positive maximum: scale = margin * amax / 448 (the dequantisation
+ * multiplier the consuming GEMM reads), inv_scale = 1 / scale; the slots are reset to 0.  Sites that recorded nothing keep their scales. */
+int cinema_fp8_sites_update(unsigned int* amax_slots, float* scale, float* inv_scale, int n_sites, float margin, void* stream);
+/* y8 = e4m3(sat(x * *inv_scale)) for a dense bf16 tensor of n elements (n % 8 == 0, 16-byte aligned) + the launch's max|x| into amax_slots: the stand-alone
+ * producer for tensors whose kernels do not write an 8-bit copy themselves (attention outputs / gradients). */
+int cinema_quantize_fp8_site(const uint16_t* x, long long n, const cinema_q8_out* q8, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * GEMM  (reference: nn.Linear / F.linear at cinema/vit.py:472-477,498-499,520, timm Mlp fc1/fc2 vit.py:570-575,
  * 1x1 ConvNd of MaskedConvBlock/ConvMlp cinema/conv.py:383-389, k==s patch convs cinema/convvit.py:94-102,252,
@@ -71,6 +88,11 @@ typedef struct {
   int conv_x, conv_y, conv_z, conv_c;
   const void* conv_coords;    /* cinema_conv_wgrad_bf16 only: device int [rows], x | y << 10 | z << 20 of every voxel row */
   int conv_zb;                /* implicit convolution: 0 / 1 = one row per voxel; ZB > 1 = one row per group of ZB consecutive z voxels (see cinema_conv_gemm_bf16) */
+  uint8_t* out8;              /* optional (bf16-output classes of cinema_gemm_bf16 / cinema_gemm_fp8): 8-bit copy of D with per-tensor DELAYED scaling (cinema_q8_out
+                                 semantics): out8[m][ld_out8] = e4m3(sat(D[m][n] * *out8_inv_scale)); max|D| of this launch is atomic-maxed into out8_amax[CINEMA_Q8_SLOTS] */
+  int ld_out8;
+  const float* out8_inv_scale;
+  unsigned int* out8_amax;    /* may be given without out8: records the maximum only (calibration step) */
   void* tail_counters;        /* optional, with `workspace` at split_k == 1: >= 8 KiB of device memory (16-byte aligned), ZERO before the first use (its last word is set if a bounded wait ever gives up) and left zero by every launch,
                                  one per stream: the split tail is finished inside the GEMM launch (no fix-up launch); NULL = fix-up launch */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)
@@ -159,6 +181,10 @@ int cinema_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* gam
  * GEMM input costs no pass of its own (the row maximum is a reduction over the lanes that already hold the row). */
 int cinema_layernorm_fwd_fp8(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act, uint16_t* y_bf16,
                              float* y_f32, int ldy, float* mean, float* rstd, uint8_t* y_fp8, float* row_scale, void* stream);
+/* the same with a per-TENSOR delayed scale (cinema_q8_out) instead of per-row scales: the copy then also serves the weight-gradient GEMM, whose reduction
+ * runs over the rows */
+int cinema_layernorm_fwd_q8(const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta, int rows, int c, float eps, int act, uint16_t* y_bf16,
+                            float* y_f32, int ldy, float* mean, float* rstd, const cinema_q8_out* q8, void* stream);
 int cinema_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma,
                          const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                          const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
@@ -179,6 +205,12 @@ int cinema_layernorm_bwd_deferred(const void* dy, int dy_is_bf16, int lddy, cons
                                   const float* beta, const float* mean, const float* rstd, int rows, int c, int act,
                                   const float* dx_residual, float* dx_f32, uint16_t* dx_bf16, int lddx, float* dgamma, float* dbeta,
                                   float* workspace, long long workspace_bytes, int* n_partials_out, void* stream);
+/* cinema_layernorm_bwd_deferred that also writes an 8-bit copy of dx (cinema_q8_out; dense [rows][c]): the gradient of the residual stream is the dY operand of
+ * the preceding projection's e4m3 data- and weight-gradient GEMMs */
+int cinema_layernorm_bwd_deferred_q8(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* gamma, const float* beta,
+                                     const float* mean, const float* rstd, int rows, int c, int act, const float* dx_residual, float* dx_f32, uint16_t* dx_bf16,
+                                     int lddx, float* dgamma, float* dbeta, float* workspace, long long workspace_bytes, int* n_partials_out,
+                                     const cinema_q8_out* q8, void* stream);
 int cinema_ln_param_reduce_batched(const cinema_ln_reduce_item* items_host, int count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -189,7 +189,8 @@ def mae_loss_parity(kw: dict, state_dict: dict, batch: int = 1, seed: int = 7, d
 
 def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 5, device: str = "cuda", threads: int | None = None) -> dict:
     """Gradients of the fp8 path against the ORACLE (not against this repository's bf16 path): one forward + backward of the oracle on the CPU and three
-    of the HIP path on identical weights / inputs / masks - bf16, e4m3 forward only, e4m3 forward + e4m3 data gradients.  The flat parameter buffers
+    of the HIP path on identical weights / inputs / masks - bf16, e4m3 forward only, e4m3 forward + e4m3 data gradients, and the same + e4m3 WEIGHT gradients
+    (per-tensor delayed scaling: a first pass records the maxima).  The flat parameter buffers
     (``cinema_amd.optim.FlatModel``) are built BEFORE the comparison: the transposed e4m3 weight shadows the data-gradient GEMM reads exist only there, and
     the number of GEMMs that really took them is returned (``fp8_dgrad_gemms``; 0 would mean the bf16 fallback was measured).  Per mode: loss rel, gradient-norm
     rel, worst relative L2 over matrices / conv filters (dim >= 2) and over vectors, and the error of the WHOLE gradient (all tensors concatenated) over
@@ -228,13 +229,29 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
         calls["n"] += hit is not None
         return hit
 
-    prev = (T.FP8_FORWARD, T.FP8_DGRAD)
+    from cinema_amd import hip as K
+
+    wg8 = {"n": 0}
+    orig_wg8 = K.gemm_fp8_wgrad_grouped
+
+    def counting_wg8(problems):  # noqa: ANN001, ANN202
+        wg8["n"] += len(problems)
+        return orig_wg8(problems)
+
+    prev = (T.FP8_FORWARD, T.FP8_DGRAD, T.FP8_WGRAD)
     out = {"oracle_loss": float(ref_loss), "oracle_grad_norm": ref_norm, "oracle_seconds": round(cpu_s, 2), "batch": batch}
     T.w_fp8_t = counting_wt
+    K.gemm_fp8_wgrad_grouped = counting_wg8
     try:
-        for mode, (fwd8, dg8) in {"bf16": (False, False), "fp8_forward": (True, False), "fp8": (True, True)}.items():
-            T.FP8_FORWARD, T.FP8_DGRAD = fwd8, dg8
-            calls["n"] = 0
+        for mode, (fwd8, dg8, wg) in {"bf16": (False, False, False), "fp8_forward": (True, False, False), "fp8": (True, True, False),
+                                      "fp8_wgrad": (True, True, True)}.items():
+            T.FP8_FORWARD, T.FP8_DGRAD, T.FP8_WGRAD = fwd8, dg8, wg
+            if wg:  # delayed per-tensor scaling: one pass records the maxima of every site, the measured pass quantises with them (same weights and inputs)
+                flat.zero_grad()
+                loss, _, _, _ = model(dimg, 0.75, enc_mask_dict=dmask)
+                loss.backward()
+                T.fp8_step_end()
+            calls["n"] = wg8["n"] = 0
             flat.zero_grad()
             loss, _, _, _ = model(dimg, 0.75, enc_mask_dict=dmask)
             loss.backward()
@@ -256,8 +273,9 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
             out[mode] = {"loss": float(loss), "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
                          "grad_norm_rel": abs(math.sqrt(sq_g) - ref_norm) / ref_norm, "whole_grad_rel_l2": math.sqrt(sq_e) / ref_norm,
                          "worst_matrix_rel_l2": {"name": worst_m[0], "value": worst_m[1]}, "worst_vector_rel_l2": {"name": worst_v[0], "value": worst_v[1]},
-                         "fp8_dgrad_gemms": calls["n"]}
+                         "fp8_dgrad_gemms": calls["n"], "fp8_wgrad_problems": wg8["n"]}
     finally:
         T.w_fp8_t = orig_wt
-        T.FP8_FORWARD, T.FP8_DGRAD = prev
+        K.gemm_fp8_wgrad_grouped = orig_wg8
+        T.FP8_FORWARD, T.FP8_DGRAD, T.FP8_WGRAD = prev
     return out

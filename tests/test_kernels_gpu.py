@@ -1032,3 +1032,65 @@ def test_gemm_fp8_wgrad_p256_vs_independent_e4m3_decoder(rows: int) -> None:
     with pytest.raises(K.HipLibraryError):  # feature counts must be multiples of 16 bytes
         K.gemm_fp8_wgrad_grouped([(torch.zeros(64, 24, dtype=torch.uint8, device=DEV), torch.ones(1, device=DEV), torch.zeros(64, 32, dtype=torch.uint8, device=DEV),
                                    torch.ones(1, device=DEV), torch.zeros(24, 32, device=DEV))])
+
+
+def test_q8_delayed_scaling_producers() -> None:
+    """8-bit output copies with per-tensor DELAYED scaling (``cinema_q8_out``): a site's first launch only records the maximum; ``cinema_fp8_sites_update`` turns it
+    into scale = margin * amax / 448; from then on the producers - stand-alone pass, LayerNorm forward / backward, the GEMM epilogues (plain bf16, GELU,
+    x GELU') of the bf16 and the e4m3 kernels - write e4m3(sat(value / scale)): decoded with an independent e4m3 decoder every copy is within half an e4m3
+    step (2^-4 relative, 2^-10 of the scale absolute) of the bf16 output of the same launch; values beyond the previous maximum saturate instead of overflowing."""
+    from cinema_amd import tape as T
+
+    sites = T.Fp8Sites(torch.device(DEV, torch.cuda.current_device()))
+
+    def check(q8, ref16, what):  # noqa: ANN001, ANN202
+        y8, sc = q8
+        dec = _e4m3_decode(y8.cpu()).to(DEV) * sc
+        err = (dec - ref16.float()).abs()
+        tol = ref16.float().abs() * 2.0 ** -4 + float(sc) * 2.0 ** -9
+        assert bool((err <= tol).all()), (what, float((err - tol).max()))
+
+    x = rnd(3000, 512, scale=2.0, seed=301)
+    s0 = sites.site(("alone", 0))
+    assert not s0.ready and K.quantize_fp8_site(x, s0) is None
+    sites.update()
+    assert s0.ready and abs(float(s0.scale) - T.FP8_MARGIN * float(x.float().abs().max()) / 448.0) <= 1e-6 * float(s0.scale)
+    check(K.quantize_fp8_site(x, s0), x, "stand-alone")
+    big = K.quantize_fp8_site((x.float() * 4).to(torch.bfloat16), s0)  # 4 x the recorded maximum: saturates at 448 x scale, no NaN byte
+    assert int(((big[0] & 0x7F) == 0x7F).sum()) == 0 and float((_e4m3_decode(big[0].cpu()) * float(s0.scale)).abs().max()) <= 448.0 * float(s0.scale) * 1.001
+    sites.update()
+    # LayerNorm forward / backward
+    xf = rnd(2053, 768, dtype=torch.float32, seed=302)
+    gamma, beta = rnd(768, dtype=torch.float32, seed=303) + 1.0, rnd(768, dtype=torch.float32, seed=304)
+    s1, s2 = sites.site(("ln", 1)), sites.site(("ln", 2))
+    dy = rnd(2053, 768, scale=0.1, seed=305)
+    res = rnd(2053, 768, dtype=torch.float32, scale=0.1, seed=306)
+    for rep in range(2):
+        y16, _, mean, rstd, q8 = K.layernorm_fwd(xf, gamma, beta, 1e-6, want_fp8=True, q8=s1)
+        dg, db, deferred = torch.zeros(768, device=DEV), torch.zeros(768, device=DEV), []
+        dx32, dx16, dq8 = K.layernorm_bwd(dy, xf, gamma, beta, mean, rstd, dx_residual=res, want_f32=True, want_bf16=True, dgamma=dg, dbeta=db, deferred=deferred, q8=s2)
+        if rep == 0:
+            assert q8[1].numel() == 2053 and dq8 is None  # first step: per-row copy from the forward, no copy from the backward
+            sites.update()
+        else:
+            assert q8[1].numel() == 1
+            check(q8, y16, "LayerNorm forward")
+            check(dq8, dx16, "LayerNorm backward")
+    # GEMM epilogues
+    a, w = rnd(2053, 512, scale=0.5, seed=307), rnd(1024, 512, scale=0.05, seed=308)
+    bias = rnd(1024, dtype=torch.float32, seed=309)
+    a8, sa = K.quantize_fp8_rows(a)
+    w8, sw = K.quantize_fp8(w)
+    gin = rnd(2053, 1024, seed=310)
+    s3, s4, s5, s6 = (sites.site(("gemm", i)) for i in range(4))
+    for rep in range(2):
+        outs = []
+        for site, fn in ((s3, lambda o8: K.gemm(a, w, bias=bias, act=1, out8=o8)), (s4, lambda o8: K.gemm_fp8(a8, sa, w8, sw, bias=bias, act=1, out8=o8)),
+                         (s5, lambda o8: K.gemm(a, w, gelu_in=gin, gelu_deriv=True, out8=o8)), (s6, lambda o8: K.gemm_fp8(a8, sa, w8, sw, gelu_in=gin, gelu_deriv=True, out8=o8))):
+            o8 = torch.empty(2053, 1024, dtype=torch.uint8, device=DEV) if site.ready else None
+            outs.append((site, fn((site, o8)), o8))
+        if rep == 0:
+            sites.update()
+        else:
+            for i, (site, y16, o8) in enumerate(outs):
+                check((o8, site.scale), y16, f"GEMM epilogue {i}")

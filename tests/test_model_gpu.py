@@ -379,12 +379,14 @@ def test_fp8_forward_path_vs_oracle_and_bf16() -> None:
     model = CineMA(**kw)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     par = mae_fp8_grad_parity(kw, sd, batch=3, seed=5, device=DEV)
-    for mode in ("bf16", "fp8_forward", "fp8"):
+    for mode in ("bf16", "fp8_forward", "fp8", "fp8_wgrad"):
         print(f"fp8 parity vs oracle [{mode}]:", par[mode])
     assert par["bf16"]["fp8_dgrad_gemms"] == 0 and par["fp8_forward"]["fp8_dgrad_gemms"] == 0
     assert par["fp8"]["fp8_dgrad_gemms"] >= 10, par["fp8"]  # q, kv, proj, fc1, fc2 of 2 + 2 blocks: the e4m3 data-gradient kernels really ran
     assert par["fp8"]["loss"] != par["bf16"]["loss"]  # ... and so did the e4m3 forward
-    for mode in ("fp8_forward", "fp8"):
+    assert par["fp8"]["fp8_wgrad_problems"] == 0
+    assert par["fp8_wgrad"]["fp8_wgrad_problems"] >= 10, par["fp8_wgrad"]  # proj, fc1, fc2 of the 2 + 2 blocks: the e4m3 weight-gradient kernel really ran
+    for mode in ("fp8_forward", "fp8", "fp8_wgrad"):
         r = par[mode]
         assert r["loss_rel"] <= FP8_LOSS_RTOL, r
         assert r["grad_norm_rel"] <= FP8_GRAD_NORM_RTOL, r
