@@ -322,20 +322,46 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
     model.to(device)
     b5 = synthetic_batch(kw5, 8, 4321, device)
     res = {}
+    fp8_roof = None
     prev = T_.FP8_FORWARD
     try:
         for name, fp8 in (("bf16", False), ("fp8", True)):
             T_.FP8_FORWARD = fp8
             st = TrainStep(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0, replay=True)
-            res[name] = timed(lambda: st(b5, 0.75), 4, 6)  # noqa: B023
+            res[name] = timed(lambda: st(b5, 0.75), 4, 6)  # noqa: B023  (fp8: the first warm-up step records the maxima of the delayed scales, eager)
+            if fp8:  # roofline of the e4m3 weight-gradient kernel: HIP events around every launch of two eager steps, against the 5 PF dense fp8 peak
+                from cinema_amd import hip as K_
+
+                st.replay = False
+                K_.GEMM_PROFILE = []
+                side_prev, T_.SIDE_WGRAD = T_.SIDE_WGRAD, False
+                try:
+                    for _ in range(2):
+                        st(b5, 0.75)
+                    torch.cuda.synchronize()
+                    recs = [r for r in K_.GEMM_PROFILE if r[0] == 4096 + 3 + 8 * 4]
+                finally:
+                    K_.GEMM_PROFILE = None
+                    T_.SIDE_WGRAD = side_prev
+                if recs:
+                    secs = sum(r[2].elapsed_time(r[3]) for r in recs) * 1e-3
+                    flops = sum(r[1] for r in recs)
+                    alg = sum(r[4][6] for r in recs)
+                    fp8_roof = {"bound": "mfma", "kernel": K_.GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4], "achieved": round(flops / secs / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
+                                "frac": round(flops / secs / 5e15, 4), "launches_per_step": len(recs) // 2, "avg_launch_us": round(secs / len(recs) * 1e6, 2),
+                                "gflop_per_launch": round(flops / len(recs) / 1e9, 3), "algorithmic_bytes_per_launch": int(alg / len(recs)), "traffic": None,
+                                "timing": "HIP events on the launch stream around every launch (two eager steps, one stream)",
+                                "what": "weight gradients of a transformer block (qkv, proj, fc1, fc2) on row-major e4m3 operands in one persistent launch, k-slices reduced in the launch"}
             del st
             gc.collect()
     finally:
         T_.FP8_FORWARD = prev
     out["config5_fp8"] = {"workload": "CineMA ViT-Large MAE, 4 views (SAX 256x256x24 + 3 LAX 256x256), mask 0.75, per-GPU batch 8, fwd+bwd+clip+AdamW, recorded step",
-                          "dtype": "fp8 (e4m3 forward projections and data gradients, per-row activation / gradient and per-tensor weight scales; bf16 weight gradients)", "ms_per_step": round(res["fp8"], 3),
+                          "dtype": "fp8 (OCP e4m3 on the MX-scaled MFMA for the forward projections, data gradients AND weight gradients of the transformer blocks; weights: "
+                                   "per-tensor current scaling; activations / gradients: per-tensor DELAYED scaling, 8-bit copies written by the producing kernels; "
+                                   "attention, LayerNorm, loss, optimiser in bf16 / fp32)", "ms_per_step": round(res["fp8"], 3),
                           "samples_per_s": round(8e3 / res["fp8"], 2), "bf16_ms_per_step": round(res["bf16"], 3), "fp8_speedup_over_bf16": round(res["bf16"] / res["fp8"], 4),
-                          "steps": 6, "warmup": 4, "reference_equiv_tflops_per_gpu": round(8e3 / res["fp8"] * 3 * 1806.7 / 1e3, 1)}
+                          "steps": 6, "warmup": 4, "reference_equiv_tflops_per_gpu": round(8e3 / res["fp8"] * 3 * 1806.7 / 1e3, 1), "roofline": fp8_roof}
     del model
     gc.collect()
     torch.cuda.empty_cache()
@@ -346,6 +372,22 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
         out["config5_fp8"]["parity"] = {"loss_rel": round(par["loss_rel"], 6), "loss": round(par["loss"], 6), "oracle_loss": round(par["oracle_loss"], 6),
                                         "view_loss_rel": {k: round(v, 6) for k, v in par["view_loss_rel"].items()},
                                         "what": "first-step loss (forward) of the fp8 path vs the fp32 CPU oracle at this shape, batch 1, identical weights / inputs / masks (stated: <= 5e-2)"}
+        # gradients of the fp8 path against the ORACLE (its backward at the config-5 shape takes minutes: a 2 + 2 block model with MFMA-sized channels instead)
+        from parity import mae_fp8_grad_parity
+
+        views = ["sax", "lax_2c"]
+        kwm = dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1), enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)},
+                   enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=2, enc_n_heads=4,
+                   dec_embed_dim=128, dec_depth=2, dec_n_heads=4)
+        torch.manual_seed(3)
+        sdm = {k: v.detach().clone() for k, v in CineMA(**kwm).state_dict().items()}
+        gp = mae_fp8_grad_parity(kwm, sdm, batch=3, seed=5, device=device, threads=min(os.cpu_count() or 1, 16))
+        out["config5_fp8"]["parity"]["gradients_midsize"] = {
+            m: {"loss_rel": round(gp[m]["loss_rel"], 6), "grad_norm_rel": round(gp[m]["grad_norm_rel"], 6), "whole_grad_rel_l2": round(gp[m]["whole_grad_rel_l2"], 5),
+                "worst_matrix_rel_l2": round(gp[m]["worst_matrix_rel_l2"]["value"], 5), "worst_vector_rel_l2": round(gp[m]["worst_vector_rel_l2"]["value"], 5),
+                "fp8_dgrad_gemms": gp[m]["fp8_dgrad_gemms"], "fp8_wgrad_problems": gp[m]["fp8_wgrad_problems"]} for m in ("bf16", "fp8_wgrad")}
+        out["config5_fp8"]["parity"]["gradients_midsize"]["what"] = ("gradients of the HIP path vs the fp32 CPU oracle on a 2 + 2 block model (encoder 256, decoder 128 channels), batch 3, "
+                                                                     "identical weights / inputs / masks: bf16 path and the full fp8 path (a first pass records the delayed scales)")
     return out
 
 

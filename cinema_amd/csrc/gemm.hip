@@ -691,6 +691,10 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     if (a->out_f32 || (a->out8 && (!a->out8_inv_scale || (a->ld_out8 & 7) || (((uintptr_t)a->out8) & 7)))) return CINEMA_ERR_BAD_ARG;
     p.out8 = a->out8; p.ld_out8 = a->ld_out8; p.out8_inv = a->out8_inv_scale; p.out8_amax = a->out8_amax;
   } else if (a->out8) return CINEMA_ERR_BAD_ARG;
+  if (a->colsum_partials) {
+    if (a->out_f32 || (((uintptr_t)a->colsum_partials) & 15) || (a->n & 7)) return CINEMA_ERR_BAD_ARG;
+    p.colsum_partials = a->colsum_partials;
+  }
   hipStream_t st = (hipStream_t)stream;
 
   auto al8 = [](int v) { return (v & 7) == 0; };
@@ -701,7 +705,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   fast = fast && (!a->residual_bf16 || (al8(a->ld_res) && ptr16(a->residual_bf16))) && (!a->gelu_in || (al8(a->ld_gelu) && ptr16(a->gelu_in)));
   fast = fast && (!a->aux_out || (al8(a->ld_aux) && ptr16(a->aux_out)));
   fast = fast && !(a->a_kmajor == 0 && a->b_kmajor == 1);  // (M-major A, K-major B) is not used by the path
-  if (!fast && p.out8_amax) return CINEMA_ERR_UNSUPPORTED;  // the 8-bit copy is written by the staged MFMA epilogues only
+  if (!fast && (p.out8_amax || p.colsum_partials)) return CINEMA_ERR_UNSUPPORTED;  // the 8-bit copy / strip sums are written by the staged MFMA epilogues only
   if (fast) {
     const int nkt = (a->k + BK - 1) / BK;
     const int sp = split > nkt ? nkt : split;
@@ -729,7 +733,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     static const int min_kt_env = getenv("CINEMA_TAIL_MIN_KT") ? atoi(getenv("CINEMA_TAIL_MIN_KT")) : 0;
     const int min_nkt = min_nkt_env > 0 ? min_nkt_env : 12;
     const int min_kt = min_kt_env > 0 ? min_kt_env : 4;
-    if (gz == 1 && a->force_generic == 0 && !p.accumulate && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= min_nkt) {  // K >= 768 (tools/tail_ab.py: 10960x768x768 38 -> 34 us, x1024 42 -> 35 us; at K = 512 the fix-up launch costs what it saves)
+    if (gz == 1 && a->force_generic == 0 && !p.accumulate && !p.colsum_partials && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= min_nkt) {  // (strip sums: whole tiles only)  // K >= 768 (tools/tail_ab.py: 10960x768x768 38 -> 34 us, x1024 42 -> 35 us; at K = 512 the fix-up launch costs what it saves)
       static int slots = 0;
       if (slots == 0) {
         int dev = 0; hipDeviceProp_t prop;
@@ -863,6 +867,10 @@ CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
     if (a->out_f32 || (a->out8 && (!a->out8_inv_scale || (a->ld_out8 & 7) || (((uintptr_t)a->out8) & 7)))) return CINEMA_ERR_BAD_ARG;
     p.out8 = a->out8; p.ld_out8 = a->ld_out8; p.out8_inv = a->out8_inv_scale; p.out8_amax = a->out8_amax;
   } else if (a->out8) return CINEMA_ERR_BAD_ARG;
+  if (a->colsum_partials) {
+    if (a->out_f32 || (((uintptr_t)a->colsum_partials) & 15)) return CINEMA_ERR_BAD_ARG;
+    p.colsum_partials = a->colsum_partials;
+  }
   const int nkt = (p.k + BK - 1) / BK;
   p.ktiles_per_split = nkt;
   dim3 grid(((a->m + BM - 1) / BM) * ((a->n + BN - 1) / BN), 1, 1);

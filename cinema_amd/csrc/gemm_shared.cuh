@@ -46,6 +46,9 @@ struct GemmP {
   // optional 8-bit copy of a bf16 output with per-tensor delayed scaling (cinema_q8_out semantics; the epilogue classes with a bf16 D): out8[m][ld_out8] =
   // e4m3(sat(D * *out8_inv)); the launch's max|D| goes into out8_amax[64] (also without out8: calibration)
   uint8_t* out8 = nullptr; int ld_out8 = 0; const float* out8_inv = nullptr; unsigned int* out8_amax = nullptr;
+  // optional (bf16-output classes): column sums of D over every strip of 32 rows, colsum_partials[m / 32][n] fp32 (every element written exactly once: no
+  // zeroing, no atomics); summed over the strips they are the bias gradient of the layer whose dY this GEMM produces
+  float* colsum_partials = nullptr;
 };
 
 __device__ __forceinline__ float frag_sum8(const short8v& f) {
@@ -267,7 +270,7 @@ __device__ __forceinline__ GemmP epi_fold(GemmP p) {  // a by-value copy with th
   if (EPI == EPI_BF16) { p.out_f32 = 0; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; p.res_f32 = nullptr; }
   if (EPI == EPI_BF16_GELU) { p.out_f32 = 0; p.act = 1; p.gelu_in = nullptr; p.res_f32 = nullptr; }                     // bias + GELU, optional pre-activation out
   if (EPI == EPI_BF16_GELU_GRAD) { p.out_f32 = 0; p.act = 0; p.aux_out = nullptr; p.res_f32 = nullptr; p.bias = nullptr; }  // dY * GELU'(pre-activation)
-  if (EPI == EPI_F32) { p.out_f32 = 1; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; p.out8 = nullptr; p.out8_amax = nullptr; }                           // optional bias and fp32 residual
+  if (EPI == EPI_F32) { p.out_f32 = 1; p.act = 0; p.aux_out = nullptr; p.gelu_in = nullptr; p.out8 = nullptr; p.out8_amax = nullptr; p.colsum_partials = nullptr; }                           // optional bias and fp32 residual
   return p;
 }
 
@@ -288,6 +291,12 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmP& p, const float16
   const int n = nw + cl;
   float bv[W];
   float q8max = 0.f;
+  constexpr int NSTRIP = (PASSES * RPP) / 32;  // 32-row strips of this call's rows (2 for a 64-row wave tile, 1 for a half)
+  float csum[NSTRIP][W];
+#pragma unroll
+  for (int h = 0; h < NSTRIP; h++)
+#pragma unroll
+    for (int i = 0; i < W; i++) csum[h][i] = 0.f;
   EpiPre<W> pre[PASSES];
   if (!ws_base) {
     epi_load_bias<W>(p, n, add_bias, bv);
@@ -321,10 +330,32 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmP& p, const float16
         for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
       } else {
         epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
+        if (W == 8 && p.colsum_partials) {
+#pragma unroll
+          for (int i = 0; i < W; i++) csum[(pss * RPP) / 32][i] += v[i];
+        }
       }
     }
   }
   if (!ws_base && p.out8_amax) q8_amax_commit(p.out8_amax, q8max, (int)blockIdx.x + (int)(threadIdx.x >> 6));
+  if (W == 8 && !ws_base && p.colsum_partials) {  // lanes with the same column group (lane % LPR) hold different rows: butterfly over the row lanes, one store per column group
+#pragma unroll
+    for (int h = 0; h < NSTRIP; h++) {
+#pragma unroll
+      for (int i = 0; i < W; i++) {
+        float t = csum[h][i];
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+        csum[h][i] = t;
+      }
+      const int strip = (mw >> 5) + h;
+      if (rl == 0 && n < p.n && strip * 32 < p.m) {
+        float* dst = p.colsum_partials + (size_t)strip * p.n + n;
+        *reinterpret_cast<float4*>(dst) = make_float4(csum[h][0], csum[h][1], csum[h][2], csum[h][3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(csum[h][W - 4], csum[h][W - 3], csum[h][W - 2], csum[h][W - 1]);
+      }
+    }
+  }
 }
 
 template <int EPI>
@@ -571,6 +602,12 @@ __device__ __forceinline__ void half_epilogue_rows(const GemmP& p, const float16
   const int n = nw + cl;
   float bv[W];
   float q8max = 0.f;
+  constexpr int NSTRIP = (PASSES * RPP) / 32;  // 32-row strips of this call's rows (2 for a 64-row wave tile, 1 for a half)
+  float csum[NSTRIP][W];
+#pragma unroll
+  for (int h = 0; h < NSTRIP; h++)
+#pragma unroll
+    for (int i = 0; i < W; i++) csum[h][i] = 0.f;
   EpiPre<W> pre[PASSES];
   if (!ws_base) {
     epi_load_bias<W>(p, n, add_bias, bv);
@@ -602,10 +639,32 @@ __device__ __forceinline__ void half_epilogue_rows(const GemmP& p, const float16
         for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
       } else {
         epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
+        if (W == 8 && p.colsum_partials) {
+#pragma unroll
+          for (int i = 0; i < W; i++) csum[(pss * RPP) / 32][i] += v[i];
+        }
       }
     }
   }
   if (!ws_base && p.out8_amax) q8_amax_commit(p.out8_amax, q8max, (int)blockIdx.x + (int)(threadIdx.x >> 6));
+  if (W == 8 && !ws_base && p.colsum_partials) {  // lanes with the same column group (lane % LPR) hold different rows: butterfly over the row lanes, one store per column group
+#pragma unroll
+    for (int h = 0; h < NSTRIP; h++) {
+#pragma unroll
+      for (int i = 0; i < W; i++) {
+        float t = csum[h][i];
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+        csum[h][i] = t;
+      }
+      const int strip = (mw >> 5) + h;
+      if (rl == 0 && n < p.n && strip * 32 < p.m) {
+        float* dst = p.colsum_partials + (size_t)strip * p.n + n;
+        *reinterpret_cast<float4*>(dst) = make_float4(csum[h][0], csum[h][1], csum[h][2], csum[h][3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(csum[h][W - 4], csum[h][W - 3], csum[h][W - 2], csum[h][W - 1]);
+      }
+    }
+  }
 }
 
 template <int EPI>

@@ -658,7 +658,55 @@ __global__ __launch_bounds__(256) void quantize_fp8_site_kernel(const bf16_t* x,
   }
   q8_amax_commit(amax, mx, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
+// the same over a [rows][c] matrix with its COLUMN SUMS on the side (colsum[c] += sum over rows): the gradient tensors whose 8-bit copy is the dY operand of a
+// weight-gradient GEMM also give that layer's bias gradient - one pass over the bf16 rows instead of two.  Block = 32 column lanes x 8 bf16 x 8 row lanes.
+__global__ __launch_bounds__(256) void quantize_fp8_site_cols_kernel(const bf16_t* x, int rows, int c, int ldx, uint8_t* y, const float* inv_p, unsigned int* amax,
+                                                                    float* colsum, int rows_per_block) {
+  __shared__ float part[8][32][9];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + tx * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const float inv = y ? *inv_p : 1.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float mx = 0.f;
+  if (col < c) {
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + (size_t)r * ldx + col);
+      const float f[8] = {bf_lo16(u.x), bf_hi16(u.x), bf_lo16(u.y), bf_hi16(u.y), bf_lo16(u.z), bf_hi16(u.z), bf_lo16(u.w), bf_hi16(u.w)};
+#pragma unroll
+      for (int e = 0; e < 8; e++) { acc[e] += f[e]; mx = fmaxf(mx, fabsf(f[e])); }
+      if (y) {
+        uint2 pk;
+        pk.x = (uint32_t)q8_pack4(f[0], f[1], f[2], f[3], inv); pk.y = (uint32_t)q8_pack4(f[4], f[5], f[6], f[7], inv);
+        *reinterpret_cast<uint2*>(y + (size_t)r * c + col) = pk;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) part[ty][tx][i] = acc[i];
+  __syncthreads();
+  const int cc = threadIdx.x;
+  if (blockIdx.x * 256 + cc < c) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += part[j][cc >> 3][cc & 7];
+    unsafeAtomicAdd(colsum + blockIdx.x * 256 + cc, s);
+  }
+  q8_amax_commit(amax, mx, ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6));
+}
 }  // namespace
+CINEMA_API int cinema_quantize_fp8_site_colsum(const uint16_t* x, int rows, int c, int ldx, const cinema_q8_out* q8, float* colsum, void* stream) {
+  if (!x || rows <= 0 || c <= 0 || (c & 7) || (ldx & 7) || !q8 || !q8->amax_slots || (q8->data && !q8->inv_scale) || !colsum || (((uintptr_t)x) & 15) ||
+      (((uintptr_t)q8->data) & 7))
+    return CINEMA_ERR_BAD_ARG;
+  const int col_blocks = (c + 255) / 256;
+  int row_chunks = (1024 + col_blocks - 1) / col_blocks;
+  if (row_chunks > (rows + 63) / 64) row_chunks = (rows + 63) / 64;
+  const int rpb = (((rows + row_chunks - 1) / row_chunks) + 7) / 8 * 8;
+  dim3 grid(col_blocks, (rows + rpb - 1) / rpb);
+  CINEMA_LAUNCH(quantize_fp8_site_cols_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, c, ldx, q8->data, q8->inv_scale, q8->amax_slots, colsum, rpb);
+  return launch_status();
+}
 CINEMA_API int cinema_fp8_sites_update(unsigned int* amax_slots, float* scale, float* inv_scale, int n_sites, float margin, void* stream) {
   if (!amax_slots || !scale || !inv_scale || n_sites <= 0 || !(margin >= 1.0f)) return CINEMA_ERR_BAD_ARG;
   CINEMA_LAUNCH(fp8_sites_update_kernel, dim3(n_sites), dim3(256), 0, (hipStream_t)stream, amax_slots, scale, inv_scale, n_sites, margin);

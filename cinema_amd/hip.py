@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p), ("scale_a_rows", C.c_int),
         ("conv_taps", C.c_void_p), ("conv_x", C.c_int), ("conv_y", C.c_int), ("conv_z", C.c_int), ("conv_c", C.c_int), ("conv_coords", C.c_void_p), ("conv_zb", C.c_int),
         ("out8", C.c_void_p), ("ld_out8", C.c_int), ("out8_inv_scale", C.c_void_p), ("out8_amax", C.c_void_p),
+        ("colsum_partials", C.c_void_p),
         ("tail_counters", C.c_void_p),
         ("kernel_used", C.c_int),
     ]
@@ -135,6 +136,7 @@ _PROTOS = {
     "cinema_quantize_fp8_rows": [_vp, _i, _i, _vp, _vp, _vp],
     "cinema_fp8_sites_update": [_vp, _vp, _vp, _i, _f, _vp],
     "cinema_quantize_fp8_site": [_vp, _ll, C.POINTER(Q8Out), _vp],
+    "cinema_quantize_fp8_site_colsum": [_vp, _i, _i, _i, C.POINTER(Q8Out), _vp, _vp],
     "cinema_layernorm_fwd_q8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(Q8Out), _vp],
     "cinema_layernorm_bwd_deferred_q8": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, C.POINTER(C.c_int), C.POINTER(Q8Out), _vp],
     "cinema_layernorm_fwd_fp8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
@@ -442,10 +444,11 @@ def _tail_workspace(device: torch.device) -> torch.Tensor:
 
 
 _TAIL_COUNTERS: dict = {}
-# 1: the split tail of the 128x128 GEMM is finished inside the launch by each tile's last k-slice instead of the fix-up launch.  Bit-identical results;
-# measured slower in the step (same box, 2 rounds: 28.58-28.80 ms with fan-in caps 2..16 vs 28.54 with the fix-up launch): ONE workgroup reads its partners'
-# partial tiles (up to 15 x 64 KiB at ~64 B/clk) at the very end of the launch, the fix-up kernel spreads the same reads over 8 workgroups per tile
-TAIL_IN_LAUNCH = bool(int(os.environ.get("CINEMA_TAIL_IN_LAUNCH", "0")))
+# 1 (default since round 4): the split tail of the 128x128 GEMM is finished inside the launch - every k-slice of a tail tile publishes its partial tile and then
+# sums and finishes ITS share of the tile (reduce-scatter over the slices, csrc/gemm.hip tail_finish_in_launch) - instead of the fix-up launch.  Bit-identical
+# results.  Round 3's form (ONE workgroup, the last arriver, read up to 15 x 64 KiB) was slower than the fix-up launch; this one is time-neutral per shape and in
+# the step (profiles/r04_b_*: 27.31 / 27.13 ms with the fix-up launch, 27.01 / 27.16 without) and removes 117 launches per step.  0: the fix-up launch.
+TAIL_IN_LAUNCH = bool(int(os.environ.get("CINEMA_TAIL_IN_LAUNCH", "1")))
 TAIL_MIN_K = int(os.environ.get("CINEMA_TAIL_MIN_K", "768"))  # shortest reduction that gets split-tail scratch (the library decides per shape)
 
 
@@ -489,11 +492,19 @@ def _set_out8(g: GemmArgs, out8: tuple, m: int, n: int) -> None:
     g.out8_inv_scale, g.out8_amax = site.inv.data_ptr(), site.amax.data_ptr()
 
 
+def _set_colsum_partials(g: GemmArgs, ws: torch.Tensor, m: int, n: int) -> None:
+    _dev(ws)
+    if ws.dtype != torch.float32 or not ws.is_contiguous() or tuple(ws.shape) != ((m + 31) // 32, n):
+        raise HipLibraryError("colsum_partials must be dense fp32 [ceil(M / 32), N]")
+    g.colsum_partials = ws.data_ptr()
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True, out: torch.Tensor | None = None,
          out_dtype: torch.dtype = torch.bfloat16, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None,
          gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, aux_out: torch.Tensor | None = None,
          act: int = 0, accumulate: bool = False, split_k: int = 1, alpha: float = 1.0, force_generic: bool = False,
-         a_rowsum: torch.Tensor | None = None, p256: int | None = None, gelu_deriv: bool = False, out8: tuple | None = None) -> torch.Tensor:
+         a_rowsum: torch.Tensor | None = None, p256: int | None = None, gelu_deriv: bool = False, out8: tuple | None = None,
+         colsum_partials: torch.Tensor | None = None) -> torch.Tensor:
     """``out8`` = (Q8Site, uint8 [M, N] | None): 8-bit copy of a bf16 result with the site's delayed scale (None: record the maximum only).
     D = epilogue(alpha * A @ B).  ``a``: [M,K] if a_kmajor else [K,M];  ``b``: [N,K] if b_kmajor else [K,N].
     ``gelu_deriv``: the auxiliary GELU tensor holds GELU'(pre-activation) - written to ``aux_out`` by an ``act=1`` launch, multiplied in from ``gelu_in``.
@@ -543,6 +554,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         g.a_rowsum = a_rowsum.data_ptr()
     if out8 is not None:
         _set_out8(g, out8, m, n)
+    if colsum_partials is not None:
+        _set_colsum_partials(g, colsum_partials, m, n)
     if p256 is not None:
         if GEMM_PROFILE is None or LANE is not None:
             _p256_call(C.byref(g), 1, p256, a.device)
@@ -607,6 +620,19 @@ def quantize_fp8_site(x: torch.Tensor, site: Q8Site) -> tuple | None:
     return None if y is None else (y, site.scale)
 
 
+def quantize_fp8_site_colsum(x: torch.Tensor, site: Q8Site, colsum_out: torch.Tensor) -> tuple | None:
+    """:func:`quantize_fp8_site` of a bf16 matrix [rows, c] plus ``colsum_out[c] += column sums of x`` from the same pass (a gradient tensor: its 8-bit copy is
+    the dY operand of the weight gradient, its column sums are the bias gradient)."""
+    _dev(x, colsum_out)
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or x.shape[1] % 8 or colsum_out.dtype != torch.float32 or colsum_out.numel() != x.shape[1] or not colsum_out.is_contiguous():
+        raise HipLibraryError("quantize_fp8_site_colsum: bf16 [rows, c] with c % 8 == 0, fp32 [c] sums")
+    y = _empty(x.shape, dtype=torch.uint8, device=x.device) if site.ready else None
+    q = site.out(y)
+    _check(load().cinema_quantize_fp8_site_colsum(x.data_ptr(), x.shape[0], x.shape[1], _rowmajor(x, "x"), C.byref(q), colsum_out.data_ptr(), _stream()),
+           "quantize_fp8_site_colsum")
+    return None if y is None else (y, site.scale)
+
+
 def fp8_sites_update(amax: torch.Tensor, scale: torch.Tensor, inv: torch.Tensor, n_sites: int, margin: float) -> None:
     _dev(amax, scale, inv)
     _check(load().cinema_fp8_sites_update(amax.data_ptr(), scale.data_ptr(), inv.data_ptr(), n_sites, margin, _stream()), "fp8_sites_update")
@@ -647,7 +673,7 @@ def quantize_fp8_segments_t(x: torch.Tensor, seg_desc: torch.Tensor, scales: tor
 def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16,
              bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, aux_out: torch.Tensor | None = None, act: int = 0,
              alpha: float = 1.0, out: torch.Tensor | None = None, gelu_in: torch.Tensor | None = None, gelu_deriv: bool = False,
-             out8: tuple | None = None) -> torch.Tensor:
+             out8: tuple | None = None, colsum_partials: torch.Tensor | None = None) -> torch.Tensor:
     """D = epilogue(alpha * scale_a * scale_b * A8 @ B8^T): e4m3 operands a8 [M, K], b8 [N, K] (uint8 storage, k-major), per-tensor fp32 [1] scales;
     bias / exact GELU (+ bf16 pre-activation copy) / fp32 residual epilogue like :func:`gemm`."""
     _dev(a8, scale_a, b8, scale_b, bias, residual, aux_out)
@@ -682,6 +708,8 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
     g.act, g.out_f32, g.gelu_deriv = act, int(out.dtype == torch.float32), int(gelu_deriv)
     if out8 is not None:
         _set_out8(g, out8, m, n)
+    if colsum_partials is not None:
+        _set_colsum_partials(g, colsum_partials, m, n)
     _check(load().cinema_gemm_fp8(C.byref(g), _stream()), "gemm_fp8")
     return out
 

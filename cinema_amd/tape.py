@@ -31,7 +31,7 @@ class Var:
     gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
     """
 
-    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site")
+    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site", "fp8t")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = True) -> None:
         self.data = data
@@ -41,6 +41,7 @@ class Var:
         self.fp8: tuple | None = None  # (e4m3 copy of data, per-row scales [rows] or per-tensor scale [1]) when the producer emitted one (op_layernorm(fp8=True))
         self.grad8: tuple | None = None  # (e4m3 copy of the complete gradient, per-tensor scale [1]): written by the LayerNorm backward that produces the gradient
         self.grad8_site = None  # Q8Site: set by the op that wants that copy (its weight- and data-gradient GEMMs read it)
+        self.fp8t = None  # (e4m3 copy, per-tensor scale [1]) of a tensor several ops read (the decoder's shared keys): made once by the first of them
 
     def add_grad(self, g: torch.Tensor, g16: torch.Tensor | None = None) -> None:
         if not self.needs_grad:
@@ -505,7 +506,8 @@ def w_fp8_t(weight: torch.nn.Parameter) -> tuple | None:
 
 
 def dgrad(dy16: torch.Tensor, weight: torch.nn.Parameter, w16: torch.Tensor, *, gelu_in: torch.Tensor | None = None, row_mask: torch.Tensor | None = None,
-          fp8: bool = False, dy8: tuple | None = None, out_f32_residual: torch.Tensor | None = None, gelu_deriv: bool = False, out8: tuple | None = None) -> torch.Tensor:
+          fp8: bool = False, dy8: tuple | None = None, out_f32_residual: torch.Tensor | None = None, gelu_deriv: bool = False, out8: tuple | None = None,
+          colsum_partials: torch.Tensor | None = None) -> torch.Tensor:
     """dX = dY W (x GELU'(gelu_in), or x gelu_in itself when it already holds the derivative: ``gelu_deriv``): bf16 MFMA GEMM, or - ``fp8`` and the shapes allow it - the e4m3 GEMM on per-row quantised dY (``dy8`` = an already
     quantised (bytes, row scales) pair of the same rows, e.g. a column slice of a fused gradient) and the transposed weight shadow.
     ``out_f32_residual``: fp8 path only, adds an fp32 tensor and returns fp32 (two weights fed by column blocks of one gradient)."""
@@ -514,11 +516,11 @@ def dgrad(dy16: torch.Tensor, weight: torch.nn.Parameter, w16: torch.Tensor, *, 
         if wt is not None:
             a8, sa = dy8 if dy8 is not None else K.quantize_fp8_rows(dy16)
             return K.gemm_fp8(a8, sa, wt[0], wt[1], gelu_in=gelu_in, residual=out_f32_residual, out_dtype=F32 if out_f32_residual is not None else BF16,
-                              gelu_deriv=gelu_deriv, out8=out8 if out_f32_residual is None else None)
+                              gelu_deriv=gelu_deriv, out8=out8 if out_f32_residual is None else None, colsum_partials=colsum_partials)
     if out_f32_residual is not None:
         raise RuntimeError("dgrad: the fp32-residual form exists on the fp8 path only")
     return K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False, gelu_in=gelu_in, row_mask=row_mask, gelu_deriv=gelu_deriv,
-                  out8=out8 if (out8 is not None and row_mask is None and dy16.is_cuda and not K.FORCE_GENERIC) else None)
+                  out8=out8 if (out8 is not None and row_mask is None and dy16.is_cuda and not K.FORCE_GENERIC) else None, colsum_partials=colsum_partials)
 
 
 def w_fp8(weight: torch.nn.Parameter) -> tuple:
@@ -894,12 +896,16 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
         else:
             wgrad(tape, dy16, a, pv[2], pv[3], tuple(w2.shape))
         dh8 = K.empty((m, hidden), dtype=torch.uint8, device=x.data.device) if (site_dh is not None and site_dh.ready) else None
-        dh = dgrad(dy16, fc2_w, w2, gelu_in=h, fp8=fp8, gelu_deriv=deriv, dy8=g8, out8=None if site_dh is None else (site_dh, dh8))
+        # fc1's bias gradient = column sums of dh: the data-gradient epilogue that produces dh leaves its sums per strip of 32 rows (3.5 MB), one small launch adds them up
+        strips = K.empty(((m + 31) // 32, hidden), dtype=F32, device=x.data.device) if (site_dh is not None and ok8 and not K.FORCE_GENERIC and w_fp8_t(fc2_w) is not None) else None
+        dh = dgrad(dy16, fc2_w, w2, gelu_in=h, fp8=fp8, gelu_deriv=deriv, dy8=g8, out8=None if site_dh is None else (site_dh, dh8), colsum_partials=strips)
+        if strips is not None:
+            K.colsum(strips, pv[1].grad_buffer((w1.shape[0],)))
         dh8t = None if dh8 is None else (dh8, site_dh.scale)
         if dh8t is not None and x8t is not None and ok8:
-            wgrad8_problem(tape, dh8t, x8t, pv[0].grad_buffer(tuple(w1.shape)), dh, pv[1].grad_buffer((w1.shape[0],)))
+            wgrad8_problem(tape, dh8t, x8t, pv[0].grad_buffer(tuple(w1.shape)), dh, None if strips is not None else pv[1].grad_buffer((w1.shape[0],)))
         else:
-            wgrad(tape, dh, x.data, pv[0], pv[1], tuple(w1.shape))
+            wgrad(tape, dh, x.data, pv[0], None if strips is not None else pv[1], tuple(w1.shape))
         if x.needs_grad:
             x.add_grad(dgrad(dh, fc1_w, w1, fp8=fp8, dy8=dh8t))
 
@@ -940,25 +946,32 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
         if rope is not None:
             K.rope_heads(dqkv, 2 * heads, heads, c // heads, rope[0], rope[1], inverse=True)
         gq, gkv = pv[0].grad_buffer((c, c)), pv[2].grad_buffer((2 * c, c))
-        # e4m3 weight gradient (FP8_WGRAD): dY = one stand-alone 8-bit copy of dq|dk|dv under a delayed per-tensor scale, X = the LayerNorm's per-tensor copy
-        # (the site is created and fed in EVERY step, whatever the state of the other sites: a site that first appears a step late would miss the recording)
-        site = fp8_site(dqkv, q_w, "dy") if (fp8 and c % 16 == 0) else None
-        d8 = K.quantize_fp8_site(dqkv, site) if site is not None else None
-        if not _tensor_scaled(x.fp8):
-            d8 = None
+        g3 = b3 = None
         if q_b is not None and pv[0].direct and pv[2].direct and _adjacent(gq, gkv):
             bq, bkv = pv[1].grad_buffer((c,)), pv[3].grad_buffer((2 * c,))
             if pv[1].direct and pv[3].direct and _adjacent(bq, bkv):  # one [3c, c] weight-gradient GEMM + one column sum
                 g3, b3 = gq.as_strided((3 * c, c), (c, 1)), bq.as_strided((3 * c,), (1,))
-                if d8 is not None:
-                    wgrad8_problem(tape, d8, x.fp8, g3, dqkv, b3)
-                else:
-                    wgrad_problem(tape, dqkv, x.data, g3, b3)
-                gq = None
-        if gq is not None and d8 is not None:
+        # e4m3 weight gradient (FP8_WGRAD): dY = one stand-alone 8-bit copy of dq|dk|dv under a delayed per-tensor scale (the same pass sums its columns =
+        # the bias gradient), X = the LayerNorm's per-tensor copy.  The site is created and fed in EVERY step, whatever the state of the other sites: a
+        # site that first appears a step late would miss the recording
+        site = fp8_site(dqkv, q_w, "dy") if (fp8 and c % 16 == 0) else None
+        d8, bias_done = None, False
+        if site is not None:
+            if b3 is not None:
+                d8, bias_done = K.quantize_fp8_site_colsum(dqkv, site, b3), True
+            else:
+                d8 = K.quantize_fp8_site(dqkv, site)
+            if not _tensor_scaled(x.fp8):
+                d8 = None
+        if g3 is not None:
+            if d8 is not None:
+                wgrad8_problem(tape, d8, x.fp8, g3, dqkv, None if bias_done else b3)
+            else:
+                wgrad_problem(tape, dqkv, x.data, g3, None if bias_done else b3)
+        elif d8 is not None:
             wgrad8_problem(tape, (d8[0][:, :c], d8[1]), x.fp8, gq, dqkv[:, :c], None if q_b is None else pv[1].grad_buffer((c,)))
             wgrad8_problem(tape, (d8[0][:, c:], d8[1]), x.fp8, gkv, dqkv[:, c:], None if kv_b is None else pv[3].grad_buffer((2 * c,)))
-        elif gq is not None:
+        else:
             wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))
             wgrad(tape, dqkv[:, c:], x.data, pv[2], pv[3], (2 * c, c))
         if x.needs_grad:
@@ -1032,14 +1045,20 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
     the k|v projection (and its gradients) are handled by :func:`op_shared_kv` for all blocks at once."""
     c = xq.data.shape[1]
     wq, wkv = w_plain(q_w), w_plain(kv_w)
+    fp8_sites_on = False
     if shared is not None:
         q = K.gemm(xq.data, wq, bias=None if q_b is None else q_b.detach())
         kv = shared[0].part(shared[1])
     elif fp8 and _fp8_ok(xq.data, q_w) and _fp8_ok(xk.data, kv_w):
         q = K.gemm_fp8(*a_fp8(xq), *w_fp8(q_w), bias=None if q_b is None else q_b.detach())
-        if xk.fp8 is None:  # the keys are the same tensor for every decoder block: quantise once
-            xk.fp8 = K.quantize_fp8_rows(xk.data)
-        kv = K.gemm_fp8(*xk.fp8, *w_fp8(kv_w), bias=None if kv_b is None else kv_b.detach())
+        if xk.fp8t is None and xk.fp8 is None:  # the keys are the same tensor for every decoder block: quantise once (the first block's site: per-tensor
+            site_k = fp8_site(xk.data, kv_w, "x")  # delayed scale, the copy then also is the X operand of every block's e4m3 k|v weight gradient)
+            if site_k is not None:
+                xk.fp8t = K.quantize_fp8_site(xk.data, site_k)
+            if xk.fp8t is None:
+                xk.fp8 = K.quantize_fp8_rows(xk.data)
+        kv = K.gemm_fp8(*(xk.fp8t if xk.fp8t is not None else xk.fp8), *w_fp8(kv_w), bias=None if kv_b is None else kv_b.detach())
+        fp8_sites_on = True
     else:
         q = K.gemm(xq.data, wq, bias=None if q_b is None else q_b.detach())
         kv = K.gemm(xk.data, wkv, bias=None if kv_b is None else kv_b.detach())
@@ -1058,13 +1077,26 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
         dkv3 = dkv.view(batch, tk, 2 * c)
         K.attention_bwd(q3, kv3[..., :c], kv3[..., c:], o, y.grad.view(batch, tq, c), lse, heads, scale, dq.view(batch, tq, c), dkv3[..., :c],
                         dkv3[..., c:])
-        wgrad(tape, dq, xq.data, pv[0], pv[1], (c, c))
+        dq8 = dkv8 = None  # e4m3 copies of the gradients under delayed per-tensor scales: dY of the weight gradients, A of the data gradients
+        if fp8_sites_on and c % 16 == 0:
+            sq, skv = fp8_site(dq, q_w, "dy"), fp8_site(dq, kv_w, "dy")
+            if sq is not None:  # one pass per gradient: 8-bit copy + column sums (= the bias gradient)
+                dq8 = K.quantize_fp8_site_colsum(dq, sq, pv[1].grad_buffer((c,))) if q_b is not None else K.quantize_fp8_site(dq, sq)
+                dkv8 = K.quantize_fp8_site_colsum(dkv, skv, pv[3].grad_buffer((2 * c,))) if kv_b is not None else K.quantize_fp8_site(dkv, skv)
+        bias_done = fp8_sites_on and c % 16 == 0 and fp8_site(dq, q_w, "dy") is not None
+        if dq8 is not None and _tensor_scaled(xq.fp8):
+            wgrad8_problem(tape, dq8, xq.fp8, pv[0].grad_buffer((c, c)), dq, None)
+        else:
+            wgrad(tape, dq, xq.data, pv[0], None if bias_done else pv[1], (c, c))
         if shared is None:
-            wgrad(tape, dkv, xk.data, pv[2], pv[3], (2 * c, c))
+            if dkv8 is not None and xk.fp8t is not None:
+                wgrad8_problem(tape, dkv8, xk.fp8t, pv[2].grad_buffer((2 * c, c)), dkv, None)
+            else:
+                wgrad(tape, dkv, xk.data, pv[2], None if bias_done else pv[3], (2 * c, c))
         if xq.needs_grad:
-            xq.add_grad(dgrad(dq, q_w, wq, fp8=fp8))
+            xq.add_grad(dgrad(dq, q_w, wq, fp8=fp8, dy8=dq8))
         if shared is None and xk.needs_grad:
-            xk.add_grad(dgrad(dkv, kv_w, wkv, fp8=fp8))
+            xk.add_grad(dgrad(dkv, kv_w, wkv, fp8=fp8, dy8=dkv8))
 
     tape.record(bwd)
     return y

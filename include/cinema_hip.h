@@ -39,6 +39,9 @@ int cinema_fp8_sites_update(unsigned int* amax_slots, float* scale, float* inv_s
 /* y8 = e4m3(sat(x * *inv_scale)) for a dense bf16 tensor of n elements (n % 8 == 0, 16-byte aligned) + the launch's max|x| into amax_slots: the stand-alone
  * producer for tensors whose kernels do not write an 8-bit copy themselves (attention outputs / gradients). */
 int cinema_quantize_fp8_site(const uint16_t* x, long long n, const cinema_q8_out* q8, void* stream);
+/* the same over a bf16 matrix x [rows][ldx] (c columns, c % 8 == 0; the copy is dense [rows][c]) with its column sums on the side: colsum[c] += sum_r x[r][:] (fp32
+ * atomics) - the 8-bit dY copy of a weight-gradient GEMM and that layer's bias gradient (the autograd of nn.Linear's bias, cinema/vit.py:472-477) in ONE pass */
+int cinema_quantize_fp8_site_colsum(const uint16_t* x, int rows, int c, int ldx, const cinema_q8_out* q8, float* colsum, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GEMM  (reference: nn.Linear / F.linear at cinema/vit.py:472-477,498-499,520, timm Mlp fc1/fc2 vit.py:570-575,
@@ -93,6 +96,8 @@ typedef struct {
   int ld_out8;
   const float* out8_inv_scale;
   unsigned int* out8_amax;    /* may be given without out8: records the maximum only (calibration step) */
+  float* colsum_partials;     /* optional (bf16-output classes, MFMA kernels): fp32 [ceil(m / 32)][n], 16-byte aligned: column sums of D over every strip of 32 rows, each element
+                                 written once (no zeroing, no atomics); cinema_colsum over the strips = the bias gradient of the layer whose dY this GEMM produces */
   void* tail_counters;        /* optional, with `workspace` at split_k == 1: >= 8 KiB of device memory (16-byte aligned), ZERO before the first use (its last word is set if a bounded wait ever gives up) and left zero by every launch,
                                  one per stream: the split tail is finished inside the GEMM launch (no fix-up launch); NULL = fix-up launch */
   int kernel_used;            /* OUT: 0 generic FMA kernel; otherwise the 128x128 MFMA kernel: operand layout (1 fwd, 2 dgrad, 3 wgrad)

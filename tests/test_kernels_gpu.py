@@ -155,15 +155,17 @@ def test_gemm_split_tail_full_size(m: int, n: int, k: int) -> None:
     wt = w.t().contiguous()  # dgrad layout: B stored [k][n]
     out2 = K.gemm(a, wt, b_kmajor=False, out_dtype=torch.float32)
     close(out2, ref - bias, 2e-4, 2e-3, "tail dgrad layout")
-    # optional form (tail_counters): the k-slices are finished INSIDE the launch by each tile's last arriver, slices summed in slice order:
-    # bit-identical to the fix-up launch form, run to run, and the counters are left zero
-    out_f, act_f = K.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32), K.gemm(a, w, bias=bias, act=1)
-    prev, K.TAIL_IN_LAUNCH = K.TAIL_IN_LAUNCH, True
+    # both forms of the tail: the k-slices finished INSIDE the launch (default: every slice sums and finishes its share of the tile, slices summed in slice
+    # order) and the fix-up launch: bit-identical to each other, run to run, and the counters / the error word are left zero
+    prev = K.TAIL_IN_LAUNCH
     try:
+        K.TAIL_IN_LAUNCH = False
+        out_f, act_f, out2_f = K.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32), K.gemm(a, w, bias=bias, act=1), K.gemm(a, wt, b_kmajor=False, out_dtype=torch.float32)
+        K.TAIL_IN_LAUNCH = True
         for _ in range(3):
             assert torch.equal(K.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32), out_f)
             assert torch.equal(K.gemm(a, w, bias=bias, act=1), act_f)
-            assert torch.equal(K.gemm(a, wt, b_kmajor=False, out_dtype=torch.float32), out2)
+            assert torch.equal(K.gemm(a, wt, b_kmajor=False, out_dtype=torch.float32), out2_f)
     finally:
         K.TAIL_IN_LAUNCH = prev
     torch.cuda.synchronize()
