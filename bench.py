@@ -508,6 +508,7 @@ def main() -> None:
         ranks = [None] * world
         dist.all_gather_object(ranks, (rank, torch.cuda.get_device_name(local_rank), local_rank))
         overlapped = mode_ms()
+        payload_bytes, n_early = sync.bytes_last, sync.n_early_last  # of the overlapped schedule (the two measurement modes below change both)
         sync.defer_all = True
         at_end = mode_ms()
         sync.defer_all, sync.disabled = False, True
@@ -515,7 +516,8 @@ def main() -> None:
         sync.disabled = False
         total_comm, exposed = max(at_end - none, 0.0), max(overlapped - none, 0.0)
         ddp_info = {"n_ranks_seen": len({r[0] for r in ranks}), "devices": sorted({r[1] for r in ranks}), "backend": dist.get_backend(), "exchange_dtype": args.grad_exchange,
-                    "payload_bytes_per_step": sync.bytes_last, "early_collectives_per_step": sync.n_early_last,
+                    "payload_bytes_per_step": payload_bytes, "early_collectives_per_step": n_early,
+                    "graph": "identical to the N = 1 step: one grouped weight-gradient launch per block, the decoder's shared k|v GEMM with its parameters as a marked range of their own",
                     "ms_per_step_overlapped": round(overlapped, 3), "ms_per_step_exchange_after_backward": round(at_end, 3), "ms_per_step_no_exchange": round(none, 3),
                     "exposed_comm_ms": round(exposed, 3), "unoverlapped_comm_ms": round(total_comm, 3),
                     "hidden_fraction": (round(1.0 - exposed / total_comm, 3) if total_comm > 0 else None),

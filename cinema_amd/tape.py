@@ -999,13 +999,15 @@ class SharedKV:
 
 # The decoder blocks all project the SAME un-normed encoder output to their keys / values (reference cinema/mae/mae.py:580-582, cinema/vit.py:472-477):
 # one GEMM with the concatenated weights (N = n_blocks * 2c: 10.75 rounds of tiles instead of 8 x 1.34), one data-gradient GEMM with K = n_blocks * 2c
-# and one grouped weight-gradient launch instead of 8 of each: 423 vs 610 us per step measured in isolation (tools/bench_gemm.py "X dec").  Off under a
-# gradient exchange (the blocks' collectives start when their own backward ops are launched; these weight gradients come later) and with fp8 forward.
+# and one grouped weight-gradient launch instead of 8 of each: 423 vs 610 us per step measured in isolation (tools/bench_gemm.py "X dec").  Off with fp8
+# forward.  Under a gradient exchange the k|v parameters form a marked range of their own (their gradients are complete after the shared backward).
 SHARE_DECODER_KV = bool(int(os.environ.get("CINEMA_SHARE_KV", "1")))
 
 
 def share_kv_ok(xk: Var, attns: list) -> bool:
-    return (SHARE_DECODER_KV and len(attns) > 1 and PARAMS_DONE_HOOK is None and not FP8_FORWARD and xk.data.is_cuda and not K.FORCE_GENERIC
+    # (legal under a gradient exchange since round 4: the k|v parameters are taken out of their blocks' marked ranges and marked as a range of their own,
+    # which fires after the shared backward below - see op_shared_kv / Block.tape_forward)
+    return (SHARE_DECODER_KV and len(attns) > 1 and not FP8_FORWARD and xk.data.is_cuda and not K.FORCE_GENERIC
             and all(a.kv.weight.shape == attns[0].kv.weight.shape and (a.kv.bias is None) == (attns[0].kv.bias is None) for a in attns)
             and attns[0].kv.weight.shape[0] % 16 == 0 and xk.data.shape[1] % 8 == 0)
 
@@ -1014,6 +1016,9 @@ def op_shared_kv(tape: Tape, xk: Var, attns: list) -> SharedKV:
     """k|v of every block in ``attns`` (modules with ``kv`` Linear layers) from xk bf16 [b*tk, c]."""
     n, (two_c, c) = len(attns), attns[0].kv.weight.shape
     rows = xk.data.shape[0]
+    # gradient exchange: the k|v weight gradients of ALL blocks are complete only after this op's backward (recorded first = runs last): their ranges are
+    # marked here, the blocks leave them out of their own marks
+    mark_params(tape, [p for a in attns for p in (a.kv.weight, a.kv.bias) if p is not None and p.requires_grad])
     wcat = K.empty((n * two_c, c), dtype=BF16, device=xk.data.device)
     K.row_copy_multi([dict(dst=wcat[i * two_c:(i + 1) * two_c], src=w_plain(a.kv.weight)) for i, a in enumerate(attns)])
     bcat = None

@@ -289,7 +289,12 @@ class Block(nn.Module, _CkptFlag):
     def tape_forward(self, tp: T.Tape, xq: T.Var, xk: T.Var | None, batch: int, shared_kv: tuple | None = None) -> T.Var:
         """xq: fp32 residual stream [b*tq, c]; xk: bf16 un-normed keys [b*tk, c] or None (``vit.py:589``)."""
         drop = self.drop_path_rate if self.training else 0.0
-        T.mark_params(tp, self._param_list())  # gradient all-reduce of this block may start once its backward ops are launched
+        # gradient all-reduce of this block may start once its backward ops are launched (k|v projected for all decoder blocks at once: those two parameters get
+        # their gradients from op_shared_kv's backward, which marks them itself)
+        pl = self._param_list()
+        if shared_kv is not None:
+            pl = [p for p in pl if p is not self.attn.kv.weight and p is not self.attn.kv.bias]
+        T.mark_params(tp, pl)
         T.wgrad_group(tp)                      # ... which includes the grouped weight-gradient launch: its flush runs before that marker fires
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps, fp8=True)
         att = self.attn.tape_forward(tp, qn, xk, batch, shared_kv=shared_kv)

@@ -108,3 +108,51 @@ def test_two_rank_product_step_on_one_gpu(tmp_path: Path) -> None:
     assert [g for _, g in b0["losses"]] == [g for _, g in b1["losses"]]  # the pre-clip norm is computed from the reduced gradient: identical
     assert b0["losses"] != b1["losses"]                             # different data per rank: different local losses
     assert all(math.isfinite(l) and math.isfinite(g) for l, g in b0["losses"])
+
+
+@pytest.mark.parametrize("exchange", ["fp32", "bf16"])
+def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str) -> None:
+    """``bench.py --gpus 2`` exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2``), with both ranks on the
+    one leased GPU and gloo as the transport (dev overrides CINEMA_BENCH_SHARE_GPU / CINEMA_BENCH_BACKEND: RCCL refuses two ranks on one device; the rank
+    environment, barrier, max-over-ranks timing, rank-0 JSON line, replayed step + GradientSynchronizer are the product's).  Checks the JSON contract of the
+    N > 1 line and its ``ddp`` object: both ranks seen, payload = every element of the flat gradient buffer once per step (4 bytes fp32, 2 bytes bf16),
+    overlapped per-block collectives issued, the three schedule timings present."""
+    import json
+    import subprocess
+
+    from cinema_amd import CineMA
+    from cinema_amd.ddp import get_free_port
+
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    env = dict(os.environ, CINEMA_BENCH_SHARE_GPU="1", CINEMA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(get_free_port()),
+           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "1", "--batch", "2", "--cpu-budget", "0", "--grad-exchange", exchange]
+    import signal
+    import tempfile
+
+    with tempfile.TemporaryFile("w+") as fo, tempfile.TemporaryFile("w+") as fe:  # files, not pipes: a killed launcher's children cannot keep a pipe open
+        proc = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, text=True, cwd=str(ROOT), start_new_session=True)
+        try:
+            rc = proc.wait(timeout=240)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)  # the whole process group: launcher + both ranks
+            proc.wait()
+            fe.seek(0)
+            pytest.fail("bench.py --gpus 2 did not finish within 240 s: " + fe.read()[-3000:])
+        fo.seek(0)
+        fe.seek(0)
+        stdout, stderr = fo.read(), fe.read()
+    assert rc == 0, stderr[-3000:]
+    line = [ln for ln in stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]  # whole-job samples/s over both ranks
+    ddp = d["ddp"]
+    model = CineMA(**bench.base_kwargs("base"))
+    flat_elems = sum(((p.numel() + 7) // 8) * 8 for p in model.parameters() if p.requires_grad)  # FlatModel pads every parameter to 8 elements
+    assert ddp["n_ranks_seen"] == 2 and ddp["backend"] == "gloo" and ddp["exchange_dtype"] == exchange
+    assert ddp["payload_bytes_per_step"] == flat_elems * (4 if exchange == "fp32" else 2), (ddp["payload_bytes_per_step"], flat_elems)
+    assert ddp["early_collectives_per_step"] >= 20  # 12 encoder + 8 decoder blocks (+ the shared k|v range) go out from the backward hooks
+    assert all(ddp[k] > 0 for k in ("ms_per_step_overlapped", "ms_per_step_exchange_after_backward", "ms_per_step_no_exchange"))
