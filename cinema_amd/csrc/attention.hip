@@ -129,7 +129,11 @@ __device__ __forceinline__ BlockCoord block_coord() {
   return c;
 }
 
-template <int HD>
+// V2 (round 4): the softmax denominator comes out of the matrix pipe (one more MFMA per 16 keys with an all-ones operand: the row sums of the bf16 probabilities
+// the P V product uses, instead of 32 dependent v_add_f32 per tile) and the running maximum is raised lazily (only when some query's tile maximum exceeds it by
+// more than 2^6: the accumulators are then rescaled, otherwise neither the rescale multiplies nor the alpha exponential run) - the kernel is bound by VALU +
+// v_exp_f32 issue, the matrix pipe has the slack.
+template <int HD, bool V2>
 __global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
   using Stage = TileStage<HD, 64>;
   constexpr int TB = Stage::BYTES;
@@ -149,6 +153,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
 #pragma unroll
   for (int i = 0; i < HD / 32; i++) zero16(o[i]);
   float m_run = NEG_INF, l_run = 0.f;
+  constexpr bool SUM_MFMA = V2 && HD == 32;  // (at head_dim 64 the 16 extra accumulator registers do not fit the 128-register budget of 4 waves per SIMD: plain sums there)
+  float16v lacc;  // SUM_MFMA: every row of this accumulator holds the running denominator of the lane's query
+  zero16(lacc);
+  short8v ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (short)0x3F80;  // bf16 1.0
 
   const int nkt = (p.tk + 63) / 64;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -190,23 +200,46 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * p.c2);  // running max in the scaled base-2 domain (c2 > 0)
-    const float alpha = fast_exp2(m_run - m_new);
-    float ps = 0.f;
+    if constexpr (V2) {
+      const float mxs = mx * p.c2;  // tile maximum in the scaled base-2 domain (c2 > 0)
+      if (__builtin_amdgcn_ballot_w64(mxs > m_run + 6.0f) != 0ull) {  // wave-uniform: somebody's maximum moved by more than 2^6 (always true in the first tile)
+        const float m_new = fmaxf(m_run, mxs);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        if (SUM_MFMA) lacc[0] *= alpha; else l_run *= alpha;
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+        for (int i = 0; i < HD / 32; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float e = fast_exp2(fmaf(s[u][r], p.c2, -m_new));  // one FMA + one v_exp_f32 per score
-        s[u][r] = e;
-        ps += e;
+          for (int r = 0; r < 16; r++) o[i][r] *= alpha;
       }
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
+      float ps = 0.f;
 #pragma unroll
-    for (int i = 0; i < HD / 32; i++)
+      for (int u = 0; u < 2; u++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+        for (int r = 0; r < 16; r++) {
+          s[u][r] = fast_exp2(fmaf(s[u][r], p.c2, -m_run));  // <= 2^6: no overflow anywhere downstream
+          if (!SUM_MFMA) ps += s[u][r];
+        }
+      if (!SUM_MFMA) l_run += ps;
+    } else {
+      const float m_new = fmaxf(m_run, mx * p.c2);  // running max in the scaled base-2 domain (c2 > 0)
+      const float alpha = fast_exp2(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float e = fast_exp2(fmaf(s[u][r], p.c2, -m_new));  // one FMA + one v_exp_f32 per score
+          s[u][r] = e;
+          ps += e;
+        }
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+    }
     // O^T[d][q] += V^T[d][key] * P^T[key][q]
 #pragma unroll
     for (int u = 0; u < 2; u++)
@@ -216,11 +249,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
 #pragma unroll
         for (int dt = 0; dt < HD / 32; dt++)
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(vs_, 32 * u + 16 * st, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+        if constexpr (SUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);  // row sums of the same bf16 probabilities
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed
     __syncthreads();
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = SUM_MFMA ? lacc[0] : l_run + __shfl_xor(l_run, 32, 64);  // (the MFMA reduces over all 16 k-slots: both lane halves hold the full sum)
   if (qrow < p.tq) {
     const float inv = 1.f / l_tot;
     bf16_t* op = p.o + ((size_t)b * p.tq + qrow) * p.ldo + h * HD;
@@ -825,8 +859,9 @@ CINEMA_API int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* 
   hipStream_t st = (hipStream_t)stream;
   if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo}, {q, k, v, o})) {
     dim3 grid((tq + 127) / 128, h, b);
-    if (hd == 64) CINEMA_LAUNCH(attn_fwd_mfma<64>, grid, dim3(256), 0, st, p);
-    else CINEMA_LAUNCH(attn_fwd_mfma<32>, grid, dim3(256), 0, st, p);
+    const int v2 = getenv("CINEMA_ATTN_FWD_V2") ? atoi(getenv("CINEMA_ATTN_FWD_V2")) : 1;  // read per call: tests / tools A/B both forms in one process
+    if (hd == 64) { if (v2) CINEMA_LAUNCH((attn_fwd_mfma<64, true>), grid, dim3(256), 0, st, p); else CINEMA_LAUNCH((attn_fwd_mfma<64, false>), grid, dim3(256), 0, st, p); }
+    else { if (v2) CINEMA_LAUNCH((attn_fwd_mfma<32, true>), grid, dim3(256), 0, st, p); else CINEMA_LAUNCH((attn_fwd_mfma<32, false>), grid, dim3(256), 0, st, p); }
     return launch_status();
   }
   const size_t smem = (size_t)4 * tk * sizeof(float);

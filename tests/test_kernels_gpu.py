@@ -372,6 +372,37 @@ def test_attention_forward_backward(hd: int, heads: int, tq: int, tk: int, gener
         close(got, want, 2e-2, tol, f"attention {name}")
 
 
+@pytest.mark.parametrize("hd", [32, 64])
+def test_attention_forward_lazy_rescale_branch(hd: int, monkeypatch: pytest.MonkeyPatch) -> None:
+    """The forward kernel raises its running maximum lazily (only when a tile's maximum exceeds it by more than 2^6) and, at head_dim 32, takes the softmax
+    denominator from an all-ones MFMA.  Bounded random inputs take the rescale branch in the first tile only, so this test FORCES it later: small scores
+    everywhere, one key in the 5th tile whose score is ~+30 (log2 domain) for half of the queries and ~-30 for the others (the vote is per wave: lanes whose
+    maximum did not move ride along), and a second, smaller spike in a later tile that stays under the threshold.  Full-tensor fp32 reference; the eager form
+    (CINEMA_ATTN_FWD_V2=0) must agree with the lazy one to rounding, and so must their log-sum-exp rows."""
+    b, heads, tq, tk = 2, 3, 300, 700
+    c = heads * hd
+    g = torch.Generator().manual_seed(77)
+    q = (torch.randn(b, tq, c, generator=g) * 0.3)
+    k = (torch.randn(b, tk, c, generator=g) * 0.3)
+    v = torch.randn(b, tk, c, generator=g)
+    sign = torch.where(torch.arange(tq) % 2 == 0, 1.0, -1.0)[None, :, None]
+    q[:, :, :4] = 2.0 * sign          # first 4 channels of head 0: +-2
+    k[:, 300, :4] = 16.0 * hd**0.5 / 4  # key 300 (tile 4): score +-(4 * 2 * 16 sqrt(hd) / 4) / sqrt(hd) = +-32 -> ~+-46 in log2 units
+    k[:, 520, :4] = 1.5 * hd**0.5 / 4   # key 520 (tile 8): +-3 -> under the 2^6 threshold relative to the running maximum of the "-" queries
+    q, k, v = (t.to(torch.bfloat16).to(DEV) for t in (q, k, v))
+    ref = attn_ref(q.float(), k.float(), v.float(), heads)
+    s = (q.float().reshape(b, tq, heads, hd).transpose(1, 2) @ k.float().reshape(b, tk, heads, hd).transpose(1, 2).transpose(-1, -2)) * hd**-0.5
+    outs = {}
+    for v2 in ("1", "0"):
+        monkeypatch.setenv("CINEMA_ATTN_FWD_V2", v2)
+        o, lse = K.attention_fwd(q, k, v, heads, hd**-0.5)
+        close(o, ref, 1e-2, 1e-2, f"attention fwd spike V2={v2}")
+        close(lse, torch.logsumexp(s, dim=-1) / math.log(2.0), 1e-4, 2e-3, f"lse spike V2={v2}")
+        assert bool(torch.isfinite(o.float()).all())
+        outs[v2] = (o.float(), lse)
+    assert float((outs["1"][0] - outs["0"][0]).abs().max()) <= 2e-2 and float((outs["1"][1] - outs["0"][1]).abs().max()) <= 2e-3
+
+
 @pytest.mark.parametrize(("heads", "tq", "tk"), [(16, 2053, 684), (4, 70, 33), (2, 130, 768), (3, 64, 97)])
 def test_attention_backward_one_pass_equals_two_kernel_form(heads: int, tq: int, tk: int, monkeypatch) -> None:  # noqa: ANN001
     """attn_bwd_fused_mfma<32> (one workgroup per (batch, head), P and dS computed once, dQ through the in-LDS transpose of dS and a fixed-order
