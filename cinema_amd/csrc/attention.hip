@@ -859,7 +859,7 @@ CINEMA_API int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* 
   hipStream_t st = (hipStream_t)stream;
   if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo}, {q, k, v, o})) {
     dim3 grid((tq + 127) / 128, h, b);
-    const int v2 = getenv("CINEMA_ATTN_FWD_V2") ? atoi(getenv("CINEMA_ATTN_FWD_V2")) : 1;  // read per call: tests / tools A/B both forms in one process
+    const int v2 = getenv("CINEMA_ATTN_FWD_V2") ? atoi(getenv("CINEMA_ATTN_FWD_V2")) : 1;  // read per call: tests / tools A/B the forms in one process
     if (hd == 64) { if (v2) CINEMA_LAUNCH((attn_fwd_mfma<64, true>), grid, dim3(256), 0, st, p); else CINEMA_LAUNCH((attn_fwd_mfma<64, false>), grid, dim3(256), 0, st, p); }
     else { if (v2) CINEMA_LAUNCH((attn_fwd_mfma<32, true>), grid, dim3(256), 0, st, p); else CINEMA_LAUNCH((attn_fwd_mfma<32, false>), grid, dim3(256), 0, st, p); }
     return launch_status();
