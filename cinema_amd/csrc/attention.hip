@@ -899,12 +899,9 @@ CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* 
     const char* fused_txt = getenv("CINEMA_ATTN_FUSED");  // read per call: tests switch between the two forms
     const int fused_env = fused_txt ? atoi(fused_txt) : 1;
     if (fused_env && hd == 32 && tk <= 8 * FUSED_MAXKB * 32 && !(ldo & 7)) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_mfma<32>), hipFuncAttributeMaxDynamicSharedMemorySize, FusedGeom<32>::SMEM);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-      }
+      static bool attr_set[16] = {};
+      const hipError_t e = dyn_lds_attr_once(attr_set, reinterpret_cast<const void*>(attn_bwd_fused_mfma<32>), FusedGeom<32>::SMEM);
+      if (e != hipSuccess) return (int)e;
       CINEMA_LAUNCH(attn_bwd_fused_mfma<32>, dim3((unsigned)(b * h)), dim3(512), (size_t)FusedGeom<32>::SMEM, st, p);
       return launch_status();
     }

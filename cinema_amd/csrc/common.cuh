@@ -230,6 +230,17 @@ __device__ __forceinline__ void q8_amax_commit(unsigned int* slots, float lane_a
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per (kernel instantiation, device ordinal), not once per process
+// (a second device of the same process would otherwise launch with more than 64 KiB of dynamic LDS without it and fail).  `flags` = one static array per call site.
+inline hipError_t dyn_lds_attr_once(bool (&flags)[16], const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (flags[dev]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) flags[dev] = true;
+  return e;
+}
+
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }  // low 32 bits of a flat LDS pointer = LDS byte address
 
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private 4 MiB L2.  xcd_remap() is a bijection

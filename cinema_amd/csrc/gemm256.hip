@@ -575,13 +575,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(P256 g) {
 
 template <bool A_KMAJ, bool B_KMAJ, int EPI, int LOOP>
 int launch_p256(const P256& g, int grid, hipStream_t st) {
-  static bool attr_set = false;
+  static bool attr_set[16] = {};
   auto fn = gemm_p256_kernel<A_KMAJ, B_KMAJ, EPI, LOOP>;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, P_SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  const hipError_t e = dyn_lds_attr_once(attr_set, reinterpret_cast<const void*>(fn), P_SMEM);
+  if (e != hipSuccess) return (int)e;
   launch_any(fn, dim3(grid), dim3(512), (size_t)P_SMEM, st, g);
   return launch_status();
 }

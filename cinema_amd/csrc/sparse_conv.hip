@@ -556,8 +556,8 @@ CINEMA_API int cinema_sparse_dwconv_bwd_weight(const uint16_t* x, const uint16_t
     else PIPE_LAUNCH(16);
 #undef PIPE_LAUNCH
   } else {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)sparse_dwconv_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static bool attr_set[16] = {};
+    (void)dyn_lds_attr_once(attr_set, (const void*)sparse_dwconv_wgrad_kernel<5>, 160 * 1024);
     launch_lanes(sparse_dwconv_wgrad_kernel<5>, sparse_dwconv_wgrad_lanes_kernel<5>, 2, dim3(blocks, (c + 63) / 64), dim3(256), smem, st, p);
   }
   const int total = c * (taps + 1);

@@ -993,7 +993,7 @@ class SharedKV:
 
     def grad_part(self, i: int) -> torch.Tensor:
         if self.grad is None:
-            self.grad = K.empty_like(self.data)
+            self.grad = K.zeros(tuple(self.data.shape), self.data.dtype, self.data.device)  # zero: a block whose backward returns early leaves its column block untouched
         return self.grad[:, i * self.width:(i + 1) * self.width]
 
 
