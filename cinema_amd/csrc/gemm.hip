@@ -113,6 +113,7 @@ __device__ __forceinline__ void block_epilogue_rows(const GemmP& p, const float1
   const int n = nw + cl;
   float bv[W];
   float q8max = 0.f;
+  const float q8inv = p.out8 ? *p.out8_inv : 0.f;
   EpiPre<W> pre[PASSES];
   epi_load_bias<W>(p, n, true, bv);
 #pragma unroll
@@ -133,7 +134,7 @@ __device__ __forceinline__ void block_epilogue_rows(const GemmP& p, const float1
       const float4 t = *reinterpret_cast<const float4*>(stg + r * 32 + ((((cl >> 2) + c) ^ (r & 7)) << 2));
       v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
     }
-    if (m < p.m && n < p.n) epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
+    if (m < p.m && n < p.n) epi_apply<W>(p, m, n, v, bv, pre[pss], q8max, q8inv);
   }
   if (p.out8_amax) q8_amax_commit(p.out8_amax, q8max, (int)blockIdx.x + (int)(threadIdx.x >> 6));
 }
@@ -675,7 +676,8 @@ CINEMA_API int cinema_debug_gemm_timing(long long* buf) {
 #endif
 
 CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
-  if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!a || !a->a || !a->b || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
+  if (!a->d && (!a->out8 || a->out_f32 || a->accumulate || a->split_k > 1 || a->force_generic)) return CINEMA_ERR_BAD_ARG;  // D may be omitted only when its 8-bit copy is the output
   if (a->accumulate && !a->out_f32) return CINEMA_ERR_BAD_ARG;
   const int split = a->split_k < 1 ? 1 : a->split_k;
   if (split > 1 && !a->accumulate && !a->workspace) return CINEMA_ERR_BAD_ARG;
@@ -705,7 +707,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   fast = fast && (!a->residual_bf16 || (al8(a->ld_res) && ptr16(a->residual_bf16))) && (!a->gelu_in || (al8(a->ld_gelu) && ptr16(a->gelu_in)));
   fast = fast && (!a->aux_out || (al8(a->ld_aux) && ptr16(a->aux_out)));
   fast = fast && !(a->a_kmajor == 0 && a->b_kmajor == 1);  // (M-major A, K-major B) is not used by the path
-  if (!fast && (p.out8_amax || p.colsum_partials)) return CINEMA_ERR_UNSUPPORTED;  // the 8-bit copy / strip sums are written by the staged MFMA epilogues only
+  if (!fast && (p.out8_amax || p.colsum_partials || !a->d)) return CINEMA_ERR_UNSUPPORTED;  // the 8-bit copy / strip sums are written by the staged MFMA epilogues only
   if (fast) {
     const int nkt = (a->k + BK - 1) / BK;
     const int sp = split > nkt ? nkt : split;
@@ -846,7 +848,8 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
 // layout), K % 16 == 0, lda / ldb % 16 == 0, 16-byte aligned; epilogue terms as cinema_gemm_bf16's forward classes: bias, exact GELU with optional
 // bf16 pre-activation copy (aux_out), fp32 residual; bf16 or fp32 output.  No split-K / split tail.
 CINEMA_API int cinema_gemm_fp8(cinema_gemm_args* a, void* stream) {
-  if (!a || !a->a || !a->b || !a->d || a->m <= 0 || a->n <= 0 || a->k <= 0 || !a->scale_a || !a->scale_b) return CINEMA_ERR_BAD_ARG;
+  if (!a || !a->a || !a->b || a->m <= 0 || a->n <= 0 || a->k <= 0 || !a->scale_a || !a->scale_b) return CINEMA_ERR_BAD_ARG;
+  if (!a->d && (!a->out8 || a->out_f32)) return CINEMA_ERR_BAD_ARG;  // D may be omitted only when its 8-bit copy is the output
   if (!a->a_kmajor || !a->b_kmajor || a->accumulate || a->split_k > 1 || a->row_mask || a->residual_bf16 || a->a_rowsum) return CINEMA_ERR_UNSUPPORTED;
   if (a->gelu_in && ((a->ld_gelu & 7) || (((uintptr_t)a->gelu_in) & 15))) return CINEMA_ERR_UNSUPPORTED;
   auto al = [](long long v, int q) { return (v % q) == 0; };

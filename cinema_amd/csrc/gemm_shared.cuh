@@ -163,7 +163,7 @@ __device__ __forceinline__ void epi_load(const GemmP& p, int m, int n0, EpiPre<W
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 template <int W>
-__device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (&v)[W], const float (&bv)[W], const EpiPre<W>& e, float& q8max) {
+__device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (&v)[W], const float (&bv)[W], const EpiPre<W>& e, float& q8max, float q8inv = 0.f) {
   const float al = p.scale_a_rows ? p.alpha * p.scale_a[m] : p.alpha;  // fp8 operands with per-row activation scales (p.alpha already holds scale_b)
 #pragma unroll
   for (int i = 0; i < W; i++) v[i] = fmaf(v[i], al, bv[i]);
@@ -231,12 +231,14 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
       else *reinterpret_cast<f32x4e*>(dp + i) = o;
     }
   } else {
-    store_bf16(reinterpret_cast<bf16_t*>(p.d) + (size_t)m * p.ldd + n0);
+    if (p.d) store_bf16(reinterpret_cast<bf16_t*>(p.d) + (size_t)m * p.ldd + n0);  // (omitted when only the 8-bit copy below is wanted)
     if (p.out8_amax) {  // 8-bit copy of the same values (per-tensor delayed scale) + this launch's maximum
 #pragma unroll
       for (int i = 0; i < W; i++) q8max = fmaxf(q8max, fabsf(v[i]));
       if (p.out8) {
-        const float inv = *p.out8_inv;
+        // (the caller loads the scale ONCE per tile, ahead of the staging: read here it was a vector load + s_waitcnt vmcnt(0) in every row pass, which on
+        // gfx9 also drains the pass's output stores - 15 us on a 13824 x 4096 GEMM)
+        const float inv = q8inv != 0.f ? q8inv : *p.out8_inv;
         uint8_t* dst8 = p.out8 + (size_t)m * p.ld_out8 + n0;
         if (W == 8) { uint2 pk; pk.x = (uint32_t)q8_pack4(v[0], v[1], v[2], v[3], inv); pk.y = (uint32_t)q8_pack4(v[W - 4], v[W - 3], v[W - 2], v[W - 1], inv); *reinterpret_cast<uint2*>(dst8) = pk; }
         else *reinterpret_cast<int*>(dst8) = q8_pack4(v[0], v[1], v[2], v[3], inv);
@@ -291,6 +293,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmP& p, const float16
   const int n = nw + cl;
   float bv[W];
   float q8max = 0.f;
+  const float q8inv = (!ws_base && p.out8) ? *p.out8_inv : 0.f;  // in flight during the LDS staging
   constexpr int NSTRIP = (PASSES * RPP) / 32;  // 32-row strips of this call's rows (2 for a 64-row wave tile, 1 for a half)
   float csum[NSTRIP][W];
 #pragma unroll
@@ -329,7 +332,7 @@ __device__ __forceinline__ void tile_epilogue_rows(const GemmP& p, const float16
 #pragma unroll
         for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
       } else {
-        epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
+        epi_apply<W>(p, m, n, v, bv, pre[pss], q8max, q8inv);
         if (W == 8 && p.colsum_partials) {
 #pragma unroll
           for (int i = 0; i < W; i++) csum[(pss * RPP) / 32][i] += v[i];
@@ -602,6 +605,7 @@ __device__ __forceinline__ void half_epilogue_rows(const GemmP& p, const float16
   const int n = nw + cl;
   float bv[W];
   float q8max = 0.f;
+  const float q8inv = (!ws_base && p.out8) ? *p.out8_inv : 0.f;  // in flight during the LDS staging
   constexpr int NSTRIP = (PASSES * RPP) / 32;  // 32-row strips of this call's rows (2 for a 64-row wave tile, 1 for a half)
   float csum[NSTRIP][W];
 #pragma unroll
@@ -638,7 +642,7 @@ __device__ __forceinline__ void half_epilogue_rows(const GemmP& p, const float16
 #pragma unroll
         for (int c = 0; c < W; c += 4) *reinterpret_cast<float4*>(ws_base + (long long)m * ws_ld + n + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
       } else {
-        epi_apply<W>(p, m, n, v, bv, pre[pss], q8max);
+        epi_apply<W>(p, m, n, v, bv, pre[pss], q8max, q8inv);
         if (W == 8 && p.colsum_partials) {
 #pragma unroll
           for (int i = 0; i < W; i++) csum[(pss * RPP) / 32][i] += v[i];

@@ -45,6 +45,7 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
   const int nch = p.c >> 2;
   const float inv_c = 1.f / (float)p.c;
   float tmax = 0.f;
+  const float tinv = (p.q8_amax && p.y_fp8) ? *p.q8_inv : 1.f;  // once, ahead of the row loop
   for (int row0 = wave_global * rows_per_wave; row0 < p.rows; row0 += n_waves * rows_per_wave) {
     const int row = row0 + lane / p.lpr;
     const bool rv = row < p.rows;
@@ -90,7 +91,7 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& p) {
     if (p.q8_amax) {  // per-tensor delayed scale: no reduction at all in the row, the maximum is committed once per wave after the loop
       tmax = fmaxf(tmax, amax);
       if (p.y_fp8) {
-        const float inv = *p.q8_inv;
+        const float inv = tinv;
 #pragma unroll
         for (int i = 0; i < CPL; i++) {
           const int ch = sub + i * p.lpr;

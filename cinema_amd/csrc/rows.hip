@@ -694,7 +694,26 @@ __global__ __launch_bounds__(256) void quantize_fp8_site_cols_kernel(const bf16_
   }
   q8_amax_commit(amax, mx, ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6));
 }
+__global__ __launch_bounds__(256) void dequantize_fp8_kernel(const uint8_t* x, long long n8, const float* scale_p, bf16_t* y) {
+  const float sc = *scale_p;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const uint2 u = reinterpret_cast<const uint2*>(x)[i];
+    const int lo = (int)u.x, hi = (int)u.y;  // (the byte selector of v_cvt_f32_fp8 is an immediate)
+    const float f[8] = {__builtin_amdgcn_cvt_f32_fp8(lo, 0) * sc, __builtin_amdgcn_cvt_f32_fp8(lo, 1) * sc, __builtin_amdgcn_cvt_f32_fp8(lo, 2) * sc, __builtin_amdgcn_cvt_f32_fp8(lo, 3) * sc,
+                        __builtin_amdgcn_cvt_f32_fp8(hi, 0) * sc, __builtin_amdgcn_cvt_f32_fp8(hi, 1) * sc, __builtin_amdgcn_cvt_f32_fp8(hi, 2) * sc, __builtin_amdgcn_cvt_f32_fp8(hi, 3) * sc};
+    uint4 o;
+    o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+    reinterpret_cast<uint4*>(y)[i] = o;
+  }
+}
 }  // namespace
+CINEMA_API int cinema_dequantize_fp8(const uint8_t* x8, long long n, const float* scale, uint16_t* y, void* stream) {
+  if (!x8 || !scale || !y || n <= 0 || (n & 7) || (((uintptr_t)x8) & 7) || (((uintptr_t)y) & 15)) return CINEMA_ERR_BAD_ARG;
+  long long g = (n / 8 + 255) / 256;
+  if (g > 2048) g = 2048;
+  CINEMA_LAUNCH(dequantize_fp8_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x8, n / 8, scale, (bf16_t*)y);
+  return launch_status();
+}
 CINEMA_API int cinema_quantize_fp8_site_colsum(const uint16_t* x, int rows, int c, int ldx, const cinema_q8_out* q8, float* colsum, void* stream) {
   if (!x || rows <= 0 || c <= 0 || (c & 7) || (ldx & 7) || !q8 || !q8->amax_slots || (q8->data && !q8->inv_scale) || !colsum || (((uintptr_t)x) & 15) ||
       (((uintptr_t)q8->data) & 7))

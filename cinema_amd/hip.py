@@ -136,6 +136,7 @@ _PROTOS = {
     "cinema_quantize_fp8_rows": [_vp, _i, _i, _vp, _vp, _vp],
     "cinema_fp8_sites_update": [_vp, _vp, _vp, _i, _f, _vp],
     "cinema_quantize_fp8_site": [_vp, _ll, C.POINTER(Q8Out), _vp],
+    "cinema_dequantize_fp8": [_vp, _ll, _vp, _vp, _vp],
     "cinema_quantize_fp8_site_colsum": [_vp, _i, _i, _i, C.POINTER(Q8Out), _vp, _vp],
     "cinema_layernorm_fwd_q8": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(Q8Out), _vp],
     "cinema_layernorm_bwd_deferred_q8": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _ll, C.POINTER(C.c_int), C.POINTER(Q8Out), _vp],
@@ -620,6 +621,17 @@ def quantize_fp8_site(x: torch.Tensor, site: Q8Site) -> tuple | None:
     return None if y is None else (y, site.scale)
 
 
+def dequantize_fp8(q8: tuple) -> torch.Tensor:
+    """bf16 tensor of an (e4m3 bytes, per-tensor scale [1]) pair (an 8-bit-only output that a consumer outside the e4m3 GEMMs asks for)."""
+    y8, sc = q8
+    _dev(y8, sc)
+    if y8.dtype != torch.uint8 or not y8.is_contiguous() or y8.numel() % 8 or sc.numel() != 1:
+        raise HipLibraryError("dequantize_fp8: contiguous uint8 with a multiple of 8 elements, one fp32 scale")
+    y = _empty(y8.shape, dtype=torch.bfloat16, device=y8.device)
+    _check(load().cinema_dequantize_fp8(y8.data_ptr(), y8.numel(), sc.data_ptr(), y.data_ptr(), _stream()), "dequantize_fp8")
+    return y
+
+
 def quantize_fp8_site_colsum(x: torch.Tensor, site: Q8Site, colsum_out: torch.Tensor) -> tuple | None:
     """:func:`quantize_fp8_site` of a bf16 matrix [rows, c] plus ``colsum_out[c] += column sums of x`` from the same pass (a gradient tensor: its 8-bit copy is
     the dY operand of the weight gradient, its column sums are the bias gradient)."""
@@ -673,7 +685,7 @@ def quantize_fp8_segments_t(x: torch.Tensor, seg_desc: torch.Tensor, scales: tor
 def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b: torch.Tensor, *, out_dtype: torch.dtype = torch.bfloat16,
              bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, aux_out: torch.Tensor | None = None, act: int = 0,
              alpha: float = 1.0, out: torch.Tensor | None = None, gelu_in: torch.Tensor | None = None, gelu_deriv: bool = False,
-             out8: tuple | None = None, colsum_partials: torch.Tensor | None = None) -> torch.Tensor:
+             out8: tuple | None = None, colsum_partials: torch.Tensor | None = None, skip_d: bool = False) -> torch.Tensor | None:
     """D = epilogue(alpha * scale_a * scale_b * A8 @ B8^T): e4m3 operands a8 [M, K], b8 [N, K] (uint8 storage, k-major), per-tensor fp32 [1] scales;
     bias / exact GELU (+ bf16 pre-activation copy) / fp32 residual epilogue like :func:`gemm`."""
     _dev(a8, scale_a, b8, scale_b, bias, residual, aux_out)
@@ -681,14 +693,18 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
         raise HipLibraryError("gemm_fp8: uint8 (e4m3) operands [M, K] and [N, K]")
     m, k = a8.shape
     n = b8.shape[0]
-    if out is None:
+    if skip_d:  # ``skip_d``: only the 8-bit copy of the (bf16) result is wanted (``out8`` with a buffer): no bf16 tensor is written or returned
+        if out8 is None or out8[1] is None or residual is not None or out_dtype != torch.bfloat16:
+            raise HipLibraryError("gemm_fp8(skip_d=True) needs out8 with a buffer and a bf16 result")
+        out = None
+    elif out is None:
         out = _empty((m, n), dtype=torch.float32 if residual is not None else out_dtype, device=a8.device)
     elif tuple(out.shape) != (m, n):
         raise HipLibraryError(f"gemm_fp8 out shape {tuple(out.shape)} != {(m, n)}")
     _dev(out)
     g = GemmArgs()
-    g.a, g.b, g.d = a8.data_ptr(), b8.data_ptr(), out.data_ptr()
-    g.m, g.n, g.k, g.lda, g.ldb, g.ldd = m, n, k, _rowmajor(a8, "a8"), _rowmajor(b8, "b8"), _rowmajor(out, "out")
+    g.a, g.b, g.d = a8.data_ptr(), b8.data_ptr(), (None if out is None else out.data_ptr())
+    g.m, g.n, g.k, g.lda, g.ldb, g.ldd = m, n, k, _rowmajor(a8, "a8"), _rowmajor(b8, "b8"), (n if out is None else _rowmajor(out, "out"))
     g.a_kmajor, g.b_kmajor, g.alpha, g.split_k = 1, 1, alpha, 1
     g.scale_a, g.scale_b = scale_a.data_ptr(), scale_b.data_ptr()
     if scale_a.numel() not in (1, m) or scale_b.numel() != 1 or scale_a.dtype != torch.float32 or scale_b.dtype != torch.float32:
@@ -705,7 +721,7 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
     if gelu_in is not None:  # D = (A8 B8^T) x GELU'(gelu_in): the data gradient through fc1's activation
         _dev(gelu_in)
         g.gelu_in, g.ld_gelu = gelu_in.data_ptr(), _rowmajor(gelu_in, "gelu_in")
-    g.act, g.out_f32, g.gelu_deriv = act, int(out.dtype == torch.float32), int(gelu_deriv)
+    g.act, g.out_f32, g.gelu_deriv = act, int(out is not None and out.dtype == torch.float32), int(gelu_deriv)
     if out8 is not None:
         _set_out8(g, out8, m, n)
     if colsum_partials is not None:

@@ -404,6 +404,7 @@ FP8_DGRAD = bool(int(os.environ.get("CINEMA_FP8_DGRAD", "1")))
 # reads the row-major copies directly (ds_read_b64_tr_b8), see csrc/gemm256.hip form 3.  A site has no scale in its first step: that step runs the per-row /
 # bf16 forms and records maxima (``Fp8Sites.update`` at the end of every optimisation step turns them into scales).
 FP8_WGRAD = bool(int(os.environ.get("CINEMA_FP8_WGRAD", "1")))
+FP8_8BIT_ONLY = bool(int(os.environ.get("CINEMA_FP8_8BIT_ONLY", "1")))  # skip the bf16 tensors whose only readers are e4m3 GEMMs (GELU output, its gradient, the bf16 copy of a residual-stream gradient)
 FP8_MARGIN = float(os.environ.get("CINEMA_FP8_MARGIN", "1.25"))  # scale = margin * amax / 448: headroom for a maximum that grows from one step to the next
 
 
@@ -490,7 +491,7 @@ def _wgrad8_launch(items: list) -> None:
         for it in items:
             if it[6] is not None:
                 K.colsum(it[5], it[6])
-    _wgrad_launch(run, *[t for it in items for t in (it[0], it[2], it[5])])
+    _wgrad_launch(run, *[t for it in items for t in (it[0], it[2], it[5]) if t is not None])
 
 
 def w_fp8_t(weight: torch.nn.Parameter) -> tuple | None:
@@ -511,7 +512,7 @@ def dgrad(dy16: torch.Tensor, weight: torch.nn.Parameter, w16: torch.Tensor, *, 
     """dX = dY W (x GELU'(gelu_in), or x gelu_in itself when it already holds the derivative: ``gelu_deriv``): bf16 MFMA GEMM, or - ``fp8`` and the shapes allow it - the e4m3 GEMM on per-row quantised dY (``dy8`` = an already
     quantised (bytes, row scales) pair of the same rows, e.g. a column slice of a fused gradient) and the transposed weight shadow.
     ``out_f32_residual``: fp8 path only, adds an fp32 tensor and returns fp32 (two weights fed by column blocks of one gradient)."""
-    if fp8 and FP8_FORWARD and FP8_DGRAD and row_mask is None and dy16.is_cuda and weight.shape[0] % 16 == 0 and weight.shape[1] % 8 == 0 and (dy8 is not None or dy16.is_contiguous()):
+    if fp8 and FP8_FORWARD and FP8_DGRAD and row_mask is None and (dy8 is not None or (dy16.is_cuda and dy16.is_contiguous())) and weight.shape[0] % 16 == 0 and weight.shape[1] % 8 == 0:
         wt = w_fp8_t(weight)
         if wt is not None:
             a8, sa = dy8 if dy8 is not None else K.quantize_fp8_rows(dy16)
@@ -519,6 +520,8 @@ def dgrad(dy16: torch.Tensor, weight: torch.nn.Parameter, w16: torch.Tensor, *, 
                               gelu_deriv=gelu_deriv, out8=out8 if out_f32_residual is None else None, colsum_partials=colsum_partials)
     if out_f32_residual is not None:
         raise RuntimeError("dgrad: the fp32-residual form exists on the fp8 path only")
+    if dy16 is None:  # an 8-bit-only gradient on a path that turned out to need bf16
+        dy16 = K.dequantize_fp8(dy8)
     return K.gemm(dy16, w16, a_kmajor=True, b_kmajor=False, gelu_in=gelu_in, row_mask=row_mask, gelu_deriv=gelu_deriv,
                   out8=out8 if (out8 is not None and row_mask is None and dy16.is_cuda and not K.FORCE_GENERIC) else None, colsum_partials=colsum_partials)
 
@@ -760,6 +763,8 @@ def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.P
         want16 = x.data.dtype == F32  # fp32 residual-stream input: also emit the bf16 copy for the upstream GEMMs
         res = x.grad if (x.grad is not None and x.grad.dtype == F32) else None
         site8 = x.grad8_site if (x.data.dtype == F32 and FP8_WGRAD and FP8_FORWARD) else None  # the producer of x wants an 8-bit copy of the complete gradient
+        if site8 is not None and site8.ready and FP8_8BIT_ONLY and FP8_DGRAD:
+            want16 = False  # the e4m3 copy is what the upstream data- / weight-gradient GEMMs read; a bf16 reader (fallback) casts the fp32 rows lazily
         out = K.layernorm_bwd(y.grad, x.data, gamma.detach(), beta.detach(), mean, rstd, act=act, dx_residual=res,
                               want_f32=x.data.dtype == F32, want_bf16=want16 or x.data.dtype == BF16,
                               dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln if DEFER_LN_REDUCE else None, q8=site8)
@@ -813,16 +818,18 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
             residual.add_grad(y.grad, y.grad16)
         # row_mask contract: y = mask * (xW^T + b) and the consumer (op_dwconv with in_mask) hands back a gradient whose
         # masked rows are already zero, so the weight/bias gradients below need no extra masking pass.
-        dy16 = y.grad_bf16()
         g8 = y.grad8 if (site_dy is not None and _tensor_scaled(y.grad8)) else None
+        # with the e4m3 copy of the gradient in hand nobody may need its bf16 form (the LayerNorm backward then did not write one): ask for it only on the bf16 paths
+        fp8_dg = g8 is not None and fp8 and w16 is None and row_mask is None and FP8_DGRAD and w_fp8_t(weight) is not None and weight.shape[0] % 16 == 0 and weight.shape[1] % 8 == 0
+        fp8_wg = g8 is not None and x8t is not None and to_param_layout is None and weight.shape[0] % 16 == 0 and x.data.shape[1] % 16 == 0
         if weight.requires_grad:
-            if g8 is not None and x8t is not None and to_param_layout is None and weight.shape[0] % 16 == 0 and x.data.shape[1] % 16 == 0:
-                wgrad8_problem(tape, g8, x8t, wv.grad_buffer(tuple(w.shape)).view(-1, x.data.shape[1]), dy16,
+            if fp8_wg:
+                wgrad8_problem(tape, g8, x8t, wv.grad_buffer(tuple(w.shape)).view(-1, x.data.shape[1]), y.grad16 if y.grad16 is not None else y.grad,
                                bv.grad_buffer((weight.shape[0],)) if (bias is not None and bias.requires_grad) else None)
             else:
-                wgrad(tape, dy16, x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
+                wgrad(tape, y.grad_bf16(), x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
         if x.needs_grad:
-            x.add_grad(dgrad(dy16, weight, w, row_mask=row_mask, fp8=fp8 and w16 is None, dy8=g8))
+            x.add_grad(dgrad(None if (fp8_dg and y.grad.dtype != BF16) else y.grad_bf16(), weight, w, row_mask=row_mask, fp8=fp8 and w16 is None, dy8=g8))
 
     tape.record(bwd)
     return y
@@ -872,7 +879,10 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
             x8t = x.fp8 if _tensor_scaled(x.fp8) else None
             a8 = K.empty((m, hidden), dtype=torch.uint8, device=x.data.device) if site_a.ready else None
         x8, sx = a_fp8(x)
-        a = K.gemm_fp8(x8, sx, *w_fp8(fc1_w), bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv, out8=None if site_a is None else (site_a, a8))
+        # with its e4m3 copy in hand the bf16 GELU output has no reader in the steady state (fc2's forward and weight gradient take the copy): it is not
+        # written at all (113 MB per ViT-Large block); a consumer outside the e4m3 GEMMs (fallback paths below) gets it by one dequantisation pass
+        a8_only = site_a is not None and a8 is not None and FP8_8BIT_ONLY
+        a = K.gemm_fp8(x8, sx, *w_fp8(fc1_w), bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv, out8=None if site_a is None else (site_a, a8), skip_d=a8_only)
         if site_a is not None and a8 is not None:
             a8t = (a8, site_a.scale)
         a8r, sa = a8t if a8t is not None else K.quantize_fp8_rows(a)
@@ -882,23 +892,37 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
         a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv)
         y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
     pv = [tape.pvar(p) for p in (fc1_w, fc1_b, fc2_w, fc2_b)]
+    a_box = [a]
 
     def bwd() -> None:
         if y.grad is None:
             return
         if residual is not None:
             residual.add_grad(y.grad, y.grad16)
-        dy16 = y.grad_bf16()
         g8 = y.grad8 if (site_dy is not None and _tensor_scaled(y.grad8)) else None
         ok8 = hidden % 16 == 0 and x.data.shape[1] % 16 == 0
+        fp8_dg2 = g8 is not None and w_fp8_t(fc2_w) is not None and FP8_DGRAD  # fc2's data gradient reads the e4m3 copy of the gradient
         if g8 is not None and a8t is not None and ok8:
-            wgrad8_problem(tape, g8, a8t, pv[2].grad_buffer(tuple(w2.shape)), dy16, pv[3].grad_buffer((w2.shape[0],)))
+            # bias gradient = column sums of the gradient: of its bf16 copy when one exists, of the fp32 rows otherwise
+            wgrad8_problem(tape, g8, a8t, pv[2].grad_buffer(tuple(w2.shape)), y.grad16 if y.grad16 is not None else y.grad, pv[3].grad_buffer((w2.shape[0],)))
         else:
-            wgrad(tape, dy16, a, pv[2], pv[3], tuple(w2.shape))
+            if a_box[0] is None:
+                a_box[0] = K.dequantize_fp8(a8t)
+            wgrad(tape, y.grad_bf16(), a_box[0], pv[2], pv[3], tuple(w2.shape))
+        dy16 = y.grad16 if (fp8_dg2 and y.grad.dtype != BF16) else y.grad_bf16()  # may be None: nobody reads it on the e4m3 path
         dh8 = K.empty((m, hidden), dtype=torch.uint8, device=x.data.device) if (site_dh is not None and site_dh.ready) else None
         # fc1's bias gradient = column sums of dh: the data-gradient epilogue that produces dh leaves its sums per strip of 32 rows (3.5 MB), one small launch adds them up
         strips = K.empty(((m + 31) // 32, hidden), dtype=F32, device=x.data.device) if (site_dh is not None and ok8 and not K.FORCE_GENERIC and w_fp8_t(fc2_w) is not None) else None
-        dh = dgrad(dy16, fc2_w, w2, gelu_in=h, fp8=fp8, gelu_deriv=deriv, dy8=g8, out8=None if site_dh is None else (site_dh, dh8), colsum_partials=strips)
+        # dh in bf16 has no reader either when fc1's weight AND data gradient take the e4m3 copy and the strips give the bias gradient
+        dh8_only = (FP8_8BIT_ONLY and fp8_dg2 and dh8 is not None and x8t is not None and ok8 and strips is not None and w_fp8_t(fc1_w) is not None
+                    and fc1_w.shape[0] % 16 == 0 and fc1_w.shape[1] % 8 == 0)
+        if dh8_only:
+            wt2 = w_fp8_t(fc2_w)
+            K.gemm_fp8(g8[0], g8[1], wt2[0], wt2[1], gelu_in=h, gelu_deriv=deriv, out8=(site_dh, dh8), colsum_partials=strips, skip_d=True)
+            dh = None
+        else:
+            dh = dgrad(dy16 if dy16 is not None else y.grad_bf16(), fc2_w, w2, gelu_in=h, fp8=fp8, gelu_deriv=deriv, dy8=g8,
+                       out8=None if site_dh is None else (site_dh, dh8), colsum_partials=strips)
         if strips is not None:
             K.colsum(strips, pv[1].grad_buffer((w1.shape[0],)))
         dh8t = None if dh8 is None else (dh8, site_dh.scale)

@@ -39,6 +39,8 @@ int cinema_fp8_sites_update(unsigned int* amax_slots, float* scale, float* inv_s
 /* y8 = e4m3(sat(x * *inv_scale)) for a dense bf16 tensor of n elements (n % 8 == 0, 16-byte aligned) + the launch's max|x| into amax_slots: the stand-alone
  * producer for tensors whose kernels do not write an 8-bit copy themselves (attention outputs / gradients). */
 int cinema_quantize_fp8_site(const uint16_t* x, long long n, const cinema_q8_out* q8, void* stream);
+/* y (bf16) = e4m3 value * *scale for n elements (n % 8 == 0): the bf16 tensor of an 8-bit-only output for a consumer outside the e4m3 GEMMs */
+int cinema_dequantize_fp8(const uint8_t* x8, long long n, const float* scale, uint16_t* y, void* stream);
 /* the same over a bf16 matrix x [rows][ldx] (c columns, c % 8 == 0; the copy is dense [rows][c]) with its column sums on the side: colsum[c] += sum_r x[r][:] (fp32
  * atomics) - the 8-bit dY copy of a weight-gradient GEMM and that layer's bias gradient (the autograd of nn.Linear's bias, cinema/vit.py:472-477) in ONE pass */
 int cinema_quantize_fp8_site_colsum(const uint16_t* x, int rows, int c, int ldx, const cinema_q8_out* q8, float* colsum, void* stream);
@@ -93,7 +95,7 @@ typedef struct {
   int conv_zb;                /* implicit convolution: 0 / 1 = one row per voxel; ZB > 1 = one row per group of ZB consecutive z voxels (see cinema_conv_gemm_bf16) */
   uint8_t* out8;              /* optional (bf16-output classes of cinema_gemm_bf16 / cinema_gemm_fp8): 8-bit copy of D with per-tensor DELAYED scaling (cinema_q8_out
                                  semantics): out8[m][ld_out8] = e4m3(sat(D[m][n] * *out8_inv_scale)); max|D| of this launch is atomic-maxed into out8_amax[CINEMA_Q8_SLOTS] */
-  int ld_out8;
+  int ld_out8;                /* with out8 given, `d` may be NULL (bf16 classes of the MFMA kernels): only the 8-bit copy is written */
   const float* out8_inv_scale;
   unsigned int* out8_amax;    /* may be given without out8: records the maximum only (calibration step) */
   float* colsum_partials;     /* optional (bf16-output classes, MFMA kernels): fp32 [ceil(m / 32)][n], 16-byte aligned: column sums of D over every strip of 32 rows, each element
