@@ -586,7 +586,7 @@ def main() -> None:
         out = {
             "metric": "MAE-pretrain samples/sec (4-view cine, 75% mask)", "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "untimed_steps": extra_untimed + args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("bf16" if args.dtype == "bf16" else "fp8 (e4m3 forward projections and data gradients: weights per tensor, activations / gradients per row, current scaling; bf16 weight gradients)"), "data": "synthetic",
+            "vs_baseline": None, "dtype": ("bf16" if args.dtype == "bf16" else "fp8 (OCP e4m3 forward, data-gradient and weight-gradient GEMMs of the transformer blocks: weights per tensor (current scaling), activations / gradients per tensor (delayed scaling))"), "data": "synthetic",
             "config": {"workload": f"CineMA ViT-{args.size.capitalize()} MAE, 4 views (SAX {args.sax.replace(',', 'x')} + LAX 2C/3C/4C {args.lax.replace(',', 'x')}), mask 0.75, "
                                    f"per-GPU batch {args.batch}, fwd+bwd+clip(5.0)+AdamW, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),

@@ -142,6 +142,48 @@ class FlatModel:
             return st["data_t"][a:a + p.numel()], st["scales"][i:i + 1]
         return st["data"][a:a + p.numel()], st["scales"][i:i + 1]
 
+    def fp8_shadow_cat_t(self, ps: tuple):  # noqa: ANN201
+        """TRANSPOSED e4m3 shadow of several 2-D weights that lie back to back in the flat buffer and share their column count, quantised as ONE matrix with
+        ONE scale: -> (uint8 [cols, total rows], fp32 [1] scale) or None.  The fused q | kv projection's data gradient dX = dQKV [W_q; W_kv] is then a single
+        e4m3 GEMM with K = 3c (with per-weight scales it was two GEMMs meeting in an fp32 residual, i.e. no faster than the bf16 GEMM)."""
+        if self.flat_shadow is None or any(p.dim() != 2 or getattr(p, "_cinema_shadow_version", -1) != p._version for p in ps):  # noqa: SLF001
+            return None
+        rngs = [self.offsets.get(id(p)) for p in ps]
+        if any(r is None for r in rngs):
+            return None
+        cols = ps[0].shape[1]
+        if any(p.shape[1] != cols or p.numel() % 8 for p in ps) or any(rngs[i][0] + ps[i].numel() != rngs[i + 1][0] for i in range(len(ps) - 1)):
+            return None
+        rows = sum(p.shape[0] for p in ps)
+        if rows % 8 or cols % 8 or rngs[0][0] % 8:
+            return None
+        st = self.__dict__.get("_fp8cat")
+        if st is None:
+            dev = self.flat_param.device
+            st = self.__dict__["_fp8cat"] = {"index": {}, "segs": [], "epoch": None, "tensors": None,
+                                           "plain": K.persistent(lambda: torch.zeros(self.numel, dtype=torch.uint8, device=dev)),
+                                           "data_t": K.persistent(lambda: torch.zeros(self.numel, dtype=torch.uint8, device=dev))}
+        key = tuple(id(p) for p in ps)
+        if key not in st["index"]:
+            st["index"][key] = len(st["segs"])
+            st["segs"].append((rngs[0][0], rows, cols))
+            st["tensors"] = None
+        if st["tensors"] is None:  # descriptors of all joint segments (rebuilt while new ones appear: first step only)
+            dev = self.flat_param.device
+            segs = list(st["segs"])
+            st["tensors"] = K.persistent(lambda: (torch.tensor([[a, a + r * c] for a, r, c in segs], dtype=torch.int64, device=dev),
+                                                  torch.tensor([[a, r, c] for a, r, c in segs], dtype=torch.int64, device=dev),
+                                                  torch.ones(len(segs), dtype=torch.float32, device=dev)))
+            st["epoch"] = None
+        if st["epoch"] != T.WEIGHTS.epoch:
+            bounds, desc, scales = st["tensors"]
+            K.quantize_fp8_segments(self.flat_shadow, bounds, st["plain"], scales)  # (its maxima -> the joint scales; the plain copy is not used)
+            K.quantize_fp8_segments_t(self.flat_shadow, desc, scales, st["data_t"])
+            st["epoch"] = T.WEIGHTS.epoch
+        i = st["index"][key]
+        a = rngs[0][0]
+        return st["data_t"][a:a + rows * cols].view(cols, rows), st["tensors"][2][i:i + 1]
+
     def refresh_shadows(self) -> None:
         """Re-derive every bf16 shadow from the fp32 masters (after construction / ``load_state_dict``); the optimiser keeps
         them in sync afterwards.  A shadow is trusted only while the parameter's autograd version is the one stamped here."""

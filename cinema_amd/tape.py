@@ -999,7 +999,16 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
             wgrad(tape, dqkv[:, :c], x.data, pv[0], pv[1], (c, c))
             wgrad(tape, dqkv[:, c:], x.data, pv[2], pv[3], (2 * c, c))
         if x.needs_grad:
-            x.add_grad(K.gemm(dqkv, w, a_kmajor=True, b_kmajor=False))
+            # data gradient of the fused projection: one e4m3 GEMM over K = 3c on the 8-bit copy of dq|dk|dv and a JOINT transposed shadow of [W_q; W_kv]
+            # (one scale for the pair), else the bf16 GEMM on the concatenated shadow
+            wt = None
+            if site is not None and FP8_DGRAD:  # (asked for in EVERY step of this path, the first included: its descriptors must exist before a step is recorded)
+                flat = getattr(q_w, "_cinema_flat", None)
+                wt = flat.fp8_shadow_cat_t((q_w, kv_w)) if flat is not None else None
+            if wt is not None and d8 is not None:
+                x.add_grad(K.gemm_fp8(d8[0], d8[1], wt[0], wt[1]))
+            else:
+                x.add_grad(K.gemm(dqkv, w, a_kmajor=True, b_kmajor=False))
 
     tape.record(bwd)
     return y
