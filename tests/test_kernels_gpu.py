@@ -1127,3 +1127,52 @@ def test_q8_delayed_scaling_producers() -> None:
         else:
             for i, (site, y16, o8) in enumerate(outs):
                 check((o8, site.scale), y16, f"GEMM epilogue {i}")
+
+
+def test_q8_column_sums_strip_sums_and_8bit_only_outputs() -> None:
+    """The pieces around the e4m3 weight-gradient path that carry the BIAS gradients and drop unread bf16 tensors: (1) ``cinema_quantize_fp8_site_colsum`` = the
+    stand-alone 8-bit copy + column sums in one pass (sums vs fp32 torch, accumulated into an existing gradient; the copy equals the plain stand-alone copy bit
+    for bit); (2) ``colsum_partials`` of the GEMM epilogues: sums over strips of 32 rows, every element written once - summed over the strips they equal the column
+    sums of the bf16 output (ragged row count, both the BK = 64 and BK = 32 kernels, bf16 and e4m3 operands); (3) ``skip_d``: only the 8-bit copy is written, and it
+    equals the copy of the launch that also wrote the bf16 tensor; (4) ``cinema_dequantize_fp8`` inverts the copy to within e4m3 rounding."""
+    from cinema_amd import tape as T
+
+    sites = T.Fp8Sites(torch.device(DEV, torch.cuda.current_device()))
+    x = rnd(5003, 768, scale=0.7, seed=401)
+    s0 = sites.site(("cs", 0))
+    base = rnd(768, dtype=torch.float32, seed=402)
+    acc = base.clone()
+    assert K.quantize_fp8_site_colsum(x, s0, acc) is None  # first launch: records the maximum, still sums
+    close(acc, base + x.float().sum(0), 1e-5, 1e-3 * float(x.float().sum(0).abs().max()), "column sums (first launch)")
+    sites.update()
+    acc2 = torch.zeros(768, device=DEV)
+    q_a = K.quantize_fp8_site_colsum(x, s0, acc2)
+    q_b = K.quantize_fp8_site(x, s0)
+    assert torch.equal(q_a[0], q_b[0]) and float(q_a[1]) == float(q_b[1])
+    close(acc2, x.float().sum(0), 1e-5, 1e-3 * float(x.float().sum(0).abs().max()), "column sums")
+    back = K.dequantize_fp8(q_b)
+    assert float((back.float() - x.float()).abs().max()) <= float(x.float().abs().max()) * 2.0 ** -4 + float(q_b[1]) * 2.0 ** -9
+    # strip sums + 8-bit-only output of the GEMM epilogues
+    for k in (768, 512):  # BK = 64 kernel / BK = 32 kernel
+        m, n = 2053, 1024
+        a, w = rnd(m, k, scale=0.5, seed=403), rnd(n, k, scale=0.05, seed=404)
+        gin = rnd(m, n, seed=405)
+        a8, sa = K.quantize_fp8_rows(a)
+        w8, sw = K.quantize_fp8(w)
+        site = sites.site(("strips", k))
+        K.gemm(a, w, gelu_in=gin, gelu_deriv=True, out8=(site, None))
+        sites.update()
+        for name, fn in (("bf16", lambda **kw: K.gemm(a, w, gelu_in=gin, gelu_deriv=True, **kw)), ("e4m3", lambda **kw: K.gemm_fp8(a8, sa, w8, sw, gelu_in=gin, gelu_deriv=True, **kw))):
+            strips = torch.full(((m + 31) // 32, n), float("nan"), device=DEV)
+            o8 = torch.empty(m, n, dtype=torch.uint8, device=DEV)
+            y = fn(out8=(site, o8), colsum_partials=strips)
+            assert bool(torch.isfinite(strips).all()), "every strip element is written"
+            ref = y.float().sum(0)
+            close(strips.sum(0), ref, 1e-3, 4e-3 * float(ref.abs().max()), f"strip sums {name} k={k}")  # (the strips sum the fp32 values before the bf16 rounding)
+            want = y.float().view(-1)[: 32 * n].view(32, n).sum(0)
+            close(strips[0], want, 1e-3, 4e-3 * float(want.abs().max()), f"first strip {name} k={k}")
+            if name == "e4m3":
+                o8b = torch.empty(m, n, dtype=torch.uint8, device=DEV)
+                strips_b = torch.empty_like(strips)
+                assert K.gemm_fp8(a8, sa, w8, sw, gelu_in=gin, gelu_deriv=True, out8=(site, o8b), colsum_partials=strips_b, skip_d=True) is None
+                assert torch.equal(o8b, o8) and torch.equal(strips_b, strips)
