@@ -637,6 +637,20 @@ def _split_k(m_red: int, n_out: int, k_out: int) -> int:
     return max(1, min(want, (m_red + SPLITK_MIN_ROWS - 1) // SPLITK_MIN_ROWS))
 
 
+CONV_SPLITK_SLOTS = int(os.environ.get("CINEMA_CONV_SPLITK_SLOTS", "256"))
+
+
+def _split_k_conv(m_red: int, n_out: int, k_out: int) -> int:
+    """k-slices of the implicit-convolution weight gradient (CINEMA_CONV_SPLITK_SLOTS workgroup slots).  ALONE these GEMMs want a full round of the 128x128
+    kernel's slots (512: the second resident workgroup covers the gathered operand's DMA latency - 1113 -> 604 us at the 32-channel level, 622 -> 340, 500 -> 301,
+    545 -> 304 us at the others, tools/bench_conv.py, profiles/r04_p_conv_split.txt; the single-stream step 53.8 -> 49.7 ms).  In the product step they run on the
+    weight-gradient stream BESIDE the main stream's kernels, which already take the slots a half round leaves free: 47.5 ms with 256 slots, 47.9 with 512
+    (profiles/r04_q_seg_split_ab.txt) - so the half round stays."""
+    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
+    want = max(1, CONV_SPLITK_SLOTS // tiles)
+    return max(1, min(want, (m_red + SPLITK_MIN_ROWS - 1) // SPLITK_MIN_ROWS))
+
+
 def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
     """Run a weight-gradient launch on the side stream (after everything queued on the main stream so far) or inline.  ``operands``
     are the activation / gradient tensors the launch reads: they were allocated on the main stream, so they are kept alive until the
@@ -1315,7 +1329,7 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
             db = bv.grad_buffer((c_out,)) if (bias is not None and bias.requires_grad) else None
             dyz = dy16.contiguous().view(-1, zb_f * c_out)
             ldz = 9 * (zb_f + 2) * c
-            split = _split_k(dyz.shape[0], zb_f * c_out, ldz)
+            split = _split_k_conv(dyz.shape[0], zb_f * c_out, ldz)
 
             # scratch of the side-stream launches: allocated here and handed over as operands, so that it lives until the side stream has been joined
             r = K.empty((zb_f * c_out, ldz), dtype=F32, device=dev)
@@ -1331,7 +1345,7 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
             dst = wv.grad_buffer(tuple(w16.shape), conv_same_grad_to_param(weight))
             db = bv.grad_buffer((c_out,)) if (bias is not None and bias.requires_grad) else None
             dyc = dy16.contiguous()
-            split = _split_k(dyc.shape[0], c_out, w16.shape[1])
+            split = _split_k_conv(dyc.shape[0], c_out, w16.shape[1])
             _wgrad_launch(lambda: K.conv_wgrad(dyc, xs, taps, coords, dst, split, a_rowsum=db), dyc, xs)
         elif weight.requires_grad:
             wgrad(tape, dy16, K.im2col(xs, ks), wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w16.shape),

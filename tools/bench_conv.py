@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from cinema_amd import hip as K  # noqa: E402
-from cinema_amd.tape import _split_k  # noqa: E402
+from cinema_amd.tape import _split_k_conv as _split_k  # noqa: E402
 from tools.bench_gemm import timeit  # noqa: E402
 
 dev = torch.device("cuda")
