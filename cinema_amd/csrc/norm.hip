@@ -130,12 +130,13 @@ struct LnBwdP {
   int lpr;
   float* ws;  // per-block partial sums [gridDim.x][2][c] (then ln_param_reduce_kernel) or nullptr: atomics from every block
   uint8_t* dx_fp8; const float* q8_inv; unsigned int* q8_amax;  // optional 8-bit copy of dx, dense [rows][c] (cinema_q8_out)
+  float* dcol;  // optional: dcol[c] += column sums of dx (the bias gradient of the projection that produced x), a THIRD row of the per-block partials
 };
 
 // RG = independent row groups per wave iteration: narrow rows (CPL <= 2) carry only 2-4 16-byte loads per lane, too few
 // bytes in flight to cover the HBM latency (measured 2.5 TB/s at C = 64), so those instantiations interleave RG groups.
-template <int CPL, int RG>
-__device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
+template <int CPL, int RG, bool DCOL>
+__device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {  // DCOL: also the column sums of dx (a compile-time flag: its accumulators cost 12-16 registers, a wave per SIMD at c = 768)
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   float* red = reinterpret_cast<float*>(dyn_smem);  // [n_waves_in_block][2][c]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -150,6 +151,9 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
   for (int i = 0; i < CPL; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
   float qmax = 0.f;
   const float q8inv = (p.q8_amax && p.dx_fp8) ? *p.q8_inv : 1.f;
+  float4 ac[CPL];
+#pragma unroll
+  for (int i = 0; i < CPL; i++) ac[i] = make_float4(0, 0, 0, 0);
 
   for (int row0 = wave_global * rows_per_wave * RG; row0 < p.rows; row0 += n_waves * rows_per_wave * RG) {
     float4 xh[RG][CPL], dxh[RG][CPL];
@@ -226,6 +230,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
         }
         if (p.dx_f32) *reinterpret_cast<float4*>(p.dx_f32 + off) = dx;
         if (p.dx_bf16) store4_bf16(p.dx_bf16 + off, dx);
+        if (DCOL) { ac[i].x += dx.x; ac[i].y += dx.y; ac[i].z += dx.z; ac[i].w += dx.w; }
         if (p.q8_amax) {
           qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(dx.x), fabsf(dx.y)), fmaxf(fabsf(dx.z), fabsf(dx.w))));
           if (p.dx_fp8) *reinterpret_cast<int*>(p.dx_fp8 + (size_t)row * p.c + ch * 4) = q8_pack4(dx.x, dx.y, dx.z, dx.w, q8inv);
@@ -234,8 +239,9 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
     }
   }
   if (p.q8_amax) q8_amax_commit(p.q8_amax, qmax, wave_global);
-  if (!p.dgamma && !p.dbeta) return;
-  // reduce over the row sub-groups of the wave (lanes that own the same columns), then over the block's waves
+  if (!p.dgamma && !p.dbeta && !DCOL) return;
+  // reduce over the row sub-groups of the wave (lanes that own the same columns), then over the block's waves; NR rows per wave / block: d gamma, d beta[, columns of dx]
+  constexpr int NR = DCOL ? 3 : 2;
 #pragma unroll
   for (int i = 0; i < CPL; i++) {
     for (int o = p.lpr; o < 64; o <<= 1) {
@@ -243,30 +249,42 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& p) {
       ag[i].z += __shfl_xor(ag[i].z, o, 64); ag[i].w += __shfl_xor(ag[i].w, o, 64);
       ab[i].x += __shfl_xor(ab[i].x, o, 64); ab[i].y += __shfl_xor(ab[i].y, o, 64);
       ab[i].z += __shfl_xor(ab[i].z, o, 64); ab[i].w += __shfl_xor(ab[i].w, o, 64);
+      if (DCOL) {
+        ac[i].x += __shfl_xor(ac[i].x, o, 64); ac[i].y += __shfl_xor(ac[i].y, o, 64);
+        ac[i].z += __shfl_xor(ac[i].z, o, 64); ac[i].w += __shfl_xor(ac[i].w, o, 64);
+      }
     }
     const int ch = sub + i * p.lpr;
     if (lane < p.lpr && ch < nch) {
-      *reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 0) * p.c + ch * 4) = ag[i];
-      *reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 1) * p.c + ch * 4) = ab[i];
+      *reinterpret_cast<float4*>(red + (size_t)(wave * NR + 0) * p.c + ch * 4) = ag[i];
+      *reinterpret_cast<float4*>(red + (size_t)(wave * NR + 1) * p.c + ch * 4) = ab[i];
+      if (DCOL) *reinterpret_cast<float4*>(red + (size_t)(wave * NR + 2) * p.c + ch * 4) = ac[i];
     }
   }
   __syncthreads();
   for (int col = threadIdx.x; col < p.c; col += blockDim.x) {
-    float g = 0.f, b = 0.f;
-    for (int w = 0; w < nw; w++) { g += red[(size_t)(w * 2 + 0) * p.c + col]; b += red[(size_t)(w * 2 + 1) * p.c + col]; }
+    float g = 0.f, b = 0.f, cs = 0.f;
+    for (int w = 0; w < nw; w++) {
+      g += red[(size_t)(w * NR + 0) * p.c + col]; b += red[(size_t)(w * NR + 1) * p.c + col];
+      if (DCOL) cs += red[(size_t)(w * NR + 2) * p.c + col];
+    }
     if (p.ws) {  // plain coalesced stores; 1024 blocks x 2c fp32 atomics on 2c addresses cost as much as the whole streaming pass
-      p.ws[((size_t)blockIdx.x * 2 + 0) * p.c + col] = g;
-      p.ws[((size_t)blockIdx.x * 2 + 1) * p.c + col] = b;
+      p.ws[((size_t)blockIdx.x * NR + 0) * p.c + col] = g;
+      p.ws[((size_t)blockIdx.x * NR + 1) * p.c + col] = b;
+      if (DCOL) p.ws[((size_t)blockIdx.x * NR + 2) * p.c + col] = cs;
     } else {
       if (p.dgamma) unsafeAtomicAdd(p.dgamma + col, g);
       if (p.dbeta) unsafeAtomicAdd(p.dbeta + col, b);
+      if (DCOL) unsafeAtomicAdd(p.dcol + col, cs);
     }
   }
 }
 template <int CPL, int RG>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) { ln_bwd_body<CPL, RG>(p); }
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) { ln_bwd_body<CPL, RG, false>(p); }
 template <int CPL, int RG>
-__global__ __launch_bounds__(256) void ln_bwd_lanes_kernel(Lanes<LnBwdP> L) { ln_bwd_body<CPL, RG>(L.p[blockIdx.y]); }
+__global__ __launch_bounds__(256) void ln_bwd_lanes_kernel(Lanes<LnBwdP> L) { ln_bwd_body<CPL, RG, false>(L.p[blockIdx.y]); }
+template <int CPL, int RG>
+__global__ __launch_bounds__(256) void ln_bwd_dcol_kernel(LnBwdP p) { ln_bwd_body<CPL, RG, true>(p); }  // + column sums of dx (fp8 path: the producing projection's bias gradient)
 // dgamma[col] += sum_blocks ws[block][0][col], dbeta likewise.  Workgroup = 64 columns of the [2c] row x 4 sub-slices of the block range
 // (combined through LDS), grid.y = 16 slices: 64 independent partial rows per column group in flight, 16 atomics per column.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* ws, int nblocks, int c, float* dgamma, float* dbeta) {
@@ -417,14 +435,15 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int lddy, const vo
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
   if (act == 1 && !beta) return CINEMA_ERR_BAD_ARG;
   LnBwdP p{dy, dy_is_bf16, lddy, x, x_is_bf16, ldx, gamma, beta, mean, rstd, rows, c, act, dx_residual, dx_f32, dx_bf16, lddx, dgamma, dbeta,
-           pick_lpr(c), nullptr, q8 ? q8->data : nullptr, q8 ? q8->inv_scale : nullptr, q8 ? q8->amax_slots : nullptr};
+           pick_lpr(c), nullptr, q8 ? q8->data : nullptr, q8 ? q8->inv_scale : nullptr, q8 ? q8->amax_slots : nullptr, q8 ? q8->colsum : nullptr};
+  const int nr = p.dcol ? 3 : 2;
   if ((c & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) {
     if (c > 64 || q8) return CINEMA_ERR_UNSUPPORTED;
     CINEMA_LAUNCH(ln_bwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();
   }
   const int cpl = ((c >> 2) + p.lpr - 1) / p.lpr;
-  const size_t smem = (size_t)4 * 2 * c * sizeof(float);
+  const size_t smem = (size_t)4 * nr * c * sizeof(float);
   return dispatch_cpl<LnBwdP>(cpl, [&](auto tag) {
     constexpr int CPL = decltype(tag)::value;
     constexpr int RG = CPL == 1 ? 4 : 1;  // RG = 2 at CPL 2-3 measured 30 % slower (registers)
@@ -432,10 +451,12 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int lddy, const vo
     int grid = (rows + rows_per_block - 1) / rows_per_block;
     const int cap = CPL == 1 ? 2048 : 1024;
     if (grid > cap) grid = cap;
-    const bool two_pass = (dgamma || dbeta) && workspace && workspace_bytes >= (long long)grid * 2 * c * 4 && grid >= 64;
+    const bool two_pass = (dgamma || dbeta || p.dcol) && workspace && workspace_bytes >= (long long)grid * nr * c * 4 && grid >= 64;
     if (two_pass) p.ws = workspace;
-    launch_lanes(ln_bwd_kernel<CPL, RG>, ln_bwd_lanes_kernel<CPL, RG>, 1, dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    if (p.dcol) CINEMA_LAUNCH((ln_bwd_dcol_kernel<CPL, RG>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    else launch_lanes(ln_bwd_kernel<CPL, RG>, ln_bwd_lanes_kernel<CPL, RG>, 1, dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
     if (two_pass && deferred_partials) *deferred_partials = grid;  // the caller reduces `grid` partial rows later (cinema_ln_param_reduce_batched)
+    else if (two_pass && p.dcol) return CINEMA_ERR_UNSUPPORTED;  // (column sums of dx: deferred form only)
     else if (two_pass) CINEMA_LAUNCH(ln_param_reduce_kernel, dim3((2 * c + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, grid, c, dgamma, dbeta);
     return launch_status();
   });
@@ -488,25 +509,26 @@ __global__ __launch_bounds__(256) void ln_param_reduce_batched_kernel(LnReduceBa
   __shared__ float red[4][64];
   const cinema_ln_reduce_item& e = b.it[blockIdx.z];
   const int c = e.c, nblocks = e.n_partials;
+  const int nr = e.dcol ? 3 : 2;  // rows per partial: d gamma, d beta[, column sums of dx]
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-  if (blockIdx.x * 64 >= 2 * c) return;
+  if (blockIdx.x * 64 >= nr * c) return;
   const int slices = gridDim.y * 4;
   const int per = (nblocks + slices - 1) / slices;
   const int b0 = (blockIdx.y * 4 + sub) * per, b1 = min(nblocks, b0 + per);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (col < 2 * c) {
+  if (col < nr * c) {
     const float* src = e.partials + col;
-    const size_t ld = (size_t)2 * c;
+    const size_t ld = (size_t)nr * c;
     int r = b0;
     for (; r + 3 < b1; r += 4) { s0 += src[r * ld]; s1 += src[(r + 1) * ld]; s2 += src[(r + 2) * ld]; s3 += src[(r + 3) * ld]; }
     for (; r < b1; r++) s0 += src[r * ld];
   }
   red[sub][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (sub == 0 && col < 2 * c) {
+  if (sub == 0 && col < nr * c) {
     const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float* dst = col < c ? e.dgamma : e.dbeta;
-    if (dst) unsafeAtomicAdd(dst + (col < c ? col : col - c), t);
+    float* dst = col < c ? e.dgamma : (col < 2 * c ? e.dbeta : e.dcol);
+    if (dst) unsafeAtomicAdd(dst + col % c, t);
   }
 }
 }  // namespace
@@ -522,7 +544,7 @@ CINEMA_API int cinema_ln_param_reduce_batched(const cinema_ln_reduce_item* items
       if (!b.it[i].partials || b.it[i].n_partials <= 0 || b.it[i].c <= 0) return CINEMA_ERR_BAD_ARG;
       if (b.it[i].c > cmax) cmax = b.it[i].c;
     }
-    CINEMA_LAUNCH(ln_param_reduce_batched_kernel, dim3((2 * cmax + 63) / 64, 16, n), dim3(256), 0, (hipStream_t)stream, b);
+    CINEMA_LAUNCH(ln_param_reduce_batched_kernel, dim3((3 * cmax + 63) / 64, 16, n), dim3(256), 0, (hipStream_t)stream, b);
   }
   return launch_status();
 }

@@ -51,7 +51,7 @@ class GemmArgs(C.Structure):
 class Q8Out(C.Structure):
     """Mirror of ``cinema_q8_out``."""
 
-    _fields_ = [("data", C.c_void_p), ("inv_scale", C.c_void_p), ("amax_slots", C.c_void_p)]
+    _fields_ = [("data", C.c_void_p), ("inv_scale", C.c_void_p), ("colsum", C.c_void_p), ("amax_slots", C.c_void_p)]
 
 
 class Q8Site:
@@ -68,8 +68,8 @@ class Q8Site:
     def ready(self) -> bool:
         return self.owner.updates > self.born
 
-    def out(self, data: torch.Tensor | None) -> Q8Out:
-        return Q8Out(None if data is None else data.data_ptr(), self.inv.data_ptr(), self.amax.data_ptr())
+    def out(self, data: torch.Tensor | None, colsum: torch.Tensor | None = None) -> Q8Out:
+        return Q8Out(None if data is None else data.data_ptr(), self.inv.data_ptr(), None if colsum is None else colsum.data_ptr(), self.amax.data_ptr())
 
 
 # cinema_gemm_args.kernel_used -> kernel name as rocprofv3 prints it: 0 generic, otherwise
@@ -108,7 +108,7 @@ class RowCopyArgs(C.Structure):
 class LnReduceItem(C.Structure):
     """Mirror of ``cinema_ln_reduce_item``."""
 
-    _fields_ = [("partials", C.c_void_p), ("n_partials", C.c_int), ("c", C.c_int), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+    _fields_ = [("partials", C.c_void_p), ("n_partials", C.c_int), ("c", C.c_int), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dcol", C.c_void_p)]
 
 
 class SparseGeom(C.Structure):
@@ -1243,32 +1243,37 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor | None, mean: torch.Tensor, rstd: torch.Tensor, *,
                   act: int = 0, dx_residual: torch.Tensor | None = None, want_f32: bool = True, want_bf16: bool = False,
                   dgamma: torch.Tensor | None = None, dbeta: torch.Tensor | None = None, dx_f32_out: torch.Tensor | None = None,
-                  deferred: list | None = None, q8: Q8Site | None = None):  # noqa: ANN201
+                  deferred: list | None = None, q8: Q8Site | None = None, q8_colsum: torch.Tensor | None = None):  # noqa: ANN201
     """-> (dx_f32 | None, dx_bf16 | None); dgamma/dbeta (fp32 [c]) are accumulated in place when given - at once, or (``deferred`` list)
-    by a later :func:`ln_param_reduce_batched` over the entries appended to that list.  ``q8``: -> (dx_f32, dx_bf16, (dx8, site.scale) | None), the 8-bit copy of
-    dx under the site's delayed scale (deferred form only)."""
+    by a later :func:`ln_param_reduce_batched` over the entries appended to that list.  ``q8``: -> (dx_f32, dx_bf16, (dx8, site.scale) | None, colsum_done), the
+    8-bit copy of dx under the site's delayed scale; ``q8_colsum`` (fp32 [c]): the column sums of dx are accumulated there by the same deferred reduce (the bias
+    gradient of the projection that produced x) - ``colsum_done`` says whether that form ran."""
     _dev(dy, x, gamma, mean, rstd, dx_residual, dgamma, dbeta)
     rows, c = x.shape
     if q8 is not None:
         if deferred is None or (dgamma is None and dbeta is None) or c % 4:
             r = layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=act, dx_residual=dx_residual, want_f32=want_f32, want_bf16=True, dgamma=dgamma, dbeta=dbeta,
                               dx_f32_out=dx_f32_out, deferred=deferred)
-            return r[0], r[1], quantize_fp8_site(r[1], q8)
+            return r[0], r[1], quantize_fp8_site(r[1], q8), False
         dx32 = dx_f32_out if dx_f32_out is not None else (_empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
         dx16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
         dx8 = _empty((rows, c), dtype=torch.uint8, device=x.device) if q8.ready else None
         if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
             raise HipLibraryError("dx_residual must be dense fp32 [rows, c]")
-        ws = _empty(max(load().cinema_layernorm_bwd_workspace_bytes(rows, c) // 4, 4), dtype=torch.float32, device=x.device)
+        if q8_colsum is not None:
+            _dev(q8_colsum)
+            if q8_colsum.dtype != torch.float32 or q8_colsum.numel() != c or not q8_colsum.is_contiguous():
+                raise HipLibraryError("q8_colsum must be dense fp32 [c]")
+        ws = _empty(max(load().cinema_layernorm_bwd_workspace_bytes(rows, c) // 8 * (3 if q8_colsum is not None else 2), 4), dtype=torch.float32, device=x.device)
         n_part = C.c_int(0)
-        q = q8.out(dx8)
+        q = q8.out(dx8, q8_colsum)
         _check(load().cinema_layernorm_bwd_deferred_q8(dy.data_ptr(), int(dy.dtype == torch.bfloat16), _rowmajor(dy, "dy"), x.data_ptr(),
                                                        int(x.dtype == torch.bfloat16), _rowmajor(x, "x"), gamma.data_ptr(), _p(beta), mean.data_ptr(),
                                                        rstd.data_ptr(), rows, c, act, _p(dx_residual), _p(dx32), _p(dx16), c, _p(dgamma), _p(dbeta),
                                                        ws.data_ptr(), ws.numel() * 4, C.byref(n_part), C.byref(q), _stream()), "layernorm_bwd_q8")
         if n_part.value > 0:
-            deferred.append((ws, n_part.value, c, dgamma, dbeta))
-        return dx32, dx16, (None if dx8 is None else (dx8, q8.scale))
+            deferred.append((ws, n_part.value, c, dgamma, dbeta, q8_colsum))
+        return dx32, dx16, (None if dx8 is None else (dx8, q8.scale)), q8_colsum is not None  # (fewer than 64 workgroups: the kernel added the sums with atomics)
     dx32 = dx_f32_out if dx_f32_out is not None else (_empty((rows, c), dtype=torch.float32, device=x.device) if want_f32 else None)
     dx16 = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     if dx_residual is not None and (dx_residual.stride(0) != c or dx_residual.dtype != torch.float32):
@@ -1298,8 +1303,10 @@ def ln_param_reduce_batched(items: list) -> None:
     if not items:
         return
     arr = (LnReduceItem * len(items))()
-    for e, (ws, n_part, c, dg, db) in zip(arr, items):
+    for e, it in zip(arr, items):
+        ws, n_part, c, dg, db = it[:5]
         e.partials, e.n_partials, e.c, e.dgamma, e.dbeta = ws.data_ptr(), n_part, c, _p(dg), _p(db)
+        e.dcol = _p(it[5]) if len(it) > 5 else None  # third partial row: column sums of dx (layernorm_bwd(q8_colsum=...))
     _check(load().cinema_ln_param_reduce_batched(arr, len(items), _stream()), "ln_param_reduce_batched")
 
 

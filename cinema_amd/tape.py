@@ -31,7 +31,7 @@ class Var:
     gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
     """
 
-    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site", "fp8t")
+    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site", "fp8t", "grad8_bias", "grad8_bias_done")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = True) -> None:
         self.data = data
@@ -42,6 +42,8 @@ class Var:
         self.grad8: tuple | None = None  # (e4m3 copy of the complete gradient, per-tensor scale [1]): written by the LayerNorm backward that produces the gradient
         self.grad8_site = None  # Q8Site: set by the op that wants that copy (its weight- and data-gradient GEMMs read it)
         self.fp8t = None  # (e4m3 copy, per-tensor scale [1]) of a tensor several ops read (the decoder's shared keys): made once by the first of them
+        self.grad8_bias = None  # the bias Parameter of the projection that produced this tensor: the LayerNorm backward that writes grad8 also sums the columns of the gradient
+        self.grad8_bias_done = False  # ... and says so here (the projection's own backward then adds no bias gradient)
 
     def add_grad(self, g: torch.Tensor, g16: torch.Tensor | None = None) -> None:
         if not self.needs_grad:
@@ -779,13 +781,17 @@ def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.P
         site8 = x.grad8_site if (x.data.dtype == F32 and FP8_WGRAD and FP8_FORWARD) else None  # the producer of x wants an 8-bit copy of the complete gradient
         if site8 is not None and site8.ready and FP8_8BIT_ONLY and FP8_DGRAD:
             want16 = False  # the e4m3 copy is what the upstream data- / weight-gradient GEMMs read; a bf16 reader (fallback) casts the fp32 rows lazily
+        bias_p = x.grad8_bias if site8 is not None else None
+        colsum = tape.pvar(bias_p).grad_buffer((c,)) if (bias_p is not None and bias_p.requires_grad and DEFER_LN_REDUCE) else None
         out = K.layernorm_bwd(y.grad, x.data, gamma.detach(), beta.detach(), mean, rstd, act=act, dx_residual=res,
                               want_f32=x.data.dtype == F32, want_bf16=want16 or x.data.dtype == BF16,
-                              dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln if DEFER_LN_REDUCE else None, q8=site8)
+                              dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln if DEFER_LN_REDUCE else None, q8=site8,
+                              **({"q8_colsum": colsum} if site8 is not None else {}))
         dx32, dx16 = out[0], out[1]
         if x.data.dtype == F32:
             x.grad, x.grad16 = dx32, dx16  # includes the previously accumulated residual gradient
             x.grad8 = out[2] if site8 is not None else None
+            x.grad8_bias_done = bool(site8 is not None and colsum is not None and out[3])
         else:
             x.add_grad(dx16)
 
@@ -820,6 +826,7 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
                            out_dtype=F32 if (out_f32 or residual is not None) else BF16))
         if y.data.dtype == F32:
             y.grad8_site = site_dy  # the LayerNorm backward that completes this residual-stream gradient writes its e4m3 copy
+            y.grad8_bias = bias if site_dy is not None else None  # ... and sums its columns into this bias' gradient
     else:
         y = Var(K.gemm(x.data, w, bias=None if bias is None else bias.detach(), residual=None if residual is None else residual.data,
                        out_dtype=F32 if (out_f32 or residual is not None) else BF16, row_mask=row_mask))
@@ -836,12 +843,13 @@ def op_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.nn.Par
         # with the e4m3 copy of the gradient in hand nobody may need its bf16 form (the LayerNorm backward then did not write one): ask for it only on the bf16 paths
         fp8_dg = g8 is not None and fp8 and w16 is None and row_mask is None and FP8_DGRAD and w_fp8_t(weight) is not None and weight.shape[0] % 16 == 0 and weight.shape[1] % 8 == 0
         fp8_wg = g8 is not None and x8t is not None and to_param_layout is None and weight.shape[0] % 16 == 0 and x.data.shape[1] % 16 == 0
+        want_bias = bias is not None and bias.requires_grad and not y.grad8_bias_done  # (done: the LayerNorm backward that produced the gradient summed its columns)
         if weight.requires_grad:
             if fp8_wg:
                 wgrad8_problem(tape, g8, x8t, wv.grad_buffer(tuple(w.shape)).view(-1, x.data.shape[1]), y.grad16 if y.grad16 is not None else y.grad,
-                               bv.grad_buffer((weight.shape[0],)) if (bias is not None and bias.requires_grad) else None)
+                               bv.grad_buffer((weight.shape[0],)) if want_bias else None)
             else:
-                wgrad(tape, y.grad_bf16(), x.data, wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w.shape), to_param_layout)
+                wgrad(tape, y.grad_bf16(), x.data, wv, bv if want_bias else None, tuple(w.shape), to_param_layout)
         if x.needs_grad:
             x.add_grad(dgrad(None if (fp8_dg and y.grad.dtype != BF16) else y.grad_bf16(), weight, w, row_mask=row_mask, fp8=fp8 and w16 is None, dy8=g8))
 
@@ -902,6 +910,7 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
         a8r, sa = a8t if a8t is not None else K.quantize_fp8_rows(a)
         y = Var(K.gemm_fp8(a8r, sa, *w_fp8(fc2_w), bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
         y.grad8_site = site_dy
+        y.grad8_bias = fc2_b if site_dy is not None else None
     else:
         a = K.gemm(x.data, w1, bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv)
         y = Var(K.gemm(a, w2, bias=fc2_b.detach(), residual=None if residual is None else residual.data, out_dtype=F32))
@@ -918,11 +927,12 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
         fp8_dg2 = g8 is not None and w_fp8_t(fc2_w) is not None and FP8_DGRAD  # fc2's data gradient reads the e4m3 copy of the gradient
         if g8 is not None and a8t is not None and ok8:
             # bias gradient = column sums of the gradient: of its bf16 copy when one exists, of the fp32 rows otherwise
-            wgrad8_problem(tape, g8, a8t, pv[2].grad_buffer(tuple(w2.shape)), y.grad16 if y.grad16 is not None else y.grad, pv[3].grad_buffer((w2.shape[0],)))
+            wgrad8_problem(tape, g8, a8t, pv[2].grad_buffer(tuple(w2.shape)), y.grad16 if y.grad16 is not None else y.grad,
+                           None if y.grad8_bias_done else pv[3].grad_buffer((w2.shape[0],)))
         else:
             if a_box[0] is None:
                 a_box[0] = K.dequantize_fp8(a8t)
-            wgrad(tape, y.grad_bf16(), a_box[0], pv[2], pv[3], tuple(w2.shape))
+            wgrad(tape, y.grad_bf16(), a_box[0], pv[2], None if y.grad8_bias_done else pv[3], tuple(w2.shape))
         dy16 = y.grad16 if (fp8_dg2 and y.grad.dtype != BF16) else y.grad_bf16()  # may be None: nobody reads it on the e4m3 path
         dh8 = K.empty((m, hidden), dtype=torch.uint8, device=x.data.device) if (site_dh is not None and site_dh.ready) else None
         # fc1's bias gradient = column sums of dh: the data-gradient epilogue that produces dh leaves its sums per strip of 32 rows (3.5 MB), one small launch adds them up

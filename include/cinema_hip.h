@@ -30,6 +30,8 @@ int cinema_hip_info(int* out_host);
 typedef struct cinema_q8_out {
   uint8_t* data;              /* [rows][c] OCP e4m3 bytes, dense: q = e4m3(sat(value * *inv_scale)); NULL = record the maximum only */
   const float* inv_scale;     /* device scalar */
+  float* colsum;              /* cinema_layernorm_bwd_deferred_q8 only, else NULL: fp32 [c], accumulated by the LATER cinema_ln_param_reduce_batched (item.dcol): the column sums of the
+                                 values = the bias gradient of the projection whose output this gradient belongs to; the partials then carry THREE rows per workgroup */
   unsigned int* amax_slots;   /* device [CINEMA_Q8_SLOTS]: float bits of max|value| over this launch, every wave raises slot (wave id mod CINEMA_Q8_SLOTS): thousands of
                                  device-scope atomics on a handful of addresses serialise (measured: 64 slots cost 20-40 us per launch) */
 } cinema_q8_out;
@@ -205,6 +207,7 @@ typedef struct {
   int n_partials, c;
   float* dgamma;          /* accumulated; either may be NULL */
   float* dbeta;
+  float* dcol;            /* non-NULL: the partials carry a third row per workgroup (column sums of dx, cinema_q8_out.colsum), accumulated here */
 } cinema_ln_reduce_item;
 /* bytes of per-block partial sums the deferred backward of a (rows, c) LayerNorm writes (host-only query; 0: no workspace needed) */
 long long cinema_layernorm_bwd_workspace_bytes(int rows, int c);

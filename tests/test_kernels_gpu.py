@@ -1101,7 +1101,16 @@ def test_q8_delayed_scaling_producers() -> None:
     for rep in range(2):
         y16, _, mean, rstd, q8 = K.layernorm_fwd(xf, gamma, beta, 1e-6, want_fp8=True, q8=s1)
         dg, db, deferred = torch.zeros(768, device=DEV), torch.zeros(768, device=DEV), []
-        dx32, dx16, dq8 = K.layernorm_bwd(dy, xf, gamma, beta, mean, rstd, dx_residual=res, want_f32=True, want_bf16=True, dgamma=dg, dbeta=db, deferred=deferred, q8=s2)
+        dcol = torch.full((768,), 0.5, device=DEV)  # the column sums of dx are ADDED (the bias gradient of the projection that produced x)
+        dx32, dx16, dq8, col_done = K.layernorm_bwd(dy, xf, gamma, beta, mean, rstd, dx_residual=res, want_f32=True, want_bf16=True, dgamma=dg, dbeta=db,
+                                                    deferred=deferred, q8=s2, q8_colsum=dcol)
+        K.ln_param_reduce_batched(deferred)
+        dg0, db0 = torch.zeros(768, device=DEV), torch.zeros(768, device=DEV)
+        ref32, _ = K.layernorm_bwd(dy, xf, gamma, beta, mean, rstd, dx_residual=res, want_f32=True, want_bf16=True, dgamma=dg0, dbeta=db0)
+        assert col_done and torch.equal(ref32, dx32)  # the third partial row changes nothing else
+        want = 0.5 + dx32.double().sum(0)
+        assert float((dcol.double() - want).abs().max()) <= 1e-5 * float(dx32.double().abs().sum(0).max())
+        assert torch.allclose(dg, dg0, rtol=1e-5, atol=1e-5) and torch.allclose(db, db0, rtol=1e-5, atol=1e-5)
         if rep == 0:
             assert q8[1].numel() == 2053 and dq8 is None  # first step: per-row copy from the forward, no copy from the backward
             sites.update()
