@@ -314,6 +314,20 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
         par = seg_step_parity(kw, sd, device=device, threads=min(os.cpu_count() or 1, 16))
         out["config4"]["parity"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in par.items()}
         out["config4"]["parity"]["what"] = "HIP path vs fp32 CPU oracle, one identical sample: argmax agreement / Dice of the argmax segmentations (>= 0.995, |1 - Dice| <= 0.01), loss and gradients"
+    # ---- config 2 at the reference's GLOBAL batch: the recipe is 64 samples per optimiser step = 16 per device x world x accumulation (mae/config.yaml:44-45,
+    # pretrain.py:259-269), i.e. four accumulated micro-steps of 16 on one GPU; 288 GB hold the 64 in ONE micro-step, which is the same update
+    kw2 = base_kwargs("base")
+    torch.manual_seed(0)
+    model = CineMA(**kw2).to(device)
+    st = TrainStep(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0, replay=True)
+    b64 = synthetic_batch(kw2, 64, 1234, device)
+    ms = timed(lambda: st(b64, 0.75), 4, 8)
+    out["config2_global_batch_64"] = {"workload": "CineMA ViT-Base MAE, 4 views, mask 0.75, bf16, ONE micro-step of 64 samples on one GPU (the reference's optimiser step at global batch "
+                                                  "64; the headline keeps its per-device 16)", "ms_per_step": round(ms, 3), "samples_per_s": round(64e3 / ms, 2), "steps": 8, "warmup": 4,
+                                      "reference_equiv_tflops_per_gpu": round(64e3 / ms * STEP_GFLOP_PER_SAMPLE / 1e3, 1)}
+    del st, model, b64
+    gc.collect()
+    torch.cuda.empty_cache()
     # ---- config 5 shape: bf16 and fp8 forward
     kw5 = base_kwargs("large", (256, 256, 24), (256, 256))
     torch.manual_seed(0)

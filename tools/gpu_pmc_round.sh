@@ -8,7 +8,7 @@ mkdir -p gpurun_out; cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmcf $R/gpurun_out/pmcw $R/gpurun_out/pmcm1 $R/gpurun_out/pmcm2
 export CINEMA_SIDE_WGRAD=0
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --profile-steps 0 --prewarm 0"
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --profile-steps 0 --prewarm 0 --no-secondary"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmcf -o t -- $CMD > $R/gpurun_out/pmcf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmcw -o t -- $CMD > $R/gpurun_out/pmcw.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmcm1 -o t -- $CMD > $R/gpurun_out/pmcm1.log 2>&1
@@ -23,7 +23,7 @@ R = os.environ["ROUND"]
 for f in (f"gpurun_out/{R}_pmc_hbm_traffic.json", f"gpurun_out/{R}_mfma_util.json"):
     d = json.load(open(f))
     d["so_sha256"], d["git_head"] = sha, os.environ.get("GIT_HEAD", "unknown")
-    d["command"] = "CINEMA_SIDE_WGRAD=0 python bench.py --steps 2 --warmup 1 --cpu-budget 0 --profile-steps 0 --prewarm 0"
+    d["command"] = "CINEMA_SIDE_WGRAD=0 python bench.py --steps 2 --warmup 1 --cpu-budget 0 --profile-steps 0 --prewarm 0 --no-secondary"
     json.dump(d, open(f, "w"), indent=1)
     top = list(d["kernels"].items())[:6]
     print(f, sha[:12], [(k[:48], v.get("hbm_bytes_per_launch") or v.get("mfma_util")) for k, v in top])

@@ -5,6 +5,8 @@ mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 timeout -s KILL 900 python -m pytest tests -m gpu -q -x --timeout 290 2>&1 | tail -3 > gpurun_out/r04_final_tests.log
 timeout -s KILL 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r04_final_smoke.log 2>&1
+ROUND=r04 timeout -s KILL 900 bash tools/gpu_pmc_round.sh > gpurun_out/r04_pmc.log 2>&1
+bash tools/pull_profiles.sh r04 > /dev/null 2>&1   # (on the box's copy: the default bench below reads the PMC files of THIS library from profiles/)
 timeout -s KILL 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r04_bench_default.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
@@ -16,7 +18,6 @@ CINEMA_SIDE_WGRAD=0 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $R/g
 rm -rf $R/gpurun_out/profseg
 cd $R
 TAG=r04_z_large_fp8 timeout -s KILL 300 bash tools/gpu_prof_large8.sh > /dev/null 2>&1
-ROUND=r04 timeout -s KILL 900 bash tools/gpu_pmc_round.sh > gpurun_out/r04_pmc.log 2>&1
 cat gpurun_out/r04_final_tests.log gpurun_out/r04_final_smoke.log | tail -5
 python -c "
 import json

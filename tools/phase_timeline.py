@@ -25,10 +25,10 @@ def last(pred):
 
 
 marks = [("stems fwd (4 views) + token assembly", 0)]
-i_enc = first(lambda n: n.startswith("attn_fwd_mfma<64>"))
+i_enc = first(lambda n: n.startswith("attn_fwd_mfma<64"))
 marks.append(("encoder fwd", i_enc - 3))
-i_dec = first(lambda n: n.startswith("attn_fwd_mfma<32>"))
-marks.append(("fusion + decoder fwd + loss", last(lambda n: n.startswith("attn_fwd_mfma<64>")) + 8))
+i_dec = first(lambda n: n.startswith("attn_fwd_mfma<32"))
+marks.append(("fusion + decoder fwd + loss", last(lambda n: n.startswith("attn_fwd_mfma<64")) + 8))
 i_bwd = first(lambda n: n.startswith("attn_bwd") or n.startswith("attn_delta"))
 marks.append(("decoder bwd", i_bwd - 12))
 marks.append(("fusion bwd + encoder bwd", last(lambda n: n.startswith("attn_bwd_dkv_mfma<32>") or n.startswith("attn_bwd_dq_mfma<32>") or n.startswith("attn_bwd_fused_mfma<32>")) + 12))
@@ -69,3 +69,23 @@ if dump:
         print(f"--- {name}")
         for k, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
             print(f"    {cnt:4d} x {us / cnt:7.1f} us = {us:8.1f} us  {k}")
+
+# idle gaps of the whole step (no kernel of either stream running): total, and the largest ones with the kernels on both sides
+ev = sorted(step, key=lambda r: r[1])
+gaps, cur_e, cur_n = [], ev[0][2], ev[0][0]
+for n, s, e in ev[1:]:
+    if s > cur_e:
+        gaps.append((s - cur_e, cur_n, n, (cur_e - t0) / 1e6))
+    if e > cur_e:
+        cur_e, cur_n = e, n
+tot = sum(g[0] for g in gaps)
+print(f"idle (no kernel running): {tot / 1e6:.2f} ms in {len(gaps)} gaps; gaps > 5 us: {sum(1 for g in gaps if g[0] > 5e3)} = {sum(g[0] for g in gaps if g[0] > 5e3) / 1e6:.2f} ms")
+hist: dict = {}
+for g in gaps:
+    k = (g[1].split("(")[0].split("<")[0][:40], g[2].split("(")[0].split("<")[0][:40])
+    t = hist.setdefault(k, [0, 0.0])
+    t[0] += 1
+    t[1] += g[0] / 1e3
+print("idle by (kernel before -> kernel after), top 25:")
+for k, (cnt, us) in sorted(hist.items(), key=lambda kv: -kv[1][1])[:25]:
+    print(f"    {cnt:4d} x {us / cnt:6.1f} us = {us:8.1f} us  {k[0]} -> {k[1]}")
