@@ -439,6 +439,9 @@ def main() -> None:
     backend = os.environ.get("CINEMA_BENCH_BACKEND", "nccl")
     if os.environ.get("CINEMA_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+        # two processes x (main + weight-gradient + long-axis stream) oversubscribe the hardware queues of ONE device: the shared-GPU check took 162 s instead of
+        # 9 s with the third stream (one process per GPU - the product layout - gains from it with RCCL collectives too: --force-sync 27.68 -> 27.38 ms)
+        os.environ.setdefault("CINEMA_LAX_STREAM", "0")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
 

@@ -340,7 +340,8 @@ def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids
 
     # consecutive views of identical geometry (the three long-axis views: same shapes, separate weights) run as ONE lane group: their ~45 forward /
     # ~95 backward tiny stem launches each go out zipped, one wide launch per position (hip.lanes; the views share nothing inside the stems)
-    T.run_in_lanes(tp, list(views), lambda v: stem_geometry(model, v, images, sels), stem, enabled=images[views[0]].is_cuda)
+    # ... and that group goes to a stream of its own, beside the short-axis stem's chain (tape.LAX_STREAM)
+    T.run_in_lanes(tp, list(views), lambda v: stem_geometry(model, v, images, sels), stem, enabled=images[views[0]].is_cuda, beside=True)
     x = T.op_assemble(tp, batch * t_e, e, segs, dev)
     x = model.encoder.tape_forward(tp, x, batch)
     return x, skips_all, cls_rows, view_rows

@@ -366,6 +366,9 @@ LANE: int | None = None      # lane being recorded, None outside a group
 LANES_ENABLED = bool(int(os.environ.get("CINEMA_LANES", "1")))
 LANE_STATS = [0, 0]          # merged / single launches issued by the lane groups so far (diagnostics)
 _LANE_KEEP: list = []
+# when set, a closing lane group hands the buffers it held over to this list instead of dropping them: its launches went to a stream the caching allocator
+# does not associate with those buffers, so they must outlive the JOIN of that stream, not merely the issue of the launches (tape.lane_group(stream=...))
+LANE_KEEP_SINK: list | None = None
 
 
 class lanes:  # noqa: N801
@@ -399,6 +402,8 @@ class lanes:  # noqa: N801
             rc = load().cinema_lanes_end(C.byref(m), C.byref(s1))
             LANE_STATS[0] += m.value
             LANE_STATS[1] += s1.value
+            if LANE_KEEP_SINK is not None:
+                LANE_KEEP_SINK.extend(_LANE_KEEP)
             _LANE_KEEP.clear()
             if exc[0] is None:
                 _check(rc, "lanes_end")
@@ -406,8 +411,9 @@ class lanes:  # noqa: N801
 
 def lanes_abort() -> None:
     """Close whatever lane group is open without issuing its launches (error paths of callers that open and close a group in separate steps)."""
-    global LANE  # noqa: PLW0603
+    global LANE, _STREAM_OVERRIDE, LANE_KEEP_SINK  # noqa: PLW0603
     LANE = None
+    _STREAM_OVERRIDE, LANE_KEEP_SINK = None, None  # (a backward lane group on a stream of its own redirects the launches between its two closures)
     _LANE_KEEP.clear()
     if _lib is not None:
         _lib.cinema_lanes_abort()

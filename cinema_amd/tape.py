@@ -211,6 +211,28 @@ def side_stream() -> "torch.cuda.Stream":
 
 _SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient launches still (possibly) running on the side stream
 
+# The lane group of the long-axis stems on a THIRD stream (default; CINEMA_LAX_STREAM=0: on the main stream, after the short-axis stem): the stems are chains of
+# ~45 forward / ~95 backward small launches per view (16-50 us each for the short-axis view, 5-15 us for the zipped long-axis group) that leave most compute
+# units idle, and the views share nothing - so the long-axis chain runs BESIDE the short-axis one: forked before the first stem launch, joined before the token
+# assembly (forward) / at the end of the backward pass.  The buffers its lanes allocate (under torch's current stream) are held until that join.
+LAX_STREAM = bool(int(os.environ.get("CINEMA_LAX_STREAM", "1")))
+_LAX_STREAMS: dict = {}
+_LAX_KEEP: list = []
+
+
+def lax_stream() -> "torch.cuda.Stream":
+    dev = torch._C._cuda_getDevice()
+    st = _LAX_STREAMS.get(dev)
+    if st is None:
+        st = _LAX_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def join_lax_stream() -> None:
+    """The current stream waits for everything issued to the long-axis stream so far."""
+    if _LAX_STREAMS and torch._C._cuda_getDevice() in _LAX_STREAMS:
+        K.stream_fork(lax_stream().cuda_stream, K._stream())
+
 
 def join_side_stream(release: bool = False) -> None:
     """Make the current stream wait for the side stream.  ``release`` (end of the backward pass): the operands kept alive for the side
@@ -219,6 +241,7 @@ def join_side_stream(release: bool = False) -> None:
         K.stream_fork(side_stream().cuda_stream, K._stream())
     if release:
         _SIDE_KEEP.clear()
+        _LAX_KEEP.clear()
 
 
 def mark_params(tape: "Tape", params: list) -> None:
@@ -288,6 +311,7 @@ class Tape:
             if K.LANE is not None:
                 K.lanes_abort()
             raise
+        join_lax_stream()  # the long-axis stems' backward (lane_group(stream=...)): their LayerNorm partials are reduced below, on this stream
         flush_wgrads(self)
         flush_ln(self)  # 86 LayerNorms per step: one launch per 48 instead of one each
         join_side_stream(release=True)
@@ -305,13 +329,21 @@ class lane_group:  # noqa: N801
     The launches of the n sequences go out zipped (one wide launch per position) when the block ends; the backward closures recorded inside
     run later under a mirrored group.  The sequences must not share parameters, gradient buffers or activations."""
 
-    def __init__(self, tape: "Tape", n: int) -> None:
+    def __init__(self, tape: "Tape", n: int, stream: int | None = None) -> None:
         self.tape, self.n = tape, n
         self.fwd = K.lanes(n)
         self.bwd = None
+        # ``stream`` (raw handle): the group's forward AND backward launches go to that stream.  The caller forks it from the current stream before the forward
+        # group and joins it afterwards; the backward group forks when it opens, Tape.backward() joins.  Only when the lanes are really deferred (their
+        # allocations are then tracked and can be held until the join).
+        self.stream = stream if self.fwd.active else None
+        self._ovr = None
 
     def __enter__(self) -> "lane_group":
         self.tape.record(self._bwd_close)  # runs LAST in the reversed backward order
+        if self.stream is not None:
+            self._ovr = K.on_stream(self.stream)
+            self._ovr.__enter__()
         self.fwd.__enter__()
         return self
 
@@ -320,37 +352,68 @@ class lane_group:  # noqa: N801
         self.tape.record(lambda: self.bwd.select(lane - 1) if (lane > 0 and self.bwd is not None) else None)  # runs after lane `lane`'s backward ops
 
     def __exit__(self, *exc) -> None:  # noqa: ANN002
-        self.fwd.__exit__(*exc)
+        if self.stream is not None:
+            K.LANE_KEEP_SINK = _LAX_KEEP
+        try:
+            self.fwd.__exit__(*exc)
+        finally:
+            if self.stream is not None:
+                K.LANE_KEEP_SINK = None
+                self._ovr.__exit__()
+                self._ovr = None
         if exc[0] is None:
             self.tape.record(self._bwd_open)  # runs FIRST in the backward pass
 
     def _bwd_open(self) -> None:
         self.bwd = K.lanes(self.n)
+        if self.stream is not None and self.bwd.active:
+            K.stream_fork(K._stream(), self.stream)  # the gradients entering the group were produced on the current stream
+            self._ovr = K.on_stream(self.stream)
+            self._ovr.__enter__()
         self.bwd.__enter__()
         self.bwd.select(self.n - 1)
 
     def _bwd_close(self) -> None:
         if self.bwd is not None:
-            self.bwd.__exit__(None, None, None)
-            self.bwd = None
+            if self._ovr is not None:
+                K.LANE_KEEP_SINK = _LAX_KEEP
+            try:
+                self.bwd.__exit__(None, None, None)
+            finally:
+                self.bwd = None
+                if self._ovr is not None:
+                    K.LANE_KEEP_SINK = None
+                    self._ovr.__exit__()
+                    self._ovr = None
 
 
-def run_in_lanes(tape: "Tape", items: list, key: Callable, body: Callable, enabled: bool = True) -> None:
+def run_in_lanes(tape: "Tape", items: list, key: Callable, body: Callable, enabled: bool = True, beside: bool = False) -> None:
     """``body(item)`` for every item, in order; runs of 2-4 consecutive items with equal ``key(item)`` (identical launch geometry, nothing shared)
-    are issued as one lane group."""
-    i = 0
+    are issued as one lane group.  ``beside``: the lane groups go to the long-axis stream (LAX_STREAM), beside the single items on the current stream - the
+    caller guarantees that the items read nothing another item of this call writes; the current stream has joined when this returns."""
+    runs, i = [], 0
     while i < len(items):
         j = i + 1
         while enabled and j < len(items) and j - i < 4 and key(items[j]) == key(items[i]):
             j += 1
+        runs.append((i, j))
+        i = j
+    lax = None
+    if (beside and LAX_STREAM and enabled and K.LANE is None and K.LANES_ENABLED and any(j - i >= 2 for i, j in runs) and any(j - i == 1 for i, j in runs)
+            and not torch._C._cuda_isCurrentStreamCapturing()):
+        lax = lax_stream().cuda_stream
+        K.stream_fork(K._stream(), lax)  # BEFORE the first single item's launches: the group must not queue behind them
+    for i, j in runs:
         if j - i >= 2:
-            with lane_group(tape, j - i) as grp:
+            with lane_group(tape, j - i, stream=lax) as grp:
                 for lane, it in enumerate(items[i:j]):
                     grp.select(lane)
                     body(it)
         else:
             body(items[i])
-        i = j
+    if lax is not None:
+        K.stream_fork(lax, K._stream())
+        _LAX_KEEP.clear()  # the next user of these buffers is ordered behind the join
 
 
 def flush_ln(tape: "Tape") -> None:
