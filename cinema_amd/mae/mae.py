@@ -18,6 +18,7 @@ No device->host synchronisation happens inside ``forward`` (the reference has ~1
 from __future__ import annotations
 
 import math
+import os
 from pathlib import Path
 
 import torch
@@ -158,7 +159,8 @@ class CineMA(nn.Module):
             fused[v] = self.enc_fusion_dict[v].tape_forward(tp, skips_all[v], part_of[v], sels[v], grids[v])
 
         geom = lambda v: stem_geometry(self, v, images, sels)  # noqa: E731
-        T.run_in_lanes(tp, views, geom, fuse, enabled=dev.type == "cuda")  # per-view weights, nothing shared: the long-axis views go out as one lane group
+        # per-view weights, nothing shared: the long-axis views go out as one lane group, on the long-axis stream beside the short-axis view's fusion
+        T.run_in_lanes(tp, views, geom, fuse, enabled=dev.type == "cuda", beside=os.environ.get("CINEMA_LAX_FUSE", "1") == "1")
         for v in views:  # dec_linear is SHARED by the views (one weight-gradient buffer): not a lane group
             z_views[v] = T.op_linear(tp, fused[v], self.dec_linear.weight, self.dec_linear.bias, out_f32=True)
 
@@ -228,7 +230,7 @@ class CineMA(nn.Module):
             if maxes is not None:
                 metrics[f"{v}_normed_target_max"], metrics[f"{v}_pred_max"] = maxes[0], maxes[1]
 
-        T.run_in_lanes(tp, views, geom, head, enabled=dev.type == "cuda")  # prediction heads + losses: per-view weights and accumulators
+        T.run_in_lanes(tp, views, geom, head, enabled=dev.type == "cuda", beside=os.environ.get("CINEMA_LAX_HEAD", "1") == "1")  # prediction heads + losses: per-view weights and accumulators
         preds = {v: preds[v] for v in views}
         metrics = {k: metrics[k] for v in views for k in metrics if k.startswith(f"{v}_")}
         losses = [loss_of[v] for v in views]

@@ -402,6 +402,7 @@ def run_in_lanes(tape: "Tape", items: list, key: Callable, body: Callable, enabl
     if (beside and LAX_STREAM and enabled and K.LANE is None and K.LANES_ENABLED and any(j - i >= 2 for i, j in runs) and any(j - i == 1 for i, j in runs)
             and not torch._C._cuda_isCurrentStreamCapturing()):
         lax = lax_stream().cuda_stream
+        tape.record(join_lax_stream)  # backward: runs AFTER the items' closures - whatever consumes their input gradients next is on the current stream
         K.stream_fork(K._stream(), lax)  # BEFORE the first single item's launches: the group must not queue behind them
     for i, j in runs:
         if j - i >= 2:

@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -s KILL 900 python -m pytest tests/test_model_gpu.py tests/test_lanes_gpu.py tests/test_boundary_gpu.py -m gpu -q -x --timeout 600 2>&1 | tail -2
+for r in 1 2; do for w in "0 0" "1 0" "1 1"; do
+  set -- $w
+  CINEMA_LAX_FUSE=$1 CINEMA_LAX_HEAD=$2 timeout -s KILL 200 python bench.py --steps 30 --warmup 10 --cpu-budget 0 --profile-steps 0 --no-secondary 2>&1 | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('LAX fuse/head=$1/$2 ms_per_step', d['ms_per_step'], 'loss', d['config']['final_loss'])"
+done; done 2>&1 | tee gpurun_out/r04_y_lax2_ab.txt
