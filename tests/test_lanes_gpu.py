@@ -96,3 +96,47 @@ def test_model_step_with_lane_groups_equals_plain_launches(replay: bool) -> None
         assert abs(la - lb) <= 1e-5 * abs(la) and abs(ga - gb) <= 1e-4 * abs(ga), (out[False][0], out[True][0])
         assert math.isfinite(la)
     assert (out[False][1] - out[True][1]).abs().max() <= 2e-3  # Adam's first steps are +-lr: identical up to sign flips of ~0 gradients
+
+
+@pytest.mark.parametrize("replay", [False, True])
+def test_long_axis_stream_changes_nothing_but_the_schedule(replay: bool) -> None:
+    """``tape.LAX_STREAM``: the long-axis lane groups (stems, fusion, prediction heads; forward and backward) on a stream of their own beside the short-axis chain.
+    Same launches, same operands, another queue: loss and gradient norm of every step and the parameters after 4 steps are BIT-identical to the two-stream
+    schedule when the only reorderable sums (fp32 atomics of bias-gradient row sums) are absent, and within their reordering noise otherwise; the stream is
+    really used (the forks into it are counted), and 12 replays of the recorded step keep matching the eager trajectory (a missing join shows up as a race)."""
+    from cinema_amd import tape as T
+    from cinema_amd.optim import TrainStep
+
+    out = {}
+    forks = {}
+    real_fork = K.stream_fork
+    for lax_on in (False, True):
+        T.LAX_STREAM = lax_on
+        n_forks = [0]
+
+        def counting_fork(a: int, b: int) -> None:
+            if T._LAX_STREAMS and b == T.lax_stream().cuda_stream:  # noqa: SLF001
+                n_forks[0] += 1
+            real_fork(a, b)
+
+        K.stream_fork = counting_fork
+        try:
+            torch.manual_seed(3)
+            model = CineMA(**mini_kwargs()).to(DEV)
+            step = TrainStep(model, lr=1e-3, replay=replay)
+            torch.manual_seed(5)
+            batch = {v: torch.rand(2, 1, *s, device=DEV) for v, s in model_sizes(model).items()}
+            traj = []
+            for _ in range(12 if replay else 4):
+                loss, gn, _ = step(batch, 0.75)
+                traj.append((float(loss), float(gn)))
+            torch.cuda.synchronize()
+            out[lax_on] = (traj, step.flat.flat_param.clone())
+            forks[lax_on] = n_forks[0]
+        finally:
+            K.stream_fork = real_fork
+            T.LAX_STREAM = True
+    assert forks[False] == 0 and forks[True] >= 6, forks  # eager / recording pass: forward + backward forks of the three groups (replays re-issue them from the list)
+    for (la, ga), (lb, gb) in zip(out[False][0], out[True][0]):
+        assert math.isfinite(la) and abs(la - lb) <= 1e-5 * abs(la) and abs(ga - gb) <= 1e-4 * abs(ga), (out[False][0], out[True][0])
+    assert (out[False][1] - out[True][1]).abs().max() <= 2e-3
