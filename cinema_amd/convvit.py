@@ -25,6 +25,9 @@ from cinema_amd import tape as T
 from cinema_amd.conv import CompactVolume, Conv2d, Conv3d, ConvNormActBlock, Linear, MaskedConvBlock, Volume, _CkptFlag
 from cinema_amd.vit import PatchEmbed, get_pos_embed, init_weights
 
+# neighbour lists of the visible-voxel depthwise convolutions built on the long-axis stream, beside the chain that precedes their first use (CINEMA_NBR_PREFETCH=0: in that chain)
+NBR_PREFETCH = os.environ.get("CINEMA_NBR_PREFETCH", "1") == "1"
+
 
 def upsample_mask(mask: torch.Tensor, scale_factor: tuple) -> torch.Tensor:
     """Nearest-neighbour upsampling of a (batch, *grid) bool mask (reference ``cinema/convvit.py:24-51``)."""
@@ -216,6 +219,17 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
         # (batch, *grid1) stage-1 volume: one launch
         rank, idx1 = K.visible_index(sel.keep, batch, grid, block1, inv1)
 
+        # the stages' sparse geometries up front: their neighbour lists depend on the mask only and are built beside the gather / patch GEMM / LayerNorm chain
+        geoms = [K.sparse_geom(batch, grid, blk, sel.keep, rank, pos) for blk, pos, _ in tables]
+        if T.LAX_STREAM and NBR_PREFETCH and K.LANE is None and image.is_cuda and not torch._C._cuda_isCurrentStreamCapturing():  # (a lane group's launches go out later, zipped)
+            items, seen = [], set()
+            for block, sg in zip(self.conv_blocks, geoms):
+                for conv in block.conv:
+                    kd = (1,) * (3 - n_dims) + tuple(int(v) for v in conv.dw_conv.weight.shape[2:])
+                    if (id(sg), kd) not in seen:
+                        seen.add((id(sg), kd))
+                        items.append((sg, kd))
+            K.sparse_nbr_prefetch(items, dev, T.lax_stream().cuda_stream)
         skips = []
         vol = None
         for lvl, (block, (blk, pos, inv)) in enumerate(zip(self.conv_blocks, tables)):
@@ -226,7 +240,7 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
                 per = math.prod(self.patch_sizes[lvl])
                 rows = T.op_cast_bf16(tp, T.op_view(tp, vol.var, (vol.var.data.shape[0] // per, per * vol.chans)))
             out = block.patch_embed.tape_forward_rows(tp, rows)
-            sg = K.sparse_geom(batch, grid, blk, sel.keep, rank, pos)
+            sg = geoms[lvl]
             vol = CompactVolume(out, n_tok, blk, block.patch_embed.conv.out_channels, sg, pos, inv)
             for conv in block.conv:
                 vol = conv.tape_forward_compact(tp, vol)

@@ -1613,7 +1613,23 @@ def sparse_geom(batch: int, tok_grid: tuple, block: tuple, keep: torch.Tensor, r
     return g
 
 
+def sparse_nbr_prefetch(items: list, device: torch.device, stream: int) -> None:
+    """Build the neighbour lists of ``items`` = [(geom, kdims), ...] on ANOTHER stream, forked from the current one here and joined by the first consumer
+    (:func:`_sparse_nbr`): the lists depend on the mask only, so they need not sit in the chain gather -> patch GEMM -> LayerNorm -> ... that precedes the first
+    depthwise convolution (110 + 30 us at config 2)."""
+    stream_fork(_stream(), stream)
+    with on_stream(stream):
+        for geom, kdims in items:
+            _sparse_nbr(geom, kdims, device)
+    for geom, _ in items:
+        geom.nbr_wait = stream
+
+
 def _sparse_nbr(geom: SparseGeom, kdims: tuple, device: torch.device) -> tuple:
+    wait = getattr(geom, "nbr_wait", None)
+    if wait is not None and wait != _stream():  # built by sparse_nbr_prefetch on another stream: this stream waits for it once
+        stream_fork(wait, _stream())
+        geom.nbr_wait = None
     hit = geom.nbr_lists.get(kdims)
     if hit is None:
         rows = geom.n_tok * geom.bx * geom.by * geom.bz
