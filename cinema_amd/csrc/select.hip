@@ -10,11 +10,12 @@
 namespace {
 
 // rank_i = #{j : noise_j < noise_i or (noise_j == noise_i and j < i)}  (argsort(argsort(noise)) with a stable sort); mask_i = rank_i >= n_keep.
-// grid = (chunks of 256 elements, batch): one element per thread, the row streamed through LDS in pieces of 2048 floats (one sample per
-// workgroup was 131 us for a 2304-token row: 16 workgroups of 9 serial elements per thread)
+// grid = (chunks of 64 elements, batch): a workgroup ranks 64 elements, each of its four waves against a quarter of every LDS piece of 2048 floats (one sample
+// per workgroup was 131 us for a 2304-token row, one element per thread over the whole row 61 us: 144 workgroups of 2304 serial compares per thread)
 __global__ __launch_bounds__(256) void mask_rank_kernel(const float* noise, uint8_t* mask, int n, int n_keep) {
   __shared__ __attribute__((aligned(16))) float piece[2048];
-  const int b = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  __shared__ int part[4][64];
+  const int b = blockIdx.y, tid = threadIdx.x, e = tid & 63, q = tid >> 6, i = blockIdx.x * 64 + e;
   const float* row = noise + (size_t)b * n;
   const float v = i < n ? row[i] : 0.f;
   int rank = 0;
@@ -23,7 +24,8 @@ __global__ __launch_bounds__(256) void mask_rank_kernel(const float* noise, uint
     for (int t = tid; t < 2048; t += 256) piece[t] = j0 + t < n ? row[j0 + t] : __builtin_inff();  // +inf never counts
     __syncthreads();
     const int lim = min(2048, n - j0);
-    for (int t = 0; t < lim; t += 4) {  // same LDS address across the wave: broadcast reads
+    const int lo = q * 512, hi = min(lim, lo + 512);  // this wave's quarter of the piece
+    for (int t = lo; t < hi; t += 4) {  // same LDS address across the wave: broadcast reads
       const float4 w = *reinterpret_cast<const float4*>(piece + t);
       const int j = j0 + t;
       rank += (w.x < v || (w.x == v && j < i)) ? 1 : 0;
@@ -32,7 +34,9 @@ __global__ __launch_bounds__(256) void mask_rank_kernel(const float* noise, uint
       rank += (w.w < v || (w.w == v && j + 3 < i)) ? 1 : 0;
     }
   }
-  if (i < n) mask[(size_t)b * n + i] = rank >= n_keep ? 1 : 0;
+  part[q][e] = rank;
+  __syncthreads();
+  if (q == 0 && i < n) mask[(size_t)b * n + i] = (part[0][e] + part[1][e] + part[2][e] + part[3][e]) >= n_keep ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void mask_select_kernel(const uint8_t* mask, int n, int* keep_pos, int* drop_pos, int* keep, int* drop) {
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void visible_index_lanes_kernel(Lanes<VisP> L)
 CINEMA_API int cinema_mask_select(const float* noise, uint8_t* mask, int batch, int n, int n_keep, int* keep_pos, int* drop_pos, int* keep, int* drop,
                                   void* stream) {
   if (!mask || batch <= 0 || n <= 0 || n_keep < 0 || n_keep > n) return CINEMA_ERR_BAD_ARG;
-  if (noise) CINEMA_LAUNCH(mask_rank_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, noise, mask, n, n_keep);
+  if (noise) CINEMA_LAUNCH(mask_rank_kernel, dim3((n + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, noise, mask, n, n_keep);
   if (keep_pos || drop_pos || keep || drop)
     CINEMA_LAUNCH(mask_select_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)mask, n, keep_pos, drop_pos, keep, drop);
   return launch_status();

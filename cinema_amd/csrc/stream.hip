@@ -2,6 +2,7 @@
 // HIP stream, one fork (event record + wait) per launch, ~200 per step.  The events come from a per-device ring created once, so a
 // fork is two HIP calls and no allocation; a host that drives the library from Python would otherwise pay an event object, a
 // stream-context switch and three interpreter round trips per launch, which made the step launch-bound on slower hosts.
+#include <cstdio>
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -76,7 +77,13 @@ int lane_submit(lane_relaunch_t relaunch, const void* fn_single, const void* fn_
 CINEMA_API int cinema_lanes_begin(int n) {
   if (n < 1 || n > MAX_LANES) return CINEMA_ERR_BAD_ARG;
   // a group left open by a caller that died between begin and end holds launches that were never issued: drop them (their buffers are gone) instead
-  // of refusing every later group - and every later launch - for the rest of the process
+  // of refusing every later group - and every later launch - for the rest of the process; a begin inside an open group is still a programming error
+  // (hosts close or cinema_lanes_abort() their groups), so it does not pass silently
+  if (g_lanes.n != 0) {
+    size_t dropped = 0;
+    for (int i = 0; i < MAX_LANES; i++) dropped += g_lanes.seq[i].size();
+    fprintf(stderr, "cinema_lanes_begin: a lane group of %d was still open, %zu recorded launches dropped\n", g_lanes.n, dropped);
+  }
   g_lanes.n = n; g_lanes.cur = 0;
   for (int i = 0; i < MAX_LANES; i++) g_lanes.seq[i].clear();
   return 0;
