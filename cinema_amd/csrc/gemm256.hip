@@ -144,15 +144,22 @@ __device__ __forceinline__ void p256_loop64(const GemmP& p, int m0, int n0, int 
   }
 }
 
-// ---- main loop, form 1: PHASES of 32 k, ring of four 32 KiB half-stages, the two waves of a SIMD half a phase apart.
+// ---- main loop, forms 1 / 2: PHASES of 32 k, ring of four 32 KiB half-stages, the two waves of a SIMD half a phase apart.
 // A phase of one wave = READ segment (its 12 operand fragments of the phase: 12 ds_read_b128 or 24 ds_read_b64_tr_b16) | barrier | MFMA segment (16 MFMAs at
-// priority 1, the LDS-DMA of the phase three ahead issued between them: its issue slots are free there) | barrier.  Waves 4-7 run one barrier behind
-// waves 0-3, so on every SIMD one wave computes while its partner reads: the matrix pipe sees MFMA segments back to back, the LDS sees one group of
-// four readers at a time.  DMA(p + 3) is issued in MFMA(p) into the half-stage last read in phase p - 1 (two barriers earlier for every wave) and waited
-// for with a COUNTED vmcnt at the end of READ(p + 2) - three intervals of flight - so no wave ever drains its queue inside the loop.
+// priority 1) | barrier.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave computes while its partner reads: the matrix pipe sees MFMA
+// segments back to back, the LDS sees one group of four readers at a time.  The LDS-DMA of the phase three ahead goes into the half-stage last read in phase
+// p - 1 and is waited for with a COUNTED vmcnt, so no wave ever drains its queue inside the loop.
+//   form 1 (rounds 3-4): DMA(p + 3) issued between the MFMAs of MFMA(p), waited for at the end of READ(p + 2).
+//   form 2 (default since round 4, CINEMA_P256_LOOP=1 selects form 1): DMA(p + 3) issued by the READING wave at the end of READ(p), waited for at the end of
+//           READ(p + 2) - see the comment in the loop.  Weight-gradient groups of the step 10-20 % faster (encoder block 213 -> 186 us, ViT-Large block 423 -> 353 us,
+//           8192^3 1015 -> 1157 TF), forward / data-gradient layouts 1-3 %, bit-identical results (profiles/r04_aa_p256_loop_ab.txt).
 #define P256_BAR() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifdef CINEMA_P256_PROBE  // dev build only (tools/p256_phase_probe.py): shader-clock sums per wave of READ segment / first barrier / MFMA segment / second barrier
+__device__ unsigned long long* g_p256_probe = nullptr;
+#define P256_CLK(v) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 constexpr int P_HS = 32768;   // half-stage: A sub-tiles 0, 1 then B sub-tiles 0, 1, 8 KiB each
-template <bool A_KMAJ, bool B_KMAJ>
+template <bool A_KMAJ, bool B_KMAJ, int FORM>
 __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int ph_begin, int ph_end, float16v (&acc)[4][2], float (&rs)[4], bool do_rowsum,
                                             char* smem) {
   using AIO = TileIO32<A_KMAJ>;
@@ -193,6 +200,7 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
     }
     glds16x4(dst, dst + 4096, dst + 16384, dst + 16384 + 4096, a0, a1, b0, b1);
   };
+  constexpr bool DMA_IN_READ = FORM == 2;
   // Transpose reads of a reduction-strided [32 k][128] sub-tile (TileIO32<false>::frag) with the address split into a per-lane, per-fragment base
   // (computed here, once per piece) and immediates: byte = kr * 256 + ((col / 8) ^ (kr & 3) * 4) * 16 + (col & 7) * 2 with kr = 16 ks + 8 (q4 / 2) + t / 4
   // (+ 4 for the second half), col = 32 f + 16 (q4 & 1) + 4 (t & 3): kr & 3 = t / 4 is a lane constant, so the swizzle turns fragment f into
@@ -224,6 +232,10 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
   P256_BAR();
   if (wr == 1) P256_BAR();   // waves 4-7 run one barrier behind
   const int bcol = (wc & 1) * 64;
+#ifdef CINEMA_P256_PROBE
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tA, tB, tC, tD, tV;
+  P256_CLK(tA);
+#endif
   for (int q = 0; q < nph; q++) {
     const int ph = ph_begin + q;
     const char* hs = smem + (ph & 3) * P_HS;
@@ -237,12 +249,37 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
 #pragma unroll
       for (int i = 0; i < 4; i++) fa[ks][i] = A_KMAJ ? AIO::frag(sa, i * 32, ks, lane) : tr_frag(hs + tr_a[i], ks);
     }
-    // DMA(ph + 1) must have landed before the barrier that lets anyone read it; DMA(ph + 2) (the youngest, if issued) stays in flight
-    if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (DMA_IN_READ) {
+      // form 2: the READING wave issues DMA(ph + 3), after its fragment reads.  The CU accepts an LDS-DMA piece every ~32-36 clocks in this loop (shader-clock probe,
+      // tools/p256_phase_probe.py: four waves issuing four pieces each take ~550 clocks), and a wave that waits for the queue issues nothing else: between the MFMAs
+      // (form 1) that wait came out of the matrix segment (measured 811 clocks for 16 MFMAs = 512), here it is spent by the wave whose partner on the SIMD computes
+      // (MFMA segment 577, READ 700 with the probe's stamps).  The half-stage (ph - 1) & 3 was last read by the other wave group one interval ago; every wave
+      // drains its fragment reads BEFORE the barrier that ends its READ segment (free: it waits there anyway), so those reads have completed.  DMA(ph + 1) must
+      // have landed before that barrier; DMA(ph + 2) and DMA(ph + 3) stay in flight.
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 3 < nph) {
+        issue(ph + 3);
+#ifdef CINEMA_P256_PROBE
+        P256_CLK(tV); pt[5] += tV - tA;   // (drains the fragment reads: issue-to-here = reads + DMA issue)
+#endif
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      // DMA(ph + 1) must have landed before the barrier that lets anyone read it; DMA(ph + 2) (the youngest, if issued) stays in flight
+      if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#ifdef CINEMA_P256_PROBE
+    P256_CLK(tB);
+#endif
     P256_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#ifdef CINEMA_P256_PROBE
+    P256_CLK(tC);
+#endif
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -250,16 +287,33 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
-      if (ks == 0 && q + 3 < nph) issue(ph + 3);
+      if (!DMA_IN_READ && ks == 0 && q + 3 < nph) issue(ph + 3);
       if (do_rowsum) {
 #pragma unroll
         for (int i = 0; i < 4; i++) rs[i] = frag_sum8_dot(fa[ks][i], rs[i]);
       }
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef CINEMA_P256_PROBE
+    __builtin_amdgcn_sched_barrier(0);
+    P256_CLK(tD);
+#endif
     P256_BAR();
+#ifdef CINEMA_P256_PROBE
+    pt[0] += tB - tA; pt[1] += tC - tB; pt[2] += tD - tC;
+    P256_CLK(tA);
+    pt[3] += tA - tD;
+#endif
   }
   if (wr == 0) P256_BAR();
+#ifdef CINEMA_P256_PROBE
+  if (g_p256_probe && lane == 0) {
+    unsigned long long* o = g_p256_probe + ((size_t)blockIdx.x * 8 + wave_u) * 8;
+    for (int i = 0; i < 4; i++) o[i] += pt[i];
+    o[4] += (unsigned long long)nph;
+    o[5] += pt[5];
+  }
+#endif
 }
 
 // ---- main loop, form 3: WEIGHT GRADIENT ON 8-BIT OPERANDS (BASELINE config 5, "fp8 MFMA path"): dW[n][k] = sa * sb * sum_t dY8[t][n] X8[t][k] with both operands
@@ -276,6 +330,7 @@ typedef int i32x8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ i32x2v lds_tr8_b64(const void* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr8_b64_v2i32((i32x2v __attribute__((address_space(3)))*)(lds_ptr));
 }
+template <bool DMA_IN_READ>
 __device__ __forceinline__ void p256_loop_fp8w(const GemmP& p, int m0, int n0, int ph_begin, int ph_end, float16v (&acc)[4][2], char* smem) {
   const int lane = threadIdx.x & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -346,8 +401,18 @@ __device__ __forceinline__ void p256_loop_fp8w(const GemmP& p, int m0, int n0, i
     for (int j = 0; j < 2; j++) fb[j] = tr_frag(hs + tr_b[j]);
 #pragma unroll
     for (int i = 0; i < 4; i++) fa[i] = tr_frag(hs + tr_a[i]);
-    if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (DMA_IN_READ) {  // as form 2 of the bf16 loop: the reading wave issues DMA(ph + 3) and drains its fragment reads before the barrier
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 3 < nph) {
+        issue(ph + 3);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     P256_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -357,7 +422,7 @@ __device__ __forceinline__ void p256_loop_fp8w(const GemmP& p, int m0, int n0, i
 #pragma unroll
       for (int j = 0; j < 2; j++)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-      if (i == 1 && q + 3 < nph) issue(ph + 3);
+      if (!DMA_IN_READ && i == 1 && q + 3 < nph) issue(ph + 3);
     }
     __builtin_amdgcn_s_setprio(0);
     P256_BAR();
@@ -398,8 +463,8 @@ __device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gt
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_rowsum = !A_KMAJ && p.a_rowsum != nullptr && wc == 0 && n0 == 0;
   if constexpr (LOOP == 0) p256_loop64<A_KMAJ, B_KMAJ>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
-  else if constexpr (LOOP == 3) p256_loop_fp8w(p, m0, n0, kt_begin, kt_end, acc, smem);
-  else p256_loop32<A_KMAJ, B_KMAJ>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
+  else if constexpr (LOOP == 3 || LOOP == 10) p256_loop_fp8w<LOOP == 10>(p, m0, n0, kt_begin, kt_end, acc, smem);
+  else p256_loop32<A_KMAJ, B_KMAJ, LOOP>(p, m0, n0, kt_begin, kt_end, acc, rs, do_rowsum, smem);
 
   if (do_rowsum) {
 #pragma unroll
@@ -486,7 +551,7 @@ __device__ __forceinline__ void p256_piece(const P256& g, const GemmP& p, int gt
   float* stg = reinterpret_cast<float*>(smem + wave * 8192);
   GemmP q = p;
   q.ws = nullptr;
-  if constexpr (LOOP == 3) { q.alpha = p.alpha * p.scale_a[0] * p.scale_b[0]; q.scale_a = nullptr; q.scale_b = nullptr; }  // dequantisation (per-tensor scales in device memory)
+  if constexpr (LOOP == 3 || LOOP == 10) { q.alpha = p.alpha * p.scale_a[0] * p.scale_b[0]; q.scale_a = nullptr; q.scale_b = nullptr; }  // dequantisation (per-tensor scales in device memory)
 #pragma unroll
   for (int i = 0; i < 4; i++) half_epilogue<EPI>(q, acc[i], m0 + wr * 128 + i * 32, n0 + wc * 64, lane, 0, stg);
   __syncthreads();  // the staging area becomes stage 0 / 1 of the next piece
@@ -600,6 +665,12 @@ int cu_count() {
 //   schedule 1 "stream": one problem, equal contiguous (tile, k-tile) ranges per workgroup.
 // workspace: >= cinema_gemm_p256_workspace_bytes(); its first 64 KiB hold the tile counters and must be ZERO before the first use (the kernel
 // leaves them zero); one workspace per stream (concurrent launches must not share one).
+#ifdef CINEMA_P256_PROBE
+extern "C" __attribute__((visibility("default"))) int cinema_debug_p256_probe(void* buf) {
+  unsigned long long* q = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p256_probe), &q, sizeof(q));
+}
+#endif
 CINEMA_API long long cinema_gemm_p256_workspace_bytes(void) { return (long long)P_COUNTER_BYTES + 2LL * cu_count() * P_SLOT_FLOATS * 4; }
 
 static int p256_launch_host(cinema_gemm_args* args, int count, int schedule, void* workspace, long long workspace_bytes, void* stream, bool fp8);
@@ -619,7 +690,8 @@ static int p256_launch_host(cinema_gemm_args* args, int count, int schedule, voi
   auto al8 = [](long long v) { return (v & 7) == 0; };
   auto ptr16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   // main-loop form (p256_loop64 / p256_loop32) and with it the k extent of a schedule unit; CINEMA_P256_LOOP=0 selects the plain k-tile loop
-  static const int loop_env = getenv("CINEMA_P256_LOOP") ? atoi(getenv("CINEMA_P256_LOOP")) : 1;
+  const char* loop_s = getenv("CINEMA_P256_LOOP");   // read per call (the A/B tools toggle it in one process)
+  const int loop_env = loop_s ? atoi(loop_s) : 2;
   const int loop_form = fp8 ? 3 : loop_env;
   const int unit_k = fp8 ? 64 : (loop_form ? 32 : BK);
   P256 g;
@@ -750,9 +822,14 @@ static int p256_launch_host(cinema_gemm_args* args, int count, int schedule, voi
   g.slots = (float*)((char*)workspace + P_COUNTER_BYTES);
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < count; i++) args[i].kernel_used = (fp8 ? 4096 : 2048) + (ak && bk ? 1 : (ak ? 2 : 3)) + 8 * epi;
-  if (fp8) return launch_p256<false, false, EPI_F32, 3>(g, grid, st);
+  if (fp8) return loop_env >= 2 ? launch_p256<false, false, EPI_F32, 10>(g, grid, st) : launch_p256<false, false, EPI_F32, 3>(g, grid, st);
 #define P256_LAYOUT(E)                                                        \
   do {                                                                        \
+    if (loop_form >= 2) {                                                     \
+      if (ak && bk) return launch_p256<true, true, E, 2>(g, grid, st);        \
+      if (ak && !bk) return launch_p256<true, false, E, 2>(g, grid, st);      \
+      return launch_p256<false, false, E, 2>(g, grid, st);                    \
+    }                                                                         \
     if (loop_form) {                                                          \
       if (ak && bk) return launch_p256<true, true, E, 1>(g, grid, st);        \
       if (ak && !bk) return launch_p256<true, false, E, 1>(g, grid, st);      \
