@@ -80,8 +80,10 @@ GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel"}
 GEMM_KERNEL_NAMES[64] = "gemm_mfma_grouped_kernel<false, false, 4>"
 GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
-GEMM_KERNEL_NAMES.update({2048 + lay + 8 * epi: f"gemm_p256_kernel<{txt}, {epi}, 1>" for lay, txt in _LAYOUTS.items() for epi in range(5)})  # csrc/gemm256.hip
-GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4] = "gemm_p256_kernel<false, false, 4, 3>"  # weight gradients on e4m3 operands (cinema_gemm_fp8_wgrad_p256)
+# main-loop form of the persistent kernel (csrc/gemm256.hip reads the same variable per call): 2 = LDS-DMA issued by the reading wave (default), 1 = between the MFMAs, 0 = k-tile loop
+_P256_LOOP = int(os.environ.get("CINEMA_P256_LOOP", "2"))
+GEMM_KERNEL_NAMES.update({2048 + lay + 8 * epi: f"gemm_p256_kernel<{txt}, {epi}, {min(_P256_LOOP, 2)}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})  # csrc/gemm256.hip
+GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4] = f"gemm_p256_kernel<false, false, 4, {10 if _P256_LOOP >= 2 else 3}>"  # weight gradients on e4m3 operands (cinema_gemm_fp8_wgrad_p256)
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (kernel_used, algorithmic_flops, start_event, end_event)
 GEMM_PROFILE: list | None = None

@@ -224,6 +224,33 @@ def test_gemm_p256_grouped_wgrad_in_launch_reduction(rows: int, remainder: int, 
     assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "tile counters / error word not left at zero"
 
 
+@pytest.mark.parametrize("rows", [200, 5000])
+def test_gemm_p256_main_loop_forms_agree_bit_for_bit(rows: int, monkeypatch: pytest.MonkeyPatch) -> None:
+    """CINEMA_P256_LOOP: form 2 (default: the reading wave issues the LDS-DMA of the phase three ahead) against form 1 (issued between the MFMAs) and form 0 (k-tile
+    loop): the same pieces, the same summation order - identical bits on the weight-gradient, forward and data-gradient layouts; short pieces (fewer phases than
+    the ring is deep: rows = 200 -> 7 phases cut into slices) exercise the counted-vmcnt tail of the loop."""
+    shapes = [(512, 256), (384, 200), (72, 512)]
+    x, w = rnd(rows, 520, seed=3), rnd(264, 520, scale=0.05, seed=4)
+    dy2 = rnd(rows, 264, seed=5)
+    outs = {}
+    for form in (2, 1, 0):
+        monkeypatch.setenv("CINEMA_P256_LOOP", str(form))
+        probs = [(rnd(rows, n, scale=0.5, seed=80 + i), rnd(rows, k, scale=0.5, seed=90 + i), torch.zeros(n, k, device=DEV), torch.zeros(n, device=DEV)) for i, (n, k) in enumerate(shapes)]
+        K.gemm_wgrad_grouped(probs, p256=True)
+        y = torch.empty(rows, 264, dtype=torch.bfloat16, device=DEV)
+        dx = torch.empty(rows, 520, dtype=torch.bfloat16, device=DEV)
+        for sched in (0, 1):
+            K.gemm(x, w, out=y, p256=sched)
+            K.gemm(dy2, w, a_kmajor=True, b_kmajor=False, out=dx, p256=sched)
+            outs.setdefault((form, sched), []).extend([y.clone(), dx.clone()])
+        outs[(form, "w")] = [dst for _, _, dst, _ in probs]
+    for key in ("w", 0, 1):
+        for a, b in zip(outs[(2, key)], outs[(1, key)]):
+            assert torch.equal(a, b), f"forms 1 and 2 differ ({key})"
+    for a, b in zip(outs[(2, "w")], outs[(0, "w")]):  # form 0 walks k-tiles of 64: same slices only when the k extents line up - compare numerically
+        close(a, b, 0.0, 1e-3 * float(b.abs().max()), "form 0 vs 2")
+
+
 @pytest.mark.parametrize("schedule", [0, 1])
 @pytest.mark.parametrize(("m", "n", "k"), [(1000, 768, 3072), (2053, 512, 2048), (685, 256, 768), (300, 264, 200)])
 def test_gemm_p256_forward_and_dgrad_epilogues(schedule: int, m: int, n: int, k: int) -> None:

@@ -34,6 +34,21 @@ for a, b in zip(rs, rs[1:]):
 print(f"queue {mq} idle between its kernels: {tot / 1e6:.2f} ms; by (before -> after), top 15:")
 for k, (c, us) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:15]:
     print(f"    {c:4d} x {us / c:6.1f} us = {us:7.1f} us  {k[0]} -> {k[1]}")
+# the long gaps one by one: when in the step, and what the other queues ran meanwhile
+big = sorted(((b[1] - a[2], a, b) for a, b in zip(rs, rs[1:]) if b[1] - a[2] > 20000), key=lambda t: -t[0])[:10]
+for g, a, b in sorted(big, key=lambda t: t[1][2]):
+    others = defaultdict(float)
+    for n, s, e, q in step:
+        if q != mq and e > a[2] and s < b[1]:
+            others[(q, n.split("(")[0][:40])] += (min(e, b[1]) - max(s, a[2])) / 1e3
+    txt = ", ".join(f"q{q} {n} {us:.0f} us" for (q, n), us in sorted(others.items(), key=lambda kv: -kv[1])[:3])
+    print(f"    gap of {g / 1e3:6.1f} us at {(a[2] - t0) / 1e6:6.2f} ms: {a[0].split('(')[0][:40]} -> {b[0].split('(')[0][:40]} | meanwhile: {txt}")
+# every kernel (all queues) that ran during the two longest gaps or ended / started within 150 us of them
+for g, a, b in sorted(big, key=lambda t: -t[0])[:2]:
+    print(f"--- around the gap of {g / 1e3:.1f} us at {(a[2] - t0) / 1e6:.2f} ms (start / end in us relative to the gap's begin):")
+    for n, s_, e, q in step:
+        if e > a[2] - 150000 and s_ < b[1] + 150000:
+            print(f"      q{q} {(s_ - a[2]) / 1e3:9.1f} .. {(e - a[2]) / 1e3:9.1f}  {n.split('(')[0][:60]}")
 for q, rs in sorted(byq.items()):
     agg = defaultdict(lambda: [0, 0.0])
     for n, s, e, _ in rs:
