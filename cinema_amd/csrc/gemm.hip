@@ -6,9 +6,9 @@
 namespace {
 
 
-// 128x128x32 kernel, 2 stages of 16 KiB, three workgroups per CU (see TileIO32).  gridDim.z = split-K slices as in the BK = 64 kernel;
+// 128x128x32 kernel, 3 stages of 16 KiB as a ring (2 as a double buffer: CINEMA_K32_STAGES=2), three workgroups per CU (see TileIO32).  gridDim.z = split-K slices as in the BK = 64 kernel;
 // no split tail, no bias-gradient row sums; K % 32 == 0.
-template <bool A_KMAJ, bool B_KMAJ, int EPI>
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int NST>
 __device__ __forceinline__ void gemm_mfma_k32_body(const GemmP& p, char* smem) {
   using AIO = TileIO32<A_KMAJ>;
   using BIO = TileIO32<B_KMAJ>;
@@ -44,6 +44,44 @@ __device__ __forceinline__ void gemm_mfma_k32_body(const GemmP& p, char* smem) {
     const size_t ka = (size_t)kt * astep, kb = (size_t)kt * bstep;
     glds16x4(sa, sa + 4096, sb, sb + 4096, asrc.p[0] + ka, asrc.p[1] + ka, bsrc.p[0] + kb, bsrc.p[1] + kb);
   };
+  if constexpr (NST > 2) {
+    // ring of NST stages (round 4): the LDS-DMA of k-tile kt + NST - 1 is issued at the top of k-tile kt - into the stage read in kt - 1, everyone has passed the
+    // barrier that ended it - and waited for with a COUNTED vmcnt at the end of k-tile kt + NST - 2: two k-tiles of flight instead of less than one, nobody drains
+    // its queue inside the loop.  With the drain at the end of every k-tile a CU has ~32 KB in flight on average, and 32 KB per ~1800 clocks of loaded latency is the
+    // 18 B/clk per CU this kernel family stages (fill-rate probe).  Alone 10-20 % faster on the K = 512 shapes (decoder q / proj 31.0 -> 28.1 us, fc1
+    // data gradient 101 -> 84 us, profiles/r04_ak_k32_ring.txt); in the step -0.2 ms on config 2, +-0.1 ms on configs 4 / 5.  Results identical to the 2-stage form.
+    load_tile(0, kt_begin);
+#pragma unroll
+    for (int s = 1; s < NST - 1; s++)
+      if (kt_begin + s < kt_end) load_tile(s, kt_begin + s);
+    if (min(NST - 2, kt_end - 1 - kt_begin) >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0, nxt = NST - 1;
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+      const char* sa = smem + cur * STAGE;
+      const char* sb = sa + AIO::BYTES;
+      if (kt + NST - 1 < kt_end) load_tile(nxt, kt + NST - 1);
+#pragma unroll
+      for (int ks = 0; ks < BK32 / 16; ks++) {
+        short8v fa[2], fb[2];
+        fa[0] = AIO::frag(sa, wm, ks, lane);
+        fa[1] = AIO::frag(sa, wm + 32, ks, lane);
+        fb[0] = BIO::frag(sb, wn, ks, lane);
+        fb[1] = BIO::frag(sb, wn + 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      // k-tile kt + 1 must have landed; kt + 2 (if issued) stays in flight
+      if (kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur = cur + 1 == NST ? 0 : cur + 1;
+      nxt = nxt + 1 == NST ? 0 : nxt + 1;
+    }
+  } else {
   load_tile(0, kt_begin);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -67,20 +105,21 @@ __device__ __forceinline__ void gemm_mfma_k32_body(const GemmP& p, char* smem) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  }
   float* stg = reinterpret_cast<float*>(smem + wave * 8192);  // 8 KiB per wave: one 32x64 half at a time
   half_epilogue<EPI>(p, acc[0], m0 + wm, n0 + wn, lane, zsplit, stg);
   half_epilogue<EPI>(p, acc[1], m0 + wm + 32, n0 + wn, lane, zsplit, stg);
 }
-template <bool A_KMAJ, bool B_KMAJ, int EPI>
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int NST = 2>
 __global__ __launch_bounds__(256, 3) void gemm_mfma_k32_kernel(GemmP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO32<A_KMAJ>::BYTES + TileIO32<B_KMAJ>::BYTES)];
-  gemm_mfma_k32_body<A_KMAJ, B_KMAJ, EPI>(p, smem);
+  __shared__ __attribute__((aligned(16))) char smem[NST * (TileIO32<A_KMAJ>::BYTES + TileIO32<B_KMAJ>::BYTES)];
+  gemm_mfma_k32_body<A_KMAJ, B_KMAJ, EPI, NST>(p, smem);
 }
 // lanes form (common.cuh): blockIdx.y = lane, one parameter block per lane (identical shapes, different pointers)
-template <bool A_KMAJ, bool B_KMAJ, int EPI>
+template <bool A_KMAJ, bool B_KMAJ, int EPI, int NST = 2>
 __global__ __launch_bounds__(256, 3) void gemm_mfma_k32_lanes_kernel(Lanes<GemmP> L) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * (TileIO32<A_KMAJ>::BYTES + TileIO32<B_KMAJ>::BYTES)];
-  gemm_mfma_k32_body<A_KMAJ, B_KMAJ, EPI>(L.p[blockIdx.y], smem);
+  __shared__ __attribute__((aligned(16))) char smem[NST * (TileIO32<A_KMAJ>::BYTES + TileIO32<B_KMAJ>::BYTES)];
+  gemm_mfma_k32_body<A_KMAJ, B_KMAJ, EPI, NST>(L.p[blockIdx.y], smem);
 }
 
 // One 128x128 output tile (or k-slice of one) of problem p: everything after the work-item decoding of the kernels below.
@@ -772,11 +811,19 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       // short reductions go to the BK = 32 kernel (3-4 workgroups per CU): in the step 32.47 vs 32.79 ms with the threshold at 512, 32.52 at 768
       // (above that the BK = 64 loop and its split tail win); CINEMA_GEMM_K32 overrides the threshold (0 = never)
       static const int k32_env = getenv("CINEMA_GEMM_K32") ? atoi(getenv("CINEMA_GEMM_K32")) : 512;
+      static const int k32_stages = getenv("CINEMA_K32_STAGES") ? atoi(getenv("CINEMA_K32_STAGES")) : 3;  // 3: ring with counted waits (default), 2: double buffer, drain per k-tile (A/B)
       const bool k32 = k32_env > 0 && epi != EPI_GENERAL && !tail && !p.a_rowsum && !(p.accumulate && !p.ws) && (a->k % 32) == 0 && a->k <= k32_env && a->force_generic == 0;
       if (k32) {
         a->kernel_used += 128;  // the BK = 32 instance of the same layout / epilogue class
+#define LAUNCH_K32_N(E, N)                                                                                                          \
+  do {                                                                                                                         \
+    if (a->a_kmajor && a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, true, E, N>, gemm_mfma_k32_lanes_kernel<true, true, E, N>, 1, grid, dim3(256), 0, st, p);        \
+    else if (a->a_kmajor && !a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, false, E, N>, gemm_mfma_k32_lanes_kernel<true, false, E, N>, 1, grid, dim3(256), 0, st, p); \
+    else launch_lanes(gemm_mfma_k32_kernel<false, false, E, N>, gemm_mfma_k32_lanes_kernel<false, false, E, N>, 1, grid, dim3(256), 0, st, p);                                 \
+  } while (0)
 #define LAUNCH_K32(E)                                                                                                          \
   do {                                                                                                                         \
+    if (k32_stages == 3) { LAUNCH_K32_N(E, 3); break; }                                                                         \
     if (a->a_kmajor && a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, true, E>, gemm_mfma_k32_lanes_kernel<true, true, E>, 1, grid, dim3(256), 0, st, p);        \
     else if (a->a_kmajor && !a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, false, E>, gemm_mfma_k32_lanes_kernel<true, false, E>, 1, grid, dim3(256), 0, st, p); \
     else launch_lanes(gemm_mfma_k32_kernel<false, false, E>, gemm_mfma_k32_lanes_kernel<false, false, E>, 1, grid, dim3(256), 0, st, p);                                 \
@@ -788,6 +835,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
           default: LAUNCH_K32(EPI_F32); break;
         }
 #undef LAUNCH_K32
+#undef LAUNCH_K32_N
       } else {
 #define LAUNCH_LAYOUT(E)                                                                                                    \
   do {                                                                                                                      \

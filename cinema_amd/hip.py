@@ -78,7 +78,8 @@ class Q8Site:
 _LAYOUTS = {1: "true, true", 2: "true, false", 3: "false, false"}
 GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel"}
 GEMM_KERNEL_NAMES[64] = "gemm_mfma_grouped_kernel<false, false, 4>"
-GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
+_K32_STAGES = 3 if int(os.environ.get("CINEMA_K32_STAGES", "3")) == 3 else 2  # csrc/gemm.hip reads the same variable: 3 = ring with counted waits (default), 2 = double buffer
+GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}, {_K32_STAGES}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 # main-loop form of the persistent kernel (csrc/gemm256.hip reads the same variable per call): 2 = LDS-DMA issued by the reading wave (default), 1 = between the MFMAs, 0 = k-tile loop
 _P256_LOOP = int(os.environ.get("CINEMA_P256_LOOP", "2"))
