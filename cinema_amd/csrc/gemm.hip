@@ -375,6 +375,12 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + AIO::BYTES;
     const bool more = kt + 1 < kt_end;
+    // The next k-tile's DMA is issued at the TOP of this k-tile (the other stage was last read before the barrier that ended the previous iteration): with two
+    // stages and a drain at the end of every k-tile the flight time of a piece is what bounds this loop (fill-rate probe), and the ~150 clocks gained over
+    // issuing it behind the first MFMA group (rounds 1-4) are worth 0.19 ms per config-2 step (four-round A/B, profiles/r04_aw_dma_first.txt); the issuing wave's
+    // stall is covered by the other workgroup on the CU.
+    if (more) load_tile(cur ^ 1, kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (FP8) {
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
@@ -388,9 +394,8 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
 #pragma unroll
           for (int j = 0; j < 2; j++)
             acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        if (ks == 0 && more) load_tile(cur ^ 1, kt + 1);
       }
-    } else
+    } else {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       short8v fa[2], fb[2];
@@ -403,9 +408,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
       if (!A_KMAJ && do_rowsum) { rs[0] += frag_sum8(fa[0]); rs[1] += frag_sum8(fa[1]); }  // VALU work in the shadow of the MFMAs
-      // the next tile's DMA is issued behind the first MFMA group, so its address arithmetic runs while the matrix pipe is busy (the other
-      // stage was last read before the barrier that ended the previous iteration)
-      if (ks == 0 && more) load_tile(cur ^ 1, kt + 1);
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA must have landed before anyone reads it
     __syncthreads();
