@@ -4,5 +4,9 @@
 R=${1:-r04}
 cd "$(dirname "$0")/.."
 for f in gpurun_out/${R}_*; do
-  [ -f "$f" ] && cp -v "$f" profiles/
+  [ -f "$f" ] || continue
+  b=profiles/$(basename "$f")
+  # a measurement that was annotated in profiles/ (leading '#' lines) is not overwritten by its raw copy
+  if [ -f "$b" ] && [ "$(head -c1 "$b")" = "#" ] && [ "$(head -c1 "$f")" != "#" ]; then continue; fi
+  cp -v "$f" profiles/
 done
