@@ -750,8 +750,18 @@ GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "2"))  # 1: whole-K 128x1
 # LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
 DEFER_LN_REDUCE = bool(int(os.environ.get("CINEMA_LN_DEFER", "1")))
 _GROUP_MIN_TILES = 384
-GROUP_FLUSH_MIN = int(os.environ.get("CINEMA_GROUP_FLUSH_MIN", "1"))  # measured: 1 (per block) 28.67, 8 (two encoder blocks) 28.81, 10 29.44 ms/step on one box
+# Without a gradient exchange a persistent launch is held back until GROUP_FLUSH_MIN problems OR GROUP_FLUSH_GFLOP of work are pending.  Round 3 (main-loop form 1): per block 28.67,
+# two encoder blocks 28.81 ms/step.  Under form 2 (round 4) two ViT-Base blocks per launch (8 problems, 310-344 GFLOP) are 0.15 ms FASTER in every round of two A/Bs (26.17 -> 26.04, 26.91 -> 26.75 ms,
+# profiles/r04_ba_knobs.txt, r04_bb_flush_min.txt), three or more slower (27.4-27.9); a ViT-Large block (319 GFLOP) must go out alone (config 5: 58.9 -> 60.1 ms with two per launch,
+# profiles/r04_bc_flush_min_cfg45.txt) - hence the work threshold.  CINEMA_GROUP_FLUSH_MIN=1 is the per-block schedule a gradient exchange uses.
+GROUP_FLUSH_MIN = int(os.environ.get("CINEMA_GROUP_FLUSH_MIN", "8"))
+GROUP_FLUSH_GFLOP = float(os.environ.get("CINEMA_GROUP_FLUSH_GFLOP", "300"))
 P256_MAX_PROBLEMS = 12
+
+
+def _pending_gflop(tape: Tape) -> float:
+    return (sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in tape.pending_wgrads)
+            + sum(2.0 * it[0].shape[0] * it[0].shape[1] * it[2].shape[1] for it in tape.pending_wgrads8)) * 1e-9
 
 
 def wgrad_group(tape: Tape) -> None:
@@ -760,7 +770,8 @@ def wgrad_group(tape: Tape) -> None:
     def flush() -> None:
         # the persistent kernel balances better and writes fewer partial tiles with more problems per launch: without a gradient exchange waiting for
         # this block's range, the launch is held back until GROUP_FLUSH_MIN problems (two transformer blocks) are pending
-        if GROUP_WGRAD != 2 or PARAMS_DONE_HOOK is not None or len(tape.pending_wgrads) + len(tape.pending_wgrads8) >= GROUP_FLUSH_MIN:
+        if (GROUP_WGRAD != 2 or PARAMS_DONE_HOOK is not None or len(tape.pending_wgrads) + len(tape.pending_wgrads8) >= GROUP_FLUSH_MIN
+                or _pending_gflop(tape) >= GROUP_FLUSH_GFLOP):
             flush_wgrads(tape)
         tape.grouping = False
 
