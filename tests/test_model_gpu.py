@@ -254,6 +254,53 @@ def test_visible_voxel_stem_equals_dense_stem() -> None:
         assert rel <= 3e-2, (k, rel)  # relative L2 per parameter tensor
 
 
+def test_weight_gradient_group_schedules_agree() -> None:
+    """Without a gradient exchange two transformer blocks share one persistent weight-gradient launch (tape.GROUP_FLUSH_MIN = 8: whole-K tiles), with one every
+    block gets its own (= 1: k-slices summed in the launch).  Same gradients up to the fp32 summation order of the k-slices, fewer launches."""
+    from cinema_amd import hip as K
+    from cinema_amd import tape as T
+
+    views = ["sax", "lax_2c"]
+    kw = dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1),
+              enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)}, enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)},
+              enc_conv_chans=[64, 128], enc_conv_n_blocks=2, enc_embed_dim=256, enc_depth=4, enc_n_heads=4, dec_embed_dim=128, dec_depth=2,
+              dec_n_heads=4)
+    torch.manual_seed(12)
+    model = CineMA(**kw).to(DEV)
+    gen = torch.Generator().manual_seed(7)
+    images = {v: torch.rand(3, 1, *kw["image_size_dict"][v], generator=gen).to(DEV) for v in views}
+    cfg = O.MAEConfig(**kw)
+    masks = {v: O.random_patch_mask(3, math.prod(cfg.grid_size(v)), 0.75, gen).to(DEV) for v in views}
+    orig, keep = K.gemm_wgrad_grouped, (T.GROUP_FLUSH_MIN, T.GROUP_WGRAD)
+    calls = {"n": 0}
+
+    def counting(problems, **kwargs):  # noqa: ANN001, ANN003, ANN202
+        calls["n"] += 1
+        return orig(problems, **kwargs)
+
+    results = []
+    K.gemm_wgrad_grouped = counting
+    try:
+        T.GROUP_WGRAD = 2
+        for flush_min in (1, 8):
+            T.GROUP_FLUSH_MIN = flush_min
+            calls["n"] = 0
+            model.zero_grad(set_to_none=True)
+            loss, _, _, _ = model(images, 0.75, enc_mask_dict=masks)
+            loss.backward()
+            results.append((float(loss.detach()), calls["n"], {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        K.gemm_wgrad_grouped = orig
+        T.GROUP_FLUSH_MIN, T.GROUP_WGRAD = keep
+    (l1, n1, g1), (l8, n8, g8) = results
+    assert l1 == l8, (l1, l8)  # the forward pass does not depend on the schedule
+    assert n8 < n1, (n1, n8)
+    assert set(g1) == set(g8)
+    for k in g1:
+        rel = float((g1[k] - g8[k]).norm() / (g1[k].norm() + 1e-12))
+        assert rel <= 1e-5, (k, rel)  # fp32 accumulation: only the order of the k-slices differs
+
+
 def test_random_masks_and_api_contract() -> None:
     model = CineMA(**mini_kwargs()).to(DEV)
     images = {v: torch.rand(2, 1, *s, device=DEV) for v, s in model_sizes(model).items()}
