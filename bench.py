@@ -541,23 +541,6 @@ def main() -> None:
                     "how": "8 steps per mode after the timed region, max over ranks; per-collective kernel overlap: tools/rccl_overlap.py on a rocprofv3 kernel trace"}
     # forward GFLOP of the reference graph x 3 (SURVEY appendix A probes): config 2 and config 5 shapes only
     ref_gflop = {("base", "192,192,16", "192,192"): STEP_GFLOP_PER_SAMPLE, ("large", "256,256,24", "256,256"): 3 * 1806.7}.get((args.size, args.sax, args.lax))
-    # the step as a gradient exchange schedules it: one persistent weight-gradient launch per transformer block (tape.GROUP_FLUSH_MIN = 1; without an exchange two
-    # ViT-Base blocks share a launch) - the N = 1 anchor of a data-parallel run (information only; single process, recorded steps like the timed region)
-    exch_ms = None
-    if world == 1 and not args.eager and args.profile_steps > 0:
-        from cinema_amd import tape as T_x
-        keep_min, T_x.GROUP_FLUSH_MIN = T_x.GROUP_FLUSH_MIN, 1
-        step.reset_recordings()
-        for i in range(4):
-            step(batches[i % 2], 0.75)
-        torch.cuda.synchronize()
-        tx = time.perf_counter()
-        for i in range(args.steps):
-            step(batches[i % 2], 0.75)
-        torch.cuda.synchronize()
-        exch_ms = round((time.perf_counter() - tx) / args.steps * 1e3, 3)
-        T_x.GROUP_FLUSH_MIN = keep_min
-        step.reset_recordings()
     step.replay = False  # the information-only runs below (dense stem, per-launch events) go through the module code
 
     # the same steps with the stem evaluated on every voxel like the reference (information only; single process)
@@ -626,7 +609,7 @@ def main() -> None:
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
                        "stem": "dense (every voxel, as the reference)" if dense_stem else
                                "visible voxels only - exact: masked voxels never reach a kept token (DESIGN.md 3a); CINEMA_DENSE_STEM=1 runs every voxel",
-                       "dense_stem_ms_per_step": dense_ms, "exchange_schedule_ms_per_step": exch_ms, "peak_mem_gib": peak_gib,
+                       "dense_stem_ms_per_step": dense_ms, "peak_mem_gib": peak_gib,
                        "host": ("module code issues every launch (--eager)" if args.eager else
                                 f"forward+backward re-issued from a recorded list of {n_launches} HIP launches (cinema_amd/replay.py); clip+AdamW eager"),
                        # the REFERENCE's dense FLOP count per sample x samples/s: a reference-equivalent rate, not executed FLOPs

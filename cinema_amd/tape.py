@@ -262,13 +262,21 @@ def mark_params(tape: "Tape", params: list) -> None:
             else:
                 hook(tape, params)
 
+        def start() -> None:
+            if K.RECORD is not None:  # recorded step: the collective is a torch call, so it enters the launch list as a host entry
+                K.RECORD.append((None, run_hook))
+            run_hook()
+
         def fire() -> None:
             # deferred LayerNorm parameter gradients of the ops launched so far (this block's included) must be in the flat buffer before any
             # of its ranges is handed to a collective: reduce the pending partials now (one extra launch per block, data-parallel runs only)
             flush_ln(tape)
-            if K.RECORD is not None:  # recorded step: the collective is a torch call, so it enters the launch list as a host entry
-                K.RECORD.append((None, run_hook))
-            run_hook()
+            if tape.pending_wgrads or tape.pending_wgrads8:
+                # this block's weight-gradient group is held back for a launch shared with the next block (GROUP_FLUSH_MIN): its collective starts
+                # behind that launch (flush_wgrads runs the held hooks) - one block later, with most of the backward pass still ahead to hide it
+                tape.held_hooks.append(start)
+                return
+            start()
 
         tape.record(fire)
 
@@ -281,6 +289,7 @@ class Tape:
         self.pending_wgrads: list = []  # (dy, x, dst, bias_grad) deferred to the enclosing weight-gradient group
         self.pending_wgrads8: list = []  # the same for weight gradients on e4m3 operands (wgrad8_problem)
         self.pending_ln: list = []      # LayerNorm parameter-gradient partials: one batched reduce at the end of the backward pass
+        self.held_hooks: list = []      # gradient-exchange hooks of blocks whose weight-gradient group has not been launched yet (mark_params)
         self.grouping = False
         self.pvars: dict = {}
         self.train = train
@@ -750,10 +759,11 @@ GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "2"))  # 1: whole-K 128x1
 # LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
 DEFER_LN_REDUCE = bool(int(os.environ.get("CINEMA_LN_DEFER", "1")))
 _GROUP_MIN_TILES = 384
-# Without a gradient exchange a persistent launch is held back until GROUP_FLUSH_MIN problems OR GROUP_FLUSH_GFLOP of work are pending.  Round 3 (main-loop form 1): per block 28.67,
+# A persistent launch is held back until GROUP_FLUSH_MIN problems OR GROUP_FLUSH_GFLOP of work are pending.  Round 3 (main-loop form 1): per block 28.67,
 # two encoder blocks 28.81 ms/step.  Under form 2 (round 4) two ViT-Base blocks per launch (8 problems, 310-344 GFLOP) are 0.15 ms FASTER in every round of two A/Bs (26.17 -> 26.04, 26.91 -> 26.75 ms,
 # profiles/r04_ba_knobs.txt, r04_bb_flush_min.txt), three or more slower (27.4-27.9); a ViT-Large block (319 GFLOP) must go out alone (config 5: 58.9 -> 60.1 ms with two per launch,
-# profiles/r04_bc_flush_min_cfg45.txt) - hence the work threshold.  CINEMA_GROUP_FLUSH_MIN=1 is the per-block schedule a gradient exchange uses.
+# profiles/r04_bc_flush_min_cfg45.txt) - hence the work threshold.  The same schedule runs under a gradient exchange: the collective of a block whose group is held
+# back starts behind the shared launch (mark_params / flush_wgrads).  CINEMA_GROUP_FLUSH_MIN=1 restores one launch per block.
 GROUP_FLUSH_MIN = int(os.environ.get("CINEMA_GROUP_FLUSH_MIN", "8"))
 GROUP_FLUSH_GFLOP = float(os.environ.get("CINEMA_GROUP_FLUSH_GFLOP", "300"))
 P256_MAX_PROBLEMS = 12
@@ -770,8 +780,7 @@ def wgrad_group(tape: Tape) -> None:
     def flush() -> None:
         # the persistent kernel balances better and writes fewer partial tiles with more problems per launch: without a gradient exchange waiting for
         # this block's range, the launch is held back until GROUP_FLUSH_MIN problems (two transformer blocks) are pending
-        if (GROUP_WGRAD != 2 or PARAMS_DONE_HOOK is not None or len(tape.pending_wgrads) + len(tape.pending_wgrads8) >= GROUP_FLUSH_MIN
-                or _pending_gflop(tape) >= GROUP_FLUSH_GFLOP):
+        if (GROUP_WGRAD != 2 or len(tape.pending_wgrads) + len(tape.pending_wgrads8) >= GROUP_FLUSH_MIN or _pending_gflop(tape) >= GROUP_FLUSH_GFLOP):
             flush_wgrads(tape)
         tape.grouping = False
 
@@ -792,6 +801,13 @@ def _wgrad_single(dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias
 
 
 def flush_wgrads(tape: Tape) -> None:
+    _flush_wgrads(tape)
+    hooks, tape.held_hooks = tape.held_hooks, []
+    for h in hooks:  # the gradient exchange of the blocks whose weight gradients just went out
+        h()
+
+
+def _flush_wgrads(tape: Tape) -> None:
     probs8, tape.pending_wgrads8 = tape.pending_wgrads8, []
     for i in range(0, len(probs8), P256_MAX_PROBLEMS):
         _wgrad8_launch(probs8[i:i + P256_MAX_PROBLEMS])

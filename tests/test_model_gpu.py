@@ -293,12 +293,12 @@ def test_weight_gradient_group_schedules_agree() -> None:
         K.gemm_wgrad_grouped = orig
         T.GROUP_FLUSH_MIN, T.GROUP_WGRAD = keep
     (l1, n1, g1), (l8, n8, g8) = results
-    assert l1 == l8, (l1, l8)  # the forward pass does not depend on the schedule
+    assert abs(l1 - l8) <= 1e-6 * abs(l1), (l1, l8)  # the forward pass does not depend on the schedule (its loss reduction uses fp32 atomics: last-bit noise)
     assert n8 < n1, (n1, n8)
     assert set(g1) == set(g8)
     for k in g1:
         rel = float((g1[k] - g8[k]).norm() / (g1[k].norm() + 1e-12))
-        assert rel <= 1e-5, (k, rel)  # fp32 accumulation: only the order of the k-slices differs
+        assert rel <= 1e-4, (k, rel)  # fp32 accumulation: only the order of the k-slices differs (+ last-bit noise of the loss reduction through the bf16 gradient chain)
 
 
 def test_random_masks_and_api_contract() -> None:
