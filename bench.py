@@ -29,6 +29,43 @@ sys.path.insert(0, str(ROOT))
 
 STEP_GFLOP_PER_SAMPLE = 835.0  # 3 x 278.4 GF forward, reference graph, no recompute credit
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0           # HBM3E, same guide (about 6.3 TB/s is what a streaming kernel can reach)
+RIDGE_FLOP_PER_BYTE = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)  # 312.5: below it the HBM roof is the one that applies
+
+
+def gemm_roof(flops: float, alg_bytes: float, secs: float, peak_tflops: float = MFMA_BF16_PEAK_TFLOPS) -> dict:
+    """Which roof applies to a GEMM instance and how far below it the instance runs: intensity = algorithmic FLOP / algorithmic byte (every operand read once,
+    the result written once, epilogue tensors included); below the ridge (peak FLOP/s / 8 TB/s) the attainable rate is intensity x 8 TB/s, i.e. the kernel is
+    priced against the HBM roof and ``frac`` = algorithmic bytes / time / 8 TB/s; above it against the MFMA peak."""
+    ridge = peak_tflops * 1e12 / (HBM_PEAK_GBS * 1e9)
+    inten = flops / max(alg_bytes, 1.0)
+    tf, gbs = flops / secs / 1e12, alg_bytes / secs / 1e9
+    hbm = inten < ridge
+    return {"bound": "hbm" if hbm else "mfma", "intensity_flop_per_byte": round(inten, 1), "tflops": round(tf, 1), "alg_gb_s": round(gbs, 1),
+            "frac": round(gbs / HBM_PEAK_GBS if hbm else tf / peak_tflops, 4), "frac_of_mfma_peak": round(tf / peak_tflops, 4)}
+
+
+HBM_KERNEL_FAMILIES = ("ln_fwd_kernel", "ln_bwd_kernel", "adamw_kernel", "sqnorm_kernel", "attn_fwd_mfma", "attn_bwd_", "row_copy_multi_kernel", "cast_kernel",
+                       "splitk_reduce_kernel", "sparse_dwconv", "mse_", "patch_")
+
+
+def hbm_kernel_rows(rel: str) -> dict | None:
+    """The bandwidth side of the step (north_star: "rocprof HBM GB/s against chip peak"): for the LayerNorm / AdamW / attention / mover kernels, PMC HBM bytes per
+    launch (FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected) over the kernel's average duration in the rocprofv3 kernel summary OF THE SAME capture
+    (tools/gpu_pmc_round.sh stores both in the stamped file) = achieved GB/s and its fraction of 8 TB/s.  Read from the committed file, not collected live."""
+    try:
+        meta = json.loads((ROOT / rel).read_text())
+    except (OSError, ValueError):
+        return None
+    rows = {}
+    for name, v in meta.get("kernels", {}).items():
+        if v.get("avg_us") and name.startswith(HBM_KERNEL_FAMILIES):
+            gbs = v["hbm_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
+            rows[name] = {"hbm_mb_per_launch": round(v["hbm_bytes_per_launch"] / 1e6, 1), "avg_us": v["avg_us"], "gb_s": round(gbs), "frac_of_8tb_s": round(gbs / HBM_PEAK_GBS, 3),
+                          "ms_per_step": v.get("ms_per_step")}
+    rows = dict(sorted(rows.items(), key=lambda kv: -(kv[1]["ms_per_step"] or 0.0))[:24])
+    return {"kernels": rows, "source": f"committed {rel}: PMC bytes per launch / average duration of the kernel in the --kernel-trace summary of the same capture (one stream)",
+            "stale": pmc_binding(rel)["stale"], "peak_gb_s": HBM_PEAK_GBS} if rows else None
 
 
 def base_kwargs(size: str = "base", sax=(192, 192, 16), lax=(192, 192)) -> dict:  # noqa: ANN001
@@ -242,7 +279,7 @@ def seg_main(args, rank: int, world: int, device: str, sync) -> None:  # noqa: A
             kind = max(agg, key=lambda k: agg[k][1])
             flops, secs, n = agg[kind]
             achieved = flops / secs / 1e12
-            roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            roofline = {"bound": "mfma",  # (the implicit-convolution launches carry no algorithmic byte count: priced against the MFMA peak) "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n // args.profile_steps,
                         "avg_launch_us": round(secs / n * 1e6, 2), "gflop_per_launch": round(flops / n / 1e9, 3),
                         "timing": "HIP events on the launch stream around every launch of this kernel, live in this process",
@@ -424,6 +461,9 @@ def main() -> None:
                     "with --size large --sax 256,256,24 --lax 256,256 --batch 8); weight gradients stay bf16.  The BASELINE metric (config 2) is bf16")
     ap.add_argument("--eager", action="store_true", help="issue every launch from the module code instead of the recorded launch list (A/B)")
     ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce payload (N > 1): bf16 halves the xGMI bytes")
+    ap.add_argument("--exchange", default=os.environ.get("CINEMA_GRAD_EXCHANGE", "all_reduce"), choices=["all_reduce", "rs_ag"],
+                    help="gradient exchange algorithm (N > 1): all_reduce = torch.distributed.all_reduce per range (RCCL chooses ring / tree / direct); rs_ag = explicit "
+                         "reduce_scatter_tensor + all_gather_into_tensor on the flat ranges (one-hop phases on the fully connected xGMI mesh)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short config-4 / config-5 measurements appended to the default one-GPU line")
     args = ap.parse_args()
 
@@ -458,7 +498,7 @@ def main() -> None:
     sync = None
     if world > 1:
         ddp_setup(rank, world, backend=backend)
-        sync = GradientSynchronizer(world, exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32)
+        sync = GradientSynchronizer(world, exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32, algorithm=args.exchange)
     elif args.force_sync:  # one-process RCCL group: runs the overlapped all-reduce schedule on one GPU (path check, not a metric)
         os.environ.setdefault("MASTER_PORT", "29533")
         ddp_setup(0, 1, backend="nccl")
@@ -533,6 +573,9 @@ def main() -> None:
         sync.disabled = False
         total_comm, exposed = max(at_end - none, 0.0), max(overlapped - none, 0.0)
         ddp_info = {"n_ranks_seen": len({r[0] for r in ranks}), "devices": sorted({r[1] for r in ranks}), "backend": dist.get_backend(), "exchange_dtype": args.grad_exchange,
+                    "exchange_algorithm": args.exchange, "collectives_per_step": sync.n_collectives_last,
+                    # the RCCL knobs in force (passed through untouched: set them in the launching environment to A/B algorithms / protocols on a real node)
+                    "rccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "HSA_FORCE_FINE_GRAIN"))},
                     "payload_bytes_per_step": payload_bytes, "early_collectives_per_step": n_early,
                     "graph": "identical to the N = 1 step: one grouped weight-gradient launch per block, the decoder's shared k|v GEMM with its parameters as a marked range of their own",
                     "ms_per_step_overlapped": round(overlapped, 3), "ms_per_step_exchange_after_backward": round(at_end, 3), "ms_per_step_no_exchange": round(none, 3),
@@ -584,8 +627,14 @@ def main() -> None:
         flops, secs, n, alg_bytes = agg[kind]
         traffic = pmc_traffic(K.GEMM_KERNEL_NAMES[kind])
         achieved = flops / secs / 1e12
-        roofline = {"bound": "mfma", "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+        dom = gemm_roof(flops, alg_bytes, secs)
+        hbm_dom = dom["bound"] == "hbm"
+        # the roof that bounds the dominant kernel follows from its algorithmic intensity (gemm_roof); `frac` is against that roof.  The AT-TRAFFIC intensity
+        # (FLOP / PMC byte) says on which side of the ridge the kernel runs with the bytes it really moves
+        roofline = {"bound": dom["bound"], "kernel": K.GEMM_KERNEL_NAMES[kind], "achieved": dom["alg_gb_s"] if hbm_dom else round(achieved, 1),
+                    "peak": HBM_PEAK_GBS if hbm_dom else MFMA_BF16_PEAK_TFLOPS, "unit": "GB/s" if hbm_dom else "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                    "intensity_flop_per_byte": dom["intensity_flop_per_byte"], "ridge_flop_per_byte": round(RIDGE_FLOP_PER_BYTE, 1),
+                    "intensity_at_measured_traffic": round(flops / n / traffic, 1) if traffic else None,
                     "algorithmic_bytes_per_launch": round(alg_bytes / n), "traffic_over_algorithmic": round(traffic / (alg_bytes / n), 2) if traffic else None,
                     "traffic_source": f"committed {PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/gpu_pmc_round.sh); not collected live",
                     "traffic_stale": pmc_binding(PMC_TRAFFIC_FILE)["stale"], "traffic_binding": pmc_binding(PMC_TRAFFIC_FILE),
@@ -595,8 +644,11 @@ def main() -> None:
                     "timing": "HIP events on the launch stream around every launch of this kernel, live in this process (a grouped persistent launch finishes its split reduction inside the kernel; for the 128x128 split-K kernel the events also cover the reduce launch behind it)",
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(secs / n * 1e6, 2),
                     "gflop_per_launch": round(flops / n / 1e9, 3),
-                    "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
-                                                                  "launches_per_step": v[2] // args.profile_steps} for k, v in agg.items()}}
+                    "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {**gemm_roof(v[0], v[3], v[1]), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
+                                                                  "launches_per_step": v[2] // args.profile_steps} for k, v in agg.items()},
+                    "all_gemm_kernels_note": "bound / frac per instance from its algorithmic intensity (FLOP per algorithmic byte vs the 312.5 FLOP/B ridge of 2.5 PF / 8 TB/s): "
+                                             "hbm-bound instances are priced against 8 TB/s, mfma-bound ones against 2.5 PF; frac_of_mfma_peak is kept for comparison with earlier rounds",
+                    "hbm_kernels": hbm_kernel_rows(PMC_TRAFFIC_FILE)}
 
     if rank == 0:
         samples_per_s = world * args.batch * args.steps / dt
@@ -631,6 +683,12 @@ def main() -> None:
                 out["secondary"] = secondary_configs(device, with_parity=args.cpu_budget > 0)
             except Exception as e:  # noqa: BLE001  (the headline line must not depend on the information-only runs)
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
+            b64 = out["secondary"].get("config2_global_batch_64") if isinstance(out["secondary"], dict) else None
+            if b64 is not None:
+                # batch-independent part of the step: the marginal cost per sample from the two batch sizes of this run, (ms64 - ms16) / 48, extrapolated to batch 0
+                per_sample = (b64["ms_per_step"] - out["ms_per_step"]) / 48.0
+                out["config"]["fixed_ms_per_step"] = round(out["ms_per_step"] - 16.0 * per_sample, 3)
+                out["config"]["marginal_ms_per_sample"] = round(per_sample, 4)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_sync:
         dist.destroy_process_group()

@@ -49,7 +49,15 @@ class GradientSynchronizer:
     """
 
     def __init__(self, world_size: int | None = None, bucket_bytes: int = 128 << 20, group=None, overlap: bool = True,
-                 force_collectives: bool = False, exchange_dtype: torch.dtype = torch.float32, min_early_bytes: int = 1 << 20) -> None:  # noqa: ANN001
+                 force_collectives: bool = False, exchange_dtype: torch.dtype = torch.float32, min_early_bytes: int = 1 << 20,
+                 algorithm: str = "all_reduce") -> None:  # noqa: ANN001
+        # "all_reduce": one torch.distributed.all_reduce per range (RCCL picks ring / tree / direct by message size).  "rs_ag": the same mean as an explicit
+        # reduce-scatter of the range followed by an all-gather of the reduced shards (both in place on the range).  On the fully connected xGMI mesh
+        # (7 point-to-point links per GPU) every rank then sends 1/N of the range straight to its owner and gets the reduced shards straight back:
+        # two one-hop phases instead of a ring's 2(N-1) steps.  Same result up to the summation order inside the collective.
+        if algorithm not in ("all_reduce", "rs_ag"):
+            raise ValueError('algorithm: "all_reduce" or "rs_ag"')
+        self.algorithm = algorithm
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.bucket_bytes = bucket_bytes
         self.group = group
@@ -76,6 +84,8 @@ class GradientSynchronizer:
         self.defer_all = False
         self.n_collectives_total = 0  # collectives issued since construction (tests: accumulation micro-steps must not communicate)
         self.bytes_last = 0      # payload bytes of the last completed exchange
+        self.n_collectives_last = 0  # collectives of the last completed exchange (rs_ag: two per range)
+        self._n_coll_armed = 0
 
     def attach(self, flat) -> None:  # noqa: ANN001
         self.flat = flat
@@ -110,14 +120,39 @@ class GradientSynchronizer:
                 stage = t.to(torch.bfloat16)
             self._staged.append((t, stage))
             t = stage
-        self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
-        self.n_collectives_total += 1
+        if self.algorithm == "rs_ag" and self.world_size > 1:
+            self._launch_rs_ag(t, op)
+        else:
+            self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+            self.n_collectives_total += 1
         self._bytes += t.numel() * t.element_size()
+
+    def _launch_rs_ag(self, t: torch.Tensor, op) -> None:  # noqa: ANN001
+        """Mean of ``t`` over the ranks as reduce-scatter + all-gather, in place: rank r reduces elements [r s, (r + 1) s) of the range (s = numel // world),
+        then every rank gathers the reduced shards back into the range.  The flat ranges are multiples of 8 elements, so for 2 / 4 / 8 ranks nothing is left
+        over; a remainder of < world elements (other world sizes) takes a small all-reduce."""
+        world = self.world_size
+        rank = dist.get_rank(self.group)
+        s = t.numel() // world
+        if s > 0:
+            main = t[:s * world]
+            shard = main[rank * s:(rank + 1) * s]
+            w = dist.reduce_scatter_tensor(shard, main, op=op, group=self.group, async_op=True)
+            if dist.get_backend(self.group) != "nccl":
+                w.wait()  # gloo (CPU tests) runs queued collectives on worker threads: the gather must not overtake the scatter.  RCCL orders both on its stream
+            else:
+                self._works.append(w)
+            self._works.append(dist.all_gather_into_tensor(main, shard, group=self.group, async_op=True))
+            self.n_collectives_total += 2
+        if s * world < t.numel():
+            self._works.append(dist.all_reduce(t[s * world:], op=op, group=self.group, async_op=True))
+            self.n_collectives_total += 1
 
     def arm(self, on: bool) -> None:
         """Called before ``backward()``: only the micro-step that ends with the optimiser update all-reduces."""
         self.armed = bool(on) and (self.world_size > 1 or self.force) and self.flat is not None and not self.disabled
         self._early, self._works, self._staged, self._bytes = [], [], [], 0
+        self._n_coll_armed = self.n_collectives_total
 
     def params_done(self, tape, params: list) -> None:  # noqa: ANN001
         """Backward-pass hook: all gradient kernels of ``params`` are in the stream -> start their all-reduce.  Every rank
@@ -169,6 +204,7 @@ class GradientSynchronizer:
             self.flat.flat_grad.div_(self.world_size)
         self.n_early_last = len(self._early)
         self.bytes_last = self._bytes
+        self.n_collectives_last = self.n_collectives_total - self._n_coll_armed
         self._early, self._works, self._staged, self.armed = [], [], [], False
 
     def all_finite(self, loss: torch.Tensor) -> torch.Tensor:

@@ -7,6 +7,8 @@ remaining callers' symbols (``get_amp_dtype_and_device``, ``print_model_info``, 
 
 from __future__ import annotations
 
+import os
+
 import logging
 
 import torch
@@ -45,7 +47,8 @@ def setup_ddp_model(model: nn.Module, device: torch.device, rank: int, world_siz
     broadcast when the flat buffers are built, DDP's ``_sync_module_states``).  Both returned handles are the model itself."""
     model.to(device)
     if world_size > 1:
-        model.grad_synchronizer = GradientSynchronizer(world_size)
+        # CINEMA_GRAD_EXCHANGE=rs_ag: explicit reduce-scatter + all-gather instead of all_reduce (cinema_amd/ddp.py), for A/B on a real xGMI node
+        model.grad_synchronizer = GradientSynchronizer(world_size, algorithm=os.environ.get("CINEMA_GRAD_EXCHANGE", "all_reduce"))
     return model, model
 
 

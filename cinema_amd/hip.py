@@ -486,6 +486,39 @@ def _p256_workspace(device: torch.device) -> torch.Tensor:
     return ws
 
 
+P256_ERROR_WORD = 65536 // 4 - 1  # csrc/gemm256.hip: last word of the 64 KiB counter head (P_COUNTER_BYTES)
+TAIL_ERROR_WORD = 2047            # csrc/gemm_shared.cuh
+
+
+def check_reduction_workspaces() -> None:
+    """Read the error word of every in-launch-reduction workspace of this process (persistent 256x256 GEMM, split-tail counters): a workgroup that waited
+    for a partial tile longer than its bounded spin (2^26 polls) gives up, finishes with what it has and sets the word - the results of that launch are then
+    WRONG.  Never observed in a healthy run; a hung or reset neighbour queue is the scenario.  One small device->host read (a synchronisation): the training
+    steps call this every ``check_every`` updates and before a checkpoint is written.  On a set word the counter regions are zeroed again (so that later
+    launches start from a clean state) and :class:`HipLibraryError` is raised."""
+    words, owners = [], []
+    for key, ws in _P256_WS.items():
+        words.append(ws[P256_ERROR_WORD:P256_ERROR_WORD + 1].view(torch.int32))
+        owners.append(("persistent GEMM workspace", key, ws))
+    for key, t in _TAIL_COUNTERS.items():
+        words.append(t[TAIL_ERROR_WORD:TAIL_ERROR_WORD + 1])
+        owners.append(("split-tail counters", key, t))
+    if not words:
+        return
+    by_dev: dict = {}
+    for w, o in zip(words, owners):
+        by_dev.setdefault(w.device, []).append((w, o))
+    bad = []
+    for items in by_dev.values():
+        vals = torch.cat([w for w, _ in items]).tolist()
+        bad += [o for v, (_, o) in zip(vals, items) if v != 0]
+    if bad:
+        for what, _key, t in bad:
+            (t[:P256_ERROR_WORD + 1] if what.startswith("persistent") else t).zero_()
+        raise HipLibraryError("an in-launch split reduction gave up waiting for a partial tile (error word set): the gradients of that launch are wrong - "
+                              + "; ".join(f"{what} of (device, stream, lane) {key}" for what, key, _ in bad) + ". The counters were reset; restart from the last checkpoint.")
+
+
 def _p256_call(arr, count: int, schedule: int, device: torch.device) -> None:  # noqa: ANN001
     ws = _p256_workspace(device)
     _check(load().cinema_gemm_bf16_p256(arr, count, schedule, ws.data_ptr(), ws.numel() * 4, _stream()), "gemm_p256")

@@ -268,8 +268,12 @@ class TrainStep:
     (``cinema/mae/pretrain.py:242-269``) without its per-step host synchronisations."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, clip_grad: float | None = 5.0,
-                 synchronizer=None, hip_graph: bool = False, replay: bool = False, audit: bool = False, param_groups: list | None = None) -> None:  # noqa: ANN001
+                 synchronizer=None, hip_graph: bool = False, replay: bool = False, audit: bool = False, param_groups: list | None = None,  # noqa: ANN001
+                 check_every: int = 100) -> None:
         self.model = model
+        # every ``check_every`` optimiser updates (and whenever a checkpoint is saved) the error words of the in-launch split reductions are read back
+        # (hip.check_reduction_workspaces: one 4-byte read per workspace, the only host synchronisation of the step loop); 0 disables
+        self.check_every, self._n_updates = int(check_every), 0
         self.flat = FlatModel(model, weight_decay, param_groups=param_groups)
         self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas, synchronizer=synchronizer)
         self.clip_grad = clip_grad
@@ -285,6 +289,11 @@ class TrainStep:
         self._graphs: dict = {}
         if hip_graph and self.sync is not None:
             raise ValueError("hip_graph=True captures the single-process step; the data-parallel step runs eagerly")
+
+    def _updated(self) -> None:
+        self._n_updates += 1
+        if self.check_every > 0 and self._n_updates % self.check_every == 0:
+            K.check_reduction_workspaces()
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
         if self.replay and enc_mask_dict is None and n_accum_steps == 1 and not T.fp8_calibrating():  # (the first fp8 step records maxima: eager)
@@ -302,6 +311,7 @@ class TrainStep:
                 self.sync.all_reduce()
             grad_norm = self.optimizer.step(self.clip_grad)
             self.optimizer.zero_grad()
+            self._updated()
         return loss.detach(), grad_norm, metrics
 
     # ------------------------------------------------------------------------------------------------ recorded step
@@ -331,10 +341,15 @@ class TrainStep:
                 self.sync.all_reduce()
             grad_norm = self.optimizer.step(self.clip_grad)
             self.optimizer.zero_grad()
+            self._updated()
         return loss, grad_norm, metrics  # static tensors: overwritten by the next step
 
     # ------------------------------------------------------------------------------------------------ HIP-graph step
     def _capture(self, image_dict: dict, enc_mask_ratio: float) -> tuple:
+        if T.FP8_FORWARD and T.FP8_WGRAD:
+            # the delayed-scaling sites need a host call per step (fp8_step_end: maxima -> next step's scales) and a calibration step that runs other
+            # kernels than the steady state; a captured graph would replay frozen scales and saturate as magnitudes drift
+            raise ValueError("hip_graph=True cannot be combined with the fp8 weight-gradient path (CINEMA_FP8=1, CINEMA_FP8_WGRAD=1): use replay=True")
         static = {k: v.clone() for k, v in image_dict.items()}
         self.optimizer.zero_grad()
         side = torch.cuda.Stream()
@@ -363,6 +378,7 @@ class TrainStep:
         graph.replay()  # random masks are drawn inside the graph (torch's graph-safe Philox offsets advance per replay)
         grad_norm = self.optimizer.step(self.clip_grad)
         self.optimizer.zero_grad()
+        self._updated()
         return loss, grad_norm, metrics  # static output buffers: overwritten by the next replay
 
 
@@ -411,6 +427,7 @@ class GradScaler:
             sync.arm(update_grad)
         if fused:
             loss.backward(create_graph=create_graph)
+            T.fp8_step_end()  # fp8 weight-gradient path: this step's recorded maxima become the next step's scales (no-op otherwise), as in TrainStep
         else:
             self._scaler.scale(loss).backward(create_graph=create_graph)
         if not update_grad:
@@ -458,6 +475,8 @@ def save_checkpoint(ckpt_dir, epoch: int, model_wo_ddp: nn.Module, optimizer, lo
     """``ckpt_dir / f"ckpt_{epoch}.pt"`` with the reference's keys (``cinema/optim.py:229-261``): model, optimizer, epoch, scaler, n_samples."""
     from pathlib import Path
 
+    if torch.cuda.is_available():
+        K.check_reduction_workspaces()  # never write a checkpoint behind a split reduction that gave up (raises HipLibraryError)
     ckpt_dir = Path(ckpt_dir)
     ckpt_dir.mkdir(parents=True, exist_ok=True)
     ckpt_path = ckpt_dir / f"ckpt_{epoch}.pt"

@@ -103,9 +103,9 @@ class SegTrainStep(FineTuneStep):
     metrics) as device tensors."""
 
     def __init__(self, model, views: list, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, layer_decay: float | None = 0.75,  # noqa: ANN001
-                 clip_grad: float | None = 5.0, synchronizer=None, replay: bool = False, audit: bool = False) -> None:  # noqa: ANN001
+                 clip_grad: float | None = 5.0, synchronizer=None, replay: bool = False, audit: bool = False, check_every: int = 100) -> None:  # noqa: ANN001
         super().__init__(model, views, segmentation_loss_tensors, lr=lr, betas=betas, weight_decay=weight_decay, layer_decay=layer_decay,
-                         clip_grad=clip_grad, synchronizer=synchronizer)
+                         clip_grad=clip_grad, synchronizer=synchronizer, check_every=check_every)
         # replay: forward + loss + backward recorded once per input signature as the flat list of this library's launches and re-issued from it
         # (cinema_amd/replay.py RecordedSegStep): the module code needs ~50 ms of host time for the ~2000 launches of config 4, as long as the GPU needs
         self.replay, self.audit = replay, audit
@@ -135,6 +135,7 @@ class SegTrainStep(FineTuneStep):
                 self.sync.all_reduce()
             grad_norm = self.optimizer.step(self.clip_grad)
             self.optimizer.zero_grad()
+            self._updated()
         return loss, grad_norm, metrics
 
 

@@ -54,6 +54,11 @@ class Var:
             K.row_copy(self.grad.view(-1, self.grad.shape[-1]), g.view(-1, g.shape[-1]), accumulate=True)
             self.grad16 = None
             self.grad8 = None
+            if self.grad8_bias_done:
+                # a LayerNorm backward summed the columns of what it believed to be the complete gradient into the producing projection's bias gradient
+                # (op_layernorm); a later contribution is not in that sum - the block wiring of this build never does this, so fail loudly instead of
+                # training with a partial bias gradient
+                raise RuntimeError("Var.add_grad: a gradient contribution arrived after a LayerNorm backward had already summed this tensor's columns as a bias gradient")
 
     def grad_bf16(self) -> torch.Tensor:
         """bf16 view of the gradient (GEMM operand)."""
@@ -230,7 +235,9 @@ def lax_stream() -> "torch.cuda.Stream":
 
 def join_lax_stream() -> None:
     """The current stream waits for everything issued to the long-axis stream so far."""
-    if _LAX_STREAMS and torch._C._cuda_getDevice() in _LAX_STREAMS:
+    # (not while the current stream is being captured into a HIP graph: run_in_lanes keeps the long-axis stream out of a capture, so there is nothing
+    # to join - and an event recorded on a stream OUTSIDE the capture must not be waited on from inside it)
+    if _LAX_STREAMS and torch._C._cuda_getDevice() in _LAX_STREAMS and not torch._C._cuda_isCurrentStreamCapturing():
         K.stream_fork(lax_stream().cuda_stream, K._stream())
 
 
@@ -484,7 +491,12 @@ FP8_MARGIN = float(os.environ.get("CINEMA_FP8_MARGIN", "1.25"))  # scale = margi
 
 
 class Fp8Sites:
-    """Device arrays of the delayed-scaling sites (maxima [cap][4096 slots], scales [cap], inverse scales [cap]) and the key -> site registry."""
+    """Device arrays of the delayed-scaling sites (maxima [cap][4096 slots], scales [cap], inverse scales [cap]) and the registry of live sites.
+
+    A site belongs to a PARAMETER OBJECT (the weight whose GEMM reads the 8-bit copy) and a tensor position: the site objects hang on the parameter
+    (``param._cinema_q8[(device, kind)]``), a ``weakref.finalize`` on the parameter hands the array slot back when the parameter dies.  (Until round 5
+    the registry was keyed by ``id(parameter)``: a new model whose parameter re-used a dead parameter's id inherited a READY site with a foreign scale -
+    no calibration step, saturated or flushed first steps - and a process that built a few models ran out of the 1024 slots.)"""
 
     CAP = 1024
     SLOTS = 4096  # CINEMA_Q8_SLOTS
@@ -494,26 +506,50 @@ class Fp8Sites:
         self.amax = K.persistent(lambda: torch.zeros(self.CAP * self.SLOTS, dtype=torch.int32, device=device))
         self.scale = K.persistent(lambda: torch.ones(self.CAP, dtype=F32, device=device))
         self.inv = K.persistent(lambda: torch.ones(self.CAP, dtype=F32, device=device))
-        self.index: dict = {}
+        self.live: dict = {}     # slot -> Q8Site of a live owner
+        self.free: list = []     # slots of dead owners, re-used before the high-water mark grows
+        self.n_alloc = 0         # high-water mark: slots [0, n_alloc) are swept by update()
         self.updates = 0
 
-    def site(self, key: tuple) -> K.Q8Site:
-        st = self.index.get(key)
-        if st is None:
-            i = len(self.index)
+    def _release(self, slots: list) -> None:
+        for i in slots:
+            if self.live.pop(i, None) is not None:
+                self.free.append(i)
+
+    def site(self, owner: object, kind: str) -> K.Q8Site:
+        sites = owner.__dict__.get("_cinema_q8")
+        if sites is None:
+            sites = owner.__dict__["_cinema_q8"] = {}
+        key = (self.device.index, kind)
+        st = sites.get(key)
+        if st is not None and st.owner is self:
+            return st
+        if self.free:
+            i = self.free.pop()
+            self.amax[i * self.SLOTS:(i + 1) * self.SLOTS].zero_()  # (swept every update; a maximum the dead owner recorded in THIS step must not leak)
+            self.scale[i:i + 1].fill_(1.0)
+            self.inv[i:i + 1].fill_(1.0)
+        else:
+            i = self.n_alloc
             if i >= self.CAP:
-                raise RuntimeError("Fp8Sites: more than CAP delayed-scaling sites")
-            st = self.index[key] = K.Q8Site(self.scale[i:i + 1], self.inv[i:i + 1], self.amax[i * self.SLOTS:(i + 1) * self.SLOTS], self, self.updates)
+                raise RuntimeError(f"Fp8Sites: more than {self.CAP} live delayed-scaling sites on {self.device}")
+            self.n_alloc += 1
+        st = sites[key] = self.live[i] = K.Q8Site(self.scale[i:i + 1], self.inv[i:i + 1], self.amax[i * self.SLOTS:(i + 1) * self.SLOTS], self, self.updates)
+        slots = owner.__dict__.get("_cinema_q8_slots")
+        if slots is None:
+            slots = owner.__dict__["_cinema_q8_slots"] = []
+            weakref.finalize(owner, Fp8Sites._release, self, slots)
+        slots.append(i)
         return st
 
     def update(self) -> None:
         """Maxima recorded since the last call -> scales (one launch); sites created before this call have a scale afterwards."""
-        if self.index:
-            K.fp8_sites_update(self.amax, self.scale, self.inv, len(self.index), FP8_MARGIN)
+        if self.n_alloc:
+            K.fp8_sites_update(self.amax, self.scale, self.inv, self.n_alloc, FP8_MARGIN)
         self.updates += 1
 
     def all_ready(self) -> bool:
-        return bool(self.index) and all(s.ready for s in self.index.values())
+        return bool(self.live) and all(s.ready for s in self.live.values())
 
 
 _FP8_SITES: dict = {}
@@ -530,7 +566,7 @@ def fp8_site(t: torch.Tensor, owner: object, kind: str):  # noqa: ANN201
     """The delayed-scaling site of tensor position ``kind`` at parameter ``owner`` (None when the fp8 weight-gradient path is off / on the CPU)."""
     if not (FP8_FORWARD and FP8_WGRAD and t.is_cuda):
         return None
-    return fp8_sites(t.device).site((id(owner), kind))
+    return fp8_sites(t.device).site(owner, kind)
 
 
 def fp8_step_end() -> None:

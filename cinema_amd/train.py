@@ -28,7 +28,7 @@ class FineTuneStep:
     whole accumulation window, good micro-batches included.  With ``n_accum_steps == 1`` the two behaviours coincide."""
 
     def __init__(self, model, views: list, loss_fn: Callable, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05,  # noqa: ANN001
-                 layer_decay: float | None = 0.75, clip_grad: float | None = 5.0, synchronizer=None) -> None:  # noqa: ANN001
+                 layer_decay: float | None = 0.75, clip_grad: float | None = 5.0, synchronizer=None, check_every: int = 100) -> None:  # noqa: ANN001
         from cinema_amd.convvit import param_groups_lr_decay
         from cinema_amd.optim import FlatModel, FusedAdamW
 
@@ -41,6 +41,14 @@ class FineTuneStep:
         self.optimizer = FusedAdamW(self.flat, lr=lr, betas=betas, synchronizer=synchronizer)
         self.sync = self.optimizer.synchronizer
         self.device = self.flat.flat_param.device
+        self.check_every, self._n_updates = int(check_every), 0  # error words of the in-launch split reductions, see cinema_amd.optim.TrainStep
+
+    def _updated(self) -> None:
+        self._n_updates += 1
+        if self.check_every > 0 and self._n_updates % self.check_every == 0:
+            from cinema_amd import hip as K
+
+            K.check_reduction_workspaces()
 
     def __call__(self, batch: dict, n_accum_steps: int = 1, update_grad: bool = True) -> tuple:
         loss, metrics = self.loss_fn(self.model, batch, self.views, self.device)
@@ -53,6 +61,7 @@ class FineTuneStep:
                 self.sync.all_reduce()
             grad_norm = self.optimizer.step(self.clip_grad)
             self.optimizer.zero_grad()
+            self._updated()
         return loss.detach(), grad_norm, metrics
 
 

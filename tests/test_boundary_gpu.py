@@ -329,3 +329,67 @@ def test_persistent_tables_are_not_allocated_from_a_recording_pool() -> None:
             assert float(table[12345]) == 12345.0
     finally:
         K.RECORD = None
+
+
+# ---------------------------------------------------------------------------------------------------- error word of the in-launch split reductions
+def _mfma_model():  # noqa: ANN202
+    views = ["sax", "lax_2c"]
+    kw = dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1), enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)},
+              enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=2, enc_n_heads=4,
+              dec_embed_dim=128, dec_depth=2, dec_n_heads=4)
+    torch.manual_seed(0)
+    model = CineMA(**kw).to(DEV)
+    gen = torch.Generator().manual_seed(1)
+    batch = {v: torch.rand(2, 1, *kw["image_size_dict"][v], generator=gen).to(DEV) for v in views}
+    return model, batch
+
+
+def test_train_step_reads_the_split_reduction_error_word(tmp_path: Path) -> None:
+    """A workgroup of the persistent GEMM (or of a split tail) that gives up its bounded wait for a partial tile sets an error word in the workspace
+    (csrc/gemm256.hip, csrc/gemm.hip): the results of that launch are wrong.  ``TrainStep`` reads the words every ``check_every`` updates and
+    ``save_checkpoint`` before writing: a planted word raises ``HipLibraryError`` at the next checked step (not before), the counter region is
+    re-zeroed, training continues."""
+    from cinema_amd.optim import GradScaler, TrainStep, save_checkpoint
+
+    model, batch = _mfma_model()
+    step = TrainStep(model, lr=1e-3, check_every=2)
+    for _ in range(2):
+        step(batch, 0.75)  # update 2 is a checked one: clean
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ws = K._p256_workspace(dev)  # noqa: SLF001  (this stream's workspace: created here if the small model's groups ran elsewhere)
+    words = ws.view(torch.int32)
+    words[K.P256_ERROR_WORD] = 1
+    step(batch, 0.75)  # update 3: not a checked one
+    with pytest.raises(K.HipLibraryError, match="error word"):
+        step(batch, 0.75)  # update 4: checked
+    assert int(words[: K.P256_ERROR_WORD + 1].abs().sum()) == 0  # counters and the word are zero again
+    for _ in range(2):
+        loss, gnorm, _ = step(batch, 0.75)  # updates 5, 6 (checked): clean again
+    assert math.isfinite(float(loss)) and math.isfinite(float(gnorm))
+    tail = K._tail_counters(dev)  # noqa: SLF001
+    tail[K.TAIL_ERROR_WORD] = 1
+    with pytest.raises(K.HipLibraryError, match="split-tail"):
+        save_checkpoint(tmp_path, 0, model, step.optimizer, GradScaler(), 0)
+    assert int(tail.abs().sum()) == 0
+    assert save_checkpoint(tmp_path, 0, model, step.optimizer, GradScaler(), 0).exists()
+
+
+def test_hip_graph_step_smoke() -> None:
+    """``TrainStep(hip_graph=True)``: forward + backward captured once and replayed as a HIP graph (kept for A/B against the recorded launch list).  The
+    long-axis stream stays outside the capture: ``Tape.backward`` must not wait, from inside the capture, on an event of that non-capturing stream
+    (ADVICE round 4).  Three optimisation steps, finite and falling loss; combining the graph with the fp8 delayed-scaling path is refused."""
+    from cinema_amd import tape as T
+    from cinema_amd.optim import TrainStep
+
+    model, batch = _mfma_model()
+    step = TrainStep(model, lr=1e-3, hip_graph=True)
+    losses = [float(step(batch, 0.75)[0]) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    prev = T.FP8_FORWARD
+    T.FP8_FORWARD = True
+    try:
+        with pytest.raises(ValueError, match="hip_graph"):
+            TrainStep(_mfma_model()[0], lr=1e-3, hip_graph=True)(batch, 0.75)
+    finally:
+        T.FP8_FORWARD = prev

@@ -250,6 +250,23 @@ def _ddp_worker(rank: int, world: int, port: int, tmp: str) -> None:
     sync.arm(False)  # accumulation micro-step: the hook must stay silent
     sync.params_done(fake_tape, blocks[0])
     assert not sync._early and not sync._works  # noqa: SLF001
+    # the same overlapped schedule as explicit reduce-scatter + all-gather on the flat ranges (algorithm="rs_ag"): two collectives per range, same payload,
+    # same mean; a range whose length is not a multiple of the world size takes a small all-reduce for the remainder
+    rs = GradientSynchronizer(world, bucket_bytes=64 << 10, algorithm="rs_ag")
+    rs.attach(flat)
+    rs.min_early = 64
+    flat.flat_grad.copy_(torch.arange(flat.numel, dtype=torch.float32) * (rank + 1))
+    rs.arm(True)
+    for b in blocks:
+        rs.params_done(fake_tape, b)
+    rs.all_reduce()
+    torch.save({"grad": flat.flat_grad.clone(), "n": rs.n_collectives_last, "n_ar": sync.n_collectives_last, "bytes": (rs.bytes_last, sync.bytes_last)}, f"{tmp}/grad_rsag{rank}.pt")
+    odd = torch.arange(11, dtype=torch.float32) * (rank + 1)  # 11 = 2 * 5 + 1: shard of 5 per rank + a remainder of 1
+    rs.arm(True)
+    rs._launch(odd)  # noqa: SLF001
+    for w in rs._works:  # noqa: SLF001
+        w.wait()
+    torch.save(odd / world, f"{tmp}/odd_rsag{rank}.pt")
     ok = sync.all_finite(torch.tensor(float("nan") if rank == 1 else 1.0))
     torch.save(ok, f"{tmp}/finite{rank}.pt")
     torch.distributed.destroy_process_group()
@@ -266,6 +283,10 @@ def test_gradient_synchronizer_world_size_2_gloo(tmp_path: Path) -> None:
     assert torch.equal(g0, g1) and torch.allclose(g0, expect)
     for r in (0, 1):
         assert torch.equal(torch.load(tmp_path / f"grad_overlap{r}.pt"), g0)  # overlapped schedule == plain bucketed schedule
+        rs = torch.load(tmp_path / f"grad_rsag{r}.pt")
+        assert torch.equal(rs["grad"], g0)  # reduce-scatter + all-gather == all-reduce (two ranks: one addition per element, no order freedom)
+        assert rs["n"] == 2 * rs["n_ar"] and rs["bytes"][0] == rs["bytes"][1] > 0
+        assert torch.equal(torch.load(tmp_path / f"odd_rsag{r}.pt"), torch.arange(11, dtype=torch.float32) * 1.5)
     assert float(torch.load(tmp_path / "finite0.pt")) == 0.0 and float(torch.load(tmp_path / "finite1.pt")) == 0.0  # collective NaN decision
 
 
@@ -520,3 +541,37 @@ def test_hot_kernels_have_no_scratch() -> None:
     hot = ("gemm_p256", "gemm_mfma", "gemm_fp8", "gemm_conv", "attn_", "ln_fwd", "ln_bwd", "sparse_dwconv", "adamw", "tail_fixup", "splitk_reduce")
     bad = [(r["name"][:80], r["private_segment_fixed_size"]) for r in rows if any(h in r["name"] for h in hot) and int(r["private_segment_fixed_size"]) > 0]
     assert not bad, bad
+
+
+def test_fp8_sites_belong_to_the_parameter_object_and_slots_are_recycled() -> None:
+    """Delayed-scaling sites hang on the parameter OBJECT (round 4 keyed them by id(parameter): a new model re-using a dead parameter's id inherited a
+    ready site with a foreign scale, and a few models exhausted the 1024 slots): a site is ready only after an update that follows ITS creation, a dead
+    parameter's slots are handed out again as fresh (not ready) sites, and the registry never grows past the live sites."""
+    import gc
+
+    from cinema_amd import tape as T
+
+    reg = T.Fp8Sites(torch.device("cpu"))
+    reg.update = lambda: setattr(reg, "updates", reg.updates + 1)  # (the real update is one HIP launch: host logic only here)
+    a = torch.nn.Parameter(torch.zeros(4))
+    sa, sb = reg.site(a, "x"), reg.site(a, "dy")
+    assert reg.site(a, "x") is sa and sa is not sb and not sa.ready and not reg.all_ready()
+    reg.update()
+    assert sa.ready and sb.ready and reg.all_ready()
+    slots_a = sorted(a._cinema_q8_slots)  # noqa: SLF001
+    del a, sa, sb
+    gc.collect()
+    assert not reg.live and sorted(reg.free) == slots_a
+    b = torch.nn.Parameter(torch.zeros(4))  # may or may not re-use the id: either way its sites start uncalibrated, in the recycled slots
+    s1 = reg.site(b, "x")
+    assert not s1.ready and reg.n_alloc == 2 and len(reg.live) == 1 and float(s1.scale) == 1.0
+    reg.update()
+    assert s1.ready
+    keep = [torch.nn.Parameter(torch.zeros(1)) for _ in range(40)]
+    for _ in range(30):  # 30 generations x 40 parameters x 2 sites = 2400 sites through 1024 slots
+        gen = [torch.nn.Parameter(torch.zeros(1)) for _ in range(40)]
+        for q in gen:
+            reg.site(q, "x"), reg.site(q, "dy")
+        del gen, q
+        gc.collect()
+    assert reg.n_alloc <= 2 + 80 and len(reg.live) == 1 and keep
