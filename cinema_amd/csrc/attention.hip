@@ -24,6 +24,13 @@ struct AttnP {
   float c2;      // scale * log2(e)
 };
 
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+// Drain every outstanding vector-memory operation of the wave (the LDS-DMA pieces of a tile and ordinary loads alike).  Issued through the BUILTIN, not inline asm:
+// hipcc's wait-count pass then KNOWS that nothing is pending behind this point.  With an asm wait it did not, and in every loop that keeps global loads in
+// registers across iterations (Q / dO / K / V row fragments) it guarded their first use in each iteration with s_waitcnt vmcnt(3..0) - which, the counter being
+// in order, waited for the LDS-DMA of the NEXT tile issued a few instructions earlier: the double buffering of every attention kernel was serialised behind a
+// global round trip per tile (round 5 finding, from the ISA of the new one-pass kernel: 2.3 us per tile).  simm16 = vmcnt 0, expcnt 7, lgkmcnt 15.
+#define WAIT_VM0() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
 constexpr float NEG_INF = -1e30f;
 __device__ __forceinline__ float bf_lo32(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   Stage::glds(smem, kbase, p.ldk, 0, p.tk, lane, wave_u);
   Stage::glds(smem + TB, vbase, p.ldv, 0, p.tk, lane, wave_u);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WAIT_VM0();
   __syncthreads();
 
   for (int kt = 0; kt < nkt; kt++) {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(vs_, 32 * u + 16 * st, 32 * dt, lane), pf, o[dt], 0, 0, 0);
         if constexpr (SUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);  // row sums of the same bf16 probabilities
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed
+    WAIT_VM0();  // the next tile's DMA has landed
     __syncthreads();
   }
   const float l_tot = SUM_MFMA ? lacc[0] : l_run + __shfl_xor(l_run, 32, 64);  // (the MFMA reduces over all 16 k-slots: both lane halves hold the full sum)
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   Stage::glds(smem, kbase, p.ldk, 0, p.tk, lane, wave_u);
   Stage::glds(smem + TB, vbase, p.ldv, 0, p.tk, lane, wave_u);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WAIT_VM0();
   __syncthreads();
   for (int kt = 0; kt < nkt; kt++) {
     const char* ks_ = smem + (kt & 1) * 2 * TB;
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ks_, 32 * u + 16 * st, 32 * dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed
+    WAIT_VM0();  // the next tile's DMA has landed
     __syncthreads();
   }
   if (qrow < p.tq) {
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
   Stage::glds(smem + TB, dobase, p.lddo, 0, p.tq, lane, wave_u);
   load_stats(0);
   store_stats(smem);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WAIT_VM0();
   __syncthreads();
   for (int qt = 0; qt < nqt; qt++) {
     const char* qs_ = smem + (qt & 1) * ST;
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
       }
     }
     if (more) store_stats(smem + ((qt + 1) & 1) * ST);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_VM0();
     __syncthreads();
   }
   if (krow < p.tk) {
@@ -499,6 +506,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
 // block dS goes through 2 KiB of wave-private LDS (four ds_write_b64 per lane, [key][query] rows) and comes back query-in-the-lane through
 // ds_read_b64_tr_b16, the same transpose read that feeds K^T.  The waves' partial dQ^T tiles (fp32) are summed through LDS in a fixed order
 // (deterministic, no atomics) and written once.  delta = rowsum(dO * O) is computed per query tile from the rows themselves.
+// Row statistics of a 64-query tile (lse and delta = rowsum(dO * O)) for the one-pass backward kernels: thread t < 64 * HD / 8 holds one 16-byte chunk of O and
+// of dO of query q0 + t / (HD / 8) and the query's lse.  load() is called at the TOP of an iteration on a fresh object and store() at its END, so that the global
+// loads fly under the tile's matrix work.  (Round 3-5 history: the first form had two waves load whole rows and sum them at once - a global round trip in front
+// of their share of the tile; a form with the loaded registers carried around the loop made hipcc copy them into the loop-carried registers right behind the
+// loads, i.e. wait for them at the top of every iteration: 2.3 us per tile, measured.)
+template <int HD>
+struct TileStats {
+  static constexpr int CPR = HD / 8;
+  uint4 o, d;
+  float lse;
+  __device__ __forceinline__ void load(const bf16_t* obase, int ldo, const bf16_t* dobase, int lddo, const float* lsebase, int q0, int tq, int tid) {
+    if (tid < 64 * CPR) {
+      const int qc = min(q0 + tid / CPR, tq - 1), c = tid % CPR;
+      o = *reinterpret_cast<const uint4*>(obase + (size_t)qc * ldo + c * 8);
+      d = *reinterpret_cast<const uint4*>(dobase + (size_t)qc * lddo + c * 8);
+      lse = lsebase[qc];
+    }
+  }
+  __device__ __forceinline__ void store(char* stats_base, int q0, int tq, int tid) const {
+    if (tid < 64 * CPR) {
+      float s = bf_lo32(o.x) * bf_lo32(d.x) + bf_hi32(o.x) * bf_hi32(d.x) + bf_lo32(o.y) * bf_lo32(d.y) + bf_hi32(o.y) * bf_hi32(d.y) +
+                bf_lo32(o.z) * bf_lo32(d.z) + bf_hi32(o.z) * bf_hi32(d.z) + bf_lo32(o.w) * bf_lo32(d.w) + bf_hi32(o.w) * bf_hi32(d.w);
+#pragma unroll
+      for (int m = 1; m < CPR; m <<= 1) s += __shfl_xor(s, m, 64);
+      if (tid % CPR == 0) {
+        float* st = reinterpret_cast<float*>(stats_base);
+        st[tid / CPR] = q0 + tid / CPR < tq ? lse : 1e30f;  // lse = +big -> P = 0 for padded queries (their delta, a repeat of the last row's, is never used)
+        st[64 + tid / CPR] = s;
+      }
+    }
+  }
+};
+
 constexpr int FUSED_MAXKB = 3;
 template <int HD>
 struct FusedGeom {
@@ -553,48 +593,28 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
   for (int kb = 0; kb < FUSED_MAXKB; kb++) { zero16(dk[kb]); zero16(dv[kb]); }
 
   const int nqt = (p.tq + 63) / 64;
-  float st_l = 0.f;  // threads 0..63: lse, 64..127: delta of the next tile's queries
-  auto load_stats = [&](int q0) {
-    if (tid < 64) {
-      const int qi = q0 + tid;
-      st_l = qi < p.tq ? lsebase[qi] : 1e30f;  // lse = +big -> P = 0 for padded queries
-    } else if (tid < 128) {
-      const int qi = q0 + tid - 64;
-      float s = 0.f;
-      if (qi < p.tq) {
-        const uint4* op = reinterpret_cast<const uint4*>(obase + (size_t)qi * p.ldo);
-        const uint4* dp = reinterpret_cast<const uint4*>(dobase + (size_t)qi * p.lddo);
-#pragma unroll
-        for (int c = 0; c < HD / 8; c++) {
-          const uint4 a = op[c], d = dp[c];
-          s += bf_lo32(a.x) * bf_lo32(d.x) + bf_hi32(a.x) * bf_hi32(d.x) + bf_lo32(a.y) * bf_lo32(d.y) + bf_hi32(a.y) * bf_hi32(d.y) +
-               bf_lo32(a.z) * bf_lo32(d.z) + bf_hi32(a.z) * bf_hi32(d.z) + bf_lo32(a.w) * bf_lo32(d.w) + bf_hi32(a.w) * bf_hi32(d.w);
-        }
-      }
-      st_l = s;
-    }
-  };
-  auto store_stats = [&](char* base) {
-    if (tid < 128) reinterpret_cast<float*>(base + 2 * G::TB)[tid] = st_l;
-  };
   auto load_tiles = [&](char* base, int q0) {  // waves 0-3: the four pieces of the Q tile, waves 4-7: of the dO tile
     if (wave_u < 4) Stage::glds(base, qbase, p.ldq, q0, p.tq, lane, wave_u);
     else Stage::glds(base + G::TB, dobase, p.lddo, q0, p.tq, lane, wave_u - 4);
   };
   load_tiles(stage0, 0);
-  load_stats(0);
-  store_stats(stage0);
+  {
+    TileStats<HD> ts;
+    ts.load(obase, p.ldo, dobase, p.lddo, lsebase, 0, p.tq, tid);
+    ts.store(stage0 + 2 * G::TB, 0, p.tq, tid);
+  }
 
   for (int qt = 0; qt < nqt; qt++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_VM0();
     __syncthreads();  // tile qt (and, first time, K) landed; everyone is done with the other stage and with `red`
     const char* qs_ = stage0 + (qt & 1) * G::ST;
     const char* dos_ = qs_ + G::TB;
     const float* stats = reinterpret_cast<const float*>(qs_ + 2 * G::TB);
     const bool more = qt + 1 < nqt;
-    if (more) {
+    TileStats<HD> ts;
+    if (more) {  // (the statistics loads first: hipcc waits for every outstanding load before it re-uses their registers, and the LDS-DMA below would be among them)
+      ts.load(obase, p.ldo, dobase, p.lddo, lsebase, (qt + 1) * 64, p.tq, tid);
       load_tiles(stage0 + ((qt + 1) & 1) * G::ST, (qt + 1) * 64);
-      load_stats((qt + 1) * 64);
     }
     const int nu = qt * 64 + 32 < p.tq ? 2 : 1;  // empty 32-query half of the last tile (workgroup-uniform)
 #pragma unroll
@@ -663,7 +683,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
         *reinterpret_cast<float4*>(red + ((size_t)(wave_u * 64 + q) * 8 + ((2 * c + g) ^ (q & 7))) * 4) =
             make_float4(dq[4 * c], dq[4 * c + 1], dq[4 * c + 2], dq[4 * c + 3]);
     }
-    if (more) store_stats(stage0 + ((qt + 1) & 1) * G::ST);
+    if (more) ts.store(stage0 + ((qt + 1) & 1) * G::ST + 2 * G::TB, (qt + 1) * 64, p.tq, tid);
     __syncthreads();
     {  // fixed-order sum over the 8 waves: wave w finishes queries 8w .. 8w + 7 of the tile, a lane 4 head-dim values of one query
       const int row = wave_u * 8 + (lane >> 3), chunk = lane & 7;
@@ -697,6 +717,289 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
         pk.x = pack_bf2(dv[kb][4 * j], dv[kb][4 * j + 1]);
         pk.y = pack_bf2(dv[kb][4 * j + 2], dv[kb][4 * j + 3]);
         *reinterpret_cast<uint2*>(vp + 8 * j + 4 * g) = pk;
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// backward, ONE pass for head_dim 64 and any number of keys (round 5): passes of 256 keys, dQ formed from SHARED dS tiles
+// ================================================================================================
+// The one-pass kernel above keeps 3 key blocks per wave and sums eight partial dQ tiles through LDS; at head_dim 64 a wave has registers for ONE key block
+// (dK + dV = 64 accumulators) and eight fp32 partial dQ tiles of 64 x 64 would be 128 KB.  This kernel therefore splits the work differently:
+//   * a workgroup (8 waves) owns a contiguous range of key blocks of one (batch, head) and walks it in PASSES of 256 keys (wave w <-> key block w of the pass:
+//     its K / V row fragments live in registers for the pass, dK / dV in its accumulators; the pass's K tile also sits in LDS for the dQ product);
+//   * per pass it walks ALL queries in tiles of 64 (Q / dO by LDS-DMA, double buffered; lse and delta = rowsum(dO * O) per tile as above); phase A, every wave:
+//     S = Q K^T, dP = dO V^T, P = exp2(S c2 - lse), dS = P (dP - delta) ONCE for its 32 keys, dV += P^T dO, dK += dS^T Q, and dS (bf16) -> a SHARED LDS
+//     tile [256 keys][64 queries] (double buffered);
+//   * phase B, one tile later (so that it overlaps phase A of the next tile: one barrier per tile): dQ^T[d][q] = sum over the pass's keys K^T[d][key] dS^T[key][q]
+//     = four 32 x 32 output blocks x 16 k-steps, both operands by transpose reads (ds_read_b64_tr_b16).  Waves 0-3 form the four blocks of the EVEN tiles, waves
+//     4-7 those of the odd tiles - every block is reduced over all 256 keys by ONE wave, so there is no cross-wave sum, no atomics, and the two waves of a SIMD
+//     alternate (the SIMD's MFMA work per tile is the same in every iteration);
+//   * dQ across passes: the block owner adds the previous passes' sum, kept in a fragment-ordered fp32 scratch (16 B per lane, fully coalesced, read back by the
+//     same lane: plain program order), and the LAST pass writes bf16 dQ.  Keys split over G workgroups per (batch, head) (few (batch, head) pairs, many keys:
+//     config 4 / 5): every workgroup publishes its sum with write-through stores, takes a ticket, and the last arriver adds the G sums in split order
+//     (deterministic) - the p256 protocol (csrc/gemm256.hip) without any waiting: whoever sees ticket G - 1 knows that all others have published.
+// P and dS are evaluated once per score (5 matmuls + 1 exponential instead of 7 + 2 of the dQ / dK-dV kernel pair).
+struct OnePassP {
+  AttnP a;
+  float* part;          // [G][b*h][ntiles][4 blocks][4][64 lanes] float4: dQ sums in fragment order (nullptr: one pass, G = 1)
+  unsigned* counters;   // [b*h] arrival tickets (zero on entry, left zero); G > 1 only
+  int G;
+  int dbg;              // CINEMA_ATTN_ONEPASS_DBG (timing ablations, results invalid): 1 no statistics reads, 2 no phase B, 4 no dK / dV products, 8 no exponentials, 16 no S / dP products
+};
+template <int HD>
+struct OnePassGeom {
+  static constexpr int RB = HD * 2;
+  static constexpr int KEYS = 256;
+  static constexpr int KS_BYTES = KEYS * RB;
+  static constexpr int TB = 64 * RB;
+  static constexpr int ST = 2 * TB + 512;       // Q | dO | lse[64] | delta[64]
+  static constexpr int DS_BYTES = KEYS * 128;   // [key][64 queries] bf16
+  static constexpr int SMEM = KS_BYTES + 2 * ST + 2 * DS_BYTES;
+  static constexpr int TILE_FLOATS = 64 * HD;   // one query tile of dQ
+};
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
+  static_assert(HD == 64, "two 32-wide head-dim blocks x two 32-query halves = the four dQ blocks of a tile");
+  using G = OnePassGeom<HD>;
+  using Stage = TileStage<HD, 64>;
+  const AttnP& p = pp.a;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks_ = smem;
+  char* stage0 = smem + G::KS_BYTES;
+  char* ds0 = stage0 + 2 * G::ST;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int l = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the G workgroups of one (batch, head) share Q / dO: neighbours on one XCD
+  const int bh = l / pp.G, sp = l - bh * pp.G;
+  const int b = bh / p.h, h = bh - b * p.h;
+  const int nkb = (p.tk + 31) / 32;
+  const int per = (nkb + pp.G - 1) / pp.G;
+  const int kb0 = sp * per, kb1 = min(nkb, kb0 + per);   // (the host picks G so that no range is empty)
+  const int npass = (kb1 - kb0 + 7) / 8;
+  const int nqt = (p.tq + 63) / 64;
+  const bf16_t* qbase = p.q + (size_t)b * p.tq * p.ldq + h * HD;
+  const bf16_t* dobase = p.d_o + (size_t)b * p.tq * p.lddo + h * HD;
+  const bf16_t* obase = p.o + (size_t)b * p.tq * p.ldo + h * HD;
+  const bf16_t* kbase = p.k + (size_t)b * p.tk * p.ldk + h * HD;
+  const bf16_t* vbase = p.v + (size_t)b * p.tk * p.ldv + h * HD;
+  const float* lsebase = p.lse + ((size_t)b * p.h + h) * p.tq;
+  float4* part4 = pp.part ? reinterpret_cast<float4*>(pp.part + ((size_t)sp * (p.b * p.h) + bh) * nqt * G::TILE_FLOATS) : nullptr;
+  const int tl = wave_u & 3, dtb = tl & 1, qh = tl >> 1;  // the dQ block this wave forms in phase B: head-dim half, query half
+
+  auto load_tiles = [&](char* base, int q0) {  // waves 0-3: the Q tile, waves 4-7: the dO tile (two 1 KiB pieces per wave)
+    if (wave_u < 4) Stage::glds(base, qbase, p.ldq, q0, p.tq, lane, wave_u);
+    else Stage::glds(base + G::TB, dobase, p.lddo, q0, p.tq, lane, wave_u - 4);
+  };
+
+  for (int ps = 0; ps < npass; ps++) {
+    const int blk0 = kb0 + 8 * ps;
+    const int blk = blk0 + wave_u;
+    const bool active = blk < kb1;                       // wave-uniform
+    const int nkk = 2 * min(8, kb1 - blk0);              // k-steps of 16 keys that phase B reduces over (only rows of active key blocks are ever read)
+    const bool has_prev = ps > 0, last_pass = ps == npass - 1;
+    const bool final_out = last_pass && pp.G == 1;
+    __syncthreads();  // everybody is done with the previous pass's K tile, dS tiles and stages
+    {  // K rows of the pass -> LDS: 32 pieces of 8 rows, swizzle on the source chunk
+      const uint32_t a0 = __builtin_amdgcn_readfirstlane(lds_address(ks_));
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int piece = wave_u + 8 * i;
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int rr = min(blk0 * 32 + row, p.tk - 1);
+        glds16(__builtin_amdgcn_readfirstlane(a0 + piece * 1024), kbase + (size_t)rr * p.ldk + c * 8);
+      }
+    }
+    short8v vf[HD / 16];
+    load_row_frags<HD>(vf, vbase + (size_t)min(blk * 32 + (lane & 31), p.tk - 1) * p.ldv, lane);
+    const char* kt_ = ks_ + wave_u * 32 * G::RB;  // this wave's 32 key rows of the pass's K tile
+    float16v dk[HD / 32], dv[HD / 32];
+#pragma unroll
+    for (int i = 0; i < HD / 32; i++) { zero16(dk[i]); zero16(dv[i]); }
+    load_tiles(stage0, 0);
+    {
+      TileStats<HD> ts;
+      ts.load(obase, p.ldo, dobase, p.lddo, lsebase, 0, p.tq, tid);
+      ts.store(stage0 + 2 * G::TB, 0, p.tq, tid);
+    }
+
+    for (int it = 0; it <= nqt; it++) {
+      WAIT_VM0();
+      __syncthreads();  // tile `it` (first time: K) landed; dS tile it - 1 is complete; everyone is done with the other stage and with dS tile it - 2
+      const bool more = it + 1 < nqt;
+      TileStats<HD> ts;
+      if (more) {  // (the statistics loads first: hipcc waits for every outstanding load before it re-uses their registers, and the LDS-DMA below would be among them)
+        ts.load(obase, p.ldo, dobase, p.lddo, lsebase, (it + 1) * 64, p.tq, tid);
+        load_tiles(stage0 + ((it + 1) & 1) * G::ST, (it + 1) * 64);
+      }
+      const int tb = it - 1;  // the tile whose dQ is formed in this iteration
+      const bool do_b = tb >= 0 && (tb & 1) == (wave_u >> 2) && tb * 64 + 32 * qh < p.tq;  // wave-uniform
+      if (it < nqt && active) {
+        const char* qs_ = stage0 + (it & 1) * G::ST;
+        const char* dos_ = qs_ + G::TB;
+        const float* stats = reinterpret_cast<const float*>(qs_ + 2 * G::TB);
+        char* dsw = ds0 + (it & 1) * G::DS_BYTES + wave_u * 4096;  // this wave's 32 key rows of the shared dS tile
+        const int nu = it * 64 + 32 < p.tq ? 2 : 1;  // empty 32-query half of the last tile (workgroup-uniform)
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          if (u < nu) {
+            float16v s, dp;
+            zero16(s); zero16(dp);
+            if (!(pp.dbg & 16)) {
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ks++) {
+              s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(qs_, 32 * u, ks, lane), frag_km<HD>(kt_, 0, ks, lane), s, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(dos_, 32 * u, ks, lane), vf[ks], dp, 0, 0, 0);
+            }
+            }
+            // acc reg r <-> query 32u + (r&3) + 8*(r>>2) + 4g of the tile; column = this lane's key
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              float4 l4 = make_float4(1.f, 1.f, 1.f, 1.f), d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (!(pp.dbg & 1)) {
+                l4 = *reinterpret_cast<const float4*>(stats + 32 * u + 8 * j + 4 * g);
+                d4 = *reinterpret_cast<const float4*>(stats + 64 + 32 * u + 8 * j + 4 * g);
+              }
+              const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                if (pp.dbg & 128) continue;
+                const float pr = (pp.dbg & 8) ? fmaf(s[4 * j + i], p.c2, -lv[i]) : fast_exp2(fmaf(s[4 * j + i], p.c2, -lv[i]));
+                s[4 * j + i] = pr;
+                dp[4 * j + i] = pr * (dp[4 * j + i] - dl[i]);
+              }
+            }
+            if (blk * 32 + 32 > p.tk) {  // ragged last key block (wave-uniform): keys past the end contribute nothing
+              const bool key_ok = blk * 32 + (lane & 31) < p.tk;
+#pragma unroll
+              for (int r = 0; r < 16; r++) { s[r] = key_ok ? s[r] : 0.f; dp[r] = key_ok ? dp[r] : 0.f; }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+              const short8v pf = pack_slots(s, st);
+              union { short8v v; uint32_t u32[4]; } dsf;
+              dsf.v = pack_slots(dp, st);
+              if (!(pp.dbg & 4)) {
+#pragma unroll
+              for (int dt = 0; dt < HD / 32; dt++) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(dos_, 32 * u + 16 * st, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(qs_, 32 * u + 16 * st, 32 * dt, lane), dsf.v, dk[dt], 0, 0, 0);
+              }
+              } else { dv[0][0] += __builtin_bit_cast(float, (int)pf[0]); dk[0][0] += __builtin_bit_cast(float, (int)dsf.u32[1]); }
+              // dS -> [key][query] rows of the shared tile: this lane's key, queries 32u + 16st + 4g .. + 3 and + 8 (16-byte chunks 4u + 2st, + 1)
+              const int j = lane & 31;
+              *reinterpret_cast<uint2*>(dsw + swz_off<128>(j, 4 * u + 2 * st) + 8 * g) = make_uint2(dsf.u32[0], dsf.u32[1]);
+              *reinterpret_cast<uint2*>(dsw + swz_off<128>(j, 4 * u + 2 * st + 1) + 8 * g) = make_uint2(dsf.u32[2], dsf.u32[3]);
+            }
+          }
+        }
+      }
+      if (do_b) {
+        // dQ^T[d][q] (d = 32 dtb .. + 31 in the registers, q = 32 qh + (lane & 31)) over the pass's keys: K^T and dS^T by transpose reads
+        const char* dsr = ds0 + (tb & 1) * G::DS_BYTES;
+        float4 prev[4];  // the earlier passes' sum of this block: issued in front of the 16 matrix steps that hide most of its latency (held across phase A it spilled)
+        if (has_prev && !(pp.dbg & 32)) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) prev[c] = part4[((size_t)(tb * 4 + tl) * 4 + c) * 64 + lane];
+        }
+        float16v dq;
+        zero16(dq);
+        if (!(pp.dbg & 2)) {
+#pragma unroll 4
+        for (int kk = 0; kk < nkk; kk++)
+          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ks_, 16 * kk, 32 * dtb, lane), frag_tr<64>(dsr, 16 * kk, 32 * qh, lane), dq, 0, 0, 0);
+        }
+        if (has_prev && !(pp.dbg & 32)) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) { dq[4 * c] += prev[c].x; dq[4 * c + 1] += prev[c].y; dq[4 * c + 2] += prev[c].z; dq[4 * c + 3] += prev[c].w; }
+        }
+        if (pp.dbg & 32) {
+          if (dq[0] == 123.f) part4[lane] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        } else if (final_out) {
+          const int qg = tb * 64 + 32 * qh + (lane & 31);
+          if (qg < p.tq) {
+            bf16_t* op = p.dq + ((size_t)b * p.tq + qg) * p.lddq + h * HD + 32 * dtb;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              uint2 pk;
+              pk.x = pack_bf2(dq[4 * j] * p.scale, dq[4 * j + 1] * p.scale);
+              pk.y = pack_bf2(dq[4 * j + 2] * p.scale, dq[4 * j + 3] * p.scale);
+              *reinterpret_cast<uint2*>(op + 8 * j + 4 * g) = pk;
+            }
+          }
+        } else if (last_pass) {  // G > 1: what the last arriver reads - write-through
+          const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(part4 + (size_t)(tb * 4 + tl) * 4 * 64, 0, 4 * 64 * 16, 0x00020000);
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            u32x4v v = {__float_as_uint(dq[4 * c]), __float_as_uint(dq[4 * c + 1]), __float_as_uint(dq[4 * c + 2]), __float_as_uint(dq[4 * c + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (c * 64 + lane) * 16, 0, 16 /* sc1 */);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; c++) part4[((size_t)(tb * 4 + tl) * 4 + c) * 64 + lane] = make_float4(dq[4 * c], dq[4 * c + 1], dq[4 * c + 2], dq[4 * c + 3]);
+        }
+      }
+      if (more) ts.store(stage0 + ((it + 1) & 1) * G::ST + 2 * G::TB, (it + 1) * 64, p.tq, tid);
+    }
+    if (active) {
+      const int krow = blk * 32 + (lane & 31);
+      if (krow < p.tk) {
+        bf16_t* kp = p.dk + ((size_t)b * p.tk + krow) * p.lddk + h * HD;
+        bf16_t* vp = p.dv + ((size_t)b * p.tk + krow) * p.lddv + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; dt++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            uint2 pk;
+            pk.x = pack_bf2(dk[dt][4 * j] * p.scale, dk[dt][4 * j + 1] * p.scale);
+            pk.y = pack_bf2(dk[dt][4 * j + 2] * p.scale, dk[dt][4 * j + 3] * p.scale);
+            *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * j + 4 * g) = pk;
+            pk.x = pack_bf2(dv[dt][4 * j], dv[dt][4 * j + 1]);
+            pk.y = pack_bf2(dv[dt][4 * j + 2], dv[dt][4 * j + 3]);
+            *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * j + 4 * g) = pk;
+          }
+      }
+    }
+  }
+  if (pp.G > 1) {
+    // publish (the last pass's stores were write-through), take a ticket; the last arriver sums the G partial sums in split order
+    WAIT_VM0();
+    __syncthreads();
+    volatile unsigned* ctl = reinterpret_cast<volatile unsigned*>(smem);
+    if (tid == 0) ctl[0] = __hip_atomic_fetch_add(pp.counters + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ctl[0] != (unsigned)(pp.G - 1)) return;
+    if (tid == 0) {
+      __hip_atomic_store(pp.counters + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // left zero for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const size_t split_stride = (size_t)(p.b * p.h) * nqt * (G::TILE_FLOATS / 4);  // float4s between the sums of two splits
+    const float4* base4 = reinterpret_cast<const float4*>(pp.part) + (size_t)bh * nqt * (G::TILE_FLOATS / 4);
+    for (int t = wave_u >> 2; t < nqt; t += 2) {
+      const int qg = t * 64 + 32 * qh + (lane & 31);
+      if (t * 64 + 32 * qh >= p.tq) continue;  // (wave-uniform)
+      float4 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s2 = 0; s2 < pp.G; s2++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float4 v = base4[s2 * split_stride + ((size_t)(t * 4 + tl) * 4 + c) * 64 + lane];
+          acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+        }
+      }
+      if (qg < p.tq) {
+        bf16_t* op = p.dq + ((size_t)b * p.tq + qg) * p.lddq + h * HD + 32 * dtb;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          uint2 pk;
+          pk.x = pack_bf2(acc[j].x * p.scale, acc[j].y * p.scale);
+          pk.y = pack_bf2(acc[j].z * p.scale, acc[j].w * p.scale);
+          *reinterpret_cast<uint2*>(op + 8 * j + 4 * g) = pk;
+        }
       }
     }
   }
@@ -871,10 +1174,44 @@ CINEMA_API int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* 
   return launch_status();
 }
 
-CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
-                                    int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
-                                    uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
-                                    int force_generic, void* stream) {
+// ---- one-pass backward for head_dim 64 (attn_bwd_onepass_mfma): how the keys of a (batch, head) are dealt to workgroups
+struct OnePassPlan { int G; int npass; long long part_floats; };
+static int onepass_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+static OnePassPlan onepass_plan(int b, int h, int tq, int tk) {
+  // one workgroup per compute unit (132 KB of LDS): with fewer (batch, head) pairs than units the keys of a pair are split over G workgroups - never below one
+  // full pass of 8 key blocks per workgroup, and so that no workgroup's range is empty
+  const int nkb = (tk + 31) / 32, bh = b * h;
+  int g = onepass_cu_count() / bh;
+  if (g < 1) g = 1;
+  const char* force = getenv("CINEMA_ATTN_ONEPASS_G");
+  if (force && atoi(force) > 0) g = atoi(force);
+  const int max_g = (nkb + 7) / 8;
+  if (g > max_g) g = max_g;
+  while (g > 1 && (g - 1) * ((nkb + g - 1) / g) >= nkb) g--;
+  OnePassPlan pl;
+  pl.G = g;
+  pl.npass = ((nkb + g - 1) / g + 7) / 8;
+  pl.part_floats = (g > 1 || pl.npass > 1) ? (long long)g * bh * ((tq + 63) / 64) * OnePassGeom<64>::TILE_FLOATS : 0;
+  return pl;
+}
+
+CINEMA_API long long cinema_attention_bwd_workspace_bytes(int b, int h, int tq, int tk, int hd) {
+  if (b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || hd != 64) return 0;
+  return onepass_plan(b, h, tq, tk).part_floats * 4;
+}
+
+static int attention_bwd_impl(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+                              int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
+                              uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
+                              int force_generic, float* workspace, long long workspace_bytes, unsigned* counters, int n_counters, void* stream) {
   if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || hd <= 0 || hd > 128)
     return CINEMA_ERR_BAD_ARG;
   AttnP p{};
@@ -905,6 +1242,27 @@ CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* 
       CINEMA_LAUNCH(attn_bwd_fused_mfma<32>, dim3((unsigned)(b * h)), dim3(512), (size_t)FusedGeom<32>::SMEM, st, p);
       return launch_status();
     }
+    // one-pass backward for head_dim 64 (any number of keys): needs its scratch when the keys take several passes or are split over workgroups.
+    // OFF by default (CINEMA_ATTN_ONEPASS=1 selects it): parity-green and deterministic, but measured SLOWER than the dQ + dK/dV pair at every shape of the
+    // BASELINE configs (profiles/r05_e_attn_waitcnt.txt: config 2 encoder 194 vs 131 us, config 4 775 vs 473, config 5 encoder 527 vs 352) - at one key block
+    // per wave the Q / dO tiles are re-read from LDS by all eight waves for 32 keys each, and the eight waves of the one resident workgroup run their
+    // matrix / exponential / LDS phases in lockstep
+    const char* op_txt = getenv("CINEMA_ATTN_ONEPASS");
+    if (fused_env && (op_txt ? atoi(op_txt) : 0) && hd == 64 && !(ldo & 7)) {
+      const OnePassPlan pl = onepass_plan(b, h, tq, tk);
+      const bool ws_ok = pl.part_floats == 0 || (workspace && workspace_bytes >= pl.part_floats * 4 && !(((uintptr_t)workspace) & 15));
+      const bool cnt_ok = pl.G == 1 || (counters && n_counters >= b * h);
+      if (ws_ok && cnt_ok) {
+        static bool attr_set64[16] = {};
+        const hipError_t e = dyn_lds_attr_once(attr_set64, reinterpret_cast<const void*>(attn_bwd_onepass_mfma<64>), OnePassGeom<64>::SMEM);
+        if (e != hipSuccess) return (int)e;
+        OnePassP pp{};
+        pp.a = p; pp.part = pl.part_floats ? workspace : nullptr; pp.counters = counters; pp.G = pl.G;
+        pp.dbg = getenv("CINEMA_ATTN_ONEPASS_DBG") ? atoi(getenv("CINEMA_ATTN_ONEPASS_DBG")) : 0;
+        CINEMA_LAUNCH(attn_bwd_onepass_mfma<64>, dim3((unsigned)(b * h * pl.G)), dim3(512), (size_t)OnePassGeom<64>::SMEM, st, pp);
+        return launch_status();
+      }
+    }
     dim3 gq((tq + 127) / 128, h, b), gk((tk + 127) / 128, h, b);
     if (hd == 64) {
       CINEMA_LAUNCH(attn_bwd_dq_mfma<64>, gq, dim3(256), 0, st, p);
@@ -920,4 +1278,20 @@ CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* 
   const long long nk = (long long)b * h * tk;
   CINEMA_LAUNCH(attn_bwd_kv_generic, dim3((unsigned)((nk + 3) / 4)), dim3(256), (size_t)8 * tq * sizeof(float), st, p);
   return launch_status();
+}
+
+CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+                                    int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
+                                    uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
+                                    int force_generic, void* stream) {
+  return attention_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, b, h, tq, tk, hd, scale, force_generic,
+                            nullptr, 0, nullptr, 0, stream);
+}
+
+CINEMA_API int cinema_attention_bwd_ws(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+                                       int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
+                                       uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
+                                       int force_generic, float* workspace, long long workspace_bytes, unsigned* counters, int n_counters, void* stream) {
+  return attention_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, b, h, tq, tk, hd, scale, force_generic,
+                            workspace, workspace_bytes, counters, n_counters, stream);
 }

@@ -155,6 +155,8 @@ _PROTOS = {
     "cinema_row_copy_multi": [_vp, _i, _vp],
     "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "cinema_attention_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
+    "cinema_attention_bwd_ws": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _i, _vp],
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_data": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -1380,10 +1382,31 @@ def attention_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Te
     tk, hd = k.shape[1], cdim // heads
     ptrs = [_attn_view(t, heads, hd, n) for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv"))]
     delta = _empty((b, heads, tq), dtype=torch.float32, device=q.device)
-    _check(load().cinema_attention_bwd(ptrs[0][0], ptrs[0][1], ptrs[1][0], ptrs[1][1], ptrs[2][0], ptrs[2][1], ptrs[3][0], ptrs[3][1],
-                                       ptrs[4][0], ptrs[4][1], lse.data_ptr(), delta.data_ptr(), ptrs[5][0], ptrs[5][1], ptrs[6][0], ptrs[6][1],
-                                       ptrs[7][0], ptrs[7][1], b, heads, tq, tk, hd, scale, int(force_generic or FORCE_GENERIC), _stream()),
+    # scratch of the one-pass backward at head_dim 64 (csrc/attention.hip attn_bwd_onepass_mfma): running dQ sums across the passes over the keys / the sums of
+    # the workgroups that share a (batch, head) pair, and their arrival tickets (zero at allocation, left zero by every launch)
+    ws_bytes = load().cinema_attention_bwd_workspace_bytes(b, heads, tq, tk, hd)
+    ws = _workspace("attn_bwd", ws_bytes // 4, q.device) if ws_bytes > 0 else None
+    cnt = _attn_counters(q.device) if (hd == 64 and b * heads <= ATTN_COUNTERS) else None
+    _check(load().cinema_attention_bwd_ws(ptrs[0][0], ptrs[0][1], ptrs[1][0], ptrs[1][1], ptrs[2][0], ptrs[2][1], ptrs[3][0], ptrs[3][1],
+                                          ptrs[4][0], ptrs[4][1], lse.data_ptr(), delta.data_ptr(), ptrs[5][0], ptrs[5][1], ptrs[6][0], ptrs[6][1],
+                                          ptrs[7][0], ptrs[7][1], b, heads, tq, tk, hd, scale, int(force_generic or FORCE_GENERIC),
+                                          None if ws is None else ws.data_ptr(), ws_bytes if ws is not None else 0,
+                                          None if cnt is None else cnt.data_ptr(), 0 if cnt is None else cnt.numel(), _stream()),
            "attention_bwd")
+
+
+ATTN_COUNTERS = 16384
+_ATTN_COUNTERS: dict = {}
+
+
+def _attn_counters(device: torch.device) -> torch.Tensor:
+    """Arrival tickets of the key-split one-pass attention backward, one buffer per (device, stream, lane): zero at allocation, left zero by every launch,
+    never handed back to the allocator (``persistent``)."""
+    key = (device.index, _stream(), LANE)
+    t = _ATTN_COUNTERS.get(key)
+    if t is None:
+        t = _ATTN_COUNTERS[key] = persistent(lambda: torch.zeros(ATTN_COUNTERS, dtype=torch.int32, device=device))
+    return t
 
 
 # --------------------------------------------------------------------------------------------------------

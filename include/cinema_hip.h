@@ -236,6 +236,15 @@ int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk,
                          int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
                          uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
                          int force_generic, void* stream);
+/* The same with scratch for the ONE-PASS backward at head_dim 64 (P and dS evaluated once per score; passes of 256 keys per workgroup, the keys of a
+ * (batch, head) split over several workgroups when there are fewer pairs than compute units): workspace >= cinema_attention_bwd_workspace_bytes(...) bytes
+ * (16-byte aligned, contents irrelevant), counters = b*h zero-initialised words that every launch leaves zero.  Without sufficient scratch the call falls back
+ * to the dQ + dK/dV kernel pair of cinema_attention_bwd (same results up to summation order).  Reference: cinema/vit.py:505-517 (backward of SDPA). */
+long long cinema_attention_bwd_workspace_bytes(int b, int h, int tq, int tk, int hd);
+int cinema_attention_bwd_ws(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+                            int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
+                            uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
+                            int force_generic, float* workspace, long long workspace_bytes, unsigned* counters, int n_counters, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Depthwise 5^n convolution, channels-last (reference: MaskedConvBlock.dw_conv, kernel 5 in every axis, "same"

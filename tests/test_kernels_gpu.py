@@ -430,12 +430,20 @@ def test_attention_forward_lazy_rescale_branch(hd: int, monkeypatch: pytest.Monk
     assert float((outs["1"][0] - outs["0"][0]).abs().max()) <= 2e-2 and float((outs["1"][1] - outs["0"][1]).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize(("heads", "tq", "tk"), [(16, 2053, 684), (4, 70, 33), (2, 130, 768), (3, 64, 97)])
-def test_attention_backward_one_pass_equals_two_kernel_form(heads: int, tq: int, tk: int, monkeypatch) -> None:  # noqa: ANN001
-    """attn_bwd_fused_mfma<32> (one workgroup per (batch, head), P and dS computed once, dQ through the in-LDS transpose of dS and a fixed-order
-    cross-wave sum) against fp32 autograd (2 % of the tensor scale: bf16 P / dS and outputs) and against the two-kernel form (same arithmetic up to
-    the summation order of dQ and the bf16 rounding points: 1 % of the tensor scale), ragged key / query tails included; run twice (determinism)."""
-    b, hd = 2, 32
+@pytest.mark.parametrize(("hd", "heads", "tq", "tk", "force_g"), [
+    (32, 16, 2053, 684, 0), (32, 4, 70, 33, 0), (32, 2, 130, 768, 0), (32, 3, 64, 97, 0),
+    # head_dim 64 (attn_bwd_onepass_mfma): the encoder of config 2 per (batch, head) - one workgroup, three passes over the keys - and split over three workgroups;
+    # 1728 keys (config 5's key count) over seven workgroups; 3073 tokens (config 4) over thirteen workgroups of one pass and over two workgroups of seven passes;
+    # single-pass shapes without scratch
+    (64, 12, 685, 685, 1), (64, 12, 685, 685, 0), (64, 4, 300, 1728, 0), (64, 2, 3073, 3073, 0), (64, 2, 3073, 3073, 2), (64, 3, 70, 33, 0), (64, 2, 130, 256, 0),
+    (64, 2, 97, 1537, 3)])
+def test_attention_backward_one_pass_equals_two_kernel_form(hd: int, heads: int, tq: int, tk: int, force_g: int, monkeypatch) -> None:  # noqa: ANN001
+    """The one-pass attention backward kernels - attn_bwd_fused_mfma<32> (one workgroup per (batch, head), <= 768 keys, dQ through the in-LDS transpose of dS and a
+    fixed-order cross-wave sum) and attn_bwd_onepass_mfma<64> (passes of 256 keys, dQ from shared dS tiles, running sums across passes, the keys of a (batch, head)
+    split over G workgroups with a last-arriver sum in split order) - against fp32 autograd (2 % of the tensor scale: bf16 P / dS and outputs) and against the
+    two-kernel form (same arithmetic up to the summation order of dQ and the bf16 rounding points: 1 % of the tensor scale), ragged key / query tails included;
+    run twice (determinism); the arrival tickets are left at zero."""
+    b = 2
     c = hd * heads
     q, kv = rnd(b, tq, c, seed=31), rnd(b, tk, 2 * c, seed=32)
     k, v = kv[..., :c], kv[..., c:]
@@ -445,6 +453,9 @@ def test_attention_backward_one_pass_equals_two_kernel_form(heads: int, tq: int,
     o, lse = K.attention_fwd(q, k, v, heads, scale)
     d_o = rnd(b, tq, c, seed=33)
     ref.backward(d_o.float())
+    monkeypatch.setenv("CINEMA_ATTN_ONEPASS", "1")  # the head_dim 64 form is an option (measured slower than the kernel pair: off by default)
+    if force_g:
+        monkeypatch.setenv("CINEMA_ATTN_ONEPASS_G", str(force_g))
     outs = {}
     for form in ("1", "0", "1"):
         monkeypatch.setenv("CINEMA_ATTN_FUSED", form)
@@ -457,6 +468,7 @@ def test_attention_backward_one_pass_equals_two_kernel_form(heads: int, tq: int,
         tol = float(want.abs().max())
         close(outs["1"][i][..., sl], want, 2e-2, 2e-2 * tol, f"one-pass {name} vs autograd")
         close(outs["1"][i][..., sl], outs["0"][i][..., sl], 0.0, 1e-2 * tol, f"one-pass {name} vs two-kernel form")
+    assert all(int(t.abs().sum()) == 0 for t in K._ATTN_COUNTERS.values())  # noqa: SLF001
 
 
 def test_attention_rescale_branch() -> None:
