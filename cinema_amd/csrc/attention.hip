@@ -524,12 +524,16 @@ struct TileStats {
       lse = lsebase[qc];
     }
   }
+  __device__ __forceinline__ float delta() const {  // rowsum(dO * O) of the thread's query: complete in every lane of the query's CPR-lane group
+    float s = bf_lo32(o.x) * bf_lo32(d.x) + bf_hi32(o.x) * bf_hi32(d.x) + bf_lo32(o.y) * bf_lo32(d.y) + bf_hi32(o.y) * bf_hi32(d.y) +
+              bf_lo32(o.z) * bf_lo32(d.z) + bf_hi32(o.z) * bf_hi32(d.z) + bf_lo32(o.w) * bf_lo32(d.w) + bf_hi32(o.w) * bf_hi32(d.w);
+#pragma unroll
+    for (int m = 1; m < CPR; m <<= 1) s += __shfl_xor(s, m, 64);
+    return s;
+  }
   __device__ __forceinline__ void store(char* stats_base, int q0, int tq, int tid) const {
     if (tid < 64 * CPR) {
-      float s = bf_lo32(o.x) * bf_lo32(d.x) + bf_hi32(o.x) * bf_hi32(d.x) + bf_lo32(o.y) * bf_lo32(d.y) + bf_hi32(o.y) * bf_hi32(d.y) +
-                bf_lo32(o.z) * bf_lo32(d.z) + bf_hi32(o.z) * bf_hi32(d.z) + bf_lo32(o.w) * bf_lo32(d.w) + bf_hi32(o.w) * bf_hi32(d.w);
-#pragma unroll
-      for (int m = 1; m < CPR; m <<= 1) s += __shfl_xor(s, m, 64);
+      const float s = delta();
       if (tid % CPR == 0) {
         float* st = reinterpret_cast<float*>(stats_base);
         st[tid / CPR] = q0 + tid / CPR < tq ? lse : 1e30f;  // lse = +big -> P = 0 for padded queries (their delta, a repeat of the last row's, is never used)
@@ -593,16 +597,37 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
   for (int kb = 0; kb < FUSED_MAXKB; kb++) { zero16(dk[kb]); zero16(dv[kb]); }
 
   const int nqt = (p.tq + 63) / 64;
+  float st_l = 0.f;  // threads 0..63: lse, 64..127: delta of the next tile's queries
+  auto load_stats = [&](int q0) {
+    if (tid < 64) {
+      const int qi = q0 + tid;
+      st_l = qi < p.tq ? lsebase[qi] : 1e30f;  // lse = +big -> P = 0 for padded queries
+    } else if (tid < 128) {
+      const int qi = q0 + tid - 64;
+      float s = 0.f;
+      if (qi < p.tq) {
+        const uint4* op = reinterpret_cast<const uint4*>(obase + (size_t)qi * p.ldo);
+        const uint4* dp = reinterpret_cast<const uint4*>(dobase + (size_t)qi * p.lddo);
+#pragma unroll
+        for (int c = 0; c < HD / 8; c++) {
+          const uint4 a = op[c], d = dp[c];
+          s += bf_lo32(a.x) * bf_lo32(d.x) + bf_hi32(a.x) * bf_hi32(d.x) + bf_lo32(a.y) * bf_lo32(d.y) + bf_hi32(a.y) * bf_hi32(d.y) +
+               bf_lo32(a.z) * bf_lo32(d.z) + bf_hi32(a.z) * bf_hi32(d.z) + bf_lo32(a.w) * bf_lo32(d.w) + bf_hi32(a.w) * bf_hi32(d.w);
+        }
+      }
+      st_l = s;
+    }
+  };
+  auto store_stats = [&](char* base) {
+    if (tid < 128) reinterpret_cast<float*>(base + 2 * G::TB)[tid] = st_l;
+  };
   auto load_tiles = [&](char* base, int q0) {  // waves 0-3: the four pieces of the Q tile, waves 4-7: of the dO tile
     if (wave_u < 4) Stage::glds(base, qbase, p.ldq, q0, p.tq, lane, wave_u);
     else Stage::glds(base + G::TB, dobase, p.lddo, q0, p.tq, lane, wave_u - 4);
   };
   load_tiles(stage0, 0);
-  {
-    TileStats<HD> ts;
-    ts.load(obase, p.ldo, dobase, p.lddo, lsebase, 0, p.tq, tid);
-    ts.store(stage0 + 2 * G::TB, 0, p.tq, tid);
-  }
+  load_stats(0);
+  store_stats(stage0);
 
   for (int qt = 0; qt < nqt; qt++) {
     WAIT_VM0();
@@ -611,10 +636,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
     const char* dos_ = qs_ + G::TB;
     const float* stats = reinterpret_cast<const float*>(qs_ + 2 * G::TB);
     const bool more = qt + 1 < nqt;
-    TileStats<HD> ts;
-    if (more) {  // (the statistics loads first: hipcc waits for every outstanding load before it re-uses their registers, and the LDS-DMA below would be among them)
-      ts.load(obase, p.ldo, dobase, p.lddo, lsebase, (qt + 1) * 64, p.tq, tid);
+    if (more) {
       load_tiles(stage0 + ((qt + 1) & 1) * G::ST, (qt + 1) * 64);
+      load_stats((qt + 1) * 64);
     }
     const int nu = qt * 64 + 32 < p.tq ? 2 : 1;  // empty 32-query half of the last tile (workgroup-uniform)
 #pragma unroll
@@ -683,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
         *reinterpret_cast<float4*>(red + ((size_t)(wave_u * 64 + q) * 8 + ((2 * c + g) ^ (q & 7))) * 4) =
             make_float4(dq[4 * c], dq[4 * c + 1], dq[4 * c + 2], dq[4 * c + 3]);
     }
-    if (more) ts.store(stage0 + ((qt + 1) & 1) * G::ST + 2 * G::TB, (qt + 1) * 64, p.tq, tid);
+    if (more) store_stats(stage0 + ((qt + 1) & 1) * G::ST);
     __syncthreads();
     {  // fixed-order sum over the 8 waves: wave w finishes queries 8w .. 8w + 7 of the tile, a lane 4 head-dim values of one query
       const int row = wave_u * 8 + (lane >> 3), chunk = lane & 7;
@@ -746,7 +770,6 @@ struct OnePassP {
   float* part;          // [G][b*h][ntiles][4 blocks][4][64 lanes] float4: dQ sums in fragment order (nullptr: one pass, G = 1)
   unsigned* counters;   // [b*h] arrival tickets (zero on entry, left zero); G > 1 only
   int G;
-  int dbg;              // CINEMA_ATTN_ONEPASS_DBG (timing ablations, results invalid): 1 no statistics reads, 2 no phase B, 4 no dK / dV products, 8 no exponentials, 16 no S / dP products
 };
 template <int HD>
 struct OnePassGeom {
@@ -788,6 +811,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
   float4* part4 = pp.part ? reinterpret_cast<float4*>(pp.part + ((size_t)sp * (p.b * p.h) + bh) * nqt * G::TILE_FLOATS) : nullptr;
   const int tl = wave_u & 3, dtb = tl & 1, qh = tl >> 1;  // the dQ block this wave forms in phase B: head-dim half, query half
 
+  // delta = rowsum(dO * O) of every query of this (batch, head), once per workgroup, into p.delta (the workgroups that share the pair write the same values):
+  // all 512 threads, 16 bytes of O and dO each per 64 queries.  The tile loop then needs two scalars per query (lse, delta), loaded by waves 0 / 1 at the top of
+  // an iteration and put into the next stage's statistics at its end.
+  float* dlbase = p.delta + ((size_t)b * p.h + h) * p.tq;
+  for (int q0 = 0; q0 < p.tq; q0 += 64) {
+    TileStats<HD> ts;
+    ts.load(obase, p.ldo, dobase, p.lddo, lsebase, q0, p.tq, tid);
+    const float dl = ts.delta();
+    const int qi = q0 + (tid >> 3);
+    if ((tid & 7) == 0 && qi < p.tq) dlbase[qi] = dl;
+  }
+  WAIT_VM0();  // (the first pass's opening barrier makes the values visible to waves 0 and 1)
+  const float* stat_src = tid < 64 ? lsebase : dlbase;   // threads 0-63 fetch lse, 64-127 delta: one pointer and one value register per thread
+  const float stat_pad = tid < 64 ? 1e30f : 0.f;         // lse = +big -> P = 0 for padded queries
   auto load_tiles = [&](char* base, int q0) {  // waves 0-3: the Q tile, waves 4-7: the dO tile (two 1 KiB pieces per wave)
     if (wave_u < 4) Stage::glds(base, qbase, p.ldq, q0, p.tq, lane, wave_u);
     else Stage::glds(base + G::TB, dobase, p.lddo, q0, p.tq, lane, wave_u - 4);
@@ -819,19 +856,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
 #pragma unroll
     for (int i = 0; i < HD / 32; i++) { zero16(dk[i]); zero16(dv[i]); }
     load_tiles(stage0, 0);
-    {
-      TileStats<HD> ts;
-      ts.load(obase, p.ldo, dobase, p.lddo, lsebase, 0, p.tq, tid);
-      ts.store(stage0 + 2 * G::TB, 0, p.tq, tid);
-    }
+    if (tid < 128) reinterpret_cast<float*>(stage0 + 2 * G::TB)[tid] = (tid & 63) < p.tq ? stat_src[tid & 63] : stat_pad;
 
     for (int it = 0; it <= nqt; it++) {
       WAIT_VM0();
       __syncthreads();  // tile `it` (first time: K) landed; dS tile it - 1 is complete; everyone is done with the other stage and with dS tile it - 2
       const bool more = it + 1 < nqt;
-      TileStats<HD> ts;
-      if (more) {  // (the statistics loads first: hipcc waits for every outstanding load before it re-uses their registers, and the LDS-DMA below would be among them)
-        ts.load(obase, p.ldo, dobase, p.lddo, lsebase, (it + 1) * 64, p.tq, tid);
+      float nx_stat = stat_pad;  // the next tile's statistics (threads 0-63: lse, 64-127: delta); loaded before the LDS-DMA, stored at the end of the iteration
+      if (more) {
+        const int qn = (it + 1) * 64 + (tid & 63);
+        if (tid < 128 && qn < p.tq) nx_stat = stat_src[qn];
         load_tiles(stage0 + ((it + 1) & 1) * G::ST, (it + 1) * 64);
       }
       const int tb = it - 1;  // the tile whose dQ is formed in this iteration
@@ -847,26 +881,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
           if (u < nu) {
             float16v s, dp;
             zero16(s); zero16(dp);
-            if (!(pp.dbg & 16)) {
 #pragma unroll
             for (int ks = 0; ks < HD / 16; ks++) {
               s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(qs_, 32 * u, ks, lane), frag_km<HD>(kt_, 0, ks, lane), s, 0, 0, 0);
               dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(dos_, 32 * u, ks, lane), vf[ks], dp, 0, 0, 0);
             }
-            }
             // acc reg r <-> query 32u + (r&3) + 8*(r>>2) + 4g of the tile; column = this lane's key
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              float4 l4 = make_float4(1.f, 1.f, 1.f, 1.f), d4 = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (!(pp.dbg & 1)) {
-                l4 = *reinterpret_cast<const float4*>(stats + 32 * u + 8 * j + 4 * g);
-                d4 = *reinterpret_cast<const float4*>(stats + 64 + 32 * u + 8 * j + 4 * g);
-              }
+              const float4 l4 = *reinterpret_cast<const float4*>(stats + 32 * u + 8 * j + 4 * g);
+              const float4 d4 = *reinterpret_cast<const float4*>(stats + 64 + 32 * u + 8 * j + 4 * g);
               const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
               for (int i = 0; i < 4; i++) {
-                if (pp.dbg & 128) continue;
-                const float pr = (pp.dbg & 8) ? fmaf(s[4 * j + i], p.c2, -lv[i]) : fast_exp2(fmaf(s[4 * j + i], p.c2, -lv[i]));
+                const float pr = fast_exp2(fmaf(s[4 * j + i], p.c2, -lv[i]));
                 s[4 * j + i] = pr;
                 dp[4 * j + i] = pr * (dp[4 * j + i] - dl[i]);
               }
@@ -881,13 +909,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
               const short8v pf = pack_slots(s, st);
               union { short8v v; uint32_t u32[4]; } dsf;
               dsf.v = pack_slots(dp, st);
-              if (!(pp.dbg & 4)) {
 #pragma unroll
               for (int dt = 0; dt < HD / 32; dt++) {
                 dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(dos_, 32 * u + 16 * st, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
                 dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(qs_, 32 * u + 16 * st, 32 * dt, lane), dsf.v, dk[dt], 0, 0, 0);
               }
-              } else { dv[0][0] += __builtin_bit_cast(float, (int)pf[0]); dk[0][0] += __builtin_bit_cast(float, (int)dsf.u32[1]); }
               // dS -> [key][query] rows of the shared tile: this lane's key, queries 32u + 16st + 4g .. + 3 and + 8 (16-byte chunks 4u + 2st, + 1)
               const int j = lane & 31;
               *reinterpret_cast<uint2*>(dsw + swz_off<128>(j, 4 * u + 2 * st) + 8 * g) = make_uint2(dsf.u32[0], dsf.u32[1]);
@@ -900,24 +926,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
         // dQ^T[d][q] (d = 32 dtb .. + 31 in the registers, q = 32 qh + (lane & 31)) over the pass's keys: K^T and dS^T by transpose reads
         const char* dsr = ds0 + (tb & 1) * G::DS_BYTES;
         float4 prev[4];  // the earlier passes' sum of this block: issued in front of the 16 matrix steps that hide most of its latency (held across phase A it spilled)
-        if (has_prev && !(pp.dbg & 32)) {
+        if (has_prev) {
 #pragma unroll
           for (int c = 0; c < 4; c++) prev[c] = part4[((size_t)(tb * 4 + tl) * 4 + c) * 64 + lane];
         }
         float16v dq;
         zero16(dq);
-        if (!(pp.dbg & 2)) {
-#pragma unroll 4
+#pragma unroll 2
         for (int kk = 0; kk < nkk; kk++)
           dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ks_, 16 * kk, 32 * dtb, lane), frag_tr<64>(dsr, 16 * kk, 32 * qh, lane), dq, 0, 0, 0);
-        }
-        if (has_prev && !(pp.dbg & 32)) {
+        if (has_prev) {
 #pragma unroll
           for (int c = 0; c < 4; c++) { dq[4 * c] += prev[c].x; dq[4 * c + 1] += prev[c].y; dq[4 * c + 2] += prev[c].z; dq[4 * c + 3] += prev[c].w; }
         }
-        if (pp.dbg & 32) {
-          if (dq[0] == 123.f) part4[lane] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-        } else if (final_out) {
+        if (final_out) {
           const int qg = tb * 64 + 32 * qh + (lane & 31);
           if (qg < p.tq) {
             bf16_t* op = p.dq + ((size_t)b * p.tq + qg) * p.lddq + h * HD + 32 * dtb;
@@ -941,7 +963,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
           for (int c = 0; c < 4; c++) part4[((size_t)(tb * 4 + tl) * 4 + c) * 64 + lane] = make_float4(dq[4 * c], dq[4 * c + 1], dq[4 * c + 2], dq[4 * c + 3]);
         }
       }
-      if (more) ts.store(stage0 + ((it + 1) & 1) * G::ST + 2 * G::TB, (it + 1) * 64, p.tq, tid);
+      if (more && tid < 128) reinterpret_cast<float*>(stage0 + ((it + 1) & 1) * G::ST + 2 * G::TB)[tid] = nx_stat;
     }
     if (active) {
       const int krow = blk * 32 + (lane & 31);
@@ -1258,7 +1280,6 @@ static int attention_bwd_impl(const uint16_t* q, int ldq, const uint16_t* k, int
         if (e != hipSuccess) return (int)e;
         OnePassP pp{};
         pp.a = p; pp.part = pl.part_floats ? workspace : nullptr; pp.counters = counters; pp.G = pl.G;
-        pp.dbg = getenv("CINEMA_ATTN_ONEPASS_DBG") ? atoi(getenv("CINEMA_ATTN_ONEPASS_DBG")) : 0;
         CINEMA_LAUNCH(attn_bwd_onepass_mfma<64>, dim3((unsigned)(b * h * pl.G)), dim3(512), (size_t)OnePassGeom<64>::SMEM, st, pp);
         return launch_status();
       }

@@ -151,6 +151,21 @@ __device__ __forceinline__ void gelu_grad2(float a, float b, float& ga, float& g
   ga = r.x; gb = r.y;
 }
 
+// GELU'(x) of the exact (erf) GELU lies in [-0.1290, 1.1290]; the 8-bit code of the derivative tensor (GemmP::gelu_deriv == 2) is the affine map of
+// [-0.13, 1.13] onto 0..255: step 0.00494, error <= 0.00247 - the size of a bf16 rounding error at |GELU'| >= 0.5 (bf16 ulp 2^-8 there), i.e. where the
+// derivative matters; half the bytes of the bf16 tensor fc1 writes and fc2's data gradient reads back (the K = 512 / 768 GEMMs around it run on the HBM side
+// of the ridge).  Uncorrelated with the gradient it multiplies: the noise averages out in every sum downstream.
+constexpr float GELU8_LO = -0.13f, GELU8_STEP = 1.26f / 255.0f, GELU8_INV = 255.0f / 1.26f;
+__device__ __forceinline__ uint32_t gelu8_pack4(float a, float b, float c, float d) {   // v_cvt_pk_u8_f32: round to nearest, saturate, byte select
+  uint32_t r = 0;
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(a, GELU8_INV, -GELU8_LO * GELU8_INV), 0, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(b, GELU8_INV, -GELU8_LO * GELU8_INV), 1, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(c, GELU8_INV, -GELU8_LO * GELU8_INV), 2, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, GELU8_INV, -GELU8_LO * GELU8_INV), 3, r);
+  return r;
+}
+__device__ __forceinline__ float gelu8_dec(uint32_t word, int byte) { return fmaf((float)((word >> (8 * byte)) & 0xffu), GELU8_STEP, GELU8_LO); }  // (v_cvt_f32_ubyteN)
+
 // wave64 reductions (all 64 lanes participate)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -20,6 +20,7 @@ struct GemmP {
   bf16_t* aux_out; int ld_aux;
   int act, out_f32, accumulate;
   int gelu_deriv;  // 1: the auxiliary GELU tensor holds GELU'(pre-activation), not the pre-activation: act == 1 writes it to aux_out, gelu_in is multiplied in as it is
+                   // 2: the same as an 8-bit code (common.cuh gelu8_*): aux_out / gelu_in are uint8 rows, ld_aux / ld_gelu count bytes
   int ktiles_per_split;
   float* ws;  // split-K partial slabs [gridDim.z][m][n] (fp32) or nullptr
   float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m][k] (the bias gradient of a weight-gradient GEMM), fused into the MFMA loop
@@ -65,7 +66,10 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
     const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0);
     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   }
-  if (p.aux_out) {
+  if (p.aux_out && p.act == 1 && p.gelu_deriv == 2) {
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.aux_out) + (size_t)m * p.ld_aux + n0) =
+        gelu8_pack4(gelu_grad_f(v[0]), gelu_grad_f(v[1]), gelu_grad_f(v[2]), gelu_grad_f(v[3]));
+  } else if (p.aux_out) {
     const bool dv = p.act == 1 && p.gelu_deriv;  // the derivative instead of the pre-activation (see GemmP::gelu_deriv)
     uint2 pk;
     pk.x = dv ? pack_bf2(gelu_grad_f(v[0]), gelu_grad_f(v[1])) : pack_bf2(v[0], v[1]);
@@ -76,7 +80,11 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
 #pragma unroll
     for (int i = 0; i < 4; i++) v[i] = gelu_f(v[i]);
   }
-  if (p.gelu_in) {
+  if (p.gelu_in && p.gelu_deriv == 2) {
+    const uint32_t gi = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p.gelu_in) + (size_t)m * p.ld_gelu + n0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] *= gelu8_dec(gi, i);
+  } else if (p.gelu_in) {
     const uint2 gi = *reinterpret_cast<const uint2*>(p.gelu_in + (size_t)m * p.ld_gelu + n0);
     const float g0 = bf2f((bf16_t)(gi.x & 0xffff)), g1 = bf2f((bf16_t)(gi.x >> 16)), g2 = bf2f((bf16_t)(gi.y & 0xffff)), g3 = bf2f((bf16_t)(gi.y >> 16));
     v[0] *= p.gelu_deriv ? g0 : gelu_grad_f(g0); v[1] *= p.gelu_deriv ? g1 : gelu_grad_f(g1);
@@ -151,7 +159,15 @@ __device__ __forceinline__ void epi_load_bias(const GemmP& p, int n0, bool add_b
 template <int W>
 __device__ __forceinline__ void epi_load(const GemmP& p, int m, int n0, EpiPre<W>& e) {
   e.keep = 1.f;
-  if (p.gelu_in) e.g = W == 8 ? ldg128(p.gelu_in + (size_t)m * p.ld_gelu + n0) : ldg64(p.gelu_in + (size_t)m * p.ld_gelu + n0);
+  if (p.gelu_in) {
+    if (p.gelu_deriv == 2) {  // W bytes of the 8-bit derivative code
+      const uint8_t* g8 = reinterpret_cast<const uint8_t*>(p.gelu_in) + (size_t)m * p.ld_gelu + n0;
+      if (W == 8) e.g = ldg64(g8);
+      else { const uint32_t u = *reinterpret_cast<const uint32_t*>(g8); u32x4 r = {u, 0u, 0u, 0u}; e.g = r; }
+    } else {
+      e.g = W == 8 ? ldg128(p.gelu_in + (size_t)m * p.ld_gelu + n0) : ldg64(p.gelu_in + (size_t)m * p.ld_gelu + n0);
+    }
+  }
   if (p.row_mask) e.keep = p.row_mask[m] ? 1.f : 0.f;
   if (p.res_f32) {
     e.ra = ldg128(p.res_f32 + (size_t)m * p.ld_res + n0);
@@ -183,7 +199,17 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
 #pragma unroll
     for (int i = 0; i < W; i += 2) gelu_both2(v[i], v[i + 1], dv[i], dv[i + 1]);
     bf16_t* dst = p.aux_out + (size_t)m * p.ld_aux + n0;
-    if (W == 8) {
+    if (p.gelu_deriv == 2) {
+      uint8_t* d8 = reinterpret_cast<uint8_t*>(p.aux_out) + (size_t)m * p.ld_aux + n0;
+      if (W == 8) {
+        typedef uint32_t u32x2e __attribute__((ext_vector_type(2)));
+        const u32x2e pk = {gelu8_pack4(dv[0], dv[1], dv[2], dv[3]), gelu8_pack4(dv[W - 4], dv[W - 3], dv[W - 2], dv[W - 1])};
+        if (NT_STORES) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2e*>(d8));
+        else *reinterpret_cast<u32x2e*>(d8) = pk;
+      } else {
+        *reinterpret_cast<uint32_t*>(d8) = gelu8_pack4(dv[0], dv[1], dv[2], dv[3]);
+      }
+    } else if (W == 8) {
       u32x4 pk = {pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3]), pack_bf2(dv[W - 4], dv[W - 3]), pack_bf2(dv[W - 2], dv[W - 1])};
       if (NT_STORES) __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(dst));
       else *reinterpret_cast<u32x4*>(dst) = pk;
@@ -199,7 +225,10 @@ __device__ __forceinline__ void epi_apply(const GemmP& p, int m, int n0, float (
     }
   }
   if (p.gelu_in) {
-    if (p.gelu_deriv) {
+    if (p.gelu_deriv == 2) {
+#pragma unroll
+      for (int i = 0; i < W; i++) v[i] *= gelu8_dec(e.g[i >> 2], i & 3);
+    } else if (p.gelu_deriv) {
 #pragma unroll
       for (int i = 0; i < W / 2; i++) { v[2 * i] *= bf_lo(e.g[i]); v[2 * i + 1] *= bf_hi(e.g[i]); }
     } else {
@@ -381,9 +410,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const float16v (&a
 __device__ __forceinline__ void epilogue1(const GemmP& p, int m, int n, float acc, bool add_bias) {
   float v = acc * p.alpha;
   if (p.bias && add_bias) v += p.bias[n];
-  if (p.aux_out) p.aux_out[(size_t)m * p.ld_aux + n] = f2bf((p.act == 1 && p.gelu_deriv) ? gelu_grad_f(v) : v);
+  if (p.aux_out && p.act == 1 && p.gelu_deriv == 2) {
+    reinterpret_cast<uint8_t*>(p.aux_out)[(size_t)m * p.ld_aux + n] = (uint8_t)(gelu8_pack4(gelu_grad_f(v), 0.f, 0.f, 0.f) & 0xffu);
+  } else if (p.aux_out) {
+    p.aux_out[(size_t)m * p.ld_aux + n] = f2bf((p.act == 1 && p.gelu_deriv) ? gelu_grad_f(v) : v);
+  }
   if (p.act == 1) v = gelu_f(v);
-  if (p.gelu_in) v *= p.gelu_deriv ? bf2f(p.gelu_in[(size_t)m * p.ld_gelu + n]) : gelu_grad_f(bf2f(p.gelu_in[(size_t)m * p.ld_gelu + n]));
+  if (p.gelu_in && p.gelu_deriv == 2) v *= gelu8_dec(reinterpret_cast<const uint8_t*>(p.gelu_in)[(size_t)m * p.ld_gelu + n], 0);
+  else if (p.gelu_in) v *= p.gelu_deriv ? bf2f(p.gelu_in[(size_t)m * p.ld_gelu + n]) : gelu_grad_f(bf2f(p.gelu_in[(size_t)m * p.ld_gelu + n]));
   if (p.row_mask) v *= p.row_mask[m] ? 1.f : 0.f;
   if (p.res_f32) v += p.res_f32[(size_t)m * p.ld_res + n];
   else if (p.res_bf16) v += bf2f(p.res_bf16[(size_t)m * p.ld_res + n]);

@@ -592,7 +592,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     if aux_out is not None:
         g.aux_out, g.ld_aux = aux_out.data_ptr(), _rowmajor(aux_out, "aux_out")
     g.act, g.out_f32, g.accumulate = act, int(out.dtype == torch.float32), int(accumulate)
-    g.gelu_deriv = int(gelu_deriv)
+    g.gelu_deriv = _gelu_deriv_mode(gelu_deriv, aux_out, gelu_in)
     g.split_k, g.force_generic = split_k, int(force_generic or FORCE_GENERIC)
     if a_rowsum is not None:  # fp32 [m], accumulated: sum_k A[m, k] (bias gradient of a weight-gradient GEMM)
         _dev(a_rowsum)
@@ -639,6 +639,17 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
 
 
 _WARNED_GENERIC: set = set()
+
+
+def _gelu_deriv_mode(gelu_deriv: bool, aux_out: torch.Tensor | None, gelu_in: torch.Tensor | None) -> int:
+    """``cinema_gemm_args.gelu_deriv``: 0 = the auxiliary GELU tensor is the bf16 pre-activation, 1 = bf16 GELU'(pre-activation), 2 = GELU' as the 8-bit affine
+    code of csrc/common.cuh (uint8 tensors; only with ``gelu_deriv``)."""
+    t = aux_out if aux_out is not None else gelu_in
+    if t is not None and t.dtype == torch.uint8:
+        if not gelu_deriv:
+            raise HipLibraryError("a uint8 auxiliary GELU tensor holds the 8-bit code of GELU': pass gelu_deriv=True")
+        return 2
+    return int(gelu_deriv)
 
 
 def quantize_fp8(x: torch.Tensor) -> tuple:
@@ -765,7 +776,7 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, b8: torch.Tensor, scale_b:
     if gelu_in is not None:  # D = (A8 B8^T) x GELU'(gelu_in): the data gradient through fc1's activation
         _dev(gelu_in)
         g.gelu_in, g.ld_gelu = gelu_in.data_ptr(), _rowmajor(gelu_in, "gelu_in")
-    g.act, g.out_f32, g.gelu_deriv = act, int(out is not None and out.dtype == torch.float32), int(gelu_deriv)
+    g.act, g.out_f32, g.gelu_deriv = act, int(out is not None and out.dtype == torch.float32), _gelu_deriv_mode(gelu_deriv, aux_out, gelu_in)
     if out8 is not None:
         _set_out8(g, out8, m, n)
     if colsum_partials is not None:

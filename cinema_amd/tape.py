@@ -1009,6 +1009,10 @@ def _op_thin_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.
 # data gradient through the activation (fc2's dgrad epilogue) is one multiply per element instead of a second erf evaluation (that epilogue was VALU-bound:
 # 10960x3072x768 data gradient 93.7 us with the erf against 61.5 us plain).  CINEMA_GELU_DERIV=0: the pre-activation form.
 GELU_DERIV = bool(int(os.environ.get("CINEMA_GELU_DERIV", "1")))
+# ... and stores it as an 8-bit code (affine map of GELU''s range [-0.13, 1.13] onto 0..255, csrc/common.cuh gelu8_*): half the bytes fc1 writes beside its
+# activation and fc2's data gradient reads back - those K = 512 / 768 GEMMs move 3-3.9 TB/s, i.e. they sit on the HBM side of the ridge.  Quantisation error
+# <= 0.0025 = a bf16 rounding error at |GELU'| >= 0.5.  CINEMA_GELU8=0: the bf16 tensor.
+GELU8 = bool(int(os.environ.get("CINEMA_GELU8", "1")))
 
 
 def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parameter, fc2_w: torch.nn.Parameter, fc2_b: torch.nn.Parameter,
@@ -1017,8 +1021,9 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     ``residual=None``: the caller adds it (behind a DropPath, :func:`op_droppath_add`)."""
     w1, w2 = w_plain(fc1_w), w_plain(fc2_w)
     m, hidden = x.data.shape[0], w1.shape[0]
-    h = K.empty((m, hidden), dtype=BF16, device=x.data.device)  # GELU'(fc1 output) (GELU_DERIV) or the fc1 output itself
     deriv = GELU_DERIV
+    # GELU'(fc1 output) (GELU_DERIV; as an 8-bit code under GELU8) or the fc1 output itself
+    h = K.empty((m, hidden), dtype=torch.uint8 if (deriv and GELU8 and x.data.is_cuda and hidden % 8 == 0) else BF16, device=x.data.device)
     x8t = a8t = None  # per-tensor e4m3 copies of x (LayerNorm output) and of the GELU output: operands of the forward AND weight-gradient GEMMs
     site_dy = site_dh = None
     if fp8 and _fp8_ok(x.data, fc1_w, fc2_w) and (residual is None or residual.data.dtype == F32):

@@ -130,8 +130,27 @@ def test_gemm_bf16_epilogue_classes_on_both_tile_depths(k: int) -> None:
     close(dv, px.grad, 1e-2, 1e-2, "stored GELU derivative")
     dh2 = K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv, gelu_deriv=True)
     close(dh2, (dy.float() @ w2.float()) * dv.float(), 1e-2, 2e-2, "data gradient x stored derivative")
+    # the derivative as an 8-bit code (uint8 tensor: affine map of [-0.13, 1.13] onto 0..255, csrc/common.cuh): half the bytes; error <= half a step
+    # (0.00247) against the exact derivative, the data gradient multiplies the DECODED value (bit-for-bit what the decoder formula gives)
+    dv8 = torch.empty(m, n, dtype=torch.uint8, device=DEV)
+    assert torch.equal(K.gemm(a, w, bias=bias, act=1, aux_out=dv8, gelu_deriv=True), out)
+    dec = dv8.float() * (1.26 / 255.0) - 0.13
+    assert float((dec - px.grad).abs().max()) <= 0.00247 + 2e-4, float((dec - px.grad).abs().max())  # (+ the erf approximation, 1.5e-7, and the products' fp32 rounding)
+    assert float(px.grad.min()) >= -0.13 and float(px.grad.max()) <= 1.13
+    dh8 = K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv8, gelu_deriv=True)
+    close(dh8, (dy.float() @ w2.float()) * dec, 1e-2, 2e-2, "data gradient x 8-bit derivative code")
+    g8 = torch.empty(m, n, dtype=torch.uint8, device=DEV)
+    K.gemm(a, w, bias=bias, act=1, aux_out=g8, gelu_deriv=True, force_generic=True)
+    assert int((g8.int() - dv8.int()).abs().max()) <= 1  # the generic kernel's code: at most one step apart (different summation order of the pre-activation)
+    close(K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv8, gelu_deriv=True, force_generic=True), (dy.float() @ w2.float()) * dec, 1e-2, 2e-2, "generic x 8-bit code")
+    with pytest.raises(K.HipLibraryError):
+        K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv8)  # a uint8 tensor is never a pre-activation
     for sched in (0, 1):  # the same two epilogues on the persistent 256x256 kernel
         dv3 = torch.empty_like(dv)
+        d8p = torch.empty_like(dv8)
+        K.gemm(a, w, bias=bias, act=1, aux_out=d8p, gelu_deriv=True, p256=sched, split_k=0)
+        assert int((d8p.int() - dv8.int()).abs().max()) <= 1
+        close(K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv8, gelu_deriv=True, p256=sched, split_k=0), (dy.float() @ w2.float()) * dec, 1e-2, 2e-2, "p256 x 8-bit code")
         close(K.gemm(a, w, bias=bias, act=1, aux_out=dv3, gelu_deriv=True, p256=sched, split_k=0), F.gelu(pre), 1e-2, 2e-2, "p256 gelu")
         close(dv3, px.grad, 1e-2, 1e-2, "p256 stored derivative")
         close(K.gemm(dy, w2, a_kmajor=True, b_kmajor=False, gelu_in=dv, gelu_deriv=True, p256=sched, split_k=0), (dy.float() @ w2.float()) * dv.float(), 1e-2, 2e-2,
