@@ -437,6 +437,23 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
             m: {"loss_rel": round(gp[m]["loss_rel"], 6), "grad_norm_rel": round(gp[m]["grad_norm_rel"], 6), "whole_grad_rel_l2": round(gp[m]["whole_grad_rel_l2"], 5),
                 "worst_matrix_rel_l2": round(gp[m]["worst_matrix_rel_l2"]["value"], 5), "worst_vector_rel_l2": round(gp[m]["worst_vector_rel_l2"]["value"], 5),
                 "fp8_dgrad_gemms": gp[m]["fp8_dgrad_gemms"], "fp8_wgrad_problems": gp[m]["fp8_wgrad_problems"]} for m in ("bf16", "fp8_wgrad")}
+        # ... and at config 5's FULL depth (ViT-Large 24 + 8 blocks) on a small spatial size, where the oracle's backward takes seconds
+        from cinema_amd.vit import get_vit_config
+
+        kwd = dict(image_size_dict={"sax": (96, 96, 8), "lax_2c": (96, 96)}, in_chans_dict=dict.fromkeys(views, 1), enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)},
+                   enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)}, enc_conv_chans=[64, 128], enc_conv_n_blocks=2, **get_vit_config("large"))
+        torch.manual_seed(11)
+        sdd = {k: v.detach().clone() for k, v in CineMA(**kwd).state_dict().items()}
+        gd = mae_fp8_grad_parity(kwd, sdd, batch=2, seed=13, device=device, threads=min(os.cpu_count() or 1, 16), modes=("bf16", "fp8_wgrad"))
+        out["config5_fp8"]["parity"]["gradients_full_depth"] = {
+            m: {"loss_rel": round(gd[m]["loss_rel"], 6), "grad_norm_rel": round(gd[m]["grad_norm_rel"], 6), "whole_grad_rel_l2": round(gd[m]["whole_grad_rel_l2"], 5),
+                "worst_matrix_rel_l2": {"name": gd[m]["worst_matrix_rel_l2"]["name"], "value": round(gd[m]["worst_matrix_rel_l2"]["value"], 5)},
+                "worst_vector_rel_l2": {"name": gd[m]["worst_vector_rel_l2"]["name"], "value": round(gd[m]["worst_vector_rel_l2"]["value"], 5)},
+                "block_matrix_rel_l2_first_last": [list(gd[m]["block_matrix_rel_l2"].items())[i] for i in (0, 23, 24, -1)],
+                "fp8_dgrad_gemms": gd[m]["fp8_dgrad_gemms"], "fp8_wgrad_problems": gd[m]["fp8_wgrad_problems"]} for m in ("bf16", "fp8_wgrad")}
+        out["config5_fp8"]["parity"]["gradients_full_depth"]["what"] = ("the same comparison on a model with config 5's full depth and widths (ViT-Large: 24 + 8 blocks, 1024 / 512 channels) at "
+                                                                         "SAX 96x96x8 + one long-axis view 96x96, batch 2 (the oracle's backward at the config-5 spatial size takes minutes); "
+                                                                         "block_matrix_rel_l2: encoder block 0 / 23, decoder block 0 / 7")
         out["config5_fp8"]["parity"]["gradients_midsize"]["what"] = ("gradients of the HIP path vs the fp32 CPU oracle on a 2 + 2 block model (encoder 256, decoder 128 channels), batch 3, "
                                                                      "identical weights / inputs / masks: bf16 path and the full fp8 path (a first pass records the delayed scales)")
     return out

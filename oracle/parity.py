@@ -187,7 +187,8 @@ def mae_loss_parity(kw: dict, state_dict: dict, batch: int = 1, seed: int = 7, d
             "fp8": fp8, "oracle_seconds": round(cpu_s, 2)}
 
 
-def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 5, device: str = "cuda", threads: int | None = None) -> dict:
+def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 5, device: str = "cuda", threads: int | None = None,
+                        modes: tuple = ("bf16", "fp8_forward", "fp8", "fp8_wgrad")) -> dict:
     """Gradients of the fp8 path against the ORACLE (not against this repository's bf16 path): one forward + backward of the oracle on the CPU and three
     of the HIP path on identical weights / inputs / masks - bf16, e4m3 forward only, e4m3 forward + e4m3 data gradients, and the same + e4m3 WEIGHT gradients
     (per-tensor delayed scaling: a first pass records the maxima).  The flat parameter buffers
@@ -245,6 +246,8 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
     try:
         for mode, (fwd8, dg8, wg) in {"bf16": (False, False, False), "fp8_forward": (True, False, False), "fp8": (True, True, False),
                                       "fp8_wgrad": (True, True, True)}.items():
+            if mode not in modes:
+                continue
             T.FP8_FORWARD, T.FP8_DGRAD, T.FP8_WGRAD = fwd8, dg8, wg
             if wg:  # delayed per-tensor scaling: one pass records the maxima of every site, the measured pass quantises with them (same weights and inputs)
                 flat.zero_grad()
@@ -257,9 +260,15 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
             loss.backward()
             sq_g = sq_e = 0.0
             worst_m, worst_v = ("", 0.0), ("", 0.0)
+            by_depth: dict = {}  # encoder / decoder block index -> (squared error, squared reference norm) over the block's matrices
             for k, r in ref.items():
                 g = named[k].grad.float().cpu()
                 e = float((g - r).double().pow(2).sum())
+                parts = k.split(".")
+                if r.dim() >= 2 and len(parts) > 3 and parts[1] == "blocks":
+                    acc = by_depth.setdefault(f"{parts[0]}.{int(parts[2]):02d}", [0.0, 0.0])
+                    acc[0] += e
+                    acc[1] += float(r.double().pow(2).sum())
                 sq_g += float(g.double().pow(2).sum())
                 sq_e += e
                 rn = float(r.norm())
@@ -273,7 +282,10 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
             out[mode] = {"loss": float(loss), "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
                          "grad_norm_rel": abs(math.sqrt(sq_g) - ref_norm) / ref_norm, "whole_grad_rel_l2": math.sqrt(sq_e) / ref_norm,
                          "worst_matrix_rel_l2": {"name": worst_m[0], "value": worst_m[1]}, "worst_vector_rel_l2": {"name": worst_v[0], "value": worst_v[1]},
-                         "fp8_dgrad_gemms": calls["n"], "fp8_wgrad_problems": wg8["n"]}
+                         "fp8_dgrad_gemms": calls["n"], "fp8_wgrad_problems": wg8["n"],
+                         # relative L2 error of each transformer block's matrices taken together: how the error grows from the last block (where the
+                         # backward pass starts) to the first
+                         "block_matrix_rel_l2": {b: round(math.sqrt(v[0] / v[1]), 5) for b, v in sorted(by_depth.items()) if v[1] > 0}}
     finally:
         T.w_fp8_t = orig_wt
         K.gemm_fp8_wgrad_grouped = orig_wg8
