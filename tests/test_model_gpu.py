@@ -458,10 +458,14 @@ def test_fp8_forward_path_vs_oracle_and_bf16() -> None:
 
 # Full DEPTH of BASELINE config 5 (ViT-Large: 24 encoder blocks of width 1024 / 16 heads, 8 decoder blocks of width 512) at a spatial size the fp32 CPU oracle
 # back-propagates in seconds (SAX 96 x 96 x 8 + one long-axis view 96 x 96, batch 2: 288 + 36 tokens per sample): the e4m3 error compounds through 24 layers,
-# which the 2 + 2 block check above cannot show.  Measured on an MI355X (round 5): see the assertion messages / profiles/r05_fp8_depth.txt; bounds = 1.6 x measured.
-FP8_DEPTH_WHOLE_GRAD_L2 = 0.25
-FP8_DEPTH_MATRIX_GRAD_L2 = 0.60
-FP8_DEPTH_BLOCK_L2 = 0.40
+# which the 2 + 2 block check above cannot show.  Measured on an MI355X (round 5, profiles/r05_fp8_depth.txt):
+#                      loss rel   grad-norm rel   whole gradient   worst matrix (encoder.blocks.22.attn.q.weight)   matrices of one block, taken together
+#   bf16               2.3e-4     9.6e-4          0.76 %           7.9 % (a tensor with ~1e-5 of the gradient norm)   0.66 - 0.82 %
+#   e4m3 fwd+dgrad+wgrad 3.2e-3   1.0e-2          10.8 %           22.2 %                                              decoder 8.7 - 9.1 %, encoder 10.9 % (block 23) ... 12.0 % (block 0)
+# i.e. the error grows by a tenth over 24 layers - it does not compound.  Bounds = 1.6 x measured.
+FP8_DEPTH_WHOLE_GRAD_L2 = 0.175
+FP8_DEPTH_MATRIX_GRAD_L2 = 0.36
+FP8_DEPTH_BLOCK_L2 = 0.195
 
 
 def large_depth_kwargs() -> dict:
