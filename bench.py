@@ -133,6 +133,7 @@ def _latest_profile(suffix: str) -> str:
 
 PMC_TRAFFIC_FILE = _latest_profile("pmc_hbm_traffic.json")
 PMC_MFMA_FILE = _latest_profile("mfma_util.json")
+PMC_TRAFFIC_FP8_FILE = _latest_profile("pmc_hbm_traffic_fp8.json")
 
 
 def _committed(rel: str, kernel: str):  # noqa: ANN202
@@ -399,8 +400,12 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
                     flops = sum(r[1] for r in recs)
                     alg = sum(r[4][6] for r in recs)
                     fp8_roof = {"bound": "mfma", "kernel": K_.GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4], "achieved": round(flops / secs / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
-                                "frac": round(flops / secs / 5e15, 4), "launches_per_step": len(recs) // 2, "avg_launch_us": round(secs / len(recs) * 1e6, 2),
-                                "gflop_per_launch": round(flops / len(recs) / 1e9, 3), "algorithmic_bytes_per_launch": int(alg / len(recs)), "traffic": None,
+                                "frac": round(flops / secs / 5e15, 4), "intensity_flop_per_byte": round(flops / max(alg, 1.0), 1), "ridge_flop_per_byte": 625.0,
+                                "launches_per_step": len(recs) // 2, "avg_launch_us": round(secs / len(recs) * 1e6, 2),
+                                "gflop_per_launch": round(flops / len(recs) / 1e9, 3), "algorithmic_bytes_per_launch": int(alg / len(recs)),
+                                "traffic": (_committed(PMC_TRAFFIC_FP8_FILE, K_.GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4]) or {}).get("hbm_bytes_per_launch"),
+                                "traffic_source": f"committed {PMC_TRAFFIC_FP8_FILE} (FETCH_SIZE / WRITE_SIZE passes over this config's fp8 step, tools/gpu_r05_final.sh)",
+                                "traffic_stale": pmc_binding(PMC_TRAFFIC_FP8_FILE)["stale"],
                                 "timing": "HIP events on the launch stream around every launch (two eager steps, one stream)",
                                 "what": "weight gradients of a transformer block (qkv, proj, fc1, fc2) on row-major e4m3 operands in one persistent launch, k-slices reduced in the launch"}
             del st

@@ -13,6 +13,8 @@ BLOCKS = {
     "cal": [(262144, 256, 256)],   # one output tile: every operand byte is needed exactly once, no reuse possible (calibrates the counter arithmetic)
     "dec": [(32848, 512, 512), (10944, 1024, 512), (32848, 512, 512), (32848, 2048, 512), (32848, 512, 2048)],
 }
+BLOCKS["enc2"] = BLOCKS["enc"] * 2   # the step's launch: two ViT-Base encoder blocks = 216 whole-K tiles, one per workgroup
+BLOCKS["dec2"] = [(32848, 512, 512), (32848, 512, 512), (32848, 2048, 512), (32848, 512, 2048)] * 2
 which = sys.argv[1] if len(sys.argv) > 1 else "enc"
 whole = "whole" in sys.argv
 probs = []
