@@ -834,7 +834,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
     const int blk0 = kb0 + 8 * ps;
     const int blk = blk0 + wave_u;
     const bool active = blk < kb1;                       // wave-uniform
-    const int nkk = 2 * min(8, kb1 - blk0);              // k-steps of 16 keys that phase B reduces over (only rows of active key blocks are ever read)
     const bool has_prev = ps > 0, last_pass = ps == npass - 1;
     const bool final_out = last_pass && pp.G == 1;
     __syncthreads();  // everybody is done with the previous pass's K tile, dS tiles and stages
@@ -848,6 +847,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
         const int rr = min(blk0 * 32 + row, p.tk - 1);
         glds16(__builtin_amdgcn_readfirstlane(a0 + piece * 1024), kbase + (size_t)rr * p.ldk + c * 8);
       }
+    }
+    if (!active) {   // phase B reduces over all 256 key rows of the dS tiles: the rows of a key block nobody owns in this pass stay zero
+      const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; i++) *reinterpret_cast<uint4*>(ds0 + (i >> 2) * G::DS_BYTES + wave_u * 4096 + ((i & 3) * 64 + lane) * 16) = z;
     }
     short8v vf[HD / 16];
     load_row_frags<HD>(vf, vbase + (size_t)min(blk * 32 + (lane & 31), p.tk - 1) * p.ldv, lane);
@@ -876,16 +880,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
         const float* stats = reinterpret_cast<const float*>(qs_ + 2 * G::TB);
         char* dsw = ds0 + (it & 1) * G::DS_BYTES + wave_u * 4096;  // this wave's 32 key rows of the shared dS tile
         const int nu = it * 64 + 32 < p.tq ? 2 : 1;  // empty 32-query half of the last tile (workgroup-uniform)
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          if (u < nu) {
+#pragma unroll 1
+        for (int u = 0; u < nu; u++) {
+          {
             float16v s, dp;
             zero16(s); zero16(dp);
+            {
+              // every LDS read of the S / dP products is issued before the first MFMA (two reads + wait + MFMA per k-step left the LDS latency in front of
+              // every MFMA: the kernel ran two waves per SIMD at the latency of its LDS reads)
+              short8v qa[HD / 16], da[HD / 16], ka[HD / 16];
 #pragma unroll
-            for (int ks = 0; ks < HD / 16; ks++) {
-              s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(qs_, 32 * u, ks, lane), frag_km<HD>(kt_, 0, ks, lane), s, 0, 0, 0);
-              dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_km<HD>(dos_, 32 * u, ks, lane), vf[ks], dp, 0, 0, 0);
+              for (int ks = 0; ks < HD / 16; ks++) { qa[ks] = frag_km<HD>(qs_, 32 * u, ks, lane); ka[ks] = frag_km<HD>(kt_, 0, ks, lane); da[ks] = frag_km<HD>(dos_, 32 * u, ks, lane); }
+#pragma unroll
+              for (int ks = 0; ks < HD / 16; ks++) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], ka[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], dp, 0, 0, 0);
+              }
             }
+            // the transposed Q / dO fragments of the dV / dK products (first 16 queries of the half): in flight under the exponentials below
+            short8v tdo[2][HD / 32], tq[2][HD / 32];
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; dt++) { tdo[0][dt] = frag_tr<HD>(dos_, 32 * u, 32 * dt, lane); tq[0][dt] = frag_tr<HD>(qs_, 32 * u, 32 * dt, lane); }
             // acc reg r <-> query 32u + (r&3) + 8*(r>>2) + 4g of the tile; column = this lane's key
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -905,14 +920,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
               for (int r = 0; r < 16; r++) { s[r] = key_ok ? s[r] : 0.f; dp[r] = key_ok ? dp[r] : 0.f; }
             }
 #pragma unroll
+            for (int dt = 0; dt < HD / 32; dt++) { tdo[1][dt] = frag_tr<HD>(dos_, 32 * u + 16, 32 * dt, lane); tq[1][dt] = frag_tr<HD>(qs_, 32 * u + 16, 32 * dt, lane); }
+#pragma unroll
             for (int st = 0; st < 2; st++) {
               const short8v pf = pack_slots(s, st);
               union { short8v v; uint32_t u32[4]; } dsf;
               dsf.v = pack_slots(dp, st);
 #pragma unroll
               for (int dt = 0; dt < HD / 32; dt++) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(dos_, 32 * u + 16 * st, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(qs_, 32 * u + 16 * st, 32 * dt, lane), dsf.v, dk[dt], 0, 0, 0);
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[st][dt], pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[st][dt], dsf.v, dk[dt], 0, 0, 0);
               }
               // dS -> [key][query] rows of the shared tile: this lane's key, queries 32u + 16st + 4g .. + 3 and + 8 (16-byte chunks 4u + 2st, + 1)
               const int j = lane & 31;
@@ -932,9 +949,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
         }
         float16v dq;
         zero16(dq);
-#pragma unroll 2
-        for (int kk = 0; kk < nkk; kk++)
-          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<HD>(ks_, 16 * kk, 32 * dtb, lane), frag_tr<64>(dsr, 16 * kk, 32 * qh, lane), dq, 0, 0, 0);
+#pragma unroll
+        for (int kb4 = 0; kb4 < 4; kb4++) {   // (a runtime trip count left one k-step per iteration behind its own four LDS reads: 16 exposed LDS latencies)
+          short8v fk[4], fd[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) { fk[i] = frag_tr<HD>(ks_, 16 * (4 * kb4 + i), 32 * dtb, lane); fd[i] = frag_tr<64>(dsr, 16 * (4 * kb4 + i), 32 * qh, lane); }
+#pragma unroll
+          for (int i = 0; i < 4; i++) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[i], fd[i], dq, 0, 0, 0);
+        }
         if (has_prev) {
 #pragma unroll
           for (int c = 0; c < 4; c++) { dq[4 * c] += prev[c].x; dq[4 * c + 1] += prev[c].y; dq[4 * c + 2] += prev[c].z; dq[4 * c + 3] += prev[c].w; }
@@ -1265,10 +1287,11 @@ static int attention_bwd_impl(const uint16_t* q, int ldq, const uint16_t* k, int
       return launch_status();
     }
     // one-pass backward for head_dim 64 (any number of keys): needs its scratch when the keys take several passes or are split over workgroups.
-    // OFF by default (CINEMA_ATTN_ONEPASS=1 selects it): parity-green and deterministic, but measured SLOWER than the dQ + dK/dV pair at every shape of the
-    // BASELINE configs (profiles/r05_e_attn_waitcnt.txt: config 2 encoder 194 vs 131 us, config 4 775 vs 473, config 5 encoder 527 vs 352) - at one key block
-    // per wave the Q / dO tiles are re-read from LDS by all eight waves for 32 keys each, and the eight waves of the one resident workgroup run their
-    // matrix / exponential / LDS phases in lockstep
+    // OFF by default (CINEMA_ATTN_ONEPASS=1 selects it): parity-green and deterministic, and after three rounds of tuning (statistics off the critical path,
+    // LDS reads issued in batches ahead of their MFMAs, phase B unrolled: 194 -> 131 us at the config-2 encoder) ON PAR with the dQ + dK/dV pair, not ahead of it:
+    // config 2 encoder 131-137 vs 137-142 us, config 5 encoder 324-352 vs 328-397, config 4 (3073 tokens, three passes on 240 workgroups) 522-548 vs 459-490;
+    // the config-2 step moves by -0.06 ms (profiles/r05_i_attn_bwd*.txt).  At one key block per wave every wave re-reads the Q / dO tiles from LDS in two
+    // layouts for 32 keys, which is what the kernel pair does as well - the saved second evaluation of P pays for the dS tile traffic and phase B, no more.
     const char* op_txt = getenv("CINEMA_ATTN_ONEPASS");
     if (fused_env && (op_txt ? atoi(op_txt) : 0) && hd == 64 && !(ldo & 7)) {
       const OnePassPlan pl = onepass_plan(b, h, tq, tk);
