@@ -454,7 +454,7 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
             m: {"loss_rel": round(gd[m]["loss_rel"], 6), "grad_norm_rel": round(gd[m]["grad_norm_rel"], 6), "whole_grad_rel_l2": round(gd[m]["whole_grad_rel_l2"], 5),
                 "worst_matrix_rel_l2": {"name": gd[m]["worst_matrix_rel_l2"]["name"], "value": round(gd[m]["worst_matrix_rel_l2"]["value"], 5)},
                 "worst_vector_rel_l2": {"name": gd[m]["worst_vector_rel_l2"]["name"], "value": round(gd[m]["worst_vector_rel_l2"]["value"], 5)},
-                "block_matrix_rel_l2_first_last": [list(gd[m]["block_matrix_rel_l2"].items())[i] for i in (0, 23, 24, -1)],
+                "block_matrix_rel_l2_first_last": {b: gd[m]["block_matrix_rel_l2"].get(b) for b in ("encoder.00", "encoder.23", "decoder.00", "decoder.07")},
                 "fp8_dgrad_gemms": gd[m]["fp8_dgrad_gemms"], "fp8_wgrad_problems": gd[m]["fp8_wgrad_problems"]} for m in ("bf16", "fp8_wgrad")}
         out["config5_fp8"]["parity"]["gradients_full_depth"]["what"] = ("the same comparison on a model with config 5's full depth and widths (ViT-Large: 24 + 8 blocks, 1024 / 512 channels) at "
                                                                          "SAX 96x96x8 + one long-axis view 96x96, batch 2 (the oracle's backward at the config-5 spatial size takes minutes); "

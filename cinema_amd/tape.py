@@ -516,7 +516,13 @@ class Fp8Sites:
             if self.live.pop(i, None) is not None:
                 self.free.append(i)
 
-    def site(self, owner: object, kind: str) -> K.Q8Site:
+    class _Named:  # owner object of a site asked for by a plain key (tests / tools): lives as long as the registry
+        pass
+
+    def site(self, owner: object, kind: str | None = None) -> K.Q8Site:
+        if kind is None:  # ``site(key)``: a stand-alone site under a hashable key
+            named = self.__dict__.setdefault("_named", {})
+            owner, kind = named.setdefault(owner, Fp8Sites._Named()), "named"
         sites = owner.__dict__.get("_cinema_q8")
         if sites is None:
             sites = owner.__dict__["_cinema_q8"] = {}
