@@ -94,7 +94,73 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
   }
 }
 
+struct AdamGroupsP {
+  float* p; const float* g; float* m; float* v;
+  float b1, b2, eps;
+  const float* clip; bf16_t* shadow; const int* state;
+  int n_groups;
+  long long total4;                       // float4 count of all groups together
+  long long first4[CINEMA_ADAMW_MAX_GROUPS + 1];  // prefix sums of the groups' float4 counts
+  long long begin4[CINEMA_ADAMW_MAX_GROUPS];
+  float lr[CINEMA_ADAMW_MAX_GROUPS], wd[CINEMA_ADAMW_MAX_GROUPS];
+};
+
+// several parameter groups (own lr / weight decay) of one flat buffer in one launch: the float4s of all groups are numbered consecutively, a thread walks its
+// grid-stride sequence and moves on through the (ascending) groups as it goes
+__global__ __launch_bounds__(256) void adamw_groups_kernel(AdamGroupsP q) {
+  const float cc = q.clip ? q.clip[0] : 1.f;
+  if (!(cc > 0.f)) return;  // non-finite gradient norm: skip (clip_coef_kernel counted it)
+  AdamP a{q.p, q.g, q.m, q.v, 0, 0.f, q.b1, q.b2, q.eps, 0.f, 1.f, 1.f, q.clip, q.shadow, q.state};
+  const double step = (double)q.state[0];
+  a.bc1 = (float)(1.0 - pow((double)a.b1, step));
+  a.bc2 = (float)(1.0 - pow((double)a.b2, step));
+  int gi = 0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < q.total4; t += (long long)gridDim.x * blockDim.x) {
+    while (t >= q.first4[gi + 1]) gi++;
+    a.lr = q.lr[gi]; a.wd = q.wd[gi];
+    const long long i = q.begin4[gi] + (t - q.first4[gi]);
+    float4 p = reinterpret_cast<float4*>(a.p)[i];
+    const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+    float4 m = reinterpret_cast<float4*>(a.m)[i];
+    float4 v = reinterpret_cast<float4*>(a.v)[i];
+    adam1(p.x, g.x, m.x, v.x, a, cc); adam1(p.y, g.y, m.y, v.y, a, cc);
+    adam1(p.z, g.z, m.z, v.z, a, cc); adam1(p.w, g.w, m.w, v.w, a, cc);
+    reinterpret_cast<float4*>(a.p)[i] = p;
+    reinterpret_cast<float4*>(a.m)[i] = m;
+    reinterpret_cast<float4*>(a.v)[i] = v;
+    if (a.shadow) {
+      uint2 u; u.x = pack_bf2(p.x, p.y); u.y = pack_bf2(p.z, p.w);
+      reinterpret_cast<uint2*>(a.shadow)[i] = u;
+    }
+  }
+}
+
 }  // namespace
+
+CINEMA_API int cinema_adamw_groups(float* p, const float* g, float* m, float* v, const cinema_adamw_group* groups, int n_groups, float beta1, float beta2, float eps,
+                                   const float* clip_coef, uint16_t* p_bf16, const int* step_state, void* stream) {
+  if (!p || !g || !m || !v || !groups || n_groups < 1 || n_groups > CINEMA_ADAMW_MAX_GROUPS || !clip_coef || !step_state) return CINEMA_ERR_BAD_ARG;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CINEMA_ERR_UNSUPPORTED;
+  if (p_bf16 && (((uintptr_t)p_bf16) & 7)) return CINEMA_ERR_UNSUPPORTED;
+  AdamGroupsP q{};
+  q.p = p; q.g = g; q.m = m; q.v = v; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.clip = clip_coef; q.shadow = p_bf16; q.state = step_state; q.n_groups = n_groups;
+  long long prev_end = 0;
+  q.first4[0] = 0;
+  for (int i = 0; i < n_groups; i++) {
+    const cinema_adamw_group& gr = groups[i];
+    if (gr.begin < prev_end || gr.end < gr.begin || (gr.begin & 3) || (gr.end & 3)) return CINEMA_ERR_BAD_ARG;
+    q.begin4[i] = gr.begin >> 2;
+    q.first4[i + 1] = q.first4[i] + ((gr.end - gr.begin) >> 2);
+    q.lr[i] = gr.lr; q.wd[i] = gr.weight_decay;
+    prev_end = gr.end;
+  }
+  q.total4 = q.first4[n_groups];
+  if (q.total4 == 0) return 0;
+  long long grid = (q.total4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  CINEMA_LAUNCH(adamw_groups_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, q);
+  return launch_status();
+}
 
 CINEMA_API int cinema_sqnorm_f32(const float* g, long long n, float* out, float* workspace, void* stream) {
   if (!g || !out || !workspace || n <= 0) return CINEMA_ERR_BAD_ARG;

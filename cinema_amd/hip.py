@@ -225,6 +225,7 @@ _PROTOS = {
     "cinema_sqnorm_f32": [_vp, _ll, _vp, _vp, _vp],
     "cinema_clip_coef": [_vp, _f, _vp, _vp, _vp, _vp],
     "cinema_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
+    "cinema_adamw_groups": [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 FORCE_GENERIC = bool(int(os.environ.get("CINEMA_HIP_FORCE_GENERIC", "0")))
@@ -1934,6 +1935,27 @@ def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr
     step = max(int(step), 1)
     _check(load().cinema_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, weight_decay,
                                1.0 - beta1**step, 1.0 - beta2**step, _p(clip), _p(shadow), _p(step_state), _stream()), "adamw")
+
+
+class AdamWGroup(C.Structure):
+    """Mirror of ``cinema_adamw_group``."""
+
+    _fields_ = [("begin", C.c_longlong), ("end", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+ADAMW_MAX_GROUPS = 64
+
+
+def adamw_groups(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, groups: list, beta1: float, beta2: float, eps: float,
+                 clip: torch.Tensor, shadow: torch.Tensor | None, step_state: torch.Tensor) -> None:
+    """AdamW over several ranges of ONE flat buffer in one launch: ``groups`` = [(begin, end, lr, weight_decay), ...], ascending element ranges (multiples of 4).
+    Same arithmetic per element as :func:`adamw` with ``step_state`` (the layer-decay groups of a fine-tuning step: one launch instead of one per group)."""
+    _dev(p, g, m, v, clip, shadow, step_state)
+    arr = (AdamWGroup * len(groups))()
+    for a, (b, e, lr, wd) in zip(arr, groups):
+        a.begin, a.end, a.lr, a.weight_decay = int(b), int(e), float(lr), float(wd)
+    _check(load().cinema_adamw_groups(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), arr, len(groups), beta1, beta2, eps, clip.data_ptr(), _p(shadow),
+                                      step_state.data_ptr(), _stream()), "adamw_groups")
 
 
 def info() -> dict:

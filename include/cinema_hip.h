@@ -517,6 +517,14 @@ int cinema_clip_coef(const float* sqnorm, float max_norm, float* coef_out, float
 int cinema_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, float bias_corr1, float bias_corr2, const float* clip_coef, uint16_t* p_bf16, const int* step_state,
                  void* stream);
+/* The same update for up to CINEMA_ADAMW_MAX_GROUPS parameter groups of ONE flat buffer in one launch (torch.optim.AdamW param_groups with their own lr /
+ * weight_decay: the layer-decay groups of cinema/convvit.py param_groups_lr_decay, cinema/train.py:262-268 - 28 launches per step for ViT-Base otherwise).
+ * groups[i] = element range [begin, end) (both multiples of 4), lr, weight_decay; the ranges must be ascending and non-overlapping (gaps are left untouched).
+ * Same arithmetic per element as cinema_adamw (bit-identical results). */
+#define CINEMA_ADAMW_MAX_GROUPS 64
+typedef struct { long long begin, end; float lr, weight_decay; } cinema_adamw_group;
+int cinema_adamw_groups(float* p, const float* g, float* m, float* v, const cinema_adamw_group* groups_host, int n_groups, float beta1, float beta2, float eps,
+                        const float* clip_coef, uint16_t* p_bf16, const int* step_state, void* stream);
 
 #ifdef __cplusplus
 }

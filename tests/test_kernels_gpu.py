@@ -1243,3 +1243,29 @@ def test_q8_column_sums_strip_sums_and_8bit_only_outputs() -> None:
                 strips_b = torch.empty_like(strips)
                 assert K.gemm_fp8(a8, sa, w8, sw, gelu_in=gin, gelu_deriv=True, out8=(site, o8b), colsum_partials=strips_b, skip_d=True) is None
                 assert torch.equal(o8b, o8) and torch.equal(strips_b, strips)
+
+
+def test_adamw_groups_one_launch_equals_one_launch_per_group() -> None:
+    """cinema_adamw_groups (the layer-decay parameter groups of a fine-tuning step in ONE launch) against one cinema_adamw launch per group: bit-identical
+    parameters, moments and bf16 shadows over three steps; gaps between the ranges are left untouched; a non-finite norm skips every group."""
+    torch.manual_seed(0)
+    n = 40000
+    bounds = [(0, 4096, 1e-3, 0.0), (4096, 12288, 5e-4, 0.05), (12288, 12296, 2e-3, 0.05), (16384, 40000, 1e-4, 0.01)]  # a gap [12296, 16384)
+    g = torch.randn(n, device=DEV)
+    state = {}
+    for form in ("grouped", "single"):
+        p, m, v = torch.linspace(-1, 1, n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        sh = p.bfloat16()
+        coef, norm, st = torch.ones(1, device=DEV), torch.zeros(1, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV)
+        for step in range(3):
+            K.clip_coef((g * g).sum().reshape(1) if step != 1 else torch.tensor([float("nan")], device=DEV), 5.0, coef, norm, st)
+            if form == "grouped":
+                K.adamw_groups(p, g, m, v, bounds, 0.9, 0.95, 1e-8, coef, sh, st)
+            else:
+                for a, b, lr, wd in bounds:
+                    K.adamw(p[a:b], g[a:b], m[a:b], v[a:b], lr, 0.9, 0.95, 1e-8, wd, 1, clip=coef, shadow=sh[a:b], step_state=st)
+        state[form] = (p, m, v, sh, st.tolist())
+    for a, b in zip(state["grouped"][:4], state["single"][:4]):
+        assert torch.equal(a, b)
+    assert state["grouped"][4] == state["single"][4] == [2, 1]  # two applied, the NaN one skipped
+    assert torch.equal(state["grouped"][0][12296:16384], torch.linspace(-1, 1, n, device=DEV)[12296:16384])
