@@ -437,6 +437,20 @@ __global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* h, con
   }
 }
 
+// out16[r, :] = bf16(scale[r / rows_per_sample] * h[r, :]): the gradient of the DropPath branch, whose only readers are the branch's weight- and data-gradient GEMMs
+__global__ __launch_bounds__(256) void scale_rows_bf16_kernel(const float* h, const float* scale, bf16_t* out, long long rows, int c, int rows_per_sample) {
+  const int c4 = c >> 2;
+  const long long total = rows * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c4;
+    const float s = scale[r / rows_per_sample];
+    const float4 v = reinterpret_cast<const float4*>(h)[i];
+    uint2 pk;
+    pk.x = pack_bf2(v.x * s, v.y * s); pk.y = pack_bf2(v.z * s, v.w * s);
+    reinterpret_cast<uint2*>(out)[i] = pk;
+  }
+}
+
 CINEMA_API int cinema_rng_advance(unsigned long long* state, void* stream) {
   if (!state) return CINEMA_ERR_BAD_ARG;
   CINEMA_LAUNCH(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
@@ -462,6 +476,13 @@ CINEMA_API int cinema_scale_rows_add(const float* h, const float* residual, cons
   if ((c & 3) || ((((uintptr_t)h) | ((uintptr_t)out) | ((uintptr_t)residual)) & 15)) return CINEMA_ERR_UNSUPPORTED;
   CINEMA_LAUNCH(scale_rows_add_kernel, dim3(grid_for(rows * (c >> 2), 256)), dim3(256), 0, (hipStream_t)stream, h, residual, scale, out, rows, c,
                      rows_per_sample);
+  return launch_status();
+}
+
+CINEMA_API int cinema_scale_rows_bf16(const float* h, const float* scale, uint16_t* out, long long rows, int c, int rows_per_sample, void* stream) {
+  if (!h || !scale || !out || rows <= 0 || c <= 0 || rows_per_sample <= 0) return CINEMA_ERR_BAD_ARG;
+  if ((c & 3) || (((uintptr_t)h) & 15) || (((uintptr_t)out) & 7)) return CINEMA_ERR_UNSUPPORTED;
+  CINEMA_LAUNCH(scale_rows_bf16_kernel, dim3(grid_for(rows * (c >> 2), 256)), dim3(256), 0, (hipStream_t)stream, h, scale, out, rows, c, rows_per_sample);
   return launch_status();
 }
 

@@ -198,6 +198,7 @@ _PROTOS = {
     "cinema_dropout_bf16": [_vp, _vp, _ll, _f, _vp, C.c_uint, _vp],
     "cinema_droppath_scale": [_vp, _i, _f, _vp, C.c_uint, _vp],
     "cinema_scale_rows_add": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "cinema_scale_rows_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_rope_heads": [_vp, _i, _ll, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "cinema_mul_scalar_f32": [_vp, _vp, _vp, _ll, _vp],
     "cinema_mask_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -1101,6 +1102,16 @@ def scale_rows_add(h: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, r
     out = _empty_like(h)
     _check(load().cinema_scale_rows_add(h.data_ptr(), _p(residual), scale.data_ptr(), out.data_ptr(), h.shape[0], h.shape[1], rows_per_sample, _stream()),
            "scale_rows_add")
+    return out
+
+
+def scale_rows_bf16(h: torch.Tensor, scale: torch.Tensor, rows_per_sample: int) -> torch.Tensor:
+    """bf16(scale[row // rows_per_sample] * h) over fp32 rows [n, c]: the gradient of a DropPath branch as the GEMM operand its readers take."""
+    _dev(h, scale)
+    if h.dtype != torch.float32 or not h.is_contiguous():
+        raise HipLibraryError("scale_rows_bf16: contiguous fp32 rows")
+    out = _empty(h.shape, dtype=torch.bfloat16, device=h.device)
+    _check(load().cinema_scale_rows_bf16(h.data_ptr(), scale.data_ptr(), out.data_ptr(), h.shape[0], h.shape[1], rows_per_sample, _stream()), "scale_rows_bf16")
     return out
 
 

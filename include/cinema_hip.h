@@ -396,6 +396,9 @@ int cinema_rng_advance(unsigned long long* state, void* stream);
 int cinema_dropout_bf16(const uint16_t* x, uint16_t* y, long long n, float p, const unsigned long long* state, unsigned int salt, void* stream);
 int cinema_droppath_scale(float* scale, int batch, float p, const unsigned long long* state, unsigned int salt, void* stream);
 int cinema_scale_rows_add(const float* h, const float* residual, const float* scale, float* out, long long rows, int c, int rows_per_sample, void* stream);
+/* out16[r,:] = bf16(scale[r / rows_per_sample] * h[r,:]): the gradient of a DropPath branch (timm DropPath backward, cinema/vit.py:606-609) in the dtype its
+ * only readers - the branch's weight- and data-gradient GEMMs - take (no fp32 tensor, no cast launch behind it). */
+int cinema_scale_rows_bf16(const float* h, const float* scale, uint16_t* out, long long rows, int c, int rows_per_sample, void* stream);
 /* Thin linear layer (n <= 8 outputs, k <= 64 inputs, k % 8 == 0; the 4-class segmentation head, cinema/segmentation/convunetr.py pred_head_dict, over millions of
  * voxels): streaming kernels instead of a GEMM.  fwd: y fp32 [rows][n] = x bf16 [rows][k] . w^T (fp32 [n][k]) + bias.  bwd (dy fp32 [rows][n]): dx bf16 [rows][k] =
  * dy . w (NULL: skip), dw fp32 [n][k] += dy^T x, db [n] += column sums of dy (NULL: skip). */
