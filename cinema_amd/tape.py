@@ -220,7 +220,18 @@ _SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient l
 # ~45 forward / ~95 backward small launches per view (16-50 us each for the short-axis view, 5-15 us for the zipped long-axis group) that leave most compute
 # units idle, and the views share nothing - so the long-axis chain runs BESIDE the short-axis one: forked before the first stem launch, joined before the token
 # assembly (forward) / at the end of the backward pass.  The buffers its lanes allocate (under torch's current stream) are held until that join.
-LAX_STREAM = bool(int(os.environ.get("CINEMA_LAX_STREAM", "1")))
+def _ranks_share_a_device() -> bool:
+    """More local ranks than visible devices (torchrun sets LOCAL_WORLD_SIZE): several processes then drive ONE GPU, and three streams per process oversubscribe
+    its hardware queues (measured: the two-rank shared-GPU check took 162 s instead of 9 s with the third stream)."""
+    try:
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        return local > 1 and torch.cuda.is_available() and local > torch.cuda.device_count()
+    except (ValueError, RuntimeError):
+        return False
+
+
+# (default on; switched off by itself when several local ranks share one device - the product layout is one process per GPU)
+LAX_STREAM = bool(int(os.environ.get("CINEMA_LAX_STREAM", "0" if _ranks_share_a_device() else "1")))
 _LAX_STREAMS: dict = {}
 _LAX_KEEP: list = []
 
