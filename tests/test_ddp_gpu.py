@@ -110,12 +110,12 @@ def test_two_rank_product_step_on_one_gpu(tmp_path: Path) -> None:
     assert all(math.isfinite(l) and math.isfinite(g) for l, g in b0["losses"])
 
 
-@pytest.mark.parametrize("exchange", ["fp32", "bf16"])
-def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str) -> None:
+@pytest.mark.parametrize(("exchange", "algorithm"), [("fp32", "all_reduce"), ("bf16", "all_reduce"), ("fp32", "rs_ag")])
+def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str, algorithm: str) -> None:
     """``bench.py --gpus 2`` exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2``), with both ranks on the
     one leased GPU and gloo as the transport (dev overrides CINEMA_BENCH_SHARE_GPU / CINEMA_BENCH_BACKEND: RCCL refuses two ranks on one device; the rank
     environment, barrier, max-over-ranks timing, rank-0 JSON line, replayed step + GradientSynchronizer are the product's).  Checks the JSON contract of the
-    N > 1 line and its ``ddp`` object: both ranks seen, payload = every element of the flat gradient buffer once per step (4 bytes fp32, 2 bytes bf16),
+    N > 1 line and its ``ddp`` object (all-reduce in fp32 and bf16, and the reduce-scatter + all-gather exchange): both ranks seen, payload = every element of the flat gradient buffer once per step (4 bytes fp32, 2 bytes bf16),
     overlapped per-block collectives issued, the three schedule timings present."""
     import json
     import subprocess
@@ -128,7 +128,7 @@ def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str) -> None
 
     env = dict(os.environ, CINEMA_BENCH_SHARE_GPU="1", CINEMA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(get_free_port()),
-           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "1", "--batch", "2", "--cpu-budget", "0", "--grad-exchange", exchange]
+           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "1", "--batch", "2", "--cpu-budget", "0", "--grad-exchange", exchange, "--exchange", algorithm]
     import signal
     import tempfile
 
@@ -155,4 +155,7 @@ def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str) -> None
     assert ddp["n_ranks_seen"] == 2 and ddp["backend"] == "gloo" and ddp["exchange_dtype"] == exchange
     assert ddp["payload_bytes_per_step"] == flat_elems * (4 if exchange == "fp32" else 2), (ddp["payload_bytes_per_step"], flat_elems)
     assert ddp["early_collectives_per_step"] >= 20  # 12 encoder + 8 decoder blocks (+ the shared k|v range) go out from the backward hooks
+    # the explicit reduce-scatter + all-gather exchange (--exchange rs_ag): two collectives per range, same payload; the RCCL / NCCL knobs in force are echoed
+    assert ddp["exchange_algorithm"] == algorithm and isinstance(ddp["rccl_env"], dict)
+    assert ddp["collectives_per_step"] >= (2 if algorithm == "rs_ag" else 1) * ddp["early_collectives_per_step"]
     assert all(ddp[k] > 0 for k in ("ms_per_step_overlapped", "ms_per_step_exchange_after_backward", "ms_per_step_no_exchange"))
