@@ -587,7 +587,7 @@ def main() -> None:
         ranks = [None] * world
         dist.all_gather_object(ranks, (rank, torch.cuda.get_device_name(local_rank), local_rank))
         overlapped = mode_ms()
-        payload_bytes, n_early = sync.bytes_last, sync.n_early_last  # of the overlapped schedule (the two measurement modes below change both)
+        payload_bytes, n_early, n_coll = sync.bytes_last, sync.n_early_last, sync.n_collectives_last  # of the overlapped schedule (the two measurement modes below change them)
         sync.defer_all = True
         at_end = mode_ms()
         sync.defer_all, sync.disabled = False, True
@@ -595,7 +595,7 @@ def main() -> None:
         sync.disabled = False
         total_comm, exposed = max(at_end - none, 0.0), max(overlapped - none, 0.0)
         ddp_info = {"n_ranks_seen": len({r[0] for r in ranks}), "devices": sorted({r[1] for r in ranks}), "backend": dist.get_backend(), "exchange_dtype": args.grad_exchange,
-                    "exchange_algorithm": args.exchange, "collectives_per_step": sync.n_collectives_last,
+                    "exchange_algorithm": args.exchange, "collectives_per_step": n_coll,
                     # the RCCL knobs in force (passed through untouched: set them in the launching environment to A/B algorithms / protocols on a real node)
                     "rccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "HSA_FORCE_FINE_GRAIN"))},
                     "payload_bytes_per_step": payload_bytes, "early_collectives_per_step": n_early,
