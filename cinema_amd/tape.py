@@ -808,6 +808,7 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
 # 32.39 ms): the group can only be issued at the end of the block's backward and its 432 workgroups each run for 160 us, so the side
 # stream no longer fills the main stream's idle slots early and the main stream's kernels wait for slots behind long tiles.  Opt-in.
 # Groups that would leave the slots mostly empty (decoder blocks: 192 tiles) keep the per-GEMM split-K path either way.
+EARLY_RELAYOUT = bool(int(os.environ.get("CINEMA_EARLY_RELAYOUT", "1")))  # kernel-layout weight gradients folded into the flat buffer right behind their GEMM (0: at the end of the backward pass)
 GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "2"))  # 1: whole-K 128x128 tiles (cinema_gemm_bf16_grouped), 2: persistent 256x256 kernel, k-slices finished in the launch
 # LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
 DEFER_LN_REDUCE = bool(int(os.environ.get("CINEMA_LN_DEFER", "1")))
@@ -898,6 +899,21 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
     dst = full.view(-1, k)[row_offset:row_offset + n]
     bias_grad = None if bv is None else bv.grad_buffer((n,) if total_rows is None else (total_rows,))[row_offset:row_offset + n]
     wgrad_problem(tape, dy16, x16, dst, bias_grad)
+    # A weight whose gradient is computed in the KERNEL's layout (k == s patch convolutions, transposed convolutions) is added into the flat gradient buffer by
+    # one re-layout launch.  Until round 5 all of them ran at the very end of the backward pass, behind the join of the streams - 16 serial launches, 0.24 ms
+    # of a step with nothing else left to run (profiles/r05_l_phase_timeline.txt); now each follows its own weight-gradient launch on the weight-gradient
+    # stream and is hidden behind the rest of the backward pass.  The kernel-layout buffer is dropped afterwards (a second use of the weight starts a new one).
+    tagged = getattr(wv.to_param_layout, "hip_relayout", None)
+    p = wv.param
+    flat = getattr(p, "_cinema_flat_grad", None)
+    if (EARLY_RELAYOUT and tagged is not None and total_rows is None and row_offset == 0 and not wv.direct and flat is not None and dst.is_cuda
+            and not getattr(tape, "grouping", False) and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)()):
+        rows = wv.grad
+        if tagged[0] == "convt":
+            _wgrad_launch(lambda: K.convt_weight_grad_accumulate(rows.contiguous(), flat.view(p.shape)), rows)
+        else:
+            _wgrad_launch(lambda: K.patch_weight_grad_accumulate(rows.view(p.shape[0], -1), flat.view(p.shape), tagged[0]), rows)
+        wv.grad = None
 
 
 # --------------------------------------------------------------------------------------------------------------

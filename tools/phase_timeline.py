@@ -9,7 +9,7 @@ kd = next(t for t in tabs if t.startswith("kernels") or t == "kernels")
 cols = [r[1] for r in con.execute(f"pragma table_info({kd})")]
 rows = con.execute(f"select name, start, end from {kd} order by start").fetchall()
 rows = [(n.replace("(anonymous namespace)::", "").replace("void ", ""), s, e) for n, s, e in rows]
-adam = [i for i, r in enumerate(rows) if r[0].startswith("adamw_kernel")]
+adam = [i for i, r in enumerate(rows) if r[0].startswith("adamw")]
 ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] - i > 8]  # last AdamW launch of every step (one per param group)
 lo, hi = ends[-2] + 1, ends[-1] + 1  # the last full step
 step = rows[lo:hi]
