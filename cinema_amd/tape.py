@@ -326,6 +326,9 @@ class Tape:
 
     def backward(self) -> None:
         debug = os.environ.get("CINEMA_TAPE_DEBUG") == "1"
+        # whatever the weight-gradient stream still has queued from before this step (TrainStep's zero_grad fill) precedes the first gradient this pass writes
+        if SIDE_WGRAD and _SIDE_STREAMS and self.ops and torch.cuda.is_available() and not torch._C._cuda_isCurrentStreamCapturing():
+            K.stream_fork(side_stream().cuda_stream, K._stream())
         try:
             for i, fn in enumerate(reversed(self.ops)):
                 fn()
