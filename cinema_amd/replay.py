@@ -42,7 +42,7 @@ _tls = threading.local()
 # The draw order - one set per step - is unchanged; the masks of a step after a re-seed are the ones drawn before it (reset_recordings() drops them).
 import os  # noqa: E402
 
-MASK_PREFETCH = bool(int(os.environ.get("CINEMA_MASK_PREFETCH", "1")))
+MASK_PREFETCH = bool(int(os.environ.get("CINEMA_MASK_PREFETCH", "0")))  # measured neutral (profiles/r05_n_prefetch_ab2.txt: 26.00 / 26.01 / 26.11 ms without, 26.02 / 26.93 / 26.15 with): off
 _PREFETCH_STREAMS: dict = {}
 
 
