@@ -206,20 +206,16 @@ SIDE_WGRAD = bool(int(os.environ.get("CINEMA_SIDE_WGRAD", "1")))
 _SIDE_STREAMS: dict = {}
 
 
-def side_stream() -> "torch.cuda.Stream":
+def side_stream(i: int = 0) -> "torch.cuda.Stream":
     dev = torch._C._cuda_getDevice()
-    st = _SIDE_STREAMS.get(dev)
+    st = _SIDE_STREAMS.get((dev, i))
     if st is None:
-        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        st = _SIDE_STREAMS[(dev, i)] = torch.cuda.Stream(device=dev)
+        if i == 0:
+            _SIDE_STREAMS[dev] = st  # ("this device has a weight-gradient stream")
     return st
 
 
-_SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient launches still (possibly) running on the side stream
-
-# The lane group of the long-axis stems on a THIRD stream (default; CINEMA_LAX_STREAM=0: on the main stream, after the short-axis stem): the stems are chains of
-# ~45 forward / ~95 backward small launches per view (16-50 us each for the short-axis view, 5-15 us for the zipped long-axis group) that leave most compute
-# units idle, and the views share nothing - so the long-axis chain runs BESIDE the short-axis one: forked before the first stem launch, joined before the token
-# assembly (forward) / at the end of the backward pass.  The buffers its lanes allocate (under torch's current stream) are held until that join.
 def _ranks_share_a_device() -> bool:
     """More local ranks than visible devices (torchrun sets LOCAL_WORLD_SIZE): several processes then drive ONE GPU, and three streams per process oversubscribe
     its hardware queues (measured: the two-rank shared-GPU check took 162 s instead of 9 s with the third stream)."""
@@ -230,6 +226,20 @@ def _ranks_share_a_device() -> bool:
         return False
 
 
+# A SECOND weight-gradient stream for the single (not grouped) weight gradients - the conv stems': an event timeline of the replayed step without the profiler
+# (tools/phase_events.py, profiles/r05_o_phase_events.txt) shows the main stream finishing its chain 0.9 ms before the end of the backward pass and then waiting
+# for the weight-gradient stream to work off ~20 small split-K GEMM + reduce pairs one after the other on an otherwise empty chip; dealt alternately to two
+# streams they run two at a time.  CINEMA_SIDE_STREAMS=1: one stream.
+SIDE_STREAMS = max(1, min(2, int(os.environ.get("CINEMA_SIDE_STREAMS", "1" if _ranks_share_a_device() else "2"))))
+_SIDE_ALT = [0]   # stream index of the last single weight-gradient launch (what depends on that launch goes to the same stream)
+
+
+_SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient launches still (possibly) running on the side stream
+
+# The lane group of the long-axis stems on a THIRD stream (default; CINEMA_LAX_STREAM=0: on the main stream, after the short-axis stem): the stems are chains of
+# ~45 forward / ~95 backward small launches per view (16-50 us each for the short-axis view, 5-15 us for the zipped long-axis group) that leave most compute
+# units idle, and the views share nothing - so the long-axis chain runs BESIDE the short-axis one: forked before the first stem launch, joined before the token
+# assembly (forward) / at the end of the backward pass.  The buffers its lanes allocate (under torch's current stream) are held until that join.
 # (default on; switched off by itself when several local ranks share one device - the product layout is one process per GPU)
 LAX_STREAM = bool(int(os.environ.get("CINEMA_LAX_STREAM", "0" if _ranks_share_a_device() else "1")))
 _LAX_STREAMS: dict = {}
@@ -257,6 +267,8 @@ def join_side_stream(release: bool = False) -> None:
     stream may go back to the allocator - their next user is ordered after this wait."""
     if SIDE_WGRAD and _SIDE_STREAMS:
         K.stream_fork(side_stream().cuda_stream, K._stream())
+        if (torch._C._cuda_getDevice(), 1) in _SIDE_STREAMS:
+            K.stream_fork(side_stream(1).cuda_stream, K._stream())
     if release:
         _SIDE_KEEP.clear()
         _LAX_KEEP.clear()
@@ -274,6 +286,8 @@ def mark_params(tape: "Tape", params: list) -> None:
                 main, side = torch.cuda.current_stream(), side_stream()
                 ev = torch.cuda.Event()
                 ev.record(main)
+                if (torch._C._cuda_getDevice(), 1) in _SIDE_STREAMS:
+                    K.stream_fork(side_stream(1).cuda_stream, side.cuda_stream)  # (weight gradients dealt to the second stream)
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
                     hook(tape, params)
@@ -782,12 +796,16 @@ def _split_k_conv(m_red: int, n_out: int, k_out: int) -> int:
     return max(1, min(want, (m_red + SPLITK_MIN_ROWS - 1) // SPLITK_MIN_ROWS))
 
 
-def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
+def _wgrad_launch(fn: Callable, *operands: torch.Tensor, alt: int = 0) -> None:
     """Run a weight-gradient launch on the side stream (after everything queued on the main stream so far) or inline.  ``operands``
     are the activation / gradient tensors the launch reads: they were allocated on the main stream, so they are kept alive until the
     backward pass joins the side stream (a closure may drop its last reference right away and the allocator would reuse the memory)."""
     if SIDE_WGRAD and operands[0].is_cuda:
-        side = side_stream().cuda_stream
+        # alt = 1: a single weight gradient - dealt alternately to the two streams; alt = 2: follows the last such launch (its re-layout); 0: stream 0 (groups)
+        if alt == 1 and SIDE_STREAMS > 1 and K.LANE is None:
+            _SIDE_ALT[0] ^= 1
+        idx = _SIDE_ALT[0] if (alt and SIDE_STREAMS > 1 and K.LANE is None) else 0
+        side = side_stream(idx).cuda_stream
         K.stream_fork(K._stream(), side)
         with K.on_stream(side):  # raw redirection: no torch stream context, no event objects (this runs ~200x per step)
             fn()
@@ -799,7 +817,7 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor) -> None:
         _SIDE_KEEP.append((K.marker_record(side), operands))  # cheaper than record_stream (allocator events on every free of these blocks)
         while _SIDE_KEEP and (len(_SIDE_KEEP) > 2048 or _SIDE_KEEP[0][0] is None or K.marker_done(_SIDE_KEEP[0][0])):
             if len(_SIDE_KEEP) > 2048:                # finished launches give their operands back (holding everything to the end of the
-                side_stream().synchronize()           # backward pass kept ~4 GB more live and cost 2 ms/step of cache locality); the
+                torch.cuda.synchronize()              # backward pass kept ~4 GB more live and cost 2 ms/step of cache locality); the
             _SIDE_KEEP.popleft()                      # marker ring holds 4096 tickets
         return
     fn()
@@ -854,7 +872,7 @@ def wgrad_group_end(tape: Tape) -> None:
 def _wgrad_single(dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias_grad: torch.Tensor | None) -> None:
     n, k = dy16.shape[1], x16.shape[1]
     _wgrad_launch(lambda: K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k),
-                                 a_rowsum=bias_grad), dy16, x16)
+                                 a_rowsum=bias_grad), dy16, x16, alt=1)
 
 
 def flush_wgrads(tape: Tape) -> None:
@@ -913,9 +931,9 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
             and not getattr(tape, "grouping", False) and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)()):
         rows = wv.grad
         if tagged[0] == "convt":
-            _wgrad_launch(lambda: K.convt_weight_grad_accumulate(rows.contiguous(), flat.view(p.shape)), rows)
+            _wgrad_launch(lambda: K.convt_weight_grad_accumulate(rows.contiguous(), flat.view(p.shape)), rows, alt=2)
         else:
-            _wgrad_launch(lambda: K.patch_weight_grad_accumulate(rows.view(p.shape[0], -1), flat.view(p.shape), tagged[0]), rows)
+            _wgrad_launch(lambda: K.patch_weight_grad_accumulate(rows.view(p.shape[0], -1), flat.view(p.shape), tagged[0]), rows, alt=2)
         wv.grad = None
 
 
@@ -1445,7 +1463,7 @@ def op_sparse_dwconv(tape: Tape, x: Var, geom, weight: torch.nn.Parameter, bias:
             return
         c = x.data.shape[1]
         dw, db, dy = wv.grad_buffer(tuple(weight.shape)), None if bias is None else bv.grad_buffer((c,)), y.grad
-        _wgrad_launch(lambda: K.sparse_dwconv_bwd_weight(x.data, dy, tuple(weight.shape), dw, db, geom), x.data, dy)  # off the critical path
+        _wgrad_launch(lambda: K.sparse_dwconv_bwd_weight(x.data, dy, tuple(weight.shape), dw, db, geom), x.data, dy, alt=1)  # off the critical path
         if x.needs_grad:
             x.add_grad(K.sparse_dwconv(y.grad, weight.detach(), None, geom, flip=True))
 
