@@ -1031,7 +1031,12 @@ def persistent(fn):  # noqa: ANN001, ANN201
     (seen as a memory fault of the implicit convolution reading a clobbered tap table).  ``torch.cuda.use_mem_pool`` routes only the CURRENT thread's
     allocations, so the build runs on a helper thread."""
     if RECORD is None:
-        return fn()
+        out = fn()
+        # built by torch ops on torch's CURRENT stream, but its first reader may be a launch that on_stream() redirected to another stream (the zeroed counters
+        # of a weight-gradient stream's first split-K GEMM): finish the build before anyone is handed the tensor.  First use only - one host wait per table
+        if torch.cuda.is_available() and not torch._C._cuda_isCurrentStreamCapturing():
+            torch.cuda.current_stream().synchronize()
+        return out
     import threading
 
     box: list = []
@@ -1753,11 +1758,15 @@ def sparse_dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, w_shape: tuple, 
     ws = _workspace("sparse_wgrad", (need + 3) // 4, x.device)
     hidx = None
     if SPARSE_WGRAD_PIPE:
-        hidx = geom.halo_idx.get((kx, ky, kz))
-        if hidx is None:  # once per mask and kernel extent, on the stream of its first user (the weight-gradient stream: all users are ordered behind it)
+        hit = geom.halo_idx.get((kx, ky, kz))
+        if hit is None:  # once per mask and kernel extent, on the stream of its first user; a user on another stream (two weight-gradient streams) waits for it
             hidx = _empty(max(load().cinema_sparse_halo_ints(C.byref(geom), kx, ky, kz), 1), dtype=torch.int32, device=x.device)
             _check(load().cinema_sparse_halo_index(C.byref(geom), kx, ky, kz, hidx.data_ptr(), _stream()), "sparse_halo_index")
-            geom.halo_idx[(kx, ky, kz)] = hidx
+            geom.halo_idx[(kx, ky, kz)] = (hidx, _stream())
+        else:
+            hidx, built_on = hit
+            if built_on != _stream():
+                stream_fork(built_on, _stream())
     _check(load().cinema_sparse_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), need, C.byref(geom), c, kx, ky, kz,
                                                   _p(hidx), _stream()), "sparse_dwconv_bwd_weight")
 
