@@ -232,6 +232,10 @@ def _ranks_share_a_device() -> bool:
 # streams they run two at a time.  CINEMA_SIDE_STREAMS=1: one stream.
 SIDE_STREAMS = max(1, min(2, int(os.environ.get("CINEMA_SIDE_STREAMS", "1" if _ranks_share_a_device() else "2"))))
 _SIDE_ALT = [0]   # stream index of the last single weight-gradient launch (what depends on that launch goes to the same stream)
+# Accumulated destination (data pointer) -> the weight-gradient stream that last added into it during this backward pass.  A weight used more than once per step
+# (dec_linear: once per view) gets several read-modify-write launches on ONE buffer; dealt to different streams they ran at the same time and lost updates
+# (found by tests/test_ddp_gpu.py: ~1 run in 8 had dec_linear.weight's gradient off by 20 %, tools/ddp_first_step_probe.py) - they follow each other on one stream.
+_DST_STREAM: dict = {}
 
 
 _SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient launches still (possibly) running on the side stream
@@ -272,6 +276,7 @@ def join_side_stream(release: bool = False) -> None:
     if release:
         _SIDE_KEEP.clear()
         _LAX_KEEP.clear()
+        _DST_STREAM.clear()
 
 
 def mark_params(tape: "Tape", params: list) -> None:
@@ -636,7 +641,8 @@ def _wgrad8_launch(items: list) -> None:
         for it in items:
             if it[6] is not None:
                 K.colsum(it[5], it[6])
-    _wgrad_launch(run, *[t for it in items for t in (it[0], it[2], it[5]) if t is not None])
+    _wgrad_launch(run, *[t for it in items for t in (it[0], it[2], it[5]) if t is not None],
+                  keys=tuple(t.data_ptr() for it in items for t in (it[4], it[6]) if t is not None))
 
 
 def w_fp8_t(weight: torch.nn.Parameter) -> tuple | None:
@@ -796,7 +802,7 @@ def _split_k_conv(m_red: int, n_out: int, k_out: int) -> int:
     return max(1, min(want, (m_red + SPLITK_MIN_ROWS - 1) // SPLITK_MIN_ROWS))
 
 
-def _wgrad_launch(fn: Callable, *operands: torch.Tensor, alt: int = 0) -> None:
+def _wgrad_launch(fn: Callable, *operands: torch.Tensor, alt: int = 0, keys: tuple = ()) -> None:
     """Run a weight-gradient launch on the side stream (after everything queued on the main stream so far) or inline.  ``operands``
     are the activation / gradient tensors the launch reads: they were allocated on the main stream, so they are kept alive until the
     backward pass joins the side stream (a closure may drop its last reference right away and the allocator would reuse the memory)."""
@@ -805,6 +811,17 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor, alt: int = 0) -> None:
         if alt == 1 and SIDE_STREAMS > 1 and K.LANE is None:
             _SIDE_ALT[0] ^= 1
         idx = _SIDE_ALT[0] if (alt and SIDE_STREAMS > 1 and K.LANE is None) else 0
+        if SIDE_STREAMS > 1:
+            # ``keys``: the buffers this launch ADDS into.  One written earlier in this pass from the other stream: a single GEMM moves over to that stream;
+            # anything else (a re-layout tied to its GEMM's stream, a group) makes its stream wait for the other one first
+            prev = {_DST_STREAM[k] for k in keys if k in _DST_STREAM}
+            if alt == 1 and len(prev) == 1 and K.LANE is None:
+                idx = _SIDE_ALT[0] = prev.pop()
+            for other in prev:
+                if other != idx:
+                    K.stream_fork(side_stream(other).cuda_stream, side_stream(idx).cuda_stream)
+            for k in keys:
+                _DST_STREAM[k] = idx
         side = side_stream(idx).cuda_stream
         K.stream_fork(K._stream(), side)
         with K.on_stream(side):  # raw redirection: no torch stream context, no event objects (this runs ~200x per step)
@@ -872,7 +889,7 @@ def wgrad_group_end(tape: Tape) -> None:
 def _wgrad_single(dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias_grad: torch.Tensor | None) -> None:
     n, k = dy16.shape[1], x16.shape[1]
     _wgrad_launch(lambda: K.gemm(dy16, x16, a_kmajor=False, b_kmajor=False, out=dst, accumulate=True, split_k=_split_k(dy16.shape[0], n, k),
-                                 a_rowsum=bias_grad), dy16, x16, alt=1)
+                                 a_rowsum=bias_grad), dy16, x16, alt=1, keys=(dst.data_ptr(),) if bias_grad is None else (dst.data_ptr(), bias_grad.data_ptr()))
 
 
 def flush_wgrads(tape: Tape) -> None:
@@ -898,7 +915,8 @@ def _flush_wgrads(tape: Tape) -> None:
     step = P256_MAX_PROBLEMS if p256 else 8
     for i in range(0, len(probs), step):
         chunk = probs[i:i + step]
-        _wgrad_launch(lambda c=chunk: K.gemm_wgrad_grouped(c, p256=p256), *[t for dy, x, _, _ in chunk for t in (dy, x)])
+        _wgrad_launch(lambda c=chunk: K.gemm_wgrad_grouped(c, p256=p256), *[t for dy, x, _, _ in chunk for t in (dy, x)],
+                      keys=tuple(t.data_ptr() for _, _, d, b in chunk for t in (d, b) if t is not None))
 
 
 def wgrad_problem(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, dst: torch.Tensor, bias_grad: torch.Tensor | None) -> None:
@@ -931,9 +949,9 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
             and not getattr(tape, "grouping", False) and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)()):
         rows = wv.grad
         if tagged[0] == "convt":
-            _wgrad_launch(lambda: K.convt_weight_grad_accumulate(rows.contiguous(), flat.view(p.shape)), rows, alt=2)
+            _wgrad_launch(lambda: K.convt_weight_grad_accumulate(rows.contiguous(), flat.view(p.shape)), rows, alt=2, keys=(flat.data_ptr(),))
         else:
-            _wgrad_launch(lambda: K.patch_weight_grad_accumulate(rows.view(p.shape[0], -1), flat.view(p.shape), tagged[0]), rows, alt=2)
+            _wgrad_launch(lambda: K.patch_weight_grad_accumulate(rows.view(p.shape[0], -1), flat.view(p.shape), tagged[0]), rows, alt=2, keys=(flat.data_ptr(),))
         wv.grad = None
 
 
@@ -1463,7 +1481,8 @@ def op_sparse_dwconv(tape: Tape, x: Var, geom, weight: torch.nn.Parameter, bias:
             return
         c = x.data.shape[1]
         dw, db, dy = wv.grad_buffer(tuple(weight.shape)), None if bias is None else bv.grad_buffer((c,)), y.grad
-        _wgrad_launch(lambda: K.sparse_dwconv_bwd_weight(x.data, dy, tuple(weight.shape), dw, db, geom), x.data, dy, alt=1)  # off the critical path
+        _wgrad_launch(lambda: K.sparse_dwconv_bwd_weight(x.data, dy, tuple(weight.shape), dw, db, geom), x.data, dy, alt=1,
+                      keys=(dw.data_ptr(),) if db is None else (dw.data_ptr(), db.data_ptr()))  # off the critical path
         if x.needs_grad:
             x.add_grad(K.sparse_dwconv(y.grad, weight.detach(), None, geom, flip=True))
 
@@ -1543,14 +1562,14 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
                 K.conv_wgrad(dyz, xs, taps_z, coords, r, split, a_rowsum=rs, zb=zb_f, accumulate=False)
                 K.conv_wgrad_zfold(r, c_out, c, zb_f, dst, rs, db)
 
-            _wgrad_launch(launch, dyz, xs, *((r,) if rs is None else (r, rs)))
+            _wgrad_launch(launch, dyz, xs, *((r,) if rs is None else (r, rs)), keys=tuple(t.data_ptr() for t in (dst, db) if t is not None))
         elif weight.requires_grad and implicit:  # dW = dy^T im2col(x) with the column matrix gathered inside the GEMM (cinema_conv_wgrad_bf16)
             coords = const(("conv_coords", batch, tuple(spatial), str(dev)), lambda: K.conv_coord_table(batch, spatial, dev))
             dst = wv.grad_buffer(tuple(w16.shape), conv_same_grad_to_param(weight))
             db = bv.grad_buffer((c_out,)) if (bias is not None and bias.requires_grad) else None
             dyc = dy16.contiguous()
             split = _split_k_conv(dyc.shape[0], c_out, w16.shape[1])
-            _wgrad_launch(lambda: K.conv_wgrad(dyc, xs, taps, coords, dst, split, a_rowsum=db), dyc, xs)
+            _wgrad_launch(lambda: K.conv_wgrad(dyc, xs, taps, coords, dst, split, a_rowsum=db), dyc, xs, keys=tuple(t.data_ptr() for t in (dst, db) if t is not None))
         elif weight.requires_grad:
             wgrad(tape, dy16, K.im2col(xs, ks), wv, bv if (bias is not None and bias.requires_grad) else None, tuple(w16.shape),
                   conv_same_grad_to_param(weight))
@@ -1587,7 +1606,7 @@ def _op_conv1ch(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.nn
         db = bv.grad_buffer((weight.shape[0],)) if (bias is not None and bias.requires_grad) else None
         g = y.grad if y.grad.dtype == F32 else K.cast(y.grad, F32)
         if dw is not None or db is not None:
-            _wgrad_launch(lambda: K.conv1ch_bwd(xs, weight.detach(), g.contiguous(), dw, db, want_dx=False), xs, g)
+            _wgrad_launch(lambda: K.conv1ch_bwd(xs, weight.detach(), g.contiguous(), dw, db, want_dx=False), xs, g, keys=tuple(t.data_ptr() for t in (dw, db) if t is not None))
         if x.needs_grad:  # data gradient: dy @ w as one skinny MFMA GEMM + the mirrored gather (measured: 0.30 ms against 0.56-1.1 ms for a direct stencil)
             w16 = w_conv_same(weight)
             dcols = K.gemm(y.grad_bf16(), w16, a_kmajor=True, b_kmajor=False)
