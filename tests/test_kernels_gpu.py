@@ -1272,32 +1272,34 @@ def test_adamw_groups_one_launch_equals_one_launch_per_group() -> None:
 
 
 def test_shared_weight_gradient_launches_stay_on_one_stream(monkeypatch: pytest.MonkeyPatch) -> None:
-    """A weight used several times per step (dec_linear: once per view, cinema/mae/mae.py:486-493 of the reference applies one nn.Linear to every view) gets one
-    ACCUMULATING weight-gradient launch per use.  With two weight-gradient streams those must follow each other on one stream; dealt alternately they ran at the
-    same time and lost updates (round 5, found by tests/test_ddp_gpu.py).  Six uses of one buffer interleaved with launches for other buffers: the sum is bit-identical
-    to the one-stream schedule, on every repeat."""
+    """A weight used several times per step (dec_linear: the reference applies one nn.Linear to every view, cinema/mae/mae.py:486-493) gets one ACCUMULATING
+    weight-gradient launch per use.  With two weight-gradient streams those must follow each other on one stream; dealt alternately they ran at the same time
+    and lost updates (round 5, found by tests/test_ddp_gpu.py: dec_linear.weight's gradient 20 % off in ~1 run of 8).  Six uses of one buffer interleaved with
+    launches for other buffers, against the fp32 sum.  (Not bit-compared: the split-K reduce of a small output adds its slices with fp32 atomics, csrc/gemm.hip
+    splitk_reduce_body, so a non-zero destination is reproducible to 1 ulp only.)"""
     from cinema_amd import tape as T  # noqa: N812
 
     torch.manual_seed(0)
     m, n, k = 16384, 256, 768
     dys = [(torch.randn(m, n, device=DEV) * 0.1).bfloat16() for _ in range(6)]
     xs = [(torch.randn(m, k, device=DEV) * 0.1).bfloat16() for _ in range(6)]
-    results = {}
-    for streams in (1, 2, 2, 2, 2):
+    ref = sum(d.float().t() @ x.float() for d, x in zip(dys, xs))
+    bref = sum(d.float().sum(0) for d in dys)
+    for streams in (1, 2, 2, 2, 2, 2):
         monkeypatch.setattr(T, "SIDE_STREAMS", streams)
         shared, bias = torch.zeros(n, k, device=DEV), torch.zeros(n, device=DEV)
         others = [torch.zeros(n, k, device=DEV) for _ in range(6)]
         torch.cuda.synchronize()
         for i in range(6):
-            T._wgrad_single(dys[i], xs[i], shared, bias)            # noqa: SLF001
+            T._wgrad_single(dys[i], xs[i], shared, bias)               # noqa: SLF001
             T._wgrad_single(dys[i], xs[(i + 1) % 6], others[i], None)  # noqa: SLF001  (keeps the alternation going)
+        if streams == 2:
+            assert len(set(T._DST_STREAM.values())) == 2 and len(T._DST_STREAM) == 8  # noqa: SLF001  (both streams in use; shared + bias + six others)
         T.join_side_stream(release=True)
         torch.cuda.synchronize()
-        if streams == 1:
-            results = {"shared": shared, "bias": bias, "others": others}
-            ref = sum(d.float().t() @ x.float() for d, x in zip(dys, xs))
-            assert float((shared - ref).norm() / ref.norm()) < 2e-3
-        else:
-            assert torch.equal(shared, results["shared"]) and torch.equal(bias, results["bias"])
-            assert all(torch.equal(a, b) for a, b in zip(others, results["others"]))
+        assert float((shared - ref).norm() / ref.norm()) < 1e-4, streams
+        assert float((bias - bref).norm() / bref.norm()) < 1e-4, streams
+        for i, o in enumerate(others):
+            r = dys[i].float().t() @ xs[(i + 1) % 6].float()
+            assert float((o - r).norm() / r.norm()) < 1e-4
     assert not T._DST_STREAM  # noqa: SLF001  (cleared with the join at the end of a backward pass)
