@@ -356,6 +356,7 @@ def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids
     # ~95 backward tiny stem launches each go out zipped, one wide launch per position (hip.lanes; the views share nothing inside the stems)
     # ... and that group goes to a stream of its own, beside the short-axis stem's chain (tape.LAX_STREAM)
     T.run_in_lanes(tp, list(views), lambda v: stem_geometry(model, v, images, sels), stem, enabled=images[views[0]].is_cuda, beside=True)
+    T.update_join()  # everything from here on reads parameters the overlapped optimiser update may still be writing (optim.TrainStep(overlap_update=True))
     x = T.op_assemble(tp, batch * t_e, e, segs, dev)
     x = model.encoder.tape_forward(tp, x, batch)
     return x, skips_all, cls_rows, view_rows

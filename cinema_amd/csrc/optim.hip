@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void adamw_groups_kernel(AdamGroupsP q) {
 
 }  // namespace
 
-CINEMA_API int cinema_adamw_groups(float* p, const float* g, float* m, float* v, const cinema_adamw_group* groups, int n_groups, float beta1, float beta2, float eps,
-                                   const float* clip_coef, uint16_t* p_bf16, const int* step_state, void* stream) {
+CINEMA_API int cinema_adamw_groups_grid(float* p, const float* g, float* m, float* v, const cinema_adamw_group* groups, int n_groups, float beta1, float beta2,
+                                        float eps, const float* clip_coef, uint16_t* p_bf16, const int* step_state, int max_blocks, void* stream) {
   if (!p || !g || !m || !v || !groups || n_groups < 1 || n_groups > CINEMA_ADAMW_MAX_GROUPS || !clip_coef || !step_state) return CINEMA_ERR_BAD_ARG;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CINEMA_ERR_UNSUPPORTED;
   if (p_bf16 && (((uintptr_t)p_bf16) & 7)) return CINEMA_ERR_UNSUPPORTED;
@@ -157,9 +157,15 @@ CINEMA_API int cinema_adamw_groups(float* p, const float* g, float* m, float* v,
   q.total4 = q.first4[n_groups];
   if (q.total4 == 0) return 0;
   long long grid = (q.total4 + 255) / 256;
-  if (grid > 4096) grid = 4096;
+  const long long cap = max_blocks > 0 ? max_blocks : 4096;
+  if (grid > cap) grid = cap;
   CINEMA_LAUNCH(adamw_groups_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, q);
   return launch_status();
+}
+
+CINEMA_API int cinema_adamw_groups(float* p, const float* g, float* m, float* v, const cinema_adamw_group* groups, int n_groups, float beta1, float beta2, float eps,
+                                   const float* clip_coef, uint16_t* p_bf16, const int* step_state, void* stream) {
+  return cinema_adamw_groups_grid(p, g, m, v, groups, n_groups, beta1, beta2, eps, clip_coef, p_bf16, step_state, 0, stream);
 }
 
 CINEMA_API int cinema_sqnorm_f32(const float* g, long long n, float* out, float* workspace, void* stream) {

@@ -227,6 +227,7 @@ _PROTOS = {
     "cinema_clip_coef": [_vp, _f, _vp, _vp, _vp, _vp],
     "cinema_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
     "cinema_adamw_groups": [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
+    "cinema_adamw_groups_grid": [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _i, _vp],
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 FORCE_GENERIC = bool(int(os.environ.get("CINEMA_HIP_FORCE_GENERIC", "0")))
@@ -1967,13 +1968,18 @@ ADAMW_MAX_GROUPS = 64
 
 
 def adamw_groups(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, groups: list, beta1: float, beta2: float, eps: float,
-                 clip: torch.Tensor, shadow: torch.Tensor | None, step_state: torch.Tensor) -> None:
+                 clip: torch.Tensor, shadow: torch.Tensor | None, step_state: torch.Tensor, max_blocks: int = 0) -> None:
     """AdamW over several ranges of ONE flat buffer in one launch: ``groups`` = [(begin, end, lr, weight_decay), ...], ascending element ranges (multiples of 4).
+    ``max_blocks`` caps the number of workgroups (0: the library's default) for an update that shares the chip with another stream's work.
     Same arithmetic per element as :func:`adamw` with ``step_state`` (the layer-decay groups of a fine-tuning step: one launch instead of one per group)."""
     _dev(p, g, m, v, clip, shadow, step_state)
     arr = (AdamWGroup * len(groups))()
     for a, (b, e, lr, wd) in zip(arr, groups):
         a.begin, a.end, a.lr, a.weight_decay = int(b), int(e), float(lr), float(wd)
+    if max_blocks:
+        _check(load().cinema_adamw_groups_grid(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), arr, len(groups), beta1, beta2, eps, clip.data_ptr(),
+                                               _p(shadow), step_state.data_ptr(), int(max_blocks), _stream()), "adamw_groups_grid")
+        return
     _check(load().cinema_adamw_groups(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), arr, len(groups), beta1, beta2, eps, clip.data_ptr(), _p(shadow),
                                       step_state.data_ptr(), _stream()), "adamw_groups")
 

@@ -24,9 +24,9 @@ def pretrain_one_epoch(step: TrainStep, dataloader: Iterable, n_accum_steps: int
     tr = config.train
     batch_size_per_step = tr.batch_size_per_device * world_size
     n_iter = len(dataloader)
-    device = step.flat.flat_param.device
+    device = next(step.model.parameters()).device
     for i, batch in enumerate(dataloader):
-        lr = adjust_learning_rate(optimizer=step.optimizer, step=i / n_iter + epoch, warmup_steps=tr.n_warmup_epochs, max_n_steps=tr.n_epochs, lr=tr.lr,
+        lr = adjust_learning_rate(optimizer=step, step=i / n_iter + epoch, warmup_steps=tr.n_warmup_epochs, max_n_steps=tr.n_epochs, lr=tr.lr,
                                   min_lr=tr.min_lr)
         update_grad = (i + 1) % n_accum_steps == 0
         images = {k: v.to(device, non_blocking=True) for k, v in batch.items()}

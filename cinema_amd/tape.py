@@ -238,6 +238,33 @@ _SIDE_ALT = [0]   # stream index of the last single weight-gradient launch (what
 _DST_STREAM: dict = {}
 
 
+# The optimiser update of everything BUT the stems on a stream of its own (optim.TrainStep(overlap_update=True)): the next step's stems - a chain of small launches
+# that leaves most of the chip idle - run beside the HBM-bound AdamW pass over the encoder / decoder parameters; the main stream waits for that stream once,
+# between the stems and the token assembly (update_join, called by convvit.encode_views; part of a recorded step's launch list).
+_UPDATE_STREAMS: dict = {}
+
+
+def update_stream(create: bool = False) -> "torch.cuda.Stream | None":
+    dev = torch._C._cuda_getDevice()
+    st = _UPDATE_STREAMS.get(dev)
+    if st is None and create:
+        prio = os.environ.get("CINEMA_UPDATE_STREAM_PRIO")  # "low": the least priority the device offers (its workgroups are dispatched behind the main stream's)
+        if prio == "low":
+            st = torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[0])
+        else:
+            st = torch.cuda.Stream(device=dev)
+        _UPDATE_STREAMS[dev] = st
+    return st
+
+
+def update_join() -> None:
+    """The current stream waits for the update stream (the late part of the previous step's AdamW + zero_grad).  No-op when no TrainStep overlaps its update."""
+    if _UPDATE_STREAMS and torch.cuda.is_available() and not torch._C._cuda_isCurrentStreamCapturing():
+        st = update_stream()
+        if st is not None:
+            K.stream_fork(st.cuda_stream, K._stream())
+
+
 _SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient launches still (possibly) running on the side stream
 
 # The lane group of the long-axis stems on a THIRD stream (default; CINEMA_LAX_STREAM=0: on the main stream, after the short-axis stem): the stems are chains of

@@ -528,6 +528,10 @@ int cinema_adamw(float* p, const float* g, float* m, float* v, long long n, floa
 typedef struct { long long begin, end; float lr, weight_decay; } cinema_adamw_group;
 int cinema_adamw_groups(float* p, const float* g, float* m, float* v, const cinema_adamw_group* groups_host, int n_groups, float beta1, float beta2, float eps,
                         const float* clip_coef, uint16_t* p_bf16, const int* step_state, void* stream);
+/* ... with the number of workgroups capped at max_blocks (0: the default, 4096 x 256 threads, grid-stride): an update that runs BESIDE other work on another
+ * stream (cinema_amd/optim.py TrainStep(overlap_update=True): the next step's convolution stems) must not take every workgroup slot of the chip. */
+int cinema_adamw_groups_grid(float* p, const float* g, float* m, float* v, const cinema_adamw_group* groups_host, int n_groups, float beta1, float beta2, float eps,
+                             const float* clip_coef, uint16_t* p_bf16, const int* step_state, int max_blocks, void* stream);
 
 #ifdef __cplusplus
 }
