@@ -555,11 +555,13 @@ def main() -> None:
     for i in range(args.warmup):
         loss, gnorm, _ = step(batches[i % 2], 0.75)
     barrier()
+    k0 = K.kernel_launch_count()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, gnorm, _ = step(batches[i % 2], 0.75)
     barrier()
     dt = time.perf_counter() - t0
+    kernels_per_step = round((K.kernel_launch_count() - k0) / max(1, args.steps), 1)  # the library's own count over the timed steps (+ 1 torch fill: zero_grad)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -685,7 +687,10 @@ def main() -> None:
                                "visible voxels only - exact: masked voxels never reach a kept token (DESIGN.md 3a); CINEMA_DENSE_STEM=1 runs every voxel",
                        "dense_stem_ms_per_step": dense_ms, "peak_mem_gib": peak_gib,
                        "host": ("module code issues every launch (--eager)" if args.eager else
-                                f"forward+backward re-issued from a recorded list of {n_launches} HIP launches (cinema_amd/replay.py); clip+AdamW eager"),
+                                f"forward+backward re-issued from a recorded list of {n_launches} entries (cinema_amd/replay.py: kernel launches, stream forks / joins, "
+                                "lane-group markers - the entries of a lane group go out as ONE merged kernel per position); clip+AdamW eager"),
+                       # kernels handed to the HIP runtime per timed step, counted by the library (cinema_kernel_launch_count): whole step incl. clip + AdamW
+                       "kernel_launches_per_step": kernels_per_step,
                        # the REFERENCE's dense FLOP count per sample x samples/s: a reference-equivalent rate, not executed FLOPs
                        "reference_equiv_tflops_per_gpu": (None if ref_gflop is None else round(samples_per_s / world * ref_gflop / 1e3, 1))},
             "roofline": roofline,

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the CineMA MAE hot path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #define CINEMA_API extern "C" __attribute__((visibility("default")))
@@ -28,6 +29,8 @@ constexpr int MAX_LANES = 4;
 template <typename P>
 struct Lanes { P p[MAX_LANES]; };
 bool lanes_active();
+// kernels actually handed to the HIP runtime by this library (cinema_kernel_launch_count: a merged lane-group launch counts once, stream forks not at all)
+inline std::atomic<long long> g_kernel_launches{0};
 // Record (inside a lane group) or issue (outside) one launch.  `relaunch(fn_single, grid, block, smem, stream, params)` issues the single form from the
 // stored parameter bytes; fn_lanes (may be NULL) is the merged form taking Lanes<P> when the parameter bytes are ONE struct P.
 typedef int (*lane_relaunch_t)(const void* fn, dim3 grid, dim3 block, size_t smem, hipStream_t st, const void* params);
@@ -35,6 +38,7 @@ int lane_submit(lane_relaunch_t relaunch, const void* fn_single, const void* fn_
                 const void* params, size_t psize);
 inline int lane_relaunch_struct(const void* fn, dim3 grid, dim3 block, size_t smem, hipStream_t st, const void* params) {
   void* args[] = {const_cast<void*>(params)};
+  g_kernel_launches.fetch_add(1, std::memory_order_relaxed);
   return (int)hipLaunchKernel(fn, grid, block, args, smem, st);
 }
 // a kernel with ONE struct parameter and a lanes form: lane_dim 1 = blockIdx.y, 2 = blockIdx.z selects the lane (that grid dimension must be 1)
@@ -47,7 +51,10 @@ template <typename... A> struct ArgPack;
 template <> struct ArgPack<> {};
 template <typename H, typename... T> struct ArgPack<H, T...> { H h; ArgPack<T...> t; };
 template <typename... KA, typename... Done>
-inline void argpack_launch(void (*k)(KA...), dim3 g, dim3 b, size_t smem, hipStream_t st, const ArgPack<>&, Done... d) { hipLaunchKernelGGL(k, g, b, smem, st, d...); }
+inline void argpack_launch(void (*k)(KA...), dim3 g, dim3 b, size_t smem, hipStream_t st, const ArgPack<>&, Done... d) {
+  g_kernel_launches.fetch_add(1, std::memory_order_relaxed);
+  hipLaunchKernelGGL(k, g, b, smem, st, d...);
+}
 template <typename... KA, typename H, typename... T, typename... Done>
 inline void argpack_launch(void (*k)(KA...), dim3 g, dim3 b, size_t smem, hipStream_t st, const ArgPack<H, T...>& p, Done... d) {
   argpack_launch(k, g, b, smem, st, p.t, d..., p.h);
@@ -63,7 +70,11 @@ inline void argpack_fill(ArgPack<H, T...>& p, A0&& a0, A&&... a) { p.h = static_
 template <typename... KA, typename... A>
 inline void launch_any(void (*kernel)(KA...), dim3 g, dim3 b, size_t smem, hipStream_t st, A&&... a) {
   static_assert(sizeof...(KA) == sizeof...(A), "argument count");
-  if (!lanes_active()) { hipLaunchKernelGGL(kernel, g, b, smem, st, static_cast<KA>(a)...); return; }
+  if (!lanes_active()) {
+    g_kernel_launches.fetch_add(1, std::memory_order_relaxed);
+    hipLaunchKernelGGL(kernel, g, b, smem, st, static_cast<KA>(a)...);
+    return;
+  }
   ArgPack<KA...> pk;
   argpack_fill(pk, static_cast<A&&>(a)...);
   (void)lane_submit(lane_relaunch_pack<KA...>, (const void*)kernel, nullptr, 0, g, b, smem, st, &pk, sizeof(pk));

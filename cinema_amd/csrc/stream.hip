@@ -145,6 +145,7 @@ CINEMA_API int cinema_lanes_end(int* merged_out, int* single_out) {
       dim3 grid = d0.grid;
       if (d0.lane_dim == 1) grid.y = n; else grid.z = n;
       void* args[] = {(void*)buf.data()};
+      g_kernel_launches.fetch_add(1, std::memory_order_relaxed);
       const int e = (int)hipLaunchKernel(d0.fn_lanes, grid, d0.block, args, d0.smem, d0.st);
       if (e != 0 && rc == 0) rc = e;
       merged++;
@@ -210,6 +211,8 @@ CINEMA_API int cinema_marker_done(long long ticket) {
 namespace {
 __global__ void empty_kernel(int) {}
 }  // namespace
+
+CINEMA_API long long cinema_kernel_launch_count(void) { return g_kernel_launches.load(std::memory_order_relaxed); }
 
 CINEMA_API int cinema_launch_probe(int n, void* stream) {
   for (int i = 0; i < n; ++i) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, i);

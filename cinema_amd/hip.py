@@ -227,6 +227,7 @@ _PROTOS = {
     "cinema_clip_coef": [_vp, _f, _vp, _vp, _vp, _vp],
     "cinema_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
     "cinema_adamw_groups": [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
+    "cinema_kernel_launch_count": [],
     "cinema_adamw_groups_grid": [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _i, _vp],
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -241,7 +242,7 @@ def library_path() -> Path:
 # after it ran.  The arguments are plain ints / floats / ctypes structs, so the same launch can be issued again verbatim; host-only queries
 # (workspace sizes) and the completion markers are not part of a step's launch list.
 RECORD: list | None = None
-_NOT_REPLAYED = ("_workspace_bytes", "_nbr_ints", "_halo_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
+_NOT_REPLAYED = ("cinema_kernel_launch_count", "_workspace_bytes", "_nbr_ints", "_halo_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
 
 
 class _Entry:
@@ -281,7 +282,7 @@ def load():  # noqa: ANN201
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib.cdll, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints", "_halo_ints", "_marker_record")) else C.c_int
+        fn.restype = C.c_longlong if name.endswith(("_workspace_bytes", "_nbr_ints", "_halo_ints", "_marker_record", "_launch_count")) else C.c_int
         setattr(lib, name, _Entry(fn, not name.endswith(_NOT_REPLAYED)))
     _lib = lib
     return lib
@@ -1982,6 +1983,11 @@ def adamw_groups(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Ten
         return
     _check(load().cinema_adamw_groups(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), arr, len(groups), beta1, beta2, eps, clip.data_ptr(), _p(shadow),
                                       step_state.data_ptr(), _stream()), "adamw_groups")
+
+
+def kernel_launch_count() -> int:
+    """Kernels the library has launched since it was loaded (merged lane-group launches count once; stream forks are not kernels)."""
+    return int(load().cinema_kernel_launch_count())
 
 
 def info() -> dict:

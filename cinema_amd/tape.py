@@ -231,6 +231,27 @@ def _ranks_share_a_device() -> bool:
 # for the weight-gradient stream to work off ~20 small split-K GEMM + reduce pairs one after the other on an otherwise empty chip; dealt alternately to two
 # streams they run two at a time.  CINEMA_SIDE_STREAMS=1: one stream.
 SIDE_STREAMS = max(1, min(2, int(os.environ.get("CINEMA_SIDE_STREAMS", "1" if _ranks_share_a_device() else "2"))))
+
+
+class side_streams_limit:  # noqa: N801
+    """``with side_streams_limit(1):`` - at most n weight-gradient streams for the launches issued (or recorded) inside, unless CINEMA_SIDE_STREAMS is set explicitly.
+    The ConvUNetR step (BASELINE config 4) is 0.35 ms SLOWER with the second stream (46.86 / 46.92 vs 47.24 / 47.25 ms, profiles/r05_p_side_streams_ab.txt): its
+    implicit-convolution weight gradients already fill the chip beside the main stream, a third runnable queue only adds contention."""
+
+    def __init__(self, n: int) -> None:
+        self.n, self.saved = n, None
+
+    def __enter__(self) -> None:
+        global SIDE_STREAMS
+        self.saved = SIDE_STREAMS
+        if "CINEMA_SIDE_STREAMS" not in os.environ:
+            SIDE_STREAMS = max(1, min(SIDE_STREAMS, self.n))
+
+    def __exit__(self, *exc) -> None:  # noqa: ANN002
+        global SIDE_STREAMS
+        SIDE_STREAMS = self.saved
+
+
 _SIDE_ALT = [0]   # stream index of the last single weight-gradient launch (what depends on that launch goes to the same stream)
 # Accumulated destination (data pointer) -> the weight-gradient stream that last added into it during this backward pass.  A weight used more than once per step
 # (dec_linear: once per view) gets several read-modify-write launches on ONE buffer; dealt to different streams they ran at the same time and lost updates

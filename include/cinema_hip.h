@@ -439,6 +439,9 @@ int cinema_lanes_end(int* merged_out, int* single_out);
 int cinema_lanes_abort(void);
 long long cinema_marker_record(void* stream);
 int cinema_marker_done(long long ticket);
+/* Kernels this library has handed to the HIP runtime since it was loaded (a merged lane-group launch counts once; stream forks and markers are not kernels):
+ * bench.py reports the difference over the timed steps as config.kernel_launches_per_step. */
+long long cinema_kernel_launch_count(void);
 /* n back-to-back launches of an empty kernel (measures the host cost of one launch; used by tools/launch_rate.py and DESIGN.md section 5). */
 int cinema_launch_probe(int n, void* stream);
 /* grid x 4 waves x iters x 16 independent v_mfma_f32_32x32x16_bf16 from registers: the sustained rate of the matrix pipe alone
