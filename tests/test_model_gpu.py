@@ -30,7 +30,10 @@ from cinema_amd.vit import get_vit_config  # noqa: E402
 from conftest import load_golden  # noqa: E402
 
 DEV = "cuda"
-LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-3, 5e-2, 6e-2, 12e-2   # mini goldens (see the table above)
+LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-3, 5e-2, 6e-2, 12e-2   # default gates (the mini goldens carry their own, below)
+# mini goldens (16 / 32-channel stems, 8- and 16-wide heads: everything below the MFMA tile sizes), 1.6 x the round-5 measurement of the worst tensor - always a
+# LayerNorm / bias vector of a long-axis stem: plain + self-attention 2.8 % rel-L2 / 3.4 % max-abs, norm_target (gradients scaled by 1 / patch std) 4.9 % / 6.9 %
+MINI_GATES = {"mini_4view": (4.6e-2, 5.5e-2), "mini_4view_selfattn": (4.6e-2, 5.5e-2), "mini_4view_normtarget": (7.8e-2, 11e-2)}
 TINY_GRAD_L2, TINY_GRAD_MAX = 2.5e-2, 2.5e-2                          # cfg 1: measured 0.75 % / 0.73 %
 MID_GRAD_L2, MID_GRAD_MAX = 5.5e-2, 10e-2                             # MFMA-sized models: measured 1.7 % / 3.3 %
 # config-2 real-shape first-step parity (test_base_4view_192_first_step_vs_oracle) = 3 x measured (6.9e-4, 1.2e-3, 5.7e-4, 0.79 %, 1.76 %)
@@ -107,7 +110,7 @@ def test_mini_4view_vs_reference_golden(name: str, kw: dict) -> None:
     model.load_state_dict(split(load_golden("mini_4view.safetensors"), "param/"))
     model.to(DEV)
     check_against(model, split(g, "image/"), {k: v.bool() for k, v in split(g, "mask/").items()}, g["loss"][0], split(g, "pred/"),
-                  {k: v[0] for k, v in split(g, "metric/").items()}, split(g, "grad/"))
+                  {k: v[0] for k, v in split(g, "metric/").items()}, split(g, "grad/"), grad_l2=MINI_GATES[name][0], grad_max=MINI_GATES[name][1])
 
 
 def test_mini_feature_forward_vs_reference_golden() -> None:
