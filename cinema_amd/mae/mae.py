@@ -173,12 +173,12 @@ class CineMA(nn.Module):
 
         if self.cross_attn:
             t_q, t_k = 1 + sum(n_drop), sum(n_keep)
-            q_segs, k_segs, mask_rows = [T.Segment(rows_of(t_q, 0, 1), src=z_cls)], [], {}
+            q_segs, k_segs, mask_rows = [T.Segment(rows_of(t_q, 0, 1), src=z_cls, grad_bf16=True)], [], {}
             offq, offk = 1, 0
             for v, nk, nd in zip(views, n_keep, n_drop):
                 emb = self.dec_embed_dict[v]
                 pe = emb.pos_embed.detach().reshape(-1, d)
-                k_segs.append(T.Segment(rows_of(t_k, offk, nk), src=z_views[v], add=pe, add_idx=sels[v].keep_pos))
+                k_segs.append(T.Segment(rows_of(t_k, offk, nk), src=z_views[v], add=pe, add_idx=sels[v].keep_pos, grad_bf16=True))
                 mask_rows[v] = rows_of(t_q, offq, nd)
                 if nd > 0:
                     q_segs.append(T.Segment(mask_rows[v], src=emb.mask_token, add=pe, add_idx=sels[v].drop_pos))
@@ -187,11 +187,11 @@ class CineMA(nn.Module):
             x_k = T.op_cast_bf16(tp, T.op_assemble(tp, batch * t_k, d, k_segs, dev))
         else:
             t_q = 1 + sum(n_keep) + sum(n_drop)
-            q_segs, mask_rows = [T.Segment(rows_of(t_q, 0, 1), src=z_cls)], {}
+            q_segs, mask_rows = [T.Segment(rows_of(t_q, 0, 1), src=z_cls, grad_bf16=True)], {}
             off = 1
             for v, nk in zip(views, n_keep):
                 pe = self.dec_embed_dict[v].pos_embed.detach().reshape(-1, d)
-                q_segs.append(T.Segment(rows_of(t_q, off, nk), src=z_views[v], add=pe, add_idx=sels[v].keep_pos))
+                q_segs.append(T.Segment(rows_of(t_q, off, nk), src=z_views[v], add=pe, add_idx=sels[v].keep_pos, grad_bf16=True))
                 off += nk
             for v, nd in zip(views, n_drop):
                 emb = self.dec_embed_dict[v]
@@ -212,7 +212,11 @@ class CineMA(nn.Module):
             chans = img.shape[1]
             patch = self.dec_patch_size_dict[v]
             stats = T.zeros(2, torch.float32, dev)
-            K.patch_stats(img, K.patch_geom(batch, chans, grids[v], patch, tuple(img.stride())), stats)
+            pgeom = K.patch_geom(batch, chans, grids[v], patch, tuple(img.stride()))
+            if T.GLUE_TRIMS and img.is_cuda and K.LANE is None:  # metrics only: beside the head GEMM, on the (idle) weight-gradient stream; joined below
+                T._wgrad_launch(lambda: K.patch_stats(img, pgeom, stats), img, stats)  # noqa: SLF001
+            else:
+                K.patch_stats(img, pgeom, stats)
             metrics[f"{v}_target_mean"], metrics[f"{v}_target_std"] = stats[0], stats[1]
             if v not in dec_parts:
                 preds[v] = T.Var(torch.empty((0, math.prod(patch) * chans), dtype=torch.float32, device=dev), needs_grad=False)
@@ -235,6 +239,8 @@ class CineMA(nn.Module):
         metrics = {k: metrics[k] for v in views for k in metrics if k.startswith(f"{v}_")}
         losses = [loss_of[v] for v in views]
         loss = T.op_mean_finite(tp, losses)
+        if T.GLUE_TRIMS and dev.type == "cuda":
+            T.join_side_stream()  # (the target statistics above: a reader of the metrics after the forward pass sees them complete)
         return loss, preds, metrics
 
     def draw_masks(self, image_dict: dict, enc_mask_ratio: float) -> tuple:

@@ -31,7 +31,7 @@ class Var:
     gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
     """
 
-    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site", "fp8t", "grad8_bias", "grad8_bias_done")
+    __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site", "fp8t", "grad8_bias", "grad8_bias_done", "grad_any")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = True) -> None:
         self.data = data
@@ -44,6 +44,7 @@ class Var:
         self.fp8t = None  # (e4m3 copy, per-tensor scale [1]) of a tensor several ops read (the decoder's shared keys): made once by the first of them
         self.grad8_bias = None  # the bias Parameter of the projection that produced this tensor: the LayerNorm backward that writes grad8 also sums the columns of the gradient
         self.grad8_bias_done = False  # ... and says so here (the projection's own backward then adds no bias gradient)
+        self.grad_any = False  # the producer's backward reads the gradient in either dtype (op_assemble: a gather + column sums): a bf16 gradient needs no fp32 copy
 
     def add_grad(self, g: torch.Tensor, g16: torch.Tensor | None = None) -> None:
         if not self.needs_grad:
@@ -894,6 +895,10 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor, alt: int = 0, keys: tup
 # 32.39 ms): the group can only be issued at the end of the block's backward and its 432 workgroups each run for 160 us, so the side
 # stream no longer fills the main stream's idle slots early and the main stream's kernels wait for slots behind long tiles.  Opt-in.
 # Groups that would leave the slots mostly empty (decoder blocks: 192 tiles) keep the per-GEMM split-K path either way.
+# Round-5 glue trims around the loss and the token assembly (A/B switch): token-parameter gradients (mask_token column sums) on the weight-gradient stream, the
+# target statistics of the metrics on that stream beside the prediction heads, the MSE gradient handed over in bf16 (it was cast to fp32 and back), one
+# launch for the per-view loss weights, assembled-row gradients gathered straight into bf16 where their only reader is a GEMM.
+GLUE_TRIMS = bool(int(os.environ.get("CINEMA_GLUE_TRIMS", "1")))
 EARLY_RELAYOUT = bool(int(os.environ.get("CINEMA_EARLY_RELAYOUT", "1")))  # kernel-layout weight gradients folded into the flat buffer right behind their GEMM (0: at the end of the backward pass)
 GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "2"))  # 1: whole-K 128x128 tiles (cinema_gemm_bf16_grouped), 2: persistent 256x256 kernel, k-slices finished in the launch
 # LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
@@ -1479,7 +1484,10 @@ def op_cast_bf16(tape: Tape, x: Var) -> Var:
 
     def bwd() -> None:
         if y.grad is not None and x.needs_grad:
-            x.add_grad(K.cast(y.grad, F32))
+            if GLUE_TRIMS and x.grad_any and x.grad is None:
+                x.add_grad(y.grad)  # (the decoder's assembled keys: 5.6 M elements that were cast to fp32 only to be gathered and cast back)
+            else:
+                x.add_grad(K.cast(y.grad, F32))
 
     tape.record(bwd)
     return y
@@ -1812,8 +1820,11 @@ class Segment:
     ``add`` is a constant table (frozen sin-cos positional embedding), indexed by ``add_idx``.
     """
 
-    def __init__(self, dst_idx: torch.Tensor, src=None, add: torch.Tensor | None = None, add_idx: torch.Tensor | None = None) -> None:  # noqa: ANN001
+    def __init__(self, dst_idx: torch.Tensor, src=None, add: torch.Tensor | None = None, add_idx: torch.Tensor | None = None,  # noqa: ANN001
+                 grad_bf16: bool = False) -> None:
         self.dst_idx, self.src, self.add, self.add_idx = dst_idx, src, add, add_idx
+        # the source's gradient is only ever read as a bf16 GEMM operand (an op_linear output with a single consumer): gather it as bf16, no cast pass later
+        self.grad_bf16 = grad_bf16
 
 
 def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.device) -> Var:
@@ -1832,6 +1843,7 @@ def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.d
             copies.append(dict(dst=out, src=None, dst_idx=s.dst_idx, add=s.add, add_idx=s.add_idx))
     K.row_copy_multi(copies)
     y = Var(out)
+    y.grad_any = True
 
     def bwd() -> None:
         if y.grad is None:
@@ -1840,11 +1852,15 @@ def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.d
         for s in segments:
             if isinstance(s.src, Var):
                 if s.src.needs_grad:
-                    g = K.empty((s.dst_idx.numel(), c), dtype=F32, device=device)
+                    g = K.empty((s.dst_idx.numel(), c), dtype=BF16 if (s.grad_bf16 and GLUE_TRIMS and s.src.grad is None) else F32, device=device)
                     gathers.append(dict(dst=g, src=y.grad, src_idx=s.dst_idx))
                     targets.append((s.src, g))
             elif s.src is not None and s.src.requires_grad:
-                K.colsum(y.grad, tape.pvar(s.src).grad_buffer((c,)), row_idx=s.dst_idx)
+                buf, yg, idx = tape.pvar(s.src).grad_buffer((c,)), y.grad, s.dst_idx
+                if GLUE_TRIMS and yg.is_cuda:  # a leaf gradient: nothing in the backward chain waits for it
+                    _wgrad_launch(lambda buf=buf, yg=yg, idx=idx: K.colsum(yg, buf, row_idx=idx), yg, keys=(buf.data_ptr(),))
+                else:
+                    K.colsum(yg, buf, row_idx=idx)
         K.row_copy_multi(gathers)
         for var, g in targets:
             var.add_grad(g)
@@ -1864,7 +1880,8 @@ def op_mse(tape: Tape, pred: Var, image: torch.Tensor, geom_masked, norm_target:
         if y.grad is None or not pred.needs_grad:
             return
         d = K.mse_bwd(image, geom_masked, pred.data, norm_target, eps, y.grad, 1.0 / pred.data.numel())
-        pred.add_grad(d if pred.data.dtype == BF16 else K.cast(d, F32))
+        # (the prediction head's backward reads the gradient as a bf16 GEMM operand only: no fp32 copy)
+        pred.add_grad(d if (pred.data.dtype == BF16 or (GLUE_TRIMS and pred.grad is None)) else K.cast(d, F32))
 
     tape.record(bwd)
     return y, maxes  # maxes: (normed_target_max, pred_max) metrics of the norm_target mode (mae.py:146-150), else None
@@ -1881,6 +1898,11 @@ def op_mean_finite(tape: Tape, losses: list) -> Var:
 
     def bwd() -> None:
         if y.grad is None:
+            return
+        if GLUE_TRIMS:
+            gs = K.mul_scalar(coef, y.grad.reshape(1))  # d loss / d loss_i = coef[i] * upstream, all views in one launch
+            for i, lv in enumerate(losses):
+                lv.add_grad(gs[i:i + 1])
             return
         for i, lv in enumerate(losses):
             lv.add_grad(K.mul_scalar(coef[i:i + 1], y.grad.reshape(1)))  # d loss / d loss_i = coef[i] * upstream
