@@ -881,3 +881,18 @@ def test_overlapped_update_walks_the_same_trajectory(replay: bool) -> None:
         assert float((a.float() - b.float()).abs().max()) <= 2e-5  # (fp32 atomics in the bias-gradient row sums reorder between runs)
     assert out[True][4] == 0.0  # zero_grad ran behind both halves
     assert T.update_stream() is not None
+
+
+def test_replayed_step_is_reproducible_at_the_real_shape() -> None:
+    """tools/replay_race_full.py: the recorded config-2 step (ViT-Base, 4 views, batch 16) replayed 12 times on identical inputs and masks - every parameter's gradient
+    agrees with the first replay's to atomics noise.  With kernels of the real durations on the main, long-axis and two weight-gradient streams, two accumulating
+    launches on one buffer running at the same time (round 5: dec_linear, one launch per view) show as a per-cent difference (`--break` re-introduces that bug:
+    dec_linear.weight 69 % off, profiles/r05_aa_replay_race_hunt.txt)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tools" / "replay_race_full.py"), "12"], capture_output=True, text=True, timeout=280, check=False)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("REPLAY RACE HUNT")]
+    assert line and line[-1].endswith("clean"), (out.stdout[-600:], out.stderr[-600:])
