@@ -524,7 +524,7 @@ def main() -> None:
     elif args.force_sync:  # one-process RCCL group: runs the overlapped all-reduce schedule on one GPU (path check, not a metric)
         os.environ.setdefault("MASTER_PORT", "29533")
         ddp_setup(0, 1, backend="nccl")
-        sync = GradientSynchronizer(1, force_collectives=True)
+        sync = GradientSynchronizer(1, force_collectives=True, exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32, algorithm=args.exchange)
 
     if args.task == "seg":
         seg_main(args, rank, world, device, sync)
@@ -606,6 +606,10 @@ def main() -> None:
                     "exposed_comm_ms": round(exposed, 3), "unoverlapped_comm_ms": round(total_comm, 3),
                     "hidden_fraction": (round(1.0 - exposed / total_comm, 3) if total_comm > 0 else None),
                     "how": "8 steps per mode after the timed region, max over ranks; per-collective kernel overlap: tools/rccl_overlap.py on a rocprofv3 kernel trace"}
+    if world == 1 and args.force_sync and sync is not None:  # one-rank RCCL path check: what was issued in the last timed step
+        ddp_info = {"n_ranks_seen": 1, "backend": dist.get_backend(), "exchange_dtype": args.grad_exchange, "exchange_algorithm": args.exchange,
+                    "collectives_per_step": sync.n_collectives_last, "early_collectives_per_step": sync.n_early_last, "payload_bytes_per_step": sync.bytes_last,
+                    "what": "--force-sync: a one-rank process group on RCCL; the overlapped schedule of the N > 1 step is issued, the mean is the identity"}
     # forward GFLOP of the reference graph x 3 (SURVEY appendix A probes): config 2 and config 5 shapes only
     ref_gflop = {("base", "192,192,16", "192,192"): STEP_GFLOP_PER_SAMPLE, ("large", "256,256,24", "256,256"): 3 * 1806.7}.get((args.size, args.sax, args.lax))
     step.replay = False  # the information-only runs below (dense stem, per-launch events) go through the module code

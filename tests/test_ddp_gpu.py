@@ -159,3 +159,28 @@ def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str, algorit
     assert ddp["exchange_algorithm"] == algorithm and isinstance(ddp["rccl_env"], dict)
     assert ddp["collectives_per_step"] >= (2 if algorithm == "rs_ag" else 1) * ddp["early_collectives_per_step"]
     assert all(ddp[k] > 0 for k in ("ms_per_step_overlapped", "ms_per_step_exchange_after_backward", "ms_per_step_no_exchange"))
+
+
+@pytest.mark.parametrize(("exchange", "algorithm"), [("fp32", "all_reduce"), ("bf16", "rs_ag")])
+def test_bench_one_rank_over_rccl_issues_the_overlapped_collectives(exchange: str, algorithm: str) -> None:
+    """``bench.py --force-sync``: a ONE-rank process group on the real RCCL backend ("nccl") - the only way RCCL itself runs on a one-GPU box.  The overlapped per-block
+    collectives (all_reduce, and reduce_scatter_tensor + all_gather_into_tensor) are issued from the weight-gradient stream's hooks inside the replayed step exactly as
+    they are for N > 1; with one rank the mean is the identity, so the loss must equal the plain single-process run's."""
+    import json
+    import subprocess
+
+    def run(extra: list) -> dict:
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--prewarm", "1", "--batch", "2", "--cpu-budget", "0", "--profile-steps", "0", "--no-secondary", *extra]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, check=False, cwd=str(ROOT), env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+    plain = run([])
+    rccl = run(["--force-sync", "--grad-exchange", exchange, "--exchange", algorithm])
+    assert rccl["n_gpus"] == 1 and rccl["config"]["final_loss"] > 0
+    ddp = rccl["ddp"]
+    assert ddp["backend"] == "nccl" and ddp["exchange_algorithm"] == algorithm and ddp["early_collectives_per_step"] >= 2
+    assert ddp["collectives_per_step"] >= (ddp["early_collectives_per_step"] if exchange == "fp32" else 2)  # (bf16 payload: the early ranges are staged, few large collectives)
+    assert ddp["payload_bytes_per_step"] > 0
+    tol = 2e-3 if exchange == "bf16" else 1e-4  # (bf16 payload: the gradients are rounded once on the way through the exchange buffer)
+    assert abs(rccl["config"]["final_loss"] - plain["config"]["final_loss"]) <= tol * plain["config"]["final_loss"], (rccl["config"]["final_loss"], plain["config"]["final_loss"])
