@@ -464,6 +464,24 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
     return out
 
 
+def self_launch(n_gpus: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: re-run this command line under ``torch.distributed.run`` with N ranks on this node (rendezvous on
+    127.0.0.1, a free port) and hand back its exit code.  The children see WORLD_SIZE and take the ordinary path; their stdout (rank 0's one JSON line) and
+    stderr are this process' own."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes fails without it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -492,8 +510,12 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): become the launcher - one rank per GPU under torch.distributed.run, the same command line the
+        # driver documents (reference: cinema/mae/pretrain.py:441-448 spawns its ranks itself); rank 0's JSON line is this process' stdout
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus {args.gpus}`)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # path check of the multi-rank branch on a ONE-GPU box (dev only, never a metric): CINEMA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and

@@ -110,8 +110,9 @@ def test_two_rank_product_step_on_one_gpu(tmp_path: Path) -> None:
     assert all(math.isfinite(l) and math.isfinite(g) for l, g in b0["losses"])
 
 
-@pytest.mark.parametrize(("exchange", "algorithm"), [("fp32", "all_reduce"), ("bf16", "all_reduce"), ("fp32", "rs_ag")])
-def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str, algorithm: str) -> None:
+@pytest.mark.parametrize(("exchange", "algorithm", "launcher"), [("fp32", "all_reduce", "torchrun"), ("bf16", "all_reduce", "torchrun"), ("fp32", "rs_ag", "torchrun"),
+                                                                 ("fp32", "all_reduce", "plain")])
+def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str, algorithm: str, launcher: str) -> None:
     """``bench.py --gpus 2`` exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2``), with both ranks on the
     one leased GPU and gloo as the transport (dev overrides CINEMA_BENCH_SHARE_GPU / CINEMA_BENCH_BACKEND: RCCL refuses two ranks on one device; the rank
     environment, barrier, max-over-ranks timing, rank-0 JSON line, replayed step + GradientSynchronizer are the product's).  Checks the JSON contract of the
@@ -127,8 +128,12 @@ def test_bench_two_ranks_on_one_gpu_reports_the_ddp_block(exchange: str, algorit
     import bench
 
     env = dict(os.environ, CINEMA_BENCH_SHARE_GPU="1", CINEMA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(get_free_port()),
-           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "1", "--batch", "2", "--cpu-budget", "0", "--grad-exchange", exchange, "--exchange", algorithm]
+    # launcher "plain": `python bench.py --gpus 2` with no launcher and no rank environment (the form the driver's BENCH command uses): bench.py re-executes itself
+    # under torch.distributed.run (bench.self_launch)
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")} if launcher == "plain" else env
+    head = [sys.executable] if launcher == "plain" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                         "--master-port", str(get_free_port())]
+    cmd = [*head, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "1", "--batch", "2", "--cpu-budget", "0", "--grad-exchange", exchange, "--exchange", algorithm]
     import signal
     import tempfile
 

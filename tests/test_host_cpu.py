@@ -575,3 +575,18 @@ def test_fp8_sites_belong_to_the_parameter_object_and_slots_are_recycled() -> No
         del gen, q
         gc.collect()
     assert reg.n_alloc <= 2 + 80 and len(reg.live) == 1 and keep
+
+
+def test_bench_gpus_n_without_a_launcher_launches_its_own_ranks(tmp_path: Path) -> None:
+    """``python bench.py --gpus 2`` with no rank environment (the driver's command form) must not die on a launch convention: it re-executes itself under
+    ``torch.distributed.run`` with two ranks.  Here (no GPU) each rank stops at the "needs an MI355X" check - which proves that two ranks were started with
+    WORLD_SIZE=2 and reached ``main()`` past the WORLD_SIZE test."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=280, check=False,
+                         cwd=str(tmp_path), env=env)
+    assert out.returncode != 0
+    assert "WORLD_SIZE=1" not in out.stderr and "launch with torch.distributed.run" not in out.stderr, out.stderr[-2000:]
+    assert out.stderr.count("bench.py needs an MI355X") >= 2, out.stderr[-2000:]
