@@ -120,7 +120,9 @@ class GradientSynchronizer:
                 stage = t.to(torch.bfloat16)
             self._staged.append((t, stage))
             t = stage
-        if self.algorithm == "rs_ag" and self.world_size > 1:
+        if self.algorithm == "rs_ag" and (self.world_size > 1 or self.force):
+            # (forced one-rank group, bench.py --force-sync: s = numel, the shard IS the range - the RCCL branch below, with its in-place reduce-scatter whose output
+            # aliases its input and the all-gather queued behind it without a wait, is what runs on a one-GPU box)
             self._launch_rs_ag(t, op)
         else:
             self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))

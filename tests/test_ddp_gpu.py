@@ -186,6 +186,8 @@ def test_bench_one_rank_over_rccl_issues_the_overlapped_collectives(exchange: st
     ddp = rccl["ddp"]
     assert ddp["backend"] == "nccl" and ddp["exchange_algorithm"] == algorithm and ddp["early_collectives_per_step"] >= 2
     assert ddp["collectives_per_step"] >= (ddp["early_collectives_per_step"] if exchange == "fp32" else 2)  # (bf16 payload: the early ranges are staged, few large collectives)
+    if algorithm == "rs_ag":  # every range really went out as reduce_scatter_tensor + all_gather_into_tensor on RCCL (two collectives per range, none as a plain all_reduce)
+        assert ddp["collectives_per_step"] % 2 == 0 and ddp["collectives_per_step"] >= 2 * ddp["early_collectives_per_step"], ddp
     assert ddp["payload_bytes_per_step"] > 0
     tol = 2e-3 if exchange == "bf16" else 1e-4  # (bf16 payload: the gradients are rounded once on the way through the exchange buffer)
     assert abs(rccl["config"]["final_loss"] - plain["config"]["final_loss"]) <= tol * plain["config"]["final_loss"], (rccl["config"]["final_loss"], plain["config"]["final_loss"])
