@@ -123,6 +123,12 @@ class SparseGeom(C.Structure):
     ]
 
 
+class StemWgradProblem(C.Structure):
+    """Mirror of ``cinema_stem_wgrad_problem``."""
+
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("rows", C.c_int), ("n", C.c_int), ("k", C.c_int)]
+
+
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 _PROTOS = {
     "cinema_hip_info": [C.POINTER(C.c_int)],
@@ -169,6 +175,15 @@ _PROTOS = {
     "cinema_sparse_halo_ints": [C.POINTER(SparseGeom), _i, _i, _i],
     "cinema_sparse_halo_index": [C.POINTER(SparseGeom), _i, _i, _i, _vp, _vp],
     "cinema_sparse_dwconv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i],
+    "cinema_stem_supported": [_i],
+    "cinema_stem_partials": [_i],
+    "cinema_stem_ln_linear": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "cinema_stem_mlp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "cinema_stem_mlp_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_int), _vp],
+    "cinema_stem_ln_linear_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_int), _vp],
+    "cinema_stem_wgrad_slices": [_i],
+    "cinema_stem_wgrad_workspace_bytes": [C.POINTER(StemWgradProblem), _i],
+    "cinema_stem_wgrad": [C.POINTER(StemWgradProblem), _i, _vp, _ll, _vp],
     "cinema_patch_gather": [_vp, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_patch_scatter": [_vp, _i, _i, _vp, _i, _i, C.POINTER(PatchGeom), _vp],
     "cinema_row_copy": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
@@ -242,7 +257,7 @@ def library_path() -> Path:
 # after it ran.  The arguments are plain ints / floats / ctypes structs, so the same launch can be issued again verbatim; host-only queries
 # (workspace sizes) and the completion markers are not part of a step's launch list.
 RECORD: list | None = None
-_NOT_REPLAYED = ("cinema_kernel_launch_count", "_workspace_bytes", "_nbr_ints", "_halo_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
+_NOT_REPLAYED = ("cinema_kernel_launch_count", "cinema_stem_supported", "cinema_stem_partials", "cinema_stem_wgrad_slices", "_workspace_bytes", "_nbr_ints", "_halo_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
 
 
 class _Entry:
@@ -1771,6 +1786,99 @@ def sparse_dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, w_shape: tuple, 
                 stream_fork(built_on, _stream())
     _check(load().cinema_sparse_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), need, C.byref(geom), c, kx, ky, kz,
                                                   _p(hidx), _stream()), "sparse_dwconv_bwd_weight")
+
+
+# ---- fused per-voxel halves of a MaskedConvBlock on compact rows (csrc/stem.hip) -------------------------------------------------------------------
+def stem_supported(c: int, hidden: int) -> bool:
+    return c in (64, 128) and hidden == 4 * c
+
+
+def _stem_rows(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
+    if t.dtype != dtype or t.dim() != 2 or not t.is_contiguous():
+        raise HipLibraryError(f"stem kernels: {name} must be dense 2-D {dtype}, got {t.dtype} {tuple(t.shape)} strides {t.stride()}")
+
+
+def stem_ln_linear(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w16: torch.Tensor, bias: torch.Tensor | None, want_xn: bool = True) -> tuple:
+    """-> (xn = LN(x) bf16 | None, h = xn w^T + bias bf16); x fp32 [rows, c], w16 bf16 [c, c]."""
+    _dev(x, gamma, beta, w16, bias)
+    _stem_rows(x, torch.float32, "x")
+    _stem_rows(w16, torch.bfloat16, "w16")
+    rows, c = x.shape
+    xn = _empty((rows, c), dtype=torch.bfloat16, device=x.device) if want_xn else None
+    h = _empty((rows, c), dtype=torch.bfloat16, device=x.device)
+    _check(load().cinema_stem_ln_linear(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w16.data_ptr(), _p(bias), _p(xn), h.data_ptr(), rows, c, _stream()), "stem_ln_linear")
+    return xn, h
+
+
+def stem_mlp_fwd(d: torch.Tensor, x: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, wf1: torch.Tensor,
+                 bf1: torch.Tensor, wf2: torch.Tensor, bf2: torch.Tensor, want_x1: bool = True) -> tuple:
+    """-> (x1 = x + d w2^T + b2 | None, x2 = x1 + fc2(GELU(fc1(LN(x1))))); d bf16, x fp32 [rows, c]; weights bf16 in nn.Linear layout."""
+    _dev(d, x, w2, b2, gamma, beta, wf1, bf1, wf2, bf2)
+    _stem_rows(d, torch.bfloat16, "d")
+    _stem_rows(x, torch.float32, "x")
+    for n, t in (("w2", w2), ("wf1", wf1), ("wf2", wf2)):
+        _stem_rows(t, torch.bfloat16, n)
+    rows, c = x.shape
+    x1 = _empty((rows, c), dtype=torch.float32, device=x.device) if want_x1 else None
+    x2 = _empty((rows, c), dtype=torch.float32, device=x.device)
+    _check(load().cinema_stem_mlp_fwd(d.data_ptr(), x.data_ptr(), w2.data_ptr(), b2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, wf1.data_ptr(), bf1.data_ptr(),
+                                      wf2.data_ptr(), bf2.data_ptr(), _p(x1), x2.data_ptr(), rows, c, _stream()), "stem_mlp_fwd")
+    return x1, x2
+
+
+def stem_mlp_bwd(g2: torch.Tensor, x1: torch.Tensor, w2: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, wf1: torch.Tensor, bf1: torch.Tensor,
+                 wf2: torch.Tensor) -> dict:
+    """Backward of :func:`stem_mlp_fwd` -> dict(dx1, dx1_16, dd, a, dz, xn2, g2_16, partials=(buffer, n_partials))."""
+    _dev(g2, x1, w2, gamma, beta, wf1, bf1, wf2)
+    _stem_rows(g2, torch.float32, "g2")
+    _stem_rows(x1, torch.float32, "x1")
+    rows, c = x1.shape
+    dev = x1.device
+    o = {"dx1": _empty((rows, c), dtype=torch.float32, device=dev)}
+    for k in ("dx1_16", "dd", "xn2", "g2_16"):
+        o[k] = _empty((rows, c), dtype=torch.bfloat16, device=dev)
+    for k in ("a", "dz"):
+        o[k] = _empty((rows, 4 * c), dtype=torch.bfloat16, device=dev)
+    part = _empty((load().cinema_stem_partials(rows), 2 * c), dtype=torch.float32, device=dev)
+    n_part = C.c_int(0)
+    _check(load().cinema_stem_mlp_bwd(g2.data_ptr(), x1.data_ptr(), w2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, wf1.data_ptr(), bf1.data_ptr(), wf2.data_ptr(),
+                                      o["dx1"].data_ptr(), o["dx1_16"].data_ptr(), o["dd"].data_ptr(), o["a"].data_ptr(), o["dz"].data_ptr(), o["xn2"].data_ptr(),
+                                      o["g2_16"].data_ptr(), part.data_ptr(), rows, c, C.byref(n_part), _stream()), "stem_mlp_bwd")
+    o["partials"] = (part, n_part.value)
+    return o
+
+
+def stem_ln_linear_bwd(dh: torch.Tensor, x: torch.Tensor, dres: torch.Tensor | None, gamma: torch.Tensor, eps: float, w16: torch.Tensor) -> tuple:
+    """Backward of :func:`stem_ln_linear` -> (dx = dres + LN'(x)(dh w) fp32, (partials, n_partials))."""
+    _dev(dh, x, dres, gamma, w16)
+    _stem_rows(dh, torch.bfloat16, "dh")
+    _stem_rows(x, torch.float32, "x")
+    if dres is not None:
+        _stem_rows(dres, torch.float32, "dres")
+    rows, c = x.shape
+    dx = _empty((rows, c), dtype=torch.float32, device=x.device)
+    part = _empty((load().cinema_stem_partials(rows), 2 * c), dtype=torch.float32, device=x.device)
+    n_part = C.c_int(0)
+    _check(load().cinema_stem_ln_linear_bwd(dh.data_ptr(), x.data_ptr(), _p(dres), gamma.data_ptr(), eps, w16.data_ptr(), dx.data_ptr(), part.data_ptr(), rows, c,
+                                            C.byref(n_part), _stream()), "stem_ln_linear_bwd")
+    return dx, (part, n_part.value)
+
+
+def stem_wgrad(problems: list) -> None:
+    """problems: (dy bf16 [rows, n], x bf16 [rows, k], dw fp32 [n, k] (accumulated), db fp32 [n] | None), at most 6 with one row count: one launch + one reduce."""
+    arr = (StemWgradProblem * len(problems))()
+    for e, (dy, x, dw, db) in zip(arr, problems):
+        _dev(dy, x, dw, db)
+        _stem_rows(dy, torch.bfloat16, "dy")
+        _stem_rows(x, torch.bfloat16, "x")
+        if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.numel() != dy.shape[1] * x.shape[1] or dy.shape[0] != x.shape[0]:
+            raise HipLibraryError("stem_wgrad: dw must be dense fp32 [n, k] for dy [rows, n], x [rows, k]")
+        e.dy, e.x, e.dw, e.db, e.rows, e.n, e.k = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), dy.shape[0], dy.shape[1], x.shape[1]
+    need = load().cinema_stem_wgrad_workspace_bytes(arr, len(problems))
+    if need <= 0:
+        raise HipLibraryError("stem_wgrad: unsupported problem list")
+    ws = _workspace("stem_wgrad", (need + 3) // 4, problems[0][0].device)
+    _check(load().cinema_stem_wgrad(arr, len(problems), ws.data_ptr(), need, _stream()), "stem_wgrad")
 
 
 def patch_geom(batch: int, chans: int, grid: tuple, patch: tuple, strides: tuple, token_idx: torch.Tensor | None = None,

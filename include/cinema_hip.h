@@ -301,6 +301,43 @@ int cinema_sparse_halo_index(const cinema_sparse_geom* geom, int kx, int ky, int
 long long cinema_sparse_dwconv_wgrad_workspace_bytes(int n_tok, int c, int kx, int ky, int kz);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Fused per-voxel halves of a MaskedConvBlock on compact rows [rows][c] (reference: cinema/conv.py:405-413
+ *   x = x + conv2(dw_conv(conv1(norm1(x)))) ; x = x + mlp(norm2(x)),  ConvLayerNorm cinema/conv.py:169-187 eps 1e-6,
+ *   ConvMlp cinema/conv.py:111-166 = fc1 -> exact GELU -> fc2 on 1x1 convolutions).  c in {64, 128} (cinema_stem_supported), hidden = 4 c.
+ * Weights are the bf16 operand shadows in nn.Linear layout [out][in]; biases / LayerNorm parameters fp32.  The depthwise conv between conv1 and conv2 stays
+ * cinema_sparse_dwconv_fwd.  In the forward pass the 4c-wide hidden activation of the MLP never leaves the registers (the unfused form wrote it and its
+ * GELU derivative to HBM); the backward pass recomputes it from the saved x1.
+ */
+int cinema_stem_supported(int c);
+/* xn = LN(x; gamma, beta) (bf16, may be NULL) and h = xn w^T + bias (bf16) */
+int cinema_stem_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const uint16_t* w, const float* bias, uint16_t* xn, uint16_t* h,
+                          int rows, int c, void* stream);
+/* x1 = x + d w2^T + b2 (fp32, may be NULL: not kept) ; x2 = x1 + fc2(GELU(fc1(LN(x1; gamma, beta)))) */
+int cinema_stem_mlp_fwd(const uint16_t* d, const float* x, const uint16_t* w2, const float* b2, const float* gamma, const float* beta, float eps, const uint16_t* wf1,
+                        const float* bf1, const uint16_t* wf2, const float* bf2, float* x1, float* x2, int rows, int c, void* stream);
+/* rows of LayerNorm parameter-gradient partials ([d gamma (c) | d beta (c)] each, the layout cinema_ln_param_reduce_batched sums) a backward call may write */
+int cinema_stem_partials(int rows);
+/* backward of cinema_stem_mlp_fwd from g2 = dL/dx2 and the saved x1: dx1 = dL/dx1 (fp32 and bf16), dd = dx1 w2 = dL/dd (bf16), and the operand pairs of the
+ * weight gradients - a = GELU(fc1 output) and dz = dL/d(fc1 output) ([rows][4c] bf16), xn2 = LN(x1), g2 in bf16; *n_partials_out rows of LN partials */
+int cinema_stem_mlp_bwd(const float* g2, const float* x1, const uint16_t* w2, const float* gamma, const float* beta, float eps, const uint16_t* wf1, const float* bf1,
+                        const uint16_t* wf2, float* dx1, uint16_t* dx1_16, uint16_t* dd, uint16_t* a, uint16_t* dz, uint16_t* xn2, uint16_t* g2_16, float* partials,
+                        int rows, int c, int* n_partials_out, void* stream);
+/* backward of cinema_stem_ln_linear: dx = dres + LN'(x)(dh w)  (dres = the residual gradient dL/dx1, may be NULL); LN partials as above */
+int cinema_stem_ln_linear_bwd(const uint16_t* dh, const float* x, const float* dres, const float* gamma, float eps, const uint16_t* w, float* dx, float* partials,
+                              int rows, int c, int* n_partials_out, void* stream);
+/* Weight gradients with small outputs over many rows (the 1x1 convolutions of the stem: reference autograd of cinema/conv.py:405-413):
+ *   dw[n][k] += sum_r dy[r][n] x[r][k],  db[n] += sum_r dy[r][n]   for up to 6 problems with the same row count in one launch + one ordered reduce.
+ * n, k multiples of 32, n + k <= 640, n k <= 64 K.  workspace >= cinema_stem_wgrad_workspace_bytes(...) bytes, contents irrelevant. */
+typedef struct {
+  const uint16_t* dy; const uint16_t* x;  /* bf16 [rows][n], [rows][k], dense */
+  float* dw; float* db;                   /* fp32 [n][k] dense, [n] or NULL */
+  int rows, n, k;
+} cinema_stem_wgrad_problem;
+int cinema_stem_wgrad_slices(int rows);
+long long cinema_stem_wgrad_workspace_bytes(const cinema_stem_wgrad_problem* probs, int count);
+int cinema_stem_wgrad(const cinema_stem_wgrad_problem* probs, int count, float* workspace, long long workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Non-overlapping patch gather / scatter (reference: patchify cinema/vit.py:67-161 and the im2col of the k==s
  * ConvNd layers cinema/convvit.py:94-102,252).  Source is addressed by element strides (sb, sc, sx, sy, sz) so both
  * channels-first images and channels-last feature maps work.  Output row = token (b, gx, gy, gz) raster order,
