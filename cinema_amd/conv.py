@@ -246,6 +246,9 @@ class MaskedConvBlock(nn.Module, _CkptFlag):
     def tape_forward_compact(self, tp: T.Tape, x: CompactVolume) -> CompactVolume:
         """The block on the visible voxels only: every row is visible, so the mask multiply disappears and the depthwise conv
         looks its neighbours up through the token rank map (masked neighbours contribute the zeros the reference multiplies in)."""
+        if T.stem_block_ok(x.var, x.chans, self.mlp.fc1.weight.shape[0]) and self.conv1.bias is not None and self.mlp.fc1.bias is not None:
+            # c = 64 / 128 (every released CineMA stem): the per-voxel halves of the block as fused kernels (csrc/stem.hip)
+            return CompactVolume(T.op_stem_block(tp, x.var, x.geom, self), x.n_tok, x.block, x.chans, x.geom, x.pos, x.inv_pos)
         xn = T.op_layernorm(tp, x.var, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h = T.op_linear(tp, xn, self.conv1.weight, self.conv1.bias)
         h = T.op_sparse_dwconv(tp, h, x.geom, self.dw_conv.weight, self.dw_conv.bias)

@@ -530,7 +530,7 @@ struct WgProb {
 };
 constexpr int WG_MAX = 6;
 struct WgP { WgProb pr[WG_MAX]; int count; float* slabs; int slab_floats; int n_slices; };
-constexpr int WG_RT = 32;              // rows per staging step (two k-steps of 16)
+constexpr int WG_RT = 64;              // rows per staging step (four k-steps of 16)
 constexpr int WG_MAX_PQ = 128 + 512;   // widest operand pair
 __device__ __forceinline__ short8v frag32_t(const char* lds, int pitch, int kr0, int col0, int lane) {  // 32x32x16 operand from a row-major [k][col] tile
   const int q4 = lane >> 4, t = lane & 15;
@@ -540,8 +540,9 @@ __device__ __forceinline__ short8v frag32_t(const char* lds, int pitch, int kr0,
   o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
   return o;
 }
-// MP x MQ 32x32 tiles per wave (P = the narrower operand)
-template <int MP, int MQ>
+// MP x MQ 32x32 tiles per wave (P = the narrower operand); RT rows per staging step.  The rows of step i + 1 are fetched into registers while step i is multiplied
+// out of LDS (the loop is bound by bytes in flight: the products are a few hundred cycles per step), widths are powers of two (index arithmetic by shifts).
+template <int MP, int MQ, int RT>
 __device__ __forceinline__ void wgrad_body(const WgP& q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WgProb& pr = q.pr[blockIdx.y];
@@ -552,7 +553,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
   const int np = swap ? pr.k : pr.n, nq = swap ? pr.n : pr.k;
   const int pp = 2 * np + 32, pq = 2 * nq + 32;        // LDS pitches (bytes)
   char* lp = smem;
-  char* lq = smem + WG_RT * pp;
+  char* lq = smem + RT * pp;
   const int tp = np >> 5, tq = nq >> 5;                // 32-wide tiles
   const int wp = tp >= 2 ? 2 : 1, wq = NW / wp;        // wave grid
   const int wpi = wave % wp, wqi = wave / wp;
@@ -565,46 +566,49 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
   float bsum = 0.f;                                     // column tid of dy
-  const bf16_t* dyt = swap ? Q : P;
   const char* ldy = swap ? lq : lp;
   const int pdy = swap ? pq : pp;
   const int per = (pr.rows + q.n_slices - 1) / q.n_slices;
-  const int rows_per = ((per + WG_RT - 1) / WG_RT) * WG_RT;
+  const int rows_per = ((per + RT - 1) / RT) * RT;
   const int r0 = blockIdx.x * rows_per, r1 = min(pr.rows, r0 + rows_per);
-  const int cp = np >> 3, cq = nq >> 3;                // 16-byte chunks per row
-  const int n_chunks = WG_RT * (cp + cq);
-  constexpr int NLD = (WG_RT * WG_MAX_PQ / 8 + NT - 1) / NT;
-  for (int rb = r0; rb < r1; rb += WG_RT) {
-    uint4 stg[NLD];
+  const int sp = __ffs(np >> 3) - 1, sq = __ffs(nq >> 3) - 1;   // log2 of the 16-byte chunks per row
+  const int n_p = RT << sp, n_chunks = n_p + (RT << sq);
+  constexpr int NLD = (RT * WG_MAX_PQ / 8 + NT - 1) / NT;
+  u4 stg[NLD];
+  auto fetch = [&](int rb) {
 #pragma unroll
     for (int u = 0; u < NLD; u++) {
       const int i = tid + u * NT;
-      stg[u] = make_uint4(0u, 0u, 0u, 0u);
+      stg[u] = u4{0u, 0u, 0u, 0u};
       if (i < n_chunks) {
-        const bool isq = i >= WG_RT * cp;
-        const int ii = isq ? i - WG_RT * cp : i, cw = isq ? cq : cp;
-        const int r = ii / cw, c = ii - r * cw;
-        if (rb + r < r1) stg[u] = *reinterpret_cast<const uint4*>((isq ? Q : P) + (size_t)(rb + r) * (isq ? nq : np) + c * 8);
+        const bool isq = i >= n_p;
+        const int ii = isq ? i - n_p : i, sh = isq ? sq : sp;
+        const int r = ii >> sh, c = ii & ((1 << sh) - 1);
+        if (rb + r < r1) stg[u] = *reinterpret_cast<const u4*>((isq ? Q : P) + ((size_t)(rb + r) << (sh + 3)) + c * 8);
       }
     }
+  };
+  if (r0 < r1) fetch(r0);
+  for (int rb = r0; rb < r1; rb += RT) {
     __syncthreads();   // the previous step's fragments have been read
 #pragma unroll
     for (int u = 0; u < NLD; u++) {
       const int i = tid + u * NT;
       if (i < n_chunks) {
-        const bool isq = i >= WG_RT * cp;
-        const int ii = isq ? i - WG_RT * cp : i, cw = isq ? cq : cp;
-        const int r = ii / cw, c = ii - r * cw;
-        *reinterpret_cast<uint4*>((isq ? lq : lp) + r * (isq ? pq : pp) + c * 16) = stg[u];
+        const bool isq = i >= n_p;
+        const int ii = isq ? i - n_p : i, sh = isq ? sq : sp;
+        const int r = ii >> sh, c = ii & ((1 << sh) - 1);
+        *reinterpret_cast<u4*>((isq ? lq : lp) + r * (isq ? pq : pp) + c * 16) = stg[u];
       }
     }
     __syncthreads();
+    if (rb + RT < r1) fetch(rb + RT);   // in flight while this step is multiplied
     if (pr.db && tid < pr.n) {
 #pragma unroll 8
-      for (int r = 0; r < WG_RT; r++) bsum += bf2f(*reinterpret_cast<const bf16_t*>(ldy + r * pdy + tid * 2));
+      for (int r = 0; r < RT; r++) bsum += bf2f(*reinterpret_cast<const bf16_t*>(ldy + r * pdy + tid * 2));
     }
 #pragma unroll
-    for (int ks = 0; ks < WG_RT / 16; ks++) {
+    for (int ks = 0; ks < RT / 16; ks++) {
       short8v fq[MQ];
 #pragma unroll
       for (int b = 0; b < MQ; b++)
@@ -638,24 +642,33 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
   }
   if (pr.db && tid < pr.n) slab[(size_t)pr.n * pr.k + tid] = bsum;
 }
-template <int MP, int MQ> __global__ __launch_bounds__(NT) void stem_wgrad_kernel(WgP q) { wgrad_body<MP, MQ>(q); }
-template <int MP, int MQ> __global__ __launch_bounds__(NT) void stem_wgrad_lanes_kernel(Lanes<WgP> L) { wgrad_body<MP, MQ>(L.p[blockIdx.z]); }
+template <int MP, int MQ, int RT> __global__ __launch_bounds__(NT) void stem_wgrad_kernel(WgP q) { wgrad_body<MP, MQ, RT>(q); }
+template <int MP, int MQ, int RT> __global__ __launch_bounds__(NT) void stem_wgrad_lanes_kernel(Lanes<WgP> L) { wgrad_body<MP, MQ, RT>(L.p[blockIdx.z]); }
 
-__device__ __forceinline__ void wgrad_reduce_body(const WgP& q) {
+__device__ __forceinline__ void wgrad_reduce_body(const WgP& q) {  // block = 32 elements x 8 slice groups
+  __shared__ float red[8][32];
   const WgProb& pr = q.pr[blockIdx.y];
   const int total = pr.n * pr.k + (pr.db ? pr.n : 0);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const float* s = q.slabs + pr.slab_off + i;
+  const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
+  if (blockIdx.x * 32 >= total) return;
+  const int per = (q.n_slices + 7) / 8, b0 = grp * per, b1 = min(q.n_slices, b0 + per);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int b = 0;
-  for (; b + 3 < q.n_slices; b += 4) {
-    a0 += s[(size_t)b * q.slab_floats]; a1 += s[(size_t)(b + 1) * q.slab_floats]; a2 += s[(size_t)(b + 2) * q.slab_floats]; a3 += s[(size_t)(b + 3) * q.slab_floats];
+  if (i < total) {
+    const float* s = q.slabs + pr.slab_off + i;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+      a0 += s[(size_t)b * q.slab_floats]; a1 += s[(size_t)(b + 1) * q.slab_floats]; a2 += s[(size_t)(b + 2) * q.slab_floats]; a3 += s[(size_t)(b + 3) * q.slab_floats];
+    }
+    for (; b < b1; b++) a0 += s[(size_t)b * q.slab_floats];
   }
-  for (; b < q.n_slices; b++) a0 += s[(size_t)b * q.slab_floats];
-  const float t = (a0 + a1) + (a2 + a3);
-  if (i < pr.n * pr.k) pr.dw[i] += t;
-  else pr.db[i - pr.n * pr.k] += t;
+  red[grp][e] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && i < total) {
+    const float t = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+    if (i < pr.n * pr.k) pr.dw[i] += t;
+    else pr.db[i - pr.n * pr.k] += t;
+  }
 }
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(WgP q) { wgrad_reduce_body(q); }
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_lanes_kernel(Lanes<WgP> L) { wgrad_reduce_body(L.p[blockIdx.z]); }
@@ -793,7 +806,7 @@ CINEMA_API int cinema_stem_wgrad(const cinema_stem_wgrad_problem* probs, int cou
   for (int i = 0; i < count; i++) {
     const cinema_stem_wgrad_problem& s = probs[i];
     if (!s.dy || !s.x || !s.dw || s.rows <= 0 || s.rows != probs[0].rows) return CINEMA_ERR_BAD_ARG;
-    if ((s.n & 31) || (s.k & 31) || s.n > 512 || s.k > 512 || s.n + s.k > WG_MAX_PQ) return CINEMA_ERR_UNSUPPORTED;
+    if ((s.n & (s.n - 1)) || (s.k & (s.k - 1)) || s.n < 32 || s.k < 32 || s.n > 512 || s.k > 512 || s.n + s.k > WG_MAX_PQ) return CINEMA_ERR_UNSUPPORTED;  // powers of two
     q.pr[i] = WgProb{s.dy, s.x, s.dw, s.db, s.rows, s.n, s.k, off};
     off += s.n * s.k + s.n;
     const int np = s.n < s.k ? s.n : s.k, nq = s.n < s.k ? s.k : s.n;
@@ -814,20 +827,21 @@ CINEMA_API int cinema_stem_wgrad(const cinema_stem_wgrad_problem* probs, int cou
   q.slab_floats = off;
   q.n_slices = cinema_stem_wgrad_slices(probs[0].rows);
   if (workspace_bytes < (long long)off * 4 * q.n_slices) return CINEMA_ERR_BAD_ARG;
-  const int lds = WG_RT * ((2 * max_np + 32) + (2 * max_nq + 32));
+  const bool big = !(mp <= 1 && mq <= 2);
+  const int lds = (big ? 32 : WG_RT) * ((2 * max_np + 32) + (2 * max_nq + 32));
   const dim3 grid(q.n_slices, count);
   hipStream_t st = (hipStream_t)stream;
-  if (mp <= 1 && mq <= 2) {
+  if (!big) {
     static bool f[16] = {};
-    if (set_lds(f, stem_wgrad_kernel<1, 2>, stem_wgrad_lanes_kernel<1, 2>, 64 * 1024)) return CINEMA_ERR_UNSUPPORTED;
-    launch_lanes(stem_wgrad_kernel<1, 2>, stem_wgrad_lanes_kernel<1, 2>, 2, grid, dim3(NT), lds, st, q);
+    if (set_lds(f, stem_wgrad_kernel<1, 2, WG_RT>, stem_wgrad_lanes_kernel<1, 2, WG_RT>, 96 * 1024)) return CINEMA_ERR_UNSUPPORTED;
+    launch_lanes(stem_wgrad_kernel<1, 2, WG_RT>, stem_wgrad_lanes_kernel<1, 2, WG_RT>, 2, grid, dim3(NT), lds, st, q);
   } else {
     static bool f[16] = {};
-    if (set_lds(f, stem_wgrad_kernel<2, 4>, stem_wgrad_lanes_kernel<2, 4>, 64 * 1024)) return CINEMA_ERR_UNSUPPORTED;
-    launch_lanes(stem_wgrad_kernel<2, 4>, stem_wgrad_lanes_kernel<2, 4>, 2, grid, dim3(NT), lds, st, q);
+    if (set_lds(f, stem_wgrad_kernel<2, 4, 32>, stem_wgrad_lanes_kernel<2, 4, 32>, 96 * 1024)) return CINEMA_ERR_UNSUPPORTED;
+    launch_lanes(stem_wgrad_kernel<2, 4, 32>, stem_wgrad_lanes_kernel<2, 4, 32>, 2, grid, dim3(NT), lds, st, q);
   }
   int max_total = 0;
   for (int i = 0; i < count; i++) { const int t = q.pr[i].n * q.pr[i].k + q.pr[i].n; if (t > max_total) max_total = t; }
-  launch_lanes(stem_wgrad_reduce_kernel, stem_wgrad_reduce_lanes_kernel, 2, dim3((max_total + 255) / 256, count), dim3(256), 0, st, q);
+  launch_lanes(stem_wgrad_reduce_kernel, stem_wgrad_reduce_lanes_kernel, 2, dim3((max_total + 31) / 32, count), dim3(256), 0, st, q);
   return launch_status();
 }

@@ -175,6 +175,10 @@ _PROTOS = {
     "cinema_sparse_halo_ints": [C.POINTER(SparseGeom), _i, _i, _i],
     "cinema_sparse_halo_index": [C.POINTER(SparseGeom), _i, _i, _i, _vp, _vp],
     "cinema_sparse_dwconv_wgrad_workspace_bytes": [_i, _i, _i, _i, _i],
+    "cinema_stem_dw_supported": [C.POINTER(SparseGeom), _i, _i, _i, _i],
+    "cinema_stem_dw_fwd": [_vp, _vp, _vp, _vp, C.POINTER(SparseGeom), _i, _i, _i, _i, _i, _vp],
+    "cinema_stem_dw_wgrad_workspace_bytes": [_i, _i, _i, _i, _i],
+    "cinema_stem_dw_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, C.POINTER(SparseGeom), _i, _i, _i, _i, _vp],
     "cinema_stem_supported": [_i],
     "cinema_stem_partials": [_i],
     "cinema_stem_ln_linear": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -257,7 +261,7 @@ def library_path() -> Path:
 # after it ran.  The arguments are plain ints / floats / ctypes structs, so the same launch can be issued again verbatim; host-only queries
 # (workspace sizes) and the completion markers are not part of a step's launch list.
 RECORD: list | None = None
-_NOT_REPLAYED = ("cinema_kernel_launch_count", "cinema_stem_supported", "cinema_stem_partials", "cinema_stem_wgrad_slices", "_workspace_bytes", "_nbr_ints", "_halo_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
+_NOT_REPLAYED = ("cinema_kernel_launch_count", "cinema_stem_dw_supported", "cinema_stem_supported", "cinema_stem_partials", "cinema_stem_wgrad_slices", "_workspace_bytes", "_nbr_ints", "_halo_ints", "cinema_marker_record", "cinema_marker_done", "cinema_launch_probe", "cinema_mfma_probe", "cinema_lanes_abort")
 
 
 class _Entry:
@@ -1745,6 +1749,9 @@ def _sparse_nbr(geom: SparseGeom, kdims: tuple, device: torch.device) -> tuple:
 
 
 SPARSE_WGRAD_PIPE = bool(int(os.environ.get("CINEMA_SPARSE_WGRAD_PIPE", "1")))  # 0: the per-token index chase (A/B)
+# the depthwise conv of the visible-voxel stem as a walk over neighbour TOKENS (csrc/stem_dw.hip; 64 / 128 channels, 4x4 / 2x2 token blocks); 0: the per-voxel neighbour
+# lists of csrc/sparse_conv.hip, which stay the form for every other geometry
+STEM_DW_PAIR = bool(int(os.environ.get("CINEMA_STEM_DW_PAIR", "1")))
 
 
 def _kernel3(w: torch.Tensor) -> tuple:
@@ -1760,6 +1767,9 @@ def sparse_dwconv(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, g
     c = x.shape[1]
     kx, ky, kz = _kernel3(w)
     y = _empty_like(x)
+    if STEM_DW_PAIR and load().cinema_stem_dw_supported(C.byref(geom), c, kx, ky, kz):  # token-pair form (csrc/stem_dw.hip): no neighbour lists
+        _check(load().cinema_stem_dw_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), C.byref(geom), c, kx, ky, kz, int(flip), _stream()), "stem_dw_fwd")
+        return y
     nbr, cnt = _sparse_nbr(geom, (kx, ky, kz), x.device)
     _check(load().cinema_sparse_dwconv_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), C.byref(geom), nbr.data_ptr(), cnt.data_ptr(), c, kx, ky, kz,
                                            int(flip), _stream()), "sparse_dwconv")
@@ -1771,6 +1781,12 @@ def sparse_dwconv_bwd_weight(x: torch.Tensor, dy: torch.Tensor, w_shape: tuple, 
     c = x.shape[1]
     ks = tuple(w_shape[2:])
     kx, ky, kz = (1,) * (3 - len(ks)) + ks
+    if STEM_DW_PAIR and load().cinema_stem_dw_supported(C.byref(geom), c, kx, ky, kz):
+        need = load().cinema_stem_dw_wgrad_workspace_bytes(geom.n_tok, c, kx, ky, kz)
+        ws = _workspace("stem_dw_wgrad", (need + 3) // 4, x.device)
+        _check(load().cinema_stem_dw_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(dbias), ws.data_ptr(), need, C.byref(geom), c, kx, ky, kz, _stream()),
+               "stem_dw_bwd_weight")
+        return
     need = load().cinema_sparse_dwconv_wgrad_workspace_bytes(geom.n_tok, c, kx, ky, kz)
     ws = _workspace("sparse_wgrad", (need + 3) // 4, x.device)
     hidx = None

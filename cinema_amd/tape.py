@@ -1546,6 +1546,60 @@ def op_sparse_dwconv(tape: Tape, x: Var, geom, weight: torch.nn.Parameter, bias:
     return y
 
 
+FUSED_STEM = bool(int(os.environ.get("CINEMA_FUSED_STEM", "1")))  # 0: the MaskedConvBlock as separate LayerNorm / GEMM launches (A/B, and the form every other channel count takes)
+
+
+def stem_block_ok(x: Var, c: int, hidden: int) -> bool:
+    return FUSED_STEM and x.data.is_cuda and x.data.dtype == F32 and x.data.is_contiguous() and K.stem_supported(c, hidden) and not K.FORCE_GENERIC
+
+
+def op_stem_block(tape: Tape, x: Var, geom, blk) -> Var:  # noqa: ANN001
+    """One MaskedConvBlock (``cinema/conv.py:405-413``) on visible-voxel compact rows x fp32 [rows, c] as three launches: LN1 -> conv1 (``stem_ln_linear``), the
+    depthwise 5^n conv over the neighbour lists, conv2 + residual -> LN2 -> fc1 -> GELU -> fc2 + residual (``stem_mlp_fwd``: the 4c-wide hidden layer stays in
+    registers).  Backward: ``stem_mlp_bwd`` (recomputes the hidden layer from the saved x1), the depthwise data / weight gradients, ``stem_ln_linear_bwd``, and the
+    four 1x1-convolution weight gradients + biases as ONE ``stem_wgrad`` launch on the weight-gradient stream."""
+    n1, n2, c1, c2, dw, fc1, fc2 = blk.norm1, blk.norm2, blk.conv1, blk.conv2, blk.dw_conv, blk.mlp.fc1, blk.mlp.fc2
+    w1, w2, wf1, wf2 = w_plain(c1.weight), w_plain(c2.weight), w_plain(fc1.weight), w_plain(fc2.weight)
+    det = lambda t: t.detach()  # noqa: E731
+    xn, h = K.stem_ln_linear(x.data, det(n1.weight), det(n1.bias), n1.eps, w1, det(c1.bias), want_xn=tape.train)
+    d = K.sparse_dwconv(h, det(dw.weight), None if dw.bias is None else det(dw.bias), geom)
+    x1, x2 = K.stem_mlp_fwd(d, x.data, w2, det(c2.bias), det(n2.weight), det(n2.bias), n2.eps, wf1, det(fc1.bias), wf2, det(fc2.bias), want_x1=tape.train)
+    y = Var(x2)
+    pv = {p_: tape.pvar(p_) for p_ in (n1.weight, n1.bias, n2.weight, n2.bias, c1.weight, c1.bias, c2.weight, c2.bias, dw.weight, dw.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+          if p_ is not None}
+    c = x.data.shape[1]
+
+    def gbuf(p_: torch.nn.Parameter | None, shape: tuple) -> torch.Tensor | None:
+        return pv[p_].grad_buffer(shape) if (p_ is not None and p_.requires_grad) else None
+
+    def bwd() -> None:
+        if y.grad is None:
+            return
+        g2 = y.grad if y.grad.dtype == F32 else K.cast(y.grad, F32)
+        o = K.stem_mlp_bwd(g2.contiguous(), x1, w2, det(n2.weight), det(n2.bias), n2.eps, wf1, det(fc1.bias), wf2)
+        part2, n_part2 = o["partials"]
+        if n2.weight.requires_grad or n2.bias.requires_grad:
+            tape.pending_ln.append((part2, n_part2, c, gbuf(n2.weight, (c,)), gbuf(n2.bias, (c,))))
+        dd = o["dd"]
+        if dw.weight.requires_grad:
+            dwg, dbg = gbuf(dw.weight, tuple(dw.weight.shape)), gbuf(dw.bias, (c,))
+            _wgrad_launch(lambda: K.sparse_dwconv_bwd_weight(h, dd, tuple(dw.weight.shape), dwg, dbg, geom), h, dd, alt=1,
+                          keys=(dwg.data_ptr(),) if dbg is None else (dwg.data_ptr(), dbg.data_ptr()))
+        dh = K.sparse_dwconv(dd, det(dw.weight), None, geom, flip=True)
+        dx, (part1, n_part1) = K.stem_ln_linear_bwd(dh, x.data, o["dx1"], det(n1.weight), n1.eps, w1)
+        if n1.weight.requires_grad or n1.bias.requires_grad:
+            tape.pending_ln.append((part1, n_part1, c, gbuf(n1.weight, (c,)), gbuf(n1.bias, (c,))))
+        probs = [(o["g2_16"], o["a"], fc2, wf2), (o["dz"], o["xn2"], fc1, wf1), (o["dx1_16"], d, c2, w2), (dh, xn, c1, w1)]
+        probs = [(dy, xx, gbuf(m.weight, tuple(w16.shape)), gbuf(m.bias, (w16.shape[0],))) for dy, xx, m, w16 in probs if m.weight.requires_grad]
+        if probs:
+            _wgrad_launch(lambda: K.stem_wgrad(probs), *[t for pr in probs for t in pr[:2]], alt=1, keys=tuple(t.data_ptr() for pr in probs for t in pr[2:] if t is not None))
+        if x.needs_grad:
+            x.add_grad(dx)
+
+    tape.record(bwd)
+    return y
+
+
 def op_view(tape: Tape, x: Var, shape: tuple) -> Var:
     """Zero-copy reshape of contiguous rows (e.g. [n*4, c] -> [n, 4*c]); the gradient is reshaped back."""
     y = Var(x.data.view(shape), needs_grad=x.needs_grad)

@@ -308,6 +308,15 @@ long long cinema_sparse_dwconv_wgrad_workspace_bytes(int n_tok, int c, int kx, i
  * cinema_sparse_dwconv_fwd.  In the forward pass the 4c-wide hidden activation of the MLP never leaves the registers (the unfused form wrote it and its
  * GELU derivative to HBM); the backward pass recomputes it from the saved x1.
  */
+/* The depthwise conv of cinema_sparse_dwconv_* as a walk over the 3 x 3 x 5 neighbour TOKENS of every kept token (no neighbour lists): supported for c in {64, 128},
+ * token blocks 4x4x1 / 2x2x1 with a 5x5x5 kernel and 1x4x4 / 1x2x2 (2-D views, leading axis 1) with a 1x5x5 kernel; same arguments and results as the list form
+ * (fp32 taps, other summation order).  workspace of the weight gradient >= cinema_stem_dw_wgrad_workspace_bytes(...). */
+int cinema_stem_dw_supported(const cinema_sparse_geom* geom, int c, int kx, int ky, int kz);
+int cinema_stem_dw_fwd(const uint16_t* x, const float* w, const float* bias, uint16_t* y, const cinema_sparse_geom* geom, int c, int kx, int ky, int kz, int flip,
+                       void* stream);
+long long cinema_stem_dw_wgrad_workspace_bytes(int n_tok, int c, int kx, int ky, int kz);
+int cinema_stem_dw_bwd_weight(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, float* workspace, long long workspace_bytes,
+                              const cinema_sparse_geom* geom, int c, int kx, int ky, int kz, void* stream);
 int cinema_stem_supported(int c);
 /* xn = LN(x; gamma, beta) (bf16, may be NULL) and h = xn w^T + bias (bf16) */
 int cinema_stem_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const uint16_t* w, const float* bias, uint16_t* xn, uint16_t* h,
@@ -327,7 +336,7 @@ int cinema_stem_ln_linear_bwd(const uint16_t* dh, const float* x, const float* d
                               int rows, int c, int* n_partials_out, void* stream);
 /* Weight gradients with small outputs over many rows (the 1x1 convolutions of the stem: reference autograd of cinema/conv.py:405-413):
  *   dw[n][k] += sum_r dy[r][n] x[r][k],  db[n] += sum_r dy[r][n]   for up to 6 problems with the same row count in one launch + one ordered reduce.
- * n, k multiples of 32, n + k <= 640, n k <= 64 K.  workspace >= cinema_stem_wgrad_workspace_bytes(...) bytes, contents irrelevant. */
+ * n, k powers of two in 32 .. 512, n + k <= 640.  workspace >= cinema_stem_wgrad_workspace_bytes(...) bytes, contents irrelevant. */
 typedef struct {
   const uint16_t* dy; const uint16_t* x;  /* bf16 [rows][n], [rows][k], dense */
   float* dw; float* db;                   /* fp32 [n][k] dense, [n] or NULL */

@@ -525,16 +525,20 @@ def test_dwconv(shape: tuple, c: int) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ patches / rows
-@pytest.mark.parametrize(("tok_grid", "block", "c", "levels"), [((3, 3, 4), (4, 4, 1), 64, 2), ((3, 4), (2, 2), 128, 1), ((2, 3, 2), (2, 2, 2), 64, 1), ((3, 5), (4, 4), 64, 2)])
-def test_sparse_dwconv_matches_dense_masked_conv(tok_grid: tuple, block: tuple, c: int, levels: int) -> None:
+@pytest.mark.parametrize("pair", [False, True])
+@pytest.mark.parametrize(("tok_grid", "block", "c", "levels"), [((3, 3, 4), (4, 4, 1), 64, 2), ((3, 4), (2, 2), 128, 1), ((2, 3, 2), (2, 2, 2), 64, 1), ((3, 5), (4, 4), 64, 2),
+                                                                ((4, 5, 7), (2, 2, 1), 128, 1), ((5, 4, 6), (4, 4, 1), 128, 2), ((6, 3, 2), (2, 2, 1), 64, 1), ((5, 6), (4, 4), 128, 2)])
+def test_sparse_dwconv_matches_dense_masked_conv(tok_grid: tuple, block: tuple, c: int, levels: int, pair: bool, monkeypatch) -> None:  # noqa: ANN001
     """Visible-voxel depthwise conv (forward, data gradient, weight gradient) == the dense kernels applied to a volume
     whose masked voxels are zero, read back at the visible voxels (the identity the MAE stem relies on)."""
     from cinema_amd.convvit import hierarchical_positions
 
+    # pair: the token-pair kernels of csrc/stem_dw.hip where they apply (every parametrisation except the 2x2x2 block); otherwise the neighbour-list kernels
+    monkeypatch.setattr(K, "STEM_DW_PAIR", pair)
     nd = len(tok_grid)
     b = 2
     n_tok_all = math.prod(tok_grid)
-    n_keep = max(2, n_tok_all // 4)
+    n_keep = max(2, n_tok_all // 4) if c == 64 else max(2, (2 * n_tok_all) // 5)
     g = torch.Generator(device="cpu").manual_seed(5)
     keep_pos = torch.stack([torch.randperm(n_tok_all, generator=g)[:n_keep].sort().values for _ in range(b)])
     keep = (torch.arange(b)[:, None] * n_tok_all + keep_pos).reshape(-1).to(torch.int32).to(DEV)
@@ -600,6 +604,13 @@ def test_sparse_dwconv_matches_dense_masked_conv(tok_grid: tuple, block: tuple, 
     close(db, db_ref, 1e-3, 1e-3 * float(db_ref.abs().max()), "sparse dwconv bias grad")
     # the default is the token-pipelined kernel on the halo index table; the per-token index chase gives the same sums (same order within a workgroup,
     # other workgroup chunks: fp32 rounding of the slab reduction only)
+    kd = (1,) * (3 - nd) + ks
+    if pair and K.load().cinema_stem_dw_supported(__import__("ctypes").byref(geom), c, *kd):
+        assert not geom.halo_idx and not geom.nbr_lists  # the token-pair kernels ran: no list, no halo table was built
+        dw3, db3 = torch.zeros_like(w), torch.zeros(c, device=DEV)
+        K.sparse_dwconv_bwd_weight(xc, dyc, tuple(w.shape), dw3, db3, geom)
+        assert torch.equal(dw, dw3) and torch.equal(db, db3)  # ordered slab reduce: bit-identical run to run
+        return
     assert K.SPARSE_WGRAD_PIPE and (5,) * 3 in geom.halo_idx or (1, 5, 5) in geom.halo_idx
     prev, K.SPARSE_WGRAD_PIPE = K.SPARSE_WGRAD_PIPE, False
     try:
