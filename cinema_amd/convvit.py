@@ -226,10 +226,13 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
             for block, sg in zip(self.conv_blocks, geoms):
                 for conv in block.conv:
                     kd = (1,) * (3 - n_dims) + tuple(int(v) for v in conv.dw_conv.weight.shape[2:])
+                    if K.sparse_pair_form(sg, conv.dw_conv.weight.shape[0], kd):  # token-pair kernels (csrc/stem_dw.hip): no list to build
+                        continue
                     if (id(sg), kd) not in seen:
                         seen.add((id(sg), kd))
                         items.append((sg, kd))
-            K.sparse_nbr_prefetch(items, dev, T.lax_stream().cuda_stream)
+            if items:
+                K.sparse_nbr_prefetch(items, dev, T.lax_stream().cuda_stream)
         skips = []
         vol = None
         for lvl, (block, (blk, pos, inv)) in enumerate(zip(self.conv_blocks, tables)):

@@ -20,6 +20,7 @@
 // gradients of a block from row-major operand pairs: every workgroup owns a full small dW for a slice of rows, deterministic slab reduce).
 #include "common.cuh"
 #include "../../include/cinema_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -64,10 +65,17 @@ __device__ __forceinline__ void stage_tile(char* lds, int pitch, const bf16_t* s
   t.load(src, ld, tid);
   t.store(lds, pitch, tid);
 }
+template <int ROWS, int COLS, int NTH>  // one-off staging by any number of threads
+__device__ __forceinline__ void stage_tile_n(char* lds, int pitch, const bf16_t* src, int ld, int tid) {
+  constexpr int CPR = COLS / 8;
+  for (int i = tid; i < ROWS * CPR; i += NTH) *reinterpret_cast<u4*>(lds + (i / CPR) * pitch + (i % CPR) * 16) = *reinterpret_cast<const u4*>(src + (size_t)(i / CPR) * ld + (i % CPR) * 8);
+}
 // A fragment (weights) for out rows m0 .. m0+15 and reduction indices k0 .. k0+31 in the CHAINED order: lane (m = l & 15, g = l >> 4) holds
 // W[m0 + m][k0 + 4g + {0..3}] and W[m0 + m][k0 + 16 + 4g + {0..3}]
 __device__ __forceinline__ short8v wfrag_n(const char* lds, int pitch, int m0, int k0, int lane) {
   const char* p = lds + (m0 + (lane & 15)) * pitch + (k0 + 4 * (lane >> 4)) * 2;
+  // (hipcc fuses the two reads into one ds_read2_b64: half rate and banks mod 32, 2-way conflicts at this pitch - 42 % of the LDS cycles; keeping them apart through an
+  // opaque pointer removed the conflicts and made the kernels SLOWER (56 -> 64 us): they are bound by instruction issue and waits, not by the LDS array)
   const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 32);
   return mk8(lo.x, lo.y, hi.x, hi.y);
 }
@@ -294,32 +302,47 @@ struct MlpFwdP {
   const bf16_t* wf1; const float* bf1; const bf16_t* wf2; const float* bf2;
   float* x1; float* x2;
   int rows; float eps;
+  int dbg;   // timing experiments only (tools/bench_stem.py, CINEMA_STEM_DBG): bit 0 no GELU, 1 no fc1 MFMAs, 2 no fc2 MFMAs, 3 no chunk loop, 4 no weight stream, 5 no barriers
 };
-template <int C>
+// RES: every chunk of the MLP weights stays in LDS (c = 64: 83 KB) - no weight stream, no barrier in the loop, the waves of a workgroup drift apart so that one
+// wave's row loads / stores hide behind the others' matrix work; otherwise (c = 128: 288 KB of weights) the chunks are double-buffered and the waves walk them in step.
+template <int C, bool RES>
 struct MlpFwdLds {
-  static constexpr int P_C = 2 * C + 16, P_H = 2 * HC + 16;
+  static constexpr int P_C = 2 * C + 16, P_H = 2 * HC + 16, NBUF = RES ? 4 * C / HC : 2;
   static constexpr int W2 = 0, BUF = C * P_C, BUF_BYTES = HC * P_C + C * P_H, WF2_OFF = HC * P_C;
-  static constexpr int VEC = BUF + 2 * BUF_BYTES;      // b2 | gamma | beta | bf2 | bf1 (4 C)
+  static constexpr int VEC = BUF + NBUF * BUF_BYTES;      // b2 | gamma | beta | bf2 | bf1 (4 C)
   static constexpr int BYTES = VEC + 8 * C * 4;
 };
-template <int C>
+template <int C, bool RES, int NWV>
 __device__ __forceinline__ void mlp_fwd_body(const MlpFwdP& p) {
-  using L = MlpFwdLds<C>;
+  static_assert(RES || NWV == NW, "the streamed form moves its tiles with NT threads");
+  constexpr int NTH = NWV * 64;
+  using L = MlpFwdLds<C, RES>;
   constexpr int RB = C / 16, KS = C / 32, H = 4 * C, NCH = H / HC, P_C = L::P_C, P_H = L::P_H;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* w2l = smem + L::W2;
   float* vec = reinterpret_cast<float*>(smem + L::VEC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, v = lane & 15, g = lane >> 4;
-  stage_tile<C, C>(w2l, P_C, p.w2, C, tid);
-  stage_tile<HC, C>(smem + L::BUF, P_C, p.wf1, C, tid);
-  stage_tile<C, HC>(smem + L::BUF + L::WF2_OFF, P_H, p.wf2, H, tid);
-  for (int i = tid; i < C; i += NT) { vec[i] = p.b2[i]; vec[C + i] = p.gamma[i]; vec[2 * C + i] = p.beta[i]; vec[3 * C + i] = p.bf2[i]; }
-  for (int i = tid; i < H; i += NT) vec[4 * C + i] = p.bf1[i];
+  stage_tile_n<C, C, NTH>(w2l, P_C, p.w2, C, tid);
+#pragma unroll
+  for (int j = 0; j < (RES ? NCH : 1); j++) {
+    stage_tile_n<HC, C, NTH>(smem + L::BUF + j * L::BUF_BYTES, P_C, p.wf1 + (size_t)j * HC * C, C, tid);
+    stage_tile_n<C, HC, NTH>(smem + L::BUF + j * L::BUF_BYTES + L::WF2_OFF, P_H, p.wf2 + j * HC, H, tid);
+  }
+  for (int i = tid; i < C; i += NTH) { vec[i] = p.b2[i]; vec[C + i] = p.gamma[i]; vec[2 * C + i] = p.beta[i]; vec[3 * C + i] = p.bf2[i]; }
+  for (int i = tid; i < H; i += NTH) vec[4 * C + i] = p.bf1[i];
   __syncthreads();
   const int n_tiles = (p.rows + 15) >> 4;
-  const int passes = (n_tiles + gridDim.x * NW - 1) / (gridDim.x * NW);
+  const int passes = (n_tiles + gridDim.x * NWV - 1) / (gridDim.x * NWV);
+  TileRegs<HC, C> na1, nb1;
+  TileRegs<C, HC> na2, nb2;
+  if constexpr (!RES) {
+    nb1.load(p.wf1 + (size_t)HC * C, C, tid);   // chunk 1 on its way
+    nb2.load(p.wf2 + HC, H, tid);
+  }
   for (int pass = 0; pass < passes; pass++) {
-    const int tile = (pass * gridDim.x + blockIdx.x) * NW + wave;
+    const int tile = (pass * gridDim.x + blockIdx.x) * NWV + wave;
+    if (RES && tile >= n_tiles) break;  // (no barrier below: a wave without rows just leaves)
     const int row = tile * 16 + v;
     const bool ok = row < p.rows;
     const int rowc = ok ? row : p.rows - 1;
@@ -349,40 +372,65 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdP& p) {
       for (int rb = 0; rb < RB; rb++) xn[rb] = xn[rb] * ldsv4(vec + C, rb * 16 + g * 4) + ldsv4(vec + 2 * C, rb * 16 + g * 4);
       pack_act<C>(bx, xn, nullptr, row, g, false);
     }
-    for (int j = 0; j < NCH; j++) {
-      const int jn = (j + 1) % NCH;
-      TileRegs<HC, C> n1;
-      TileRegs<C, HC> n2;
-      n1.load(p.wf1 + (size_t)jn * HC * C, C, tid);
-      n2.load(p.wf2 + jn * HC, H, tid);
-      const char* wf1c = smem + L::BUF + (j & 1) * L::BUF_BYTES;
+    auto chunk = [&](int j, const char* wf1c) {
       const char* wf2c = wf1c + L::WF2_OFF;
       const float* b1 = vec + 4 * C + j * HC;
 #pragma unroll
       for (int t = 0; t < HC / 32; t++) {
         f4 z0 = ldsv4(b1, t * 32 + g * 4), z1 = ldsv4(b1, t * 32 + 16 + g * 4);
+        if (!(p.dbg & 2)) {
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-          z0 = mfma16(wfrag_n(wf1c, P_C, t * 32, s * 32, lane), bx[s], z0);
-          z1 = mfma16(wfrag_n(wf1c, P_C, t * 32 + 16, s * 32, lane), bx[s], z1);
+          for (int s = 0; s < KS; s++) {
+            z0 = mfma16(wfrag_n(wf1c, P_C, t * 32, s * 32, lane), bx[s], z0);
+            z1 = mfma16(wfrag_n(wf1c, P_C, t * 32 + 16, s * 32, lane), bx[s], z1);
+          }
         }
-        gelu_v4(z0); gelu_v4(z1);
+        if (!(p.dbg & 1)) { gelu_v4(z0); gelu_v4(z1); }
         const uint2 lo = pack4(z0), hi = pack4(z1);
         const short8v ba = mk8(lo.x, lo.y, hi.x, hi.y);
+        if (!(p.dbg & 4)) {
 #pragma unroll
-        for (int ob = 0; ob < RB; ob++) y[ob] = mfma16(wfrag_n(wf2c, P_H, ob * 16, t * 32, lane), ba, y[ob]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int ob = 0; ob < RB; ob++) y[ob] = mfma16(wfrag_n(wf2c, P_H, ob * 16, t * 32, lane), ba, y[ob]);
+        }
+        if (p.dbg & 64) __builtin_amdgcn_sched_barrier(0);
       }
-      char* nb = smem + L::BUF + ((j + 1) & 1) * L::BUF_BYTES;
-      n1.store(nb, P_C, tid);
-      n2.store(nb + L::WF2_OFF, P_H, tid);
-      __syncthreads();
+    };
+    if (p.dbg & 8) {
+    } else if constexpr (RES) {
+      for (int j = 0; j < NCH; j++) chunk(j, smem + L::BUF + j * L::BUF_BYTES);
+    } else {
+      // the chunk's weights are fetched TWO chunks ahead (registers: sets A / B) and written to the other LDS buffer one chunk ahead: one chunk of matrix work
+      // (~1 us) did not cover the fetch (8 x ~2.7 us of waiting per pass at c = 128)
+      const bool stream = !(p.dbg & 16), bar = !(p.dbg & 32);
+      for (int j = 0; j < NCH; j += 2) {
+        if (stream) {
+          na1.load(p.wf1 + (size_t)((j + 2) % NCH) * HC * C, C, tid);
+          na2.load(p.wf2 + ((j + 2) % NCH) * HC, H, tid);
+        }
+        chunk(j, smem + L::BUF);
+        if (stream) {
+          nb1.store(smem + L::BUF + L::BUF_BYTES, P_C, tid);          // chunk j + 1 (fetched during chunk j - 1)
+          nb2.store(smem + L::BUF + L::BUF_BYTES + L::WF2_OFF, P_H, tid);
+        }
+        if (bar) __syncthreads();
+        if (stream) {
+          nb1.load(p.wf1 + (size_t)((j + 3) % NCH) * HC * C, C, tid);
+          nb2.load(p.wf2 + ((j + 3) % NCH) * HC, H, tid);
+        }
+        chunk(j + 1, smem + L::BUF + L::BUF_BYTES);
+        if (stream) {
+          na1.store(smem + L::BUF, P_C, tid);                          // chunk j + 2
+          na2.store(smem + L::BUF + L::WF2_OFF, P_H, tid);
+        }
+        if (bar) __syncthreads();
+      }
     }
     if (ok) store_act<C>(y, p.x2, row, g);
   }
 }
-template <int C> __global__ __launch_bounds__(NT) void stem_mlp_fwd_kernel(MlpFwdP p) { mlp_fwd_body<C>(p); }
-template <int C> __global__ __launch_bounds__(NT) void stem_mlp_fwd_lanes_kernel(Lanes<MlpFwdP> L) { mlp_fwd_body<C>(L.p[blockIdx.y]); }
+constexpr int fwd_waves(int c) { return c == 64 ? 16 : NW; }  // c = 64: resident weights, 16 free-running waves per CU
+template <int C> __global__ __launch_bounds__(fwd_waves(C) * 64) void stem_mlp_fwd_kernel(MlpFwdP p) { mlp_fwd_body<C, C == 64, fwd_waves(C)>(p); }
+template <int C> __global__ __launch_bounds__(fwd_waves(C) * 64) void stem_mlp_fwd_lanes_kernel(Lanes<MlpFwdP> L) { mlp_fwd_body<C, C == 64, fwd_waves(C)>(L.p[blockIdx.y]); }
 
 // =====================================================================================================================================================
 // backward of that half.  In: g2 = dL/dx2 (fp32), x1 (saved).  Out: dx1 (fp32 + bf16), dd = dL/d(dw output) (bf16), and the operands of the weight
@@ -747,15 +795,17 @@ CINEMA_API int cinema_stem_mlp_fwd(const uint16_t* d, const float* x, const uint
                                    const float* bf1, const uint16_t* wf2, const float* bf2, float* x1, float* x2, int rows, int c, void* stream) {
   if (!d || !x || !w2 || !b2 || !gamma || !beta || !wf1 || !bf1 || !wf2 || !bf2 || !x2 || rows <= 0) return CINEMA_ERR_BAD_ARG;
   if (!cinema_stem_supported(c)) return CINEMA_ERR_UNSUPPORTED;
-  const MlpFwdP p{d, x, w2, b2, gamma, beta, wf1, bf1, wf2, bf2, x1, x2, rows, eps};
+  static const int dbg = getenv("CINEMA_STEM_DBG") ? atoi(getenv("CINEMA_STEM_DBG")) : 0;
+  const MlpFwdP p{d, x, w2, b2, gamma, beta, wf1, bf1, wf2, bf2, x1, x2, rows, eps, dbg};
   if (c == 64) {
     static bool f[16] = {};
-    constexpr int lds = MlpFwdLds<64>::BYTES;
+    constexpr int lds = MlpFwdLds<64, true>::BYTES;
     if (set_lds(f, stem_mlp_fwd_kernel<64>, stem_mlp_fwd_lanes_kernel<64>, lds)) return CINEMA_ERR_UNSUPPORTED;
-    launch_lanes(stem_mlp_fwd_kernel<64>, stem_mlp_fwd_lanes_kernel<64>, 1, dim3(grid_for(rows, 2)), dim3(NT), lds, (hipStream_t)stream, p);
+    const int tiles = (rows + 15) / 16, want = (tiles + 15) / 16;
+    launch_lanes(stem_mlp_fwd_kernel<64>, stem_mlp_fwd_lanes_kernel<64>, 1, dim3(want < n_cus() ? want : n_cus()), dim3(16 * 64), lds, (hipStream_t)stream, p);
   } else {
     static bool f[16] = {};
-    constexpr int lds = MlpFwdLds<128>::BYTES;
+    constexpr int lds = MlpFwdLds<128, false>::BYTES;
     if (set_lds(f, stem_mlp_fwd_kernel<128>, stem_mlp_fwd_lanes_kernel<128>, lds)) return CINEMA_ERR_UNSUPPORTED;
     launch_lanes(stem_mlp_fwd_kernel<128>, stem_mlp_fwd_lanes_kernel<128>, 1, dim3(grid_for(rows, 1)), dim3(NT), lds, (hipStream_t)stream, p);
   }

@@ -1754,6 +1754,11 @@ SPARSE_WGRAD_PIPE = bool(int(os.environ.get("CINEMA_SPARSE_WGRAD_PIPE", "1")))  
 STEM_DW_PAIR = bool(int(os.environ.get("CINEMA_STEM_DW_PAIR", "1")))
 
 
+def sparse_pair_form(geom: SparseGeom, c: int, kdims: tuple) -> bool:
+    """Whether :func:`sparse_dwconv` / :func:`sparse_dwconv_bwd_weight` take the token-pair kernels for this geometry (then no neighbour list is ever built)."""
+    return bool(STEM_DW_PAIR and load().cinema_stem_dw_supported(C.byref(geom), c, *kdims))
+
+
 def _kernel3(w: torch.Tensor) -> tuple:
     ks = tuple(w.shape[2:])
     return (1,) * (3 - len(ks)) + ks

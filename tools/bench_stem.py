@@ -46,7 +46,7 @@ def main() -> None:
     torch.manual_seed(0)
     out = []
     for name, c, block, ps in (("stage1", 64, (4, 4, 1), [(1, 1, 1), (2, 2, 1), (2, 2, 1)]), ("stage2", 128, (2, 2, 1), [(1, 1, 1), (2, 2, 1)])):
-        geom, rows = geom_for(16, (12, 12, 16), block, ps)
+        geom, rows = geom_for(int(__import__('os').environ.get('BENCH_BATCH', '16')), (12, 12, 16), block, ps)
         h = 4 * c
         f32 = lambda *s: torch.randn(*s, device=DEV)  # noqa: E731
         b16 = lambda *s: torch.randn(*s, device=DEV).to(torch.bfloat16)  # noqa: E731
@@ -77,7 +77,7 @@ def main() -> None:
             if flt and flt not in nm:
                 continue
             us = timeit(fn)
-            out.append(f"{name} {nm:14s} {us:8.1f} us   {mbytes:7.1f} MB algorithmic   {mbytes / us * 1e-3:5.2f} TB/s")
+            out.append(f"{name} {nm:14s} {us:8.1f} us   {mbytes:7.1f} MB algorithmic   {mbytes / us:5.2f} TB/s")
     print("\n".join(out))
 
 
