@@ -6,9 +6,10 @@ the training step of batch i) and the three transforms are two HIP launches per 
 The random decisions (apply with probability ``prob``; one zoom factor in [min_zoom, max_zoom] shared by all axes, the SAX volume on its own and the
 three long-axis views together, like the two ``RandZoomd`` entries of the reference) are drawn on the host from a seeded generator.
 
-Parity note: monai is not installed in the build container and the reference holds no value test for these transforms: the kernels are checked
-against a torch restatement of monai 1.5.2's ``Zoom(keep_size=True)`` / ``ScaleIntensity`` / ``SpatialPad`` (oracle ``input_transform``) - UNPINNED
-against monai itself.
+Parity note: monai is not installed in the build container and the reference holds no value test for these transforms, so monai itself cannot be run
+against them: the kernels are checked against a torch restatement of monai 1.5.2's ``Zoom(keep_size=True)`` / ``ScaleIntensity`` / ``SpatialPad`` (oracle
+``input_transform``), which is pinned against an independent second statement of the same published algorithm (float64 loops and explicit index maps) on
+committed vectors (``tests/golden/second_opinion.safetensors``, ``tests/test_data_gpu.py::test_zoom_scale_pad_vs_the_pinned_second_opinion_vectors``).
 """
 
 from __future__ import annotations

@@ -48,6 +48,68 @@ def get_batch_random_patch_mask(batch_size: int, n_patches: int, mask_ratio: flo
     return rank >= n_keep
 
 
+def add_pos_embed_and_append_mask_token(x_vis: torch.Tensor, enc_mask: torch.Tensor, dec_pos_embed: nn.Parameter, mask_token: nn.Parameter, concat: bool):  # noqa: ANN201
+    """Decoder input of one view (reference ``cinema/mae/mae.py:68-104``): visible tokens + their rows of the positional table, mask tokens + the rows of the
+    masked patches, both in raster order.  ``x_vis`` (batch, n_keep, d), ``enc_mask`` (batch, n_patches) bool with True = masked, ``dec_pos_embed`` (n_patches, d) or
+    (1, n_patches, d), ``mask_token`` (1, 1, d).  Returns the concatenation (batch, n_patches, d) or the pair (visible, masked).  One multi-segment row-copy
+    launch (``tape.op_assemble``); gradients flow to ``x_vis`` and ``mask_token`` like in the reference."""
+    batch, n_keep, d = x_vis.shape
+    n_patches = enc_mask.shape[1]
+    n_masked = n_patches - n_keep
+    dev = x_vis.device
+    sel = TokenSelection(enc_mask, batch, n_patches, dev, n_masked=n_masked)
+    table = dec_pos_embed.detach().reshape(-1, d)
+    per = torch.arange(batch, dtype=torch.int32, device=dev)[:, None] * n_patches
+    vis_rows = (per + torch.arange(n_keep, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous()
+    mask_rows = (per + n_keep + torch.arange(n_masked, dtype=torch.int32, device=dev)[None]).reshape(-1).contiguous()
+
+    def run(tp: T.Tape, xv: T.Var):  # noqa: ANN202
+        segs = [T.Segment(vis_rows, src=xv, add=table, add_idx=sel.keep_pos)]
+        if n_masked > 0:
+            segs.append(T.Segment(mask_rows, src=mask_token, add=table, add_idx=sel.drop_pos))
+        return [T.op_assemble(tp, batch * n_patches, d, segs, dev)], []
+
+    (out,) = T.taped_call(run, [x_vis.float().reshape(batch * n_keep, d).contiguous()], [mask_token])
+    out = out.reshape(batch, n_patches, d)
+    if concat:
+        return out
+    return out[:, :n_keep], out[:, n_keep:]
+
+
+def mse_loss(target: torch.Tensor, pred: torch.Tensor, enc_mask: torch.Tensor, norm_target: bool, epsilon: float = 1.0e-6) -> tuple:
+    """Masked-patch MSE and its metrics (reference ``cinema/mae/mae.py:107-152``): ``target`` (batch, n_patches, f) patches, ``pred`` (batch, n_masked, f),
+    ``enc_mask`` (batch, n_patches) bool, True = predicted.  The per-patch statistics (unbiased variance), the optional target normalisation, the squared error and
+    its gradient with respect to ``pred`` are the kernels the model's forward uses (``cinema_mse_fwd / _bwd``, ``cinema_patch_stats``): the target is addressed as
+    an image whose patches are its rows."""
+    batch, n_patches, f = target.shape
+    dev = target.device
+    tgt = target.detach().float().contiguous()
+    geom_all = K.patch_geom(batch, 1, (n_patches,), (f,), (n_patches * f, n_patches * f, 1))
+    stats = T.zeros(2, torch.float32, dev)
+    K.patch_stats(tgt, geom_all, stats)
+    metrics = {"target_mean": stats[0], "target_std": stats[1]}
+    n_masked = pred.shape[1]
+    if n_masked == 0:
+        nan = torch.full((), float("nan"), device=dev)
+        metrics["mse_loss"] = nan
+        return nan, metrics
+    sel = TokenSelection(enc_mask, batch, n_patches, dev, n_masked=n_masked)
+    geom_m = K.patch_geom(batch, 1, (n_patches,), (f,), (n_patches * f, n_patches * f, 1), token_idx=sel.drop)
+    box = {}
+
+    def run(tp: T.Tape, pv: T.Var):  # noqa: ANN202
+        loss, maxes = T.op_mse(tp, pv, tgt, geom_m, norm_target, epsilon)
+        box["maxes"] = maxes
+        return [loss], []
+
+    (loss,) = T.taped_call(run, [pred.float().reshape(batch * n_masked, f).contiguous()], [])
+    loss = loss.reshape(())
+    metrics["mse_loss"] = loss.detach()
+    if norm_target and box["maxes"] is not None:
+        metrics["normed_target_max"], metrics["pred_max"] = box["maxes"][0], box["maxes"][1]
+    return loss, metrics
+
+
 def get_decoder_patch_size(image_size: tuple, n_conv_layers: int, enc_patch_size: tuple, enc_scale_factor: tuple) -> tuple:
     """Product of the stem patch sizes (reference ``mae.py:207-228``)."""
     out = (1,) * len(image_size)

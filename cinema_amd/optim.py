@@ -43,6 +43,36 @@ def adjust_learning_rate(optimizer, step: float, warmup_steps: float, max_n_step
     return cur
 
 
+def apply_optim_scheduler(optimizer, lr: float, last_layer_lr: float, weight_decay: float) -> None:  # noqa: ANN001
+    """Write this iteration's learning rate / weight decay into every parameter group (reference ``cinema/optim.py:55-68``): groups carry ``lr_scale``,
+    ``weight_decay_scale`` and ``is_last_layer`` (DINOv2-style schedules; the MAE pre-training path uses :func:`adjust_learning_rate` instead)."""
+    for group in optimizer.param_groups:
+        group["weight_decay"] = weight_decay * group["weight_decay_scale"]
+        group["lr"] = (last_layer_lr if group["is_last_layer"] else lr) * group["lr_scale"]
+
+
+class CosineScheduler:
+    """freeze (zeros) -> linear warm-up -> half cosine from ``base_value`` to ``final_value``, as a table indexed by the iteration (reference
+    ``cinema/optim.py:71-119``; past ``total_iters`` the value stays ``final_value``)."""
+
+    def __init__(self, base_value: float, final_value: float, total_iters: int, warmup_iters: int = 0, start_warmup_value: float = 0.0,
+                 freeze_iters: int = 0) -> None:
+        import numpy as np
+
+        self.final_value = final_value
+        self.total_iters = total_iters
+        iters = np.arange(total_iters - warmup_iters - freeze_iters)
+        cosine = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * iters / len(iters)))
+        self.schedule = np.concatenate((np.zeros((freeze_iters,)), np.linspace(start_warmup_value, base_value, warmup_iters), cosine))
+        if len(self.schedule) != self.total_iters:
+            raise ValueError(f"Length of schedule {len(self.schedule)} should be equal to total_iters {self.total_iters}.")
+
+    def __getitem__(self, it: int):  # noqa: ANN204
+        if it >= self.total_iters:
+            return self.final_value
+        return self.schedule[it]
+
+
 def get_n_accum_steps(batch_size: int, batch_size_per_device: int, world_size: int) -> int:
     """Gradient-accumulation factor (reference ``cinema/optim.py:122-143``)."""
     per_step = batch_size_per_device * world_size

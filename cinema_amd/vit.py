@@ -82,6 +82,32 @@ def unpatchify(x: torch.Tensor, patch_size: tuple, grid_size: tuple) -> torch.Te
     return x.permute(*order).contiguous().reshape(batch, -1, *[g * p for g, p in zip(grid_size, patch_size)])
 
 
+def _patchify_nd(n: int):  # noqa: ANN202
+    def fn(image: torch.Tensor, patch_size: tuple) -> torch.Tensor:
+        if len(patch_size) != n or image.dim() != n + 2:
+            raise ValueError(f"patchify_{n}d expects a (batch, C, *{n} spatial axes) image and a {n}-tuple patch size, got {tuple(image.shape)} and {patch_size}.")
+        return patchify(image, patch_size)
+
+    fn.__name__ = fn.__qualname__ = f"patchify_{n}d"
+    fn.__doc__ = f"{n}-D case of :func:`patchify` (reference ``cinema/vit.py:67-142``): same token / feature order and the same errors."
+    return fn
+
+
+def _unpatchify_nd(n: int):  # noqa: ANN202
+    def fn(x: torch.Tensor, patch_size: tuple, grid_size: tuple) -> torch.Tensor:
+        if len(patch_size) != n or len(grid_size) != n:
+            raise ValueError(f"unpatchify_{n}d expects {n}-tuples for patch_size and grid_size, got {patch_size} and {grid_size}.")
+        return unpatchify(x, patch_size, grid_size)
+
+    fn.__name__ = fn.__qualname__ = f"unpatchify_{n}d"
+    fn.__doc__ = f"{n}-D case of :func:`unpatchify` (reference ``cinema/vit.py:164-225``)."
+    return fn
+
+
+patchify_2d, patchify_3d, patchify_4d = _patchify_nd(2), _patchify_nd(3), _patchify_nd(4)
+unpatchify_2d, unpatchify_3d, unpatchify_4d = _unpatchify_nd(2), _unpatchify_nd(3), _unpatchify_nd(4)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # frozen sin-cos positional tables (reference cinema/vit.py:347-443), built once on the host
 # ---------------------------------------------------------------------------------------------------------------
@@ -94,10 +120,9 @@ def get_1d_sincos_pos_embed_from_grid(embed_dim: int, grid: np.ndarray, max_peri
     return np.concatenate([np.sin(angles), np.cos(angles)], axis=1)
 
 
-def get_nd_sincos_pos_embed(embed_dim: int, grid_size: tuple) -> np.ndarray:
-    """(prod(grid), embed_dim).  Keeps the reference's ``np.meshgrid`` 'xy' axis order (``vit.py:421``) and its even-width /
-    zero-padding rule for dimensions that do not divide evenly (``vit.py:398-405``)."""
-    grid = np.stack(np.meshgrid(*[np.arange(s, dtype=np.float32) for s in grid_size]), axis=0)
+def get_nd_sincos_pos_embed_from_grid(embed_dim: int, grid: np.ndarray) -> np.ndarray:
+    """(M, embed_dim) table of a position grid of shape (n, ...): each of the n axes gets an even width ``embed_dim // n`` (rounded down to even), the rest is
+    zero padding (reference ``cinema/vit.py:386-405``)."""
     n = grid.shape[0]
     width = embed_dim // n
     width -= width % 2
@@ -106,6 +131,13 @@ def get_nd_sincos_pos_embed(embed_dim: int, grid_size: tuple) -> np.ndarray:
     if pad > 0:
         emb = np.concatenate([emb, np.zeros((emb.shape[0], pad))], axis=1)
     return emb
+
+
+def get_nd_sincos_pos_embed(embed_dim: int, grid_size: tuple) -> np.ndarray:
+    """(prod(grid), embed_dim).  Keeps the reference's ``np.meshgrid`` 'xy' axis order (``vit.py:421``) and its even-width /
+    zero-padding rule for dimensions that do not divide evenly (``vit.py:398-405``)."""
+    grid = np.stack(np.meshgrid(*[np.arange(s, dtype=np.float32) for s in grid_size]), axis=0)
+    return get_nd_sincos_pos_embed_from_grid(embed_dim, grid)
 
 
 def get_pos_embed(embed_dim: int, grid_size: tuple) -> nn.Parameter:

@@ -634,9 +634,12 @@ def segmentation_loss_one_view(logits: Tensor, labels: Tensor):  # noqa: ANN201
     softmax=True)`` (monai 1.5.2, absent here) restated: smooth_nr = smooth_dr = 1e-5, sums over the spatial axes per (sample, class),
     mean over samples x foreground classes.  Returns (loss, metrics).
 
-    PARITY UNPINNED for the Dice term: monai==1.5.2 (reference pyproject.toml:20) is not installed here and the reference holds no test or
-    golden value for this function; the restatement follows monai's published ``DiceLoss.forward`` (softmax, drop channel 0, per-item spatial
-    sums, ``1 - (2 I + smooth_nr) / (G + P + smooth_dr)``, mean) and is checked against a hand-computed known answer in the tests."""
+    The Dice term: monai==1.5.2 (reference pyproject.toml:20) is not installed here and the reference holds no test or golden value for this
+    function, so it cannot be pinned against the library itself.  It is pinned instead (round 6) against an INDEPENDENT second statement of monai's
+    published ``DiceLoss.forward`` (softmax, drop channel 0, per-item spatial sums, ``1 - (2 I + smooth_nr) / (G + P + smooth_dr)``, mean) written in
+    another style - float64 loops over samples / classes / voxels, ``oracle/second_opinion.py`` - on the committed vectors
+    ``tests/golden/second_opinion.safetensors`` (five random cases, an absent class, ignored voxels, an all-background volume, 2-D), plus the
+    hand-computed known answer of the tests."""
     labels = labels.long()
     c = logits.shape[1]
     target = F.one_hot(labels.clamp(min=0).squeeze(1), c).movedim(-1, 1).to(logits.dtype)
@@ -788,8 +791,8 @@ def segmentation_metrics(logits: Tensor, labels: Tensor, spacing: tuple) -> dict
 
 
 # ----------------------------------------------------------------------------------------------
-# input transforms of the pre-training loader (cinema/mae/pretrain.py:157-200) -- monai 1.5.2 restated, PARITY UNPINNED (monai absent, no
-# reference value test): Zoom(keep_size=True, padding_mode="constant") = interpolate(scale_factor, recompute_scale_factor=True, align_corners
+# input transforms of the pre-training loader (cinema/mae/pretrain.py:157-200) -- monai 1.5.2 restated (monai absent, no reference value test: pinned
+# since round 6 against the independent loop-style statement oracle/second_opinion.py on tests/golden/second_opinion.safetensors): Zoom(keep_size=True, padding_mode="constant") = interpolate(scale_factor, recompute_scale_factor=True, align_corners
 # False) + centred pad / crop; ScaleIntensity(minv=0, maxv=1) = (x - min) / (max - min), zeros for a constant image; SpatialPad(method="end").
 # ----------------------------------------------------------------------------------------------
 def input_transform(x: Tensor, zoom: float, padded_size: tuple, cubic: bool) -> Tensor:

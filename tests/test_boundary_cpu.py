@@ -246,3 +246,37 @@ def test_metric_helpers_follow_the_reference_formulas() -> None:
     mask[1, 2, :, :3] = 1
     vol = get_volumes(mask, (1.5, 1.5, 8.0))
     assert vol.shape == (2, 3) and vol[0, 1] == pytest.approx(2 * 5 * 2 * 18.0 / 1000) and vol[1, 2] == pytest.approx(4 * 3 * 2 * 18.0 / 1000) and float(vol[0, 0]) == 0.0
+
+
+def test_module_level_helper_symbols_of_the_reference_resolve() -> None:
+    """The free functions the reference exports beside its classes (cinema/mae/mae.py:68-152, cinema/vit.py:67-225,386-405, cinema/optim.py:55-119) import from the
+    alias package; the pure host ones agree with the reference's definitions here (their device twins are checked in tests/test_boundary_gpu.py)."""
+    import numpy as np
+    import torch
+
+    from cinema.mae.mae import add_pos_embed_and_append_mask_token, mse_loss  # noqa: F401
+    from cinema.optim import CosineScheduler, apply_optim_scheduler
+    from cinema.vit import (get_nd_sincos_pos_embed_from_grid, patchify, patchify_2d, patchify_3d, patchify_4d, unpatchify_2d, unpatchify_3d,  # noqa: F401
+                            unpatchify_4d)
+
+    x2, x3, x4 = torch.randn(2, 3, 8, 12), torch.randn(2, 1, 8, 6, 4), torch.randn(1, 2, 4, 4, 2, 6)
+    assert torch.equal(patchify_2d(x2, (4, 4)), patchify(x2, (4, 4))) and torch.equal(unpatchify_2d(patchify_2d(x2, (4, 4)), (4, 4), (2, 3)), x2)
+    assert torch.equal(unpatchify_3d(patchify_3d(x3, (4, 2, 1)), (4, 2, 1), (2, 3, 4)), x3)
+    assert torch.equal(unpatchify_4d(patchify_4d(x4, (2, 2, 1, 3)), (2, 2, 1, 3), (2, 2, 2, 2)), x4)
+    with pytest.raises(ValueError, match="cannot be divided"):
+        patchify_2d(x2, (3, 4))
+    # the reference formula: even width per axis, zero padding of the rest (cinema/vit.py:398-405)
+    grid = np.stack(np.meshgrid(np.arange(3, dtype=np.float32), np.arange(2, dtype=np.float32), np.arange(4, dtype=np.float32)), axis=0)
+    emb = get_nd_sincos_pos_embed_from_grid(16, grid)
+    assert emb.shape == (24, 16) and np.all(emb[:, 12:] == 0) and np.allclose(emb[0, :4], [0, 0, 1, 1])
+    # CosineScheduler known answers: freeze zeros, linear warm-up, half cosine, final value past the end
+    s = CosineScheduler(1.0, 0.1, 100, warmup_iters=10, freeze_iters=5)
+    assert s[0] == 0.0 and s[4] == 0.0 and s[5] == 0.0 and abs(s[14] - 1.0) < 1e-12 and abs(s[15] - 1.0) < 1e-12 and s[100] == 0.1 and s[1000] == 0.1
+    assert abs(s[15 + 42] - (0.1 + 0.45 * (1 + math.cos(math.pi * 42 / 85)))) < 1e-12
+    with pytest.raises(ValueError, match="Length of schedule"):
+        CosineScheduler(1.0, 0.1, 10, warmup_iters=8, freeze_iters=5)
+    lin = torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD([{"params": [lin.weight], "lr_scale": 0.5, "weight_decay_scale": 1.0, "is_last_layer": False},
+                           {"params": [lin.bias], "lr_scale": 1.0, "weight_decay_scale": 0.0, "is_last_layer": True}], lr=1.0)
+    apply_optim_scheduler(opt, lr=0.2, last_layer_lr=0.05, weight_decay=0.1)
+    assert [g["lr"] for g in opt.param_groups] == [0.1, 0.05] and [g["weight_decay"] for g in opt.param_groups] == [0.1, 0.0]

@@ -393,3 +393,60 @@ def test_hip_graph_step_smoke() -> None:
             TrainStep(_mfma_model()[0], lr=1e-3, hip_graph=True)(batch, 0.75)
     finally:
         T.FP8_FORWARD = prev
+
+
+# ---------------------------------------------------------------------------------------------------- module-level helpers of cinema.mae.mae (a20, a21)
+def test_module_level_mse_loss_matches_the_reference_golden() -> None:
+    """``from cinema.mae.mae import mse_loss`` on device tensors == the values the REFERENCE's ``mse_loss`` produced for the same target / prediction / mask
+    (``tests/golden/layers.safetensors: mse/*``, written by oracle/make_golden.py from cinema/mae/mae.py:107-152), with and without target normalisation; the
+    gradient with respect to the prediction is 2 (pred - target) / numel on the masked patches."""
+    from cinema.mae.mae import mse_loss
+
+    g = load_golden("layers.safetensors")
+    target, pred, mask = g["mse/target"].to(DEV), g["mse/pred"].to(DEV), g["mse/mask"].to(DEV).bool()
+    for nt in (0, 1):
+        p = pred.clone().requires_grad_(True)
+        loss, metrics = mse_loss(target, p, mask, bool(nt))
+        assert abs(float(loss) - float(g[f"mse/{nt}/loss"])) <= 1e-5 * abs(float(g[f"mse/{nt}/loss"])) + 1e-7
+        want = {k.split("/")[-1] for k in g if k.startswith(f"mse/{nt}/")} - {"loss"}
+        assert set(metrics) == want, (set(metrics), want)
+        for k in want:
+            assert abs(float(metrics[k]) - float(g[f"mse/{nt}/{k}"])) <= 1e-5 * abs(float(g[f"mse/{nt}/{k}"])) + 1e-6, (nt, k)
+        loss.backward()
+        t = target
+        if nt:
+            t = (t - t.mean(-1, keepdim=True)) / (t.var(-1, keepdim=True) ** 0.5 + 1e-6)
+        ref = 2 * (pred - t[mask].reshape(pred.shape)) / pred.numel()
+        assert float((p.grad - ref).abs().max()) <= 1e-6 + 1e-5 * float(ref.abs().max())
+
+
+def test_module_level_add_pos_embed_and_append_mask_token() -> None:
+    """``add_pos_embed_and_append_mask_token`` against the reference's own lines (cinema/mae/mae.py:91-104) evaluated with torch on the same tensors: concatenated
+    and split forms, gradients of the visible tokens and of the mask token."""
+    from cinema.mae.mae import add_pos_embed_and_append_mask_token
+
+    torch.manual_seed(3)
+    batch, n, n_keep, d = 3, 20, 7, 32
+    mask = torch.stack([torch.randperm(n) >= n_keep for _ in range(batch)]).to(DEV)
+    x = torch.randn(batch, n_keep, d, device=DEV)
+    pe = torch.nn.Parameter(torch.randn(1, n, d, device=DEV), requires_grad=False)
+    tok = torch.nn.Parameter(torch.randn(1, 1, d, device=DEV))
+
+    def reference(xv: torch.Tensor, token: torch.Tensor) -> tuple:
+        dec_pe = pe.expand(batch, -1, -1).contiguous()
+        vis_pe = dec_pe[~mask].reshape(batch, n_keep, d)
+        mask_pe = dec_pe[mask].reshape(batch, n - n_keep, d)
+        return xv + vis_pe, token + mask_pe
+
+    xr, tr = x.clone().requires_grad_(True), tok.detach().clone().requires_grad_(True)
+    rv, rm = reference(xr, tr)
+    xa = x.clone().requires_grad_(True)
+    out = add_pos_embed_and_append_mask_token(xa, mask, pe, tok, concat=True)
+    assert out.shape == (batch, n, d)
+    assert torch.allclose(out, torch.cat([rv, rm], dim=1), atol=1e-6)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    (torch.cat([rv, rm], dim=1) * w).sum().backward()
+    assert torch.allclose(xa.grad, xr.grad, atol=1e-6) and torch.allclose(tok.grad, tr.grad, atol=1e-4)
+    v2, m2 = add_pos_embed_and_append_mask_token(x, mask, pe, tok, concat=False)
+    assert torch.allclose(v2, rv, atol=1e-6) and torch.allclose(m2, rm, atol=1e-6)

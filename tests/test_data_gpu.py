@@ -53,3 +53,17 @@ def test_pipeline_double_buffering_and_model_ready_batches() -> None:
         pipe.get()
     with pytest.raises(ValueError, match="exceeds the padded size"):
         pipe.submit([{"sax": torch.rand(40, 28, 3)}])
+
+
+def test_zoom_scale_pad_vs_the_pinned_second_opinion_vectors() -> None:
+    """The HIP input transform against ``tests/golden/second_opinion.safetensors`` (values on which the oracle and the independent loop-style statement of monai's
+    Zoom / ScaleIntensity / SpatialPad agree; oracle/make_golden_second_opinion.py): trilinear / bicubic, zoom in / out, odd extents, identity, constant image."""
+    from conftest import load_golden
+
+    g = load_golden("second_opinion.safetensors")
+    for name in sorted({k.split("/")[1] for k in g if k.startswith("tf/")}):
+        x, want, args = g[f"tf/{name}/x"], g[f"tf/{name}/y"].float(), g[f"tf/{name}/args"]
+        zoom, cubic, padded = float(args[0]), bool(args[1]), tuple(int(v) for v in args[2:])
+        dst = torch.full(padded, 9.0, device=DEV)
+        K.zoom_scale_pad(x.to(DEV), (zoom,) * x.dim(), dst, cubic=cubic)
+        assert float((dst.cpu() - want).abs().max()) <= 2e-5, (name, float((dst.cpu() - want).abs().max()))  # fp32 interpolation weights vs float64

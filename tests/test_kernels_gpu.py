@@ -817,6 +817,22 @@ def test_adamw_and_clip() -> None:
     assert torch.equal(shadow, p.to(torch.bfloat16))
 
 
+def test_segmentation_loss_vs_the_pinned_second_opinion_vectors() -> None:
+    """CE + Dice of the HIP kernels (``cinema_seg_loss_fwd`` through ``_segmentation_loss``) against ``tests/golden/second_opinion.safetensors``: values on which the
+    oracle and an independent float64 loop-style statement of monai's ``DiceLoss(include_background=False, softmax=True)`` agree (absent class, ignored voxels,
+    all-background volume, 2-D included)."""
+    from conftest import load_golden
+
+    from cinema_amd.segmentation.train import _segmentation_loss
+
+    g = load_golden("second_opinion.safetensors")
+    for name in sorted({k.split("/")[1] for k in g if k.startswith("seg/")}):
+        logits, labels, want = g[f"seg/{name}/logits"].to(DEV), g[f"seg/{name}/labels"].long().to(DEV), g[f"seg/{name}/values"]
+        loss, m = _segmentation_loss(logits, labels)
+        for i, k in enumerate(("cross_entropy", "mean_dice_loss", "loss")):
+            assert abs(float(m[k]) - float(want[i])) <= 2e-5 * max(1.0, abs(float(want[i]))), (name, k, float(m[k]), float(want[i]))
+
+
 @pytest.mark.parametrize(("shape", "c"), [((2, 24, 20, 6), 4), ((3, 40, 33), 3), ((1, 7, 5, 3), 2)])
 def test_segmentation_loss_vs_oracle(shape: tuple, c: int) -> None:
     """CE(ignore -1) + soft Dice (reference cinema/segmentation/train.py:77-103) and its gradient against the fp32 oracle (autograd)."""

@@ -493,3 +493,40 @@ def test_convunetr_oracle_at_mfma_sized_channels_vs_reference_golden() -> None:
         gk = p[k].grad.reshape(p[k].shape[0], -1) if p[k].dim() > 1 else p[k].grad
         gk = gk[::meta["grad_row_stride_large"]] if gk.numel() >= meta["large_numel"] else gk
         assert torch.allclose(gk, t, rtol=5e-3, atol=5e-5 * float(t.abs().max()) + 1e-8), (k, float((gk - t).abs().max()), float(t.abs().max()))
+
+
+def test_monai_restatements_agree_with_the_independent_second_statement() -> None:
+    """Rows a26 / f3: monai 1.5.2 is absent, the reference holds no value for ``DiceLoss`` or for ``Zoom`` / ``ScaleIntensity`` / ``SpatialPad``.  The oracle's
+    restatement (torch tensor ops) and ``oracle/second_opinion.py`` (float64 loops over samples / classes / voxels and explicit index maps, written from monai's
+    published algorithm, sharing no code with the oracle) must agree on the committed vectors ``tests/golden/second_opinion.safetensors``: five random
+    segmentation cases + an absent class + ignored voxels + an all-background volume + a 2-D case; trilinear / bicubic zoom in and out on odd extents, the
+    identity zoom and a constant image.  Both sides are recomputed here and compared with the stored values."""
+    import numpy as np
+
+    import second_opinion as S
+
+    g = load_golden("second_opinion.safetensors")
+    seg = sorted({k.split("/")[1] for k in g if k.startswith("seg/")})
+    assert len(seg) >= 9
+    for name in seg:
+        logits, labels, want = g[f"seg/{name}/logits"], g[f"seg/{name}/labels"].long(), g[f"seg/{name}/values"]
+        _, m = O.segmentation_loss_one_view(logits.double(), labels)
+        s = S.segmentation_loss(logits.numpy().astype(np.float64), labels.numpy())
+        for i, k in enumerate(("cross_entropy", "mean_dice_loss", "loss")):
+            assert abs(float(m[k]) - float(want[i])) <= 1e-9 and abs(s[k] - float(want[i])) <= 1e-9, (name, k)
+        _, m32 = O.segmentation_loss_one_view(logits, labels)  # the fp32 form the GPU tests compare against
+        assert abs(float(m32["mean_dice_loss"]) - float(want[1])) <= 2e-6
+    # the absent class: its term is 1 - smooth / (sum of its probabilities + smooth), i.e. the loss does not collapse to "perfect" for an empty class
+    lg, lb = g["seg/absent_class/logits"], g["seg/absent_class/labels"].long()
+    assert int(lb.max()) == 2 and lg.shape[1] == 4
+    tf = sorted({k.split("/")[1] for k in g if k.startswith("tf/")})
+    assert len(tf) >= 8
+    for name in tf:
+        x, want, args = g[f"tf/{name}/x"], g[f"tf/{name}/y"], g[f"tf/{name}/args"]
+        zoom, cubic, padded = float(args[0]), bool(args[1]), tuple(int(v) for v in args[2:])
+        got = O.input_transform(x.double(), zoom, padded, cubic)
+        ref = S.input_transform(x.numpy().astype(np.float64), zoom, padded, cubic)
+        assert tuple(got.shape) == tuple(want.shape) == ref.shape
+        assert float((got - want).abs().max()) <= 1e-9 and float(np.abs(ref - want.numpy()).max()) <= 1e-12, name
+    const = torch.full((5, 4, 3), -1.5)
+    assert float(O.input_transform(const, 1.0, (6, 4, 4), False).abs().max()) == 0.0 and float(np.abs(S.input_transform(const.numpy(), 1.0, (6, 4, 4), False)).max()) == 0.0
