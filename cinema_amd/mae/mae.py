@@ -80,7 +80,7 @@ def mse_loss(target: torch.Tensor, pred: torch.Tensor, enc_mask: torch.Tensor, n
     """Masked-patch MSE and its metrics (reference ``cinema/mae/mae.py:107-152``): ``target`` (batch, n_patches, f) patches, ``pred`` (batch, n_masked, f),
     ``enc_mask`` (batch, n_patches) bool, True = predicted.  The per-patch statistics (unbiased variance), the optional target normalisation, the squared error and
     its gradient with respect to ``pred`` are the kernels the model's forward uses (``cinema_mse_fwd / _bwd``, ``cinema_patch_stats``): the target is addressed as
-    an image whose patches are its rows."""
+    an image whose patches are its rows.  The gradient with respect to ``pred`` comes back rounded to bf16 (what the prediction head's backward GEMMs read)."""
     batch, n_patches, f = target.shape
     dev = target.device
     tgt = target.detach().float().contiguous()

@@ -399,7 +399,7 @@ def test_hip_graph_step_smoke() -> None:
 def test_module_level_mse_loss_matches_the_reference_golden() -> None:
     """``from cinema.mae.mae import mse_loss`` on device tensors == the values the REFERENCE's ``mse_loss`` produced for the same target / prediction / mask
     (``tests/golden/layers.safetensors: mse/*``, written by oracle/make_golden.py from cinema/mae/mae.py:107-152), with and without target normalisation; the
-    gradient with respect to the prediction is 2 (pred - target) / numel on the masked patches."""
+    gradient with respect to the prediction is 2 (pred - target) / numel on the masked patches (rounded once to bf16, as the model's backward pass receives it)."""
     from cinema.mae.mae import mse_loss
 
     g = load_golden("layers.safetensors")
@@ -417,7 +417,7 @@ def test_module_level_mse_loss_matches_the_reference_golden() -> None:
         if nt:
             t = (t - t.mean(-1, keepdim=True)) / (t.var(-1, keepdim=True) ** 0.5 + 1e-6)
         ref = 2 * (pred - t[mask].reshape(pred.shape)) / pred.numel()
-        assert float((p.grad - ref).abs().max()) <= 1e-6 + 1e-5 * float(ref.abs().max())
+        assert float(((p.grad - ref).abs() - 4e-3 * ref.abs()).max()) <= 1e-7  # the kernel hands the gradient over in bf16 (the operand of the head's backward GEMMs): one rounding
 
 
 def test_module_level_add_pos_embed_and_append_mask_token() -> None:
