@@ -18,6 +18,7 @@ struct AttnP {
   const bf16_t* q; int ldq; const bf16_t* k; int ldk; const bf16_t* v; int ldv;
   bf16_t* o; int ldo; float* lse;
   const bf16_t* d_o; int lddo; float* delta;
+  bf16_t* o_lo;  // optional second half of the output, same addressing as o: bf16(O - float(bf16(O))).  delta = rowsum(dO (o + o_lo)) then carries O to 2^-17 (see attn_bwd_dq_mfma)
   bf16_t* dq; int lddq; bf16_t* dk; int lddk; bf16_t* dv; int lddv;
   int b, h, tq, tk, hd;
   float scale;   // softmax scale (head_dim^-0.5)
@@ -270,9 +271,16 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_mfma(AttnP p) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         uint2 pk;
-        pk.x = pack_bf2(o[dt][4 * j] * inv, o[dt][4 * j + 1] * inv);
-        pk.y = pack_bf2(o[dt][4 * j + 2] * inv, o[dt][4 * j + 3] * inv);
+        const float v0 = o[dt][4 * j] * inv, v1 = o[dt][4 * j + 1] * inv, v2 = o[dt][4 * j + 2] * inv, v3 = o[dt][4 * j + 3] * inv;
+        pk.x = pack_bf2(v0, v1);
+        pk.y = pack_bf2(v2, v3);
         *reinterpret_cast<uint2*>(op + dt * 32 + 8 * j + 4 * g) = pk;
+        if (p.o_lo) {  // what the bf16 rounding took away, as a second bf16 (training: the backward pass forms delta from both halves)
+          uint2 lo;
+          lo.x = pack_bf2(v0 - bf_lo32(pk.x), v1 - bf_hi32(pk.x));
+          lo.y = pack_bf2(v2 - bf_lo32(pk.y), v3 - bf_hi32(pk.y));
+          *reinterpret_cast<uint2*>(p.o_lo + (op - p.o) + dt * 32 + 8 * j + 4 * g) = lo;
+        }
       }
     if (g == 0 && p.lse) p.lse[((size_t)b * p.h + h) * p.tq + qrow] = m_run + log2f(l_tot);
   }
@@ -310,6 +318,18 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma(AttnP p) {
 #pragma unroll
       for (int e = 0; e < 8; e++)
         dl = fmaf(__uint_as_float((uint32_t)(uint16_t)of[ks][e] << 16), __uint_as_float((uint32_t)(uint16_t)dof[ks][e] << 16), dl);
+    if (p.o_lo) {
+      // delta from the STORED bf16 O alone carries a relative error of 2^-9 per element; it shifts every dS of the query by P eps, i.e. dQ by eps * sum_j P_ij K_j.
+      // In the late encoder blocks the keys are a large common vector plus small differences (|mean key| / |key - mean| = 5.4 at ViT-Large block 22) and the
+      // softmax is nearly uniform: that error was 13 % of dQ and 5 % of attn.q.weight's gradient, while the bf16 rounding of P and dS costs 0.25 %
+      // (tools/attn_dq_error.py, profiles/r06_i_attn_dq_error.txt).  With the second half of O the error of delta is 2^-17.
+      load_row_frags<HD>(of, p.o_lo + ((size_t)b * p.tq + qc) * p.ldo + h * HD, lane);
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          dl = fmaf(__uint_as_float((uint32_t)(uint16_t)of[ks][e] << 16), __uint_as_float((uint32_t)(uint16_t)dof[ks][e] << 16), dl);
+    }
     dl += __shfl_xor(dl, 32, 64);
     if (g == 0 && qrow < p.tq) p.delta[sidx] = dl;
   }
@@ -514,19 +534,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(AttnP p) {
 template <int HD>
 struct TileStats {
   static constexpr int CPR = HD / 8;
-  uint4 o, d;
+  uint4 o, d, ol;
   float lse;
-  __device__ __forceinline__ void load(const bf16_t* obase, int ldo, const bf16_t* dobase, int lddo, const float* lsebase, int q0, int tq, int tid) {
+  // olo_off: element offset of the optional second half of O from obase (0: none) - delta then comes from both halves (see attn_bwd_dq_mfma)
+  __device__ __forceinline__ void load(const bf16_t* obase, int ldo, const bf16_t* dobase, int lddo, const float* lsebase, int q0, int tq, int tid, ptrdiff_t olo_off = 0) {
+    ol = make_uint4(0u, 0u, 0u, 0u);
     if (tid < 64 * CPR) {
       const int qc = min(q0 + tid / CPR, tq - 1), c = tid % CPR;
       o = *reinterpret_cast<const uint4*>(obase + (size_t)qc * ldo + c * 8);
+      if (olo_off) ol = *reinterpret_cast<const uint4*>(obase + olo_off + (size_t)qc * ldo + c * 8);
       d = *reinterpret_cast<const uint4*>(dobase + (size_t)qc * lddo + c * 8);
       lse = lsebase[qc];
     }
   }
   __device__ __forceinline__ float delta() const {  // rowsum(dO * O) of the thread's query: complete in every lane of the query's CPR-lane group
-    float s = bf_lo32(o.x) * bf_lo32(d.x) + bf_hi32(o.x) * bf_hi32(d.x) + bf_lo32(o.y) * bf_lo32(d.y) + bf_hi32(o.y) * bf_hi32(d.y) +
-              bf_lo32(o.z) * bf_lo32(d.z) + bf_hi32(o.z) * bf_hi32(d.z) + bf_lo32(o.w) * bf_lo32(d.w) + bf_hi32(o.w) * bf_hi32(d.w);
+    float s = (bf_lo32(o.x) + bf_lo32(ol.x)) * bf_lo32(d.x) + (bf_hi32(o.x) + bf_hi32(ol.x)) * bf_hi32(d.x) + (bf_lo32(o.y) + bf_lo32(ol.y)) * bf_lo32(d.y) +
+              (bf_hi32(o.y) + bf_hi32(ol.y)) * bf_hi32(d.y) + (bf_lo32(o.z) + bf_lo32(ol.z)) * bf_lo32(d.z) + (bf_hi32(o.z) + bf_hi32(ol.z)) * bf_hi32(d.z) +
+              (bf_lo32(o.w) + bf_lo32(ol.w)) * bf_lo32(d.w) + (bf_hi32(o.w) + bf_hi32(ol.w)) * bf_hi32(d.w);
 #pragma unroll
     for (int m = 1; m < CPR; m <<= 1) s += __shfl_xor(s, m, 64);
     return s;
@@ -613,6 +637,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_mfma(AttnP p) {
           const uint4 a = op[c], d = dp[c];
           s += bf_lo32(a.x) * bf_lo32(d.x) + bf_hi32(a.x) * bf_hi32(d.x) + bf_lo32(a.y) * bf_lo32(d.y) + bf_hi32(a.y) * bf_hi32(d.y) +
                bf_lo32(a.z) * bf_lo32(d.z) + bf_hi32(a.z) * bf_hi32(d.z) + bf_lo32(a.w) * bf_lo32(d.w) + bf_hi32(a.w) * bf_hi32(d.w);
+        }
+        if (p.o_lo) {  // the second half of O (see attn_bwd_dq_mfma)
+          const uint4* lp = reinterpret_cast<const uint4*>(p.o_lo + (obase - p.o) + (size_t)qi * p.ldo);
+#pragma unroll
+          for (int c = 0; c < HD / 8; c++) {
+            const uint4 a = lp[c], d = dp[c];
+            s += bf_lo32(a.x) * bf_lo32(d.x) + bf_hi32(a.x) * bf_hi32(d.x) + bf_lo32(a.y) * bf_lo32(d.y) + bf_hi32(a.y) * bf_hi32(d.y) +
+                 bf_lo32(a.z) * bf_lo32(d.z) + bf_hi32(a.z) * bf_hi32(d.z) + bf_lo32(a.w) * bf_lo32(d.w) + bf_hi32(a.w) * bf_hi32(d.w);
+          }
         }
       }
       st_l = s;
@@ -817,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_mfma(OnePassP pp) {
   float* dlbase = p.delta + ((size_t)b * p.h + h) * p.tq;
   for (int q0 = 0; q0 < p.tq; q0 += 64) {
     TileStats<HD> ts;
-    ts.load(obase, p.ldo, dobase, p.lddo, lsebase, q0, p.tq, tid);
+    ts.load(obase, p.ldo, dobase, p.lddo, lsebase, q0, p.tq, tid, p.o_lo ? p.o_lo - p.o : 0);
     const float dl = ts.delta();
     const int qi = q0 + (tid >> 3);
     if ((tid & 7) == 0 && qi < p.tq) dlbase[qi] = dl;
@@ -1061,6 +1094,10 @@ __global__ void attn_delta_kernel(AttnP p) {
   const bf16_t* dop = p.d_o + ((size_t)b * p.tq + q) * p.lddo + h * p.hd;
   float s = 0.f;
   for (int d = 0; d < p.hd; d++) s += bf2f(op[d]) * bf2f(dop[d]);
+  if (p.o_lo) {
+    const bf16_t* lp = p.o_lo + (op - p.o);
+    for (int d = 0; d < p.hd; d++) s += bf2f(lp[d]) * bf2f(dop[d]);
+  }
   p.delta[idx] = s;
 }
 
@@ -1124,7 +1161,10 @@ __global__ __launch_bounds__(256) void attn_fwd_generic(AttnP p) {
     float acc = 0.f;
     // P is rounded to bf16 before the PV product, like the MFMA kernel and like a bf16 SDPA
     for (int j = 0; j < p.tk; j++) acc += bf2f(f2bf(sc[j])) * bf2f(p.v[((size_t)b * p.tk + j) * p.ldv + h * p.hd + d]);
-    p.o[((size_t)b * p.tq + q) * p.ldo + h * p.hd + d] = f2bf(acc / l);
+    const float val = acc / l;
+    const bf16_t hi = f2bf(val);
+    p.o[((size_t)b * p.tq + q) * p.ldo + h * p.hd + d] = hi;
+    if (p.o_lo) p.o_lo[((size_t)b * p.tq + q) * p.ldo + h * p.hd + d] = f2bf(val - bf2f(hi));
   }
   if (lane == 0 && p.lse) p.lse[row] = mx + log2f(l);
 }
@@ -1197,11 +1237,12 @@ bool mfma_ok(int hd, int force_generic, std::initializer_list<int> lds, std::ini
 
 }  // namespace
 
-CINEMA_API int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
+CINEMA_API int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, uint16_t* o_lo, int ldo,
                                     float* lse, int b, int h, int tq, int tk, int hd, float scale, int force_generic, void* stream) {
   if (!q || !k || !v || !o || b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || hd <= 0 || hd > 128) return CINEMA_ERR_BAD_ARG;
+  if (o_lo && (((uintptr_t)o_lo) & 15)) return CINEMA_ERR_BAD_ARG;
   AttnP p{};
-  p.q = q; p.ldq = ldq; p.k = k; p.ldk = ldk; p.v = v; p.ldv = ldv; p.o = o; p.ldo = ldo; p.lse = lse;
+  p.q = q; p.ldq = ldq; p.k = k; p.ldk = ldk; p.v = v; p.ldv = ldv; p.o = o; p.o_lo = o_lo; p.ldo = ldo; p.lse = lse;
   p.b = b; p.h = h; p.tq = tq; p.tk = tk; p.hd = hd; p.scale = scale; p.c2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   if (mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo}, {q, k, v, o})) {
@@ -1252,14 +1293,15 @@ CINEMA_API long long cinema_attention_bwd_workspace_bytes(int b, int h, int tq, 
   return onepass_plan(b, h, tq, tk).part_floats * 4;
 }
 
-static int attention_bwd_impl(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+static int attention_bwd_impl(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o, const uint16_t* o_lo,
                               int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
                               uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
                               int force_generic, float* workspace, long long workspace_bytes, unsigned* counters, int n_counters, void* stream) {
   if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || hd <= 0 || hd > 128)
     return CINEMA_ERR_BAD_ARG;
   AttnP p{};
-  p.q = q; p.ldq = ldq; p.k = k; p.ldk = ldk; p.v = v; p.ldv = ldv; p.o = const_cast<uint16_t*>(o); p.ldo = ldo;
+  if (o_lo && (((uintptr_t)o_lo) & 15)) return CINEMA_ERR_BAD_ARG;
+  p.q = q; p.ldq = ldq; p.k = k; p.ldk = ldk; p.v = v; p.ldv = ldv; p.o = const_cast<uint16_t*>(o); p.o_lo = const_cast<uint16_t*>(o_lo); p.ldo = ldo;
   p.lse = const_cast<float*>(lse); p.d_o = d_o; p.lddo = lddo; p.delta = delta;
   p.dq = dq; p.lddq = lddq; p.dk = dk; p.lddk = lddk; p.dv = dv; p.lddv = lddv;
   p.b = b; p.h = h; p.tq = tq; p.tk = tk; p.hd = hd; p.scale = scale; p.c2 = scale * 1.4426950408889634f;
@@ -1269,7 +1311,7 @@ static int attention_bwd_impl(const uint16_t* q, int ldq, const uint16_t* k, int
   const bool mfma = mfma_ok(hd, force_generic, {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv}, {q, k, v, d_o, dq, dk, dv}) && !(((uintptr_t)o) & 15);
   if (mfma) {
     // delta is produced by the dQ kernel (from its O / dO row fragments) and consumed by the dK/dV kernel behind it
-  } else if (pow2 && !(ldo & 7) && !(lddo & 7) && !(((uintptr_t)o) & 15) && !(((uintptr_t)d_o) & 15)) {
+  } else if (!o_lo && pow2 && !(ldo & 7) && !(lddo & 7) && !(((uintptr_t)o) & 15) && !(((uintptr_t)d_o) & 15)) {
     const long long rows = (long long)b * tq;
     CINEMA_LAUNCH(attn_delta_vec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   } else {
@@ -1324,18 +1366,18 @@ static int attention_bwd_impl(const uint16_t* q, int ldq, const uint16_t* k, int
   return launch_status();
 }
 
-CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+CINEMA_API int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o, const uint16_t* o_lo,
                                     int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
                                     uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
                                     int force_generic, void* stream) {
-  return attention_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, b, h, tq, tk, hd, scale, force_generic,
+  return attention_bwd_impl(q, ldq, k, ldk, v, ldv, o, o_lo, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, b, h, tq, tk, hd, scale, force_generic,
                             nullptr, 0, nullptr, 0, stream);
 }
 
-CINEMA_API int cinema_attention_bwd_ws(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+CINEMA_API int cinema_attention_bwd_ws(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o, const uint16_t* o_lo,
                                        int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
                                        uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
                                        int force_generic, float* workspace, long long workspace_bytes, unsigned* counters, int n_counters, void* stream) {
-  return attention_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, b, h, tq, tk, hd, scale, force_generic,
+  return attention_bwd_impl(q, ldq, k, ldk, v, ldv, o, o_lo, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, b, h, tq, tk, hd, scale, force_generic,
                             workspace, workspace_bytes, counters, n_counters, stream);
 }

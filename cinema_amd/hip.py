@@ -159,10 +159,10 @@ _PROTOS = {
     "cinema_layernorm_bwd_workspace_bytes": [_i, _i],
     "cinema_ln_param_reduce_batched": [_vp, _i, _vp],
     "cinema_row_copy_multi": [_vp, _i, _vp],
-    "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
-    "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "cinema_attention_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "cinema_attention_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "cinema_attention_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
-    "cinema_attention_bwd_ws": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _i, _vp],
+    "cinema_attention_bwd_ws": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _i, _vp],
     "cinema_dwconv_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_data": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cinema_dwconv_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -1410,38 +1410,44 @@ def _attn_view(t: torch.Tensor, heads: int, hd: int, name: str):  # noqa: ANN202
     return t.data_ptr(), t.stride(1)
 
 
-def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, force_generic: bool = False):  # noqa: ANN201
-    """q: [b,tq,C], k/v: [b,tk,C] bf16 views (C = heads*hd) -> (o [b,tq,C] bf16, lse [b,heads,tq] fp32 log2-domain)."""
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, force_generic: bool = False, want_lo: bool = False):  # noqa: ANN201
+    """q: [b,tq,C], k/v: [b,tk,C] bf16 views (C = heads*hd) -> (o [b,tq,C] bf16, lse [b,heads,tq] fp32 log2-domain); ``want_lo``: -> (o, lse, o_lo) with
+    o_lo = bf16(O - float(o)), the second half of the output that :func:`attention_bwd` adds when it forms delta = rowsum(dO O) (training)."""
     _dev(q, k, v)
     b, tq, cdim = q.shape
     tk, hd = k.shape[1], cdim // heads
     (qp, ldq), (kp, ldk), (vp, ldv) = _attn_view(q, heads, hd, "q"), _attn_view(k, heads, hd, "k"), _attn_view(v, heads, hd, "v")
     o = _empty((b, tq, cdim), dtype=torch.bfloat16, device=q.device)
+    o_lo = _empty((b, tq, cdim), dtype=torch.bfloat16, device=q.device) if want_lo else None
     lse = _empty((b, heads, tq), dtype=torch.float32, device=q.device)
-    _check(load().cinema_attention_fwd(qp, ldq, kp, ldk, vp, ldv, o.data_ptr(), cdim, lse.data_ptr(), b, heads, tq, tk, hd, scale,
+    _check(load().cinema_attention_fwd(qp, ldq, kp, ldk, vp, ldv, o.data_ptr(), _p(o_lo), cdim, lse.data_ptr(), b, heads, tq, tk, hd, scale,
                                        int(force_generic or FORCE_GENERIC), _stream()), "attention_fwd")
-    return o, lse
+    return (o, lse, o_lo) if want_lo else (o, lse)
 
 
 def attention_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, d_o: torch.Tensor, lse: torch.Tensor, heads: int,
-                  scale: float, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, force_generic: bool = False) -> None:
-    """Writes dq/dk/dv (bf16 views with the same addressing rules as q/k/v)."""
-    _dev(q, k, v, o, d_o, lse, dq, dk, dv)
+                  scale: float, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, force_generic: bool = False, o_lo: torch.Tensor | None = None) -> None:
+    """Writes dq/dk/dv (bf16 views with the same addressing rules as q/k/v).  ``o_lo``: the second half of the forward output (``attention_fwd(want_lo=True)``)."""
+    _dev(q, k, v, o, d_o, lse, dq, dk, dv, o_lo)
     b, tq, cdim = q.shape
     tk, hd = k.shape[1], cdim // heads
     ptrs = [_attn_view(t, heads, hd, n) for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv"))]
+    if o_lo is not None and (o_lo.shape != o.shape or o_lo.stride() != o.stride() or o_lo.dtype != torch.bfloat16):
+        raise HipLibraryError("attention_bwd: o_lo must have the layout of o")
     delta = _empty((b, heads, tq), dtype=torch.float32, device=q.device)
+    args = (ptrs[0][0], ptrs[0][1], ptrs[1][0], ptrs[1][1], ptrs[2][0], ptrs[2][1], ptrs[3][0], _p(o_lo), ptrs[3][1], ptrs[4][0], ptrs[4][1], lse.data_ptr(),
+            delta.data_ptr(), ptrs[5][0], ptrs[5][1], ptrs[6][0], ptrs[6][1], ptrs[7][0], ptrs[7][1], b, heads, tq, tk, hd, scale, int(force_generic or FORCE_GENERIC))
+    if not (hd == 64 and os.environ.get("CINEMA_ATTN_ONEPASS", "0") == "1"):  # the dQ + dK/dV kernel pair / the one-pass kernel at head_dim 32: no scratch, no
+        # counters (the library reads the same variable per call; the head_dim 64 one-pass form is an option, off by default)
+        _check(load().cinema_attention_bwd(*args, _stream()), "attention_bwd")
+        return
     # scratch of the one-pass backward at head_dim 64 (csrc/attention.hip attn_bwd_onepass_mfma): running dQ sums across the passes over the keys / the sums of
     # the workgroups that share a (batch, head) pair, and their arrival tickets (zero at allocation, left zero by every launch)
     ws_bytes = load().cinema_attention_bwd_workspace_bytes(b, heads, tq, tk, hd)
     ws = _workspace("attn_bwd", ws_bytes // 4, q.device) if ws_bytes > 0 else None
-    cnt = _attn_counters(q.device) if (hd == 64 and b * heads <= ATTN_COUNTERS) else None
-    _check(load().cinema_attention_bwd_ws(ptrs[0][0], ptrs[0][1], ptrs[1][0], ptrs[1][1], ptrs[2][0], ptrs[2][1], ptrs[3][0], ptrs[3][1],
-                                          ptrs[4][0], ptrs[4][1], lse.data_ptr(), delta.data_ptr(), ptrs[5][0], ptrs[5][1], ptrs[6][0], ptrs[6][1],
-                                          ptrs[7][0], ptrs[7][1], b, heads, tq, tk, hd, scale, int(force_generic or FORCE_GENERIC),
-                                          None if ws is None else ws.data_ptr(), ws_bytes if ws is not None else 0,
-                                          None if cnt is None else cnt.data_ptr(), 0 if cnt is None else cnt.numel(), _stream()),
-           "attention_bwd")
+    cnt = _attn_counters(q.device) if b * heads <= ATTN_COUNTERS else None
+    _check(load().cinema_attention_bwd_ws(*args, None if ws is None else ws.data_ptr(), ws_bytes if ws is not None else 0,
+                                          None if cnt is None else cnt.data_ptr(), 0 if cnt is None else cnt.numel(), _stream()), "attention_bwd")
 
 
 ATTN_COUNTERS = 16384

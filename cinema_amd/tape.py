@@ -1221,6 +1221,12 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     return y
 
 
+ATTN_CAPTURE: list | None = None  # set to a list: every self-attention backward appends its operands (dev tooling only)
+# training keeps the second bf16 half of every attention output, O = o + o_lo, for delta = rowsum(dO O) of the backward pass (csrc/attention.hip attn_bwd_dq_mfma:
+# delta from the bf16 output alone put 13 % of error into dQ of the late ViT-Large blocks); 0: one half (A/B, tools/attn_dq_error.py)
+ATTN_O_LO = bool(int(os.environ.get("CINEMA_ATTN_O_LO", "1")))
+
+
 def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, rope: tuple | None = None, fp8: bool = False) -> Var:  # noqa: ANN001
     """Fused q|k|v projection (one N=3C GEMM on concatenated shadow weights) + flash attention.  x bf16 [b*t, c].
     ``rope`` = (cos, sin) fp32 [heads, hd/2]: the reference's head-indexed rotary embedding (``cinema/vit.py:496-499``), applied in place to the
@@ -1240,7 +1246,8 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
     t = qkv.shape[0] // batch
     q3 = qkv.view(batch, t, 3 * c)
     scale = (c // heads) ** -0.5
-    o, lse = K.attention_fwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], heads, scale)
+    o, lse, o_lo = K.attention_fwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], heads, scale, want_lo=True) if (tape.train and ATTN_O_LO) else \
+        (*K.attention_fwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], heads, scale), None)
     y = Var(o.view(batch * t, c))
     pv = [tape.pvar(p) for p in (q_w, q_b, kv_w, kv_b)]
 
@@ -1250,7 +1257,9 @@ def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w
         dqkv = K.empty_like(qkv)
         d3 = dqkv.view(batch, t, 3 * c)
         K.attention_bwd(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], o, y.grad.view(batch, t, c), lse, heads, scale, d3[..., :c],
-                        d3[..., c:2 * c], d3[..., 2 * c:])
+                        d3[..., c:2 * c], d3[..., 2 * c:], o_lo=o_lo)
+        if ATTN_CAPTURE is not None:  # dev tooling (tools/attn_dq_error.py): the operands of this block's attention backward
+            ATTN_CAPTURE.append(dict(qkv=qkv.clone(), o=o.clone(), do=y.grad.clone(), lse=lse.clone(), dqkv=dqkv.clone(), x=x.data.clone(), batch=batch, heads=heads))
         if rope is not None:
             K.rope_heads(dqkv, 2 * heads, heads, c // heads, rope[0], rope[1], inverse=True)
         gq, gkv = pv[0].grad_buffer((c, c)), pv[2].grad_buffer((2 * c, c))
@@ -1387,7 +1396,8 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
     tq, tk = q.shape[0] // batch, kv.shape[0] // batch
     q3, kv3 = q.view(batch, tq, c), kv.view(batch, tk, 2 * c)
     scale = (c // heads) ** -0.5
-    o, lse = K.attention_fwd(q3, kv3[..., :c], kv3[..., c:], heads, scale)
+    o, lse, o_lo = K.attention_fwd(q3, kv3[..., :c], kv3[..., c:], heads, scale, want_lo=True) if (tape.train and ATTN_O_LO) else \
+        (*K.attention_fwd(q3, kv3[..., :c], kv3[..., c:], heads, scale), None)
     y = Var(o.view(batch * tq, c))
     pv = [tape.pvar(p) for p in (q_w, q_b, kv_w, kv_b)]
 
@@ -1398,7 +1408,7 @@ def op_cross_attention(tape: Tape, xq: Var, xk: Var, batch: int, heads: int, q_w
         dkv = K.empty_like(kv) if shared is None else shared[0].grad_part(shared[1])
         dkv3 = dkv.view(batch, tk, 2 * c)
         K.attention_bwd(q3, kv3[..., :c], kv3[..., c:], o, y.grad.view(batch, tq, c), lse, heads, scale, dq.view(batch, tq, c), dkv3[..., :c],
-                        dkv3[..., c:])
+                        dkv3[..., c:], o_lo=o_lo)
         dq8 = dkv8 = None  # e4m3 copies of the gradients under delayed per-tensor scales: dY of the weight gradients, A of the data gradients
         if fp8_sites_on and c % 16 == 0:
             sq, skv = fp8_site(dq, q_w, "dy"), fp8_site(dq, kv_w, "dy")

@@ -228,11 +228,14 @@ int cinema_ln_param_reduce_batched(const cinema_ln_reduce_item* items_host, int 
  * dropout).  q:[b,tq,h,hd] k,v:[b,tk,h,hd] addressed as base + (b*t + t_i)*ld + h*hd + d (bf16) so that the fused
  * qkv / kv GEMM outputs are consumed in place.  o:[b,tq,h*hd] bf16.  lse:[b,h,tq] fp32 = log2-domain
  * log-sum-exp of scale*log2(e)*q.k.  hd in {32,64} -> MFMA flash kernel; any hd<=128 -> generic kernel.
+ * o_lo (optional, NULL = not wanted; same addressing and ld as o): bf16(O - float(bf16(O))), the part of the fp32 output the bf16 rounding removed.  Training keeps
+ * it for the backward pass: delta = rowsum(dO (o + o_lo)) is then exact to 2^-17.  Formed from o alone its 2^-9 error shifts every dS of a query and is multiplied
+ * by the keys' common component: 13 % of dQ / 5 % of attn.q.weight's gradient in the late blocks of ViT-Large (profiles/r06_i_attn_dq_error.txt).
  */
-int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
+int cinema_attention_fwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, uint16_t* o_lo, int ldo,
                          float* lse, int b, int h, int tq, int tk, int hd, float scale, int force_generic, void* stream);
-/* delta:[b,h,tq] fp32 scratch (rowsum(dO*O)) is written by the call. dq/dk/dv use the same addressing as q/k/v. */
-int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+/* delta:[b,h,tq] fp32 scratch (rowsum(dO*(o + o_lo))) is written by the call; o_lo may be NULL (delta from o alone). dq/dk/dv use the same addressing as q/k/v. */
+int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o, const uint16_t* o_lo,
                          int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
                          uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
                          int force_generic, void* stream);
@@ -241,7 +244,7 @@ int cinema_attention_bwd(const uint16_t* q, int ldq, const uint16_t* k, int ldk,
  * (16-byte aligned, contents irrelevant), counters = b*h zero-initialised words that every launch leaves zero.  Without sufficient scratch the call falls back
  * to the dQ + dK/dV kernel pair of cinema_attention_bwd (same results up to summation order).  Reference: cinema/vit.py:505-517 (backward of SDPA). */
 long long cinema_attention_bwd_workspace_bytes(int b, int h, int tq, int tk, int hd);
-int cinema_attention_bwd_ws(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o,
+int cinema_attention_bwd_ws(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, const uint16_t* o, const uint16_t* o_lo,
                             int ldo, const uint16_t* d_o, int lddo, const float* lse, float* delta, uint16_t* dq, int lddq,
                             uint16_t* dk, int lddk, uint16_t* dv, int lddv, int b, int h, int tq, int tk, int hd, float scale,
                             int force_generic, float* workspace, long long workspace_bytes, unsigned* counters, int n_counters, void* stream);

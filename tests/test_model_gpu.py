@@ -36,8 +36,9 @@ LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-3, 5e-2, 6e-2, 12e-2   # default ga
 MINI_GATES = {"mini_4view": (4.6e-2, 5.5e-2), "mini_4view_selfattn": (4.6e-2, 5.5e-2), "mini_4view_normtarget": (7.8e-2, 11e-2)}
 TINY_GRAD_L2, TINY_GRAD_MAX = 2.5e-2, 2.5e-2                          # cfg 1: measured 0.75 % / 0.73 %
 MID_GRAD_L2, MID_GRAD_MAX = 5.5e-2, 10e-2                             # MFMA-sized models: measured 1.7 % / 3.3 %
-# config-2 real-shape first-step parity (test_base_4view_192_first_step_vs_oracle) = 3 x measured (6.9e-4, 1.2e-3, 5.7e-4, 0.79 %, 1.76 %)
-CFG2_LOSS_RTOL, CFG2_VIEW_LOSS_RTOL, CFG2_GRAD_NORM_RTOL, CFG2_NAMED_GRAD_L2, CFG2_WORST_GRAD_L2 = 2.1e-3, 3.6e-3, 1.8e-3, 2.4e-2, 5.3e-2
+# config-2 real-shape first-step parity (test_base_4view_192_first_step_vs_oracle) = 3 x measured (6.9e-4, 1.2e-3, 5.7e-4, 0.79 %); the worst tensor: a REQUIRED
+# 3 % since round 6 (measured 1.46 %, a LayerNorm vector of a long-axis stem; 1.76 % before the attention outputs kept their second half)
+CFG2_LOSS_RTOL, CFG2_VIEW_LOSS_RTOL, CFG2_GRAD_NORM_RTOL, CFG2_NAMED_GRAD_L2, CFG2_WORST_GRAD_L2 = 2.1e-3, 3.6e-3, 1.8e-3, 2.4e-2, 3.0e-2
 
 
 def split(t: dict, prefix: str) -> dict:
@@ -499,6 +500,9 @@ def test_fp8_gradients_at_vit_large_depth_vs_oracle() -> None:
     b16, f8 = par["bf16"], par["fp8_wgrad"]
     assert f8["fp8_dgrad_gemms"] >= 5 * 32 - 8 and f8["fp8_wgrad_problems"] >= 3 * 32, f8  # the e4m3 kernels really ran in all 32 blocks
     assert b16["loss_rel"] <= 2e-3 and b16["grad_norm_rel"] <= 1e-2 and b16["whole_grad_rel_l2"] <= 0.03, b16
+    # round 6: the worst bf16 matrix was encoder.blocks.22.attn.q.weight at 7.9 % - the bf16 rounding of the attention OUTPUT inside delta = rowsum(dO O), amplified by
+    # the keys' common component (profiles/r06_i_attn_dq_error.txt); with both halves of O it is a decoder q weight at 1.5 %.  Required: 3 %.
+    assert b16["worst_matrix_rel_l2"]["value"] <= 3e-2, b16["worst_matrix_rel_l2"]
     assert f8["loss_rel"] <= FP8_LOSS_RTOL and f8["grad_norm_rel"] <= 5e-2, f8
     assert f8["whole_grad_rel_l2"] <= FP8_DEPTH_WHOLE_GRAD_L2, f8
     assert f8["worst_matrix_rel_l2"]["value"] <= FP8_DEPTH_MATRIX_GRAD_L2, f8
