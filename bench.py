@@ -428,6 +428,18 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
         out["config5_fp8"]["parity"] = {"loss_rel": round(par["loss_rel"], 6), "loss": round(par["loss"], 6), "oracle_loss": round(par["oracle_loss"], 6),
                                         "view_loss_rel": {k: round(v, 6) for k, v in par["view_loss_rel"].items()},
                                         "what": "first-step loss (forward) of the fp8 path vs the fp32 CPU oracle at this shape, batch 1, identical weights / inputs / masks (stated: <= 5e-2)"}
+        # ... and the GRADIENTS at this very shape (the oracle's forward + backward takes ~13 s of host time): whole gradient, worst matrix, six named tensors, bf16 and e4m3
+        from parity import mae_fp8_grad_parity as _gp5
+
+        names5 = ("encoder.blocks.0.attn.kv.weight", "encoder.blocks.23.mlp.fc1.weight", "decoder.blocks.0.attn.q.weight", "decoder.blocks.7.mlp.fc2.weight",
+                  "enc_down_dict.sax.conv_blocks.0.conv.0.mlp.fc1.weight", "pred_head_dict.sax.weight")
+        g5 = _gp5(kw5, sd5, batch=1, seed=17, device=device, threads=min(os.cpu_count() or 1, 16), modes=("bf16", "fp8_wgrad"), report=names5)
+        out["config5_fp8"]["parity"]["gradients_own_shape"] = {
+            m: {"loss_rel": round(g5[m]["loss_rel"], 6), "grad_norm_rel": round(g5[m]["grad_norm_rel"], 6), "whole_grad_rel_l2": round(g5[m]["whole_grad_rel_l2"], 5),
+                "worst_matrix_rel_l2": {"name": g5[m]["worst_matrix_rel_l2"]["name"], "value": round(g5[m]["worst_matrix_rel_l2"]["value"], 5)},
+                "named_rel_l2": g5[m]["named_rel_l2"]} for m in ("bf16", "fp8_wgrad")}
+        out["config5_fp8"]["parity"]["gradients_own_shape"]["what"] = ("gradients of the HIP path vs the fp32 CPU oracle at config 5's own spatial size and depth, batch 1, identical weights / "
+                                                                       f"inputs / masks (oracle forward + backward {g5['oracle_seconds']} s): bf16 path and the full e4m3 path")
         # gradients of the fp8 path against the ORACLE (its backward at the config-5 shape takes minutes: a 2 + 2 block model with MFMA-sized channels instead)
         from parity import mae_fp8_grad_parity
 

@@ -188,7 +188,7 @@ def mae_loss_parity(kw: dict, state_dict: dict, batch: int = 1, seed: int = 7, d
 
 
 def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 5, device: str = "cuda", threads: int | None = None,
-                        modes: tuple = ("bf16", "fp8_forward", "fp8", "fp8_wgrad")) -> dict:
+                        modes: tuple = ("bf16", "fp8_forward", "fp8", "fp8_wgrad"), report: tuple = ()) -> dict:
     """Gradients of the fp8 path against the ORACLE (not against this repository's bf16 path): one forward + backward of the oracle on the CPU and three
     of the HIP path on identical weights / inputs / masks - bf16, e4m3 forward only, e4m3 forward + e4m3 data gradients, and the same + e4m3 WEIGHT gradients
     (per-tensor delayed scaling: a first pass records the maxima).  The flat parameter buffers
@@ -259,6 +259,7 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
             loss, _, _, _ = model(dimg, 0.75, enc_mask_dict=dmask)
             loss.backward()
             sq_g = sq_e = 0.0
+            named_l2 = {}
             worst_m, worst_v = ("", 0.0), ("", 0.0)
             by_depth: dict = {}  # encoder / decoder block index -> (squared error, squared reference norm) over the block's matrices
             for k, r in ref.items():
@@ -275,6 +276,8 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
                 if rn < 1e-6 * ref_norm:  # numerically nothing on both sides (LayerNorm over one channel)
                     continue
                 l2 = math.sqrt(e) / rn
+                if k in report:
+                    named_l2[k] = round(l2, 5)
                 if r.dim() >= 2 and l2 > worst_m[1]:
                     worst_m = (k, l2)
                 if r.dim() < 2 and l2 > worst_v[1]:
@@ -282,7 +285,7 @@ def mae_fp8_grad_parity(kw: dict, state_dict: dict, batch: int = 3, seed: int = 
             out[mode] = {"loss": float(loss), "loss_rel": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
                          "grad_norm_rel": abs(math.sqrt(sq_g) - ref_norm) / ref_norm, "whole_grad_rel_l2": math.sqrt(sq_e) / ref_norm,
                          "worst_matrix_rel_l2": {"name": worst_m[0], "value": worst_m[1]}, "worst_vector_rel_l2": {"name": worst_v[0], "value": worst_v[1]},
-                         "fp8_dgrad_gemms": calls["n"], "fp8_wgrad_problems": wg8["n"],
+                         "fp8_dgrad_gemms": calls["n"], "fp8_wgrad_problems": wg8["n"], "named_rel_l2": named_l2,
                          # relative L2 error of each transformer block's matrices taken together: how the error grows from the last block (where the
                          # backward pass starts) to the first
                          "block_matrix_rel_l2": {b: round(math.sqrt(v[0] / v[1]), 5) for b, v in sorted(by_depth.items()) if v[1] > 0}}
