@@ -119,7 +119,20 @@ def cpu_baseline(kw: dict, state_dict: dict, batch: int, budget_s: float, device
         loss, _, _, _ = trainer.step(images, masks())
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(batch * n / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+    # SURVEY 8d asks for os.cpu_count() threads.  On the 256-core GPU-box host that setting is not measurable inside a bench run (one probe step at batch 2
+    # took 640 s = 0.003 samples/s, torch's CPU kernels oversubscribe on this graph), so the line reports the fastest setting as `value` (16 threads), ONE live
+    # step at 64 threads beside it (the trend), and the all-cores probe figure with its provenance.
+    more = {}
+    if host_cores >= 64 and budget_s >= 10:
+        torch.set_num_threads(64)
+        t1 = time.perf_counter()
+        trainer.step(images, masks())
+        more["64"] = round(batch / (time.perf_counter() - t1), 4)
+        torch.set_num_threads(cores)
+    all_cores = {"cores": host_cores, "value": 0.0031 if host_cores >= 128 else None,
+                 "source": "probe at os.cpu_count() = 256 threads, one step at batch 2: 640 s (round 4, same host type); not re-timed in the default run"}
+    return {"value": round(batch * n / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": host_cores, "kind": "port", "samples_per_s_by_threads": {str(cores): round(batch * n / dt, 4), **more},
+            "at_os_cpu_count_threads": all_cores,
             "sample": f"{n} optimisation steps (fwd+bwd+clip+AdamW) of the same Base 4-view config at batch {batch}, fp32 torch-CPU oracle, "
                       f"after 1 warm-up step ({warm:.1f} s); final loss {float(loss):.4f} (different data and step count than the GPU run: not comparable; "
                       f"see `parity` for the like-for-like comparison); {cores} intra-op threads of the host's {host_cores} cores (more threads are slower on this graph)"}, parity

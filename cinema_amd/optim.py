@@ -434,7 +434,7 @@ class TrainStep:
     def _updated(self) -> None:
         self._n_updates += 1
         if self.check_every > 0 and self._n_updates % self.check_every == 0:
-            K.check_reduction_workspaces()
+            _check_reductions_on_every_rank(self.sync)
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
         if self.replay and enc_mask_dict is None and n_accum_steps == 1 and not T.fp8_calibrating():  # (the first fp8 step records maxima: eager)
@@ -612,13 +612,37 @@ def _all_reduce_param_grads(parameters: list) -> None:
         off += g.numel()
 
 
+def _check_reductions_on_every_rank(sync=None) -> None:  # noqa: ANN001
+    """``hip.check_reduction_workspaces`` as a COLLECTIVE decision under data parallelism: a rank that raised alone would leave the others waiting in their next
+    gradient collective, so the flag is MAX-reduced over the ranks first (like ``GradientSynchronizer.all_finite``) and every rank raises together.  One 4-byte
+    device -> host read every ``check_every`` updates (the only host synchronisation of the step loop) plus, with more than one rank, one scalar all-reduce."""
+    err = None
+    try:
+        K.check_reduction_workspaces()
+    except K.HipLibraryError as e:
+        err = e
+    world = getattr(sync, "world_size", 1) if sync is not None else 1
+    if world > 1:
+        import torch.distributed as dist
+
+        dev = "cuda" if dist.get_backend(sync.group) == "nccl" else "cpu"
+        flag = torch.tensor([1.0 if err is not None else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=sync.group)
+        if err is None and float(flag) > 0:
+            err = K.HipLibraryError("an in-launch split reduction gave up on ANOTHER rank (error word set there): its gradients were wrong and have been averaged "
+                                    "into this rank's - restart from the last checkpoint.")
+    if err is not None:
+        raise err
+
+
 def save_checkpoint(ckpt_dir, epoch: int, model_wo_ddp: nn.Module, optimizer, loss_scaler: GradScaler, n_samples: int):  # noqa: ANN001, ANN201
     """``ckpt_dir / f"ckpt_{epoch}.pt"`` with the reference's keys (``cinema/optim.py:229-261``): model, optimizer, epoch, scaler, n_samples."""
     from pathlib import Path
 
     T.update_join()  # (an overlapped optimiser update, TrainStep(overlap_update=True), may still be writing the parameters)
     if torch.cuda.is_available():
-        K.check_reduction_workspaces()  # never write a checkpoint behind a split reduction that gave up (raises HipLibraryError)
+        # never write a checkpoint behind a split reduction that gave up (raises HipLibraryError - on every rank when the optimiser carries a synchronizer)
+        _check_reductions_on_every_rank(getattr(optimizer, "synchronizer", None))
     ckpt_dir = Path(ckpt_dir)
     ckpt_dir.mkdir(parents=True, exist_ok=True)
     ckpt_path = ckpt_dir / f"ckpt_{epoch}.pt"

@@ -27,8 +27,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 class Var:
     """An activation on the tape: ``data`` plus its (lazily created) gradient.
 
-    ``grad`` is fp32 for fp32 data and bf16 for bf16 data.  ``grad16`` optionally carries a bf16 copy of an fp32
-    gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
+    ``grad`` is fp32 for fp32 data and bf16 for bf16 data - except that a producer whose gradient has exactly ONE reader which takes bf16 anyway (a GEMM operand)
+    may hand a bf16 gradient to fp32 data; ``add_grad`` widens it to fp32 the moment a second contribution arrives.  ``grad16`` optionally carries a bf16 copy of
+    an fp32 gradient (written for free by the LayerNorm backward) so that dgrad/wgrad GEMMs need no extra cast pass.
     """
 
     __slots__ = ("data", "grad", "grad16", "needs_grad", "fp8", "grad8", "grad8_site", "fp8t", "grad8_bias", "grad8_bias_done", "grad_any")
@@ -52,6 +53,10 @@ class Var:
         if self.grad is None:
             self.grad, self.grad16 = g, g16
         else:
+            if self.grad.dtype == BF16 and self.data.dtype == F32:
+                # the first contribution was handed over in bf16 (op_mse, Segment(grad_bf16=True), op_droppath_add, op_cast_bf16 with grad_any: single-consumer
+                # shortcuts of the glue trims); a SECOND consumer exists after all: widen once, accumulate in fp32 from here on
+                self.grad = K.cast(self.grad, F32)
             K.row_copy(self.grad.view(-1, self.grad.shape[-1]), g.view(-1, g.shape[-1]), accumulate=True)
             self.grad16 = None
             self.grad8 = None
@@ -623,9 +628,12 @@ class Fp8Sites:
                 raise RuntimeError(f"Fp8Sites: more than {self.CAP} live delayed-scaling sites on {self.device}")
             self.n_alloc += 1
         st = sites[key] = self.live[i] = K.Q8Site(self.scale[i:i + 1], self.inv[i:i + 1], self.amax[i * self.SLOTS:(i + 1) * self.SLOTS], self, self.updates)
-        slots = owner.__dict__.get("_cinema_q8_slots")
+        # one slot list and one finalizer per (owner, REGISTRY): a list shared between registries (the same parameter used on a second device, or under a second
+        # Fp8Sites instance) would release that registry's indices into this one when the owner dies, freeing a slot that belongs to a live parameter here
+        by_reg = owner.__dict__.setdefault("_cinema_q8_slots", {})
+        slots = by_reg.get(id(self))
         if slots is None:
-            slots = owner.__dict__["_cinema_q8_slots"] = []
+            slots = by_reg[id(self)] = []
             weakref.finalize(owner, Fp8Sites._release, self, slots)
         slots.append(i)
         return st

@@ -46,9 +46,9 @@ class FineTuneStep:
     def _updated(self) -> None:
         self._n_updates += 1
         if self.check_every > 0 and self._n_updates % self.check_every == 0:
-            from cinema_amd import hip as K
+            from cinema_amd.optim import _check_reductions_on_every_rank
 
-            K.check_reduction_workspaces()
+            _check_reductions_on_every_rank(self.sync)  # (collective under data parallelism: every rank raises together)
 
     def __call__(self, batch: dict, n_accum_steps: int = 1, update_grad: bool = True) -> tuple:
         loss, metrics = self.loss_fn(self.model, batch, self.views, self.device)
