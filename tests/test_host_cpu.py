@@ -558,7 +558,7 @@ def test_fp8_sites_belong_to_the_parameter_object_and_slots_are_recycled() -> No
     assert reg.site(a, "x") is sa and sa is not sb and not sa.ready and not reg.all_ready()
     reg.update()
     assert sa.ready and sb.ready and reg.all_ready()
-    slots_a = sorted(a._cinema_q8_slots)  # noqa: SLF001
+    slots_a = sorted(a._cinema_q8_slots[id(reg)])  # noqa: SLF001  (one slot list per registry)
     del a, sa, sb
     gc.collect()
     assert not reg.live and sorted(reg.free) == slots_a
@@ -575,6 +575,18 @@ def test_fp8_sites_belong_to_the_parameter_object_and_slots_are_recycled() -> No
         del gen, q
         gc.collect()
     assert reg.n_alloc <= 2 + 80 and len(reg.live) == 1 and keep
+    # the same parameter under TWO registries (a second device / a second Fp8Sites): each registry gets its own slots back when the parameter dies - with one
+    # shared list the second registry's indices were released into the first one and freed a slot that belonged to a live parameter there (round-5 ADVICE)
+    reg2 = T.Fp8Sites(torch.device("cpu"))
+    live_before, free_before = dict(reg.live), list(reg.free)
+    c = torch.nn.Parameter(torch.zeros(2))
+    s_first = reg.site(c, "x")
+    s_second = [reg2.site(c, "x"), reg2.site(c, "dy"), reg2.site(c, "w")]
+    assert s_first.owner is reg and all(st.owner is reg2 for st in s_second) and len(reg2.live) == 3
+    del c, s_first, s_second
+    gc.collect()
+    assert not reg2.live and sorted(reg2.free) == [0, 1, 2]
+    assert reg.live.keys() == live_before.keys() and sorted(reg.free) == sorted(free_before), "the other registry's release must not touch this one"
 
 
 def test_bench_gpus_n_without_a_launcher_launches_its_own_ranks(tmp_path: Path) -> None:
