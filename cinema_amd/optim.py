@@ -153,11 +153,11 @@ class FlatModel:
             return None
         if getattr(self, "_fp8", None) is None:
             mats = [q for q in self.params if q.dim() >= 2]
-            bounds = torch.tensor([[self.offsets[id(q)][0], self.offsets[id(q)][0] + q.numel() // 8 * 8] for q in mats], dtype=torch.int64,
-                                  device=self.flat_param.device)
-            self._fp8 = {"index": {id(q): i for i, q in enumerate(mats)}, "bounds": bounds, "epoch": None,
-                         "data": torch.zeros(self.numel, dtype=torch.uint8, device=self.flat_param.device),
-                         "scales": torch.ones(len(mats), dtype=torch.float32, device=self.flat_param.device)}
+            dev, rows = self.flat_param.device, [[self.offsets[id(q)][0], self.offsets[id(q)][0] + q.numel() // 8 * 8] for q in mats]
+            # (persistent: tables and shadows that outlive the step must not be carved out of a recording's memory pool, whose replayed launches rewrite it)
+            bounds, data, scales = K.persistent(lambda: (torch.tensor(rows, dtype=torch.int64, device=dev), torch.zeros(self.numel, dtype=torch.uint8, device=dev),
+                                                         torch.ones(len(mats), dtype=torch.float32, device=dev)))
+            self._fp8 = {"index": {id(q): i for i, q in enumerate(mats)}, "bounds": bounds, "epoch": None, "data": data, "scales": scales}
         st = self._fp8
         if p.numel() % 8 or id(p) not in st["index"]:
             return None
@@ -171,9 +171,9 @@ class FlatModel:
                 return None
             if "data_t" not in st:
                 mats = [q for q in self.params if q.dim() >= 2]
-                st["desc_t"] = torch.tensor([[self.offsets[id(q)][0], q.shape[0], q.numel() // q.shape[0]] if (q.dim() == 2 and q.shape[0] % 8 == 0 and q.shape[1] % 8 == 0)
-                                             else [self.offsets[id(q)][0], 0, 0] for q in mats], dtype=torch.int64, device=self.flat_param.device)
-                st["data_t"] = torch.zeros(self.numel, dtype=torch.uint8, device=self.flat_param.device)
+                dev, rows = self.flat_param.device, [[self.offsets[id(q)][0], q.shape[0], q.numel() // q.shape[0]] if (q.dim() == 2 and q.shape[0] % 8 == 0 and q.shape[1] % 8 == 0)
+                                                     else [self.offsets[id(q)][0], 0, 0] for q in mats]
+                st["desc_t"], st["data_t"] = K.persistent(lambda: (torch.tensor(rows, dtype=torch.int64, device=dev), torch.zeros(self.numel, dtype=torch.uint8, device=dev)))
                 st["epoch_t"] = None
             if st["epoch_t"] != T.WEIGHTS.epoch:
                 K.quantize_fp8_segments_t(self.flat_shadow, st["desc_t"], st["scales"], st["data_t"])
@@ -206,6 +206,8 @@ class FlatModel:
         if key not in st["index"]:
             st["index"][key] = len(st["segs"])
             st["segs"].append((rngs[0][0], rows, cols))
+            if st["tensors"] is not None:
+                st.setdefault("retired", []).append(st["tensors"])  # launches already issued (or RECORDED) with the shorter lists read them: never freed
             st["tensors"] = None
         if st["tensors"] is None:  # descriptors of all joint segments (rebuilt while new ones appear: first step only)
             dev = self.flat_param.device
@@ -381,6 +383,7 @@ class TrainStep:
         # from that list (cinema_amd/replay.py) - the host cost of a step drops from ~33 ms of module code to ~3 us per launch
         self.replay, self.audit = replay, audit
         self._recorded: dict = {}
+        self._fp8_calibrated = False  # set by the first eager step taken with the fp8 weight-gradient path on (see __call__)
         self._graphs: dict = {}
         if hip_graph and self.sync is not None:
             raise ValueError("hip_graph=True captures the single-process step; the data-parallel step runs eagerly")
@@ -437,7 +440,12 @@ class TrainStep:
             _check_reductions_on_every_rank(self.sync)
 
     def __call__(self, image_dict: dict, enc_mask_ratio: float, enc_mask_dict: dict | None = None, n_accum_steps: int = 1, update_grad: bool = True):  # noqa: ANN204
-        if self.replay and enc_mask_dict is None and n_accum_steps == 1 and not T.fp8_calibrating():  # (the first fp8 step records maxima: eager)
+        # the first fp8 step of THIS model runs eagerly: it records the maxima its sites take their first scales from and registers the joint e4m3 weight shadows
+        # (FlatModel.fp8_shadow_cat_t), both of which a recording must find complete.  The registry of sites is per device, not per model - sites of an earlier
+        # model that are still alive say nothing about this one (round 6: a recording taken on a model's very first step after another fp8 model had run in the
+        # process replayed re-quantisation launches whose descriptor tensors had been replaced and freed -> memory fault) - so the step keeps its own flag
+        calibrating = T.FP8_FORWARD and T.FP8_WGRAD and (not self._fp8_calibrated or T.fp8_calibrating())
+        if self.replay and enc_mask_dict is None and n_accum_steps == 1 and not calibrating:
             return self._replay_step(image_dict, enc_mask_ratio, update_grad)
         if self.hip_graph and enc_mask_dict is None and n_accum_steps == 1 and update_grad:
             return self._graph_step(image_dict, enc_mask_ratio)
@@ -446,6 +454,8 @@ class TrainStep:
             self.sync.arm(update_grad)  # on the micro-step that ends with the optimiser update, blocks all-reduce as their gradients complete
         (loss / n_accum_steps if n_accum_steps > 1 else loss).backward()
         T.fp8_step_end()  # fp8 weight-gradient path: this step's recorded maxima become the next step's scales (no-op otherwise)
+        if T.FP8_FORWARD and T.FP8_WGRAD:
+            self._fp8_calibrated = True
         grad_norm = None
         if update_grad:
             if self.sync is not None:

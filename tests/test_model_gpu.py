@@ -612,6 +612,51 @@ def test_fp8_training_trajectory_vs_oracle() -> None:
     assert got[-1][0] < got[0][0]
 
 
+def test_fp8_replay_of_a_second_model_calibrates_before_it_records() -> None:
+    """Round-6 fault: the delayed-scaling registry is per device, so after one fp8 model had trained in the process a SECOND model's first replayed step was taken as
+    "calibrated", recorded straight away and replayed launches whose descriptor tensors had meanwhile been replaced (memory fault in
+    cinema_quantize_fp8_segments_t).  Required: with the first model still alive, the second model's first step is eager (no recording yet), the recording is
+    taken on its second step, its launch list holds each joint re-quantisation once, and 12 replayed steps with small allocations in between stay finite and
+    reduce the loss."""
+    from cinema_amd import hip as K
+    from cinema_amd import tape as T
+    from cinema_amd.optim import TrainStep
+
+    views = ["sax", "lax_2c"]
+    kw = dict(image_size_dict={"sax": (64, 64, 8), "lax_2c": (64, 64)}, in_chans_dict=dict.fromkeys(views, 1),
+              enc_patch_size_dict={"sax": (4, 4, 1), "lax_2c": (4, 4)}, enc_scale_factor_dict={"sax": (2, 2, 1), "lax_2c": (2, 2)},
+              enc_conv_chans=[64, 128], enc_conv_n_blocks=1, enc_embed_dim=256, enc_depth=3, enc_n_heads=4, dec_embed_dim=128, dec_depth=2,
+              dec_n_heads=4)
+    gen = torch.Generator().manual_seed(5)
+    batches = [{v: torch.rand(2, 1, *kw["image_size_dict"][v], generator=gen).to(DEV) for v in views} for _ in range(4)]
+    prev = (T.FP8_FORWARD, T.FP8_DGRAD, T.FP8_WGRAD)
+    try:
+        T.FP8_FORWARD, T.FP8_DGRAD, T.FP8_WGRAD = True, True, True
+        torch.manual_seed(3)
+        first = CineMA(**kw).to(DEV)
+        step_a = TrainStep(first, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0)
+        for i in range(2):
+            step_a(batches[i], 0.75)
+        assert not T.fp8_calibrating()  # the registry alone would now wave a new model through
+        torch.manual_seed(4)
+        second = CineMA(**kw).to(DEV)
+        step_b = TrainStep(second, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, clip_grad=5.0, replay=True)
+        losses = [float(step_b(batches[0], 0.75)[0])]
+        assert not step_b._recorded, "the first fp8 step of a model must run eagerly"  # noqa: SLF001
+        keep = []
+        for i in range(1, 13):
+            loss = step_b(batches[i % 4], 0.75)[0]
+            keep.append(loss.detach().float().reshape(()).clone())  # small allocations between the steps: what landed on the freed descriptors in round 6
+            losses.append(float(loss))
+        (rec,) = step_b._recorded.values()  # noqa: SLF001
+        names = [fn.__name__ for fn, _ in rec.calls if fn is not None]
+        assert names.count("cinema_quantize_fp8_segments_t") <= 2, names.count("cinema_quantize_fp8_segments_t")  # per-weight + joint shadows, once each
+        del step_a, first
+    finally:
+        T.FP8_FORWARD, T.FP8_DGRAD, T.FP8_WGRAD = prev
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0], losses
+
+
 def test_large_config_256_fp8_first_step_loss_vs_oracle() -> None:
     """BASELINE config 5 at its OWN shape (ViT-Large, SAX 256 x 256 x 24 + 3 LAX 256 x 256, batch 1): first-step loss of the fp8 path (e4m3 forward
     projections) and of the bf16 path against the fp32 CPU oracle's forward on identical weights, inputs and masks (oracle/parity.py::mae_loss_parity).
