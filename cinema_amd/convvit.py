@@ -25,10 +25,6 @@ from cinema_amd import tape as T
 from cinema_amd.conv import CompactVolume, Conv2d, Conv3d, ConvNormActBlock, Linear, MaskedConvBlock, Volume, _CkptFlag
 from cinema_amd.vit import PatchEmbed, get_pos_embed, init_weights
 
-# neighbour lists of the visible-voxel depthwise convolutions built on the long-axis stream, beside the chain that precedes their first use (CINEMA_NBR_PREFETCH=0: in that chain)
-NBR_PREFETCH = os.environ.get("CINEMA_NBR_PREFETCH", "1") == "1"
-
-
 def upsample_mask(mask: torch.Tensor, scale_factor: tuple) -> torch.Tensor:
     """Nearest-neighbour upsampling of a (batch, *grid) bool mask (reference ``cinema/convvit.py:24-51``)."""
     if mask.ndim != len(scale_factor) + 1:
@@ -221,7 +217,8 @@ class DownsampleEncoder(nn.Module, _CkptFlag):
 
         # the stages' sparse geometries up front: their neighbour lists depend on the mask only and are built beside the gather / patch GEMM / LayerNorm chain
         geoms = [K.sparse_geom(batch, grid, blk, sel.keep, rank, pos) for blk, pos, _ in tables]
-        if T.LAX_STREAM and NBR_PREFETCH and K.LANE is None and image.is_cuda and not torch._C._cuda_isCurrentStreamCapturing():  # (a lane group's launches go out later, zipped)
+        # neighbour lists of the visible-voxel depthwise convolutions are built on the long-axis stream, beside the chain that precedes their first use
+        if T.LAX_STREAM and K.LANE is None and image.is_cuda and not torch._C._cuda_isCurrentStreamCapturing():  # (a lane group's launches go out later, zipped)
             items, seen = [], set()
             for block, sg in zip(self.conv_blocks, geoms):
                 for conv in block.conv:
@@ -359,7 +356,6 @@ def encode_views(model, tp: T.Tape, views: list, images: dict, sels: dict, grids
     # ~95 backward tiny stem launches each go out zipped, one wide launch per position (hip.lanes; the views share nothing inside the stems)
     # ... and that group goes to a stream of its own, beside the short-axis stem's chain (tape.LAX_STREAM)
     T.run_in_lanes(tp, list(views), lambda v: stem_geometry(model, v, images, sels), stem, enabled=images[views[0]].is_cuda, beside=True)
-    T.update_join()  # everything from here on reads parameters the overlapped optimiser update may still be writing (optim.TrainStep(overlap_update=True))
     x = T.op_assemble(tp, batch * t_e, e, segs, dev)
     x = model.encoder.tape_forward(tp, x, batch)
     return x, skips_all, cls_rows, view_rows

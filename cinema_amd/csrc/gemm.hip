@@ -257,7 +257,6 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
   tile_of(tile, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   if (kt_begin >= kt_end) return;
-  GEMM_STAMP(0);
 
   float16v acc[2][2];
 #pragma unroll
@@ -368,7 +367,6 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
   load_tile(0, kt_begin);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  GEMM_STAMP(1);
 
   for (int kt = kt_begin; kt < kt_end; kt++) {
     const int cur = (kt - kt_begin) & 1;
@@ -414,7 +412,6 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
     __syncthreads();
   }
 
-  GEMM_STAMP(2);
   if (!A_KMAJ && do_rowsum) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -454,11 +451,6 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, int tile, int zsplit, 
   }
   if (tail_dst) tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, 0, stg, tail_dst - ((long long)m0 * BN + n0), BN);
   else tile_epilogue<EPI>(p, acc, m0 + wm, n0 + wn, lane, zsplit, stg);
-#ifdef CINEMA_GEMM_TIMING
-  GEMM_STAMP(3);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  GEMM_STAMP(4);
-#endif
 }
 
 template <bool A_KMAJ, bool B_KMAJ, int EPI, int MODE = MODE_PLAIN>
@@ -711,12 +703,6 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* x, i
 
 }  // namespace
 
-#ifdef CINEMA_GEMM_TIMING
-CINEMA_API int cinema_debug_gemm_timing(long long* buf) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_timing), &buf, sizeof(buf));
-}
-#endif
-
 CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
   if (!a || !a->a || !a->b || a->m <= 0 || a->n <= 0 || a->k <= 0) return CINEMA_ERR_BAD_ARG;
   if (!a->d && (!a->out8 || a->out_f32 || a->accumulate || a->split_k > 1 || a->force_generic)) return CINEMA_ERR_BAD_ARG;  // D may be omitted only when its 8-bit copy is the output
@@ -770,13 +756,9 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     // launch only when the reduction has >= 12 k-tiles and the left-over tiles can be cut at least in two
     p.tail_split = 0; p.tail_begin = 0; p.tail_ktiles = 0; p.tail_ws = nullptr; p.tail_cnt = nullptr;
     bool tail = false;
-    const bool in_launch = a->tail_counters != nullptr && !(((uintptr_t)a->tail_counters) & 15);
     // thresholds: with the fix-up launch a tail pays from 12 k-tiles (K >= 768) and >= 4 k-tiles per slice; finished in the launch (no kernel boundary, the
-    // finish spread over the slices) shorter reductions and slices pay too (CINEMA_TAIL_MIN_NKT / CINEMA_TAIL_MIN_KT override both)
-    static const int min_nkt_env = getenv("CINEMA_TAIL_MIN_NKT") ? atoi(getenv("CINEMA_TAIL_MIN_NKT")) : 0;
-    static const int min_kt_env = getenv("CINEMA_TAIL_MIN_KT") ? atoi(getenv("CINEMA_TAIL_MIN_KT")) : 0;
-    const int min_nkt = min_nkt_env > 0 ? min_nkt_env : 12;
-    const int min_kt = min_kt_env > 0 ? min_kt_env : 4;
+    // finish spread over the slices) shorter reductions and slices pay too
+    constexpr int min_nkt = 12, min_kt = 4;
     if (gz == 1 && a->force_generic == 0 && !p.accumulate && !p.colsum_partials && a->workspace && !(((uintptr_t)a->workspace) & 15) && nkt >= min_nkt) {  // (strip sums: whole tiles only)  // K >= 768 (tools/tail_ab.py: 10960x768x768 38 -> 34 us, x1024 42 -> 35 us; at K = 512 the fix-up launch costs what it saves)
       static int slots = 0;
       if (slots == 0) {
@@ -788,8 +770,6 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
         int sp2 = slots / rem;
         if (sp2 > nkt / min_kt) sp2 = nkt / min_kt;  // >= min_kt k-tiles per slice
         if (sp2 > 16) sp2 = 16;  // = the 32x32 accumulator blocks of a tile: every slice finishes at least one of them
-        static const int cap_env = getenv("CINEMA_TAIL_MAX_SPLIT") ? atoi(getenv("CINEMA_TAIL_MAX_SPLIT")) : 0;
-        if (in_launch && cap_env > 1 && sp2 > cap_env) sp2 = cap_env;
         const int kts = (nkt + sp2 - 1) / sp2;
         sp2 = (nkt + kts - 1) / kts;
         if (sp2 >= 2 && a->workspace_bytes >= (long long)rem * sp2 * BM * BN * 4) {
@@ -812,10 +792,9 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
       a->kernel_used += 8 * epi;  // 1..3 = operand layout, + 8 x epilogue class
       if (epi == EPI_GENERAL) p.tail_cnt = nullptr;
       // short reductions go to the BK = 32 kernel (3-4 workgroups per CU): in the step 32.47 vs 32.79 ms with the threshold at 512, 32.52 at 768
-      // (above that the BK = 64 loop and its split tail win); CINEMA_GEMM_K32 overrides the threshold (0 = never)
-      static const int k32_env = getenv("CINEMA_GEMM_K32") ? atoi(getenv("CINEMA_GEMM_K32")) : 512;
-      static const int k32_stages = getenv("CINEMA_K32_STAGES") ? atoi(getenv("CINEMA_K32_STAGES")) : 3;  // 3: ring with counted waits (default), 2: double buffer, drain per k-tile (A/B)
-      const bool k32 = k32_env > 0 && epi != EPI_GENERAL && !tail && !p.a_rowsum && !(p.accumulate && !p.ws) && (a->k % 32) == 0 && a->k <= k32_env && a->force_generic == 0;
+      // (above that the BK = 64 loop and its split tail win).  Three LDS stages: a ring with counted waits
+      constexpr int k32_env = 512;
+      const bool k32 = epi != EPI_GENERAL && !tail && !p.a_rowsum && !(p.accumulate && !p.ws) && (a->k % 32) == 0 && a->k <= k32_env && a->force_generic == 0;
       if (k32) {
         a->kernel_used += 128;  // the BK = 32 instance of the same layout / epilogue class
 #define LAUNCH_K32_N(E, N)                                                                                                          \
@@ -824,13 +803,7 @@ CINEMA_API int cinema_gemm_bf16(cinema_gemm_args* a, void* stream) {
     else if (a->a_kmajor && !a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, false, E, N>, gemm_mfma_k32_lanes_kernel<true, false, E, N>, 1, grid, dim3(256), 0, st, p); \
     else launch_lanes(gemm_mfma_k32_kernel<false, false, E, N>, gemm_mfma_k32_lanes_kernel<false, false, E, N>, 1, grid, dim3(256), 0, st, p);                                 \
   } while (0)
-#define LAUNCH_K32(E)                                                                                                          \
-  do {                                                                                                                         \
-    if (k32_stages == 3) { LAUNCH_K32_N(E, 3); break; }                                                                         \
-    if (a->a_kmajor && a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, true, E>, gemm_mfma_k32_lanes_kernel<true, true, E>, 1, grid, dim3(256), 0, st, p);        \
-    else if (a->a_kmajor && !a->b_kmajor) launch_lanes(gemm_mfma_k32_kernel<true, false, E>, gemm_mfma_k32_lanes_kernel<true, false, E>, 1, grid, dim3(256), 0, st, p); \
-    else launch_lanes(gemm_mfma_k32_kernel<false, false, E>, gemm_mfma_k32_lanes_kernel<false, false, E>, 1, grid, dim3(256), 0, st, p);                                 \
-  } while (0)
+#define LAUNCH_K32(E) LAUNCH_K32_N(E, 3)
         switch (epi) {
           case EPI_BF16: LAUNCH_K32(EPI_BF16); break;
           case EPI_BF16_GELU: LAUNCH_K32(EPI_BF16_GELU); break;

@@ -154,10 +154,6 @@ __device__ __forceinline__ void p256_loop64(const GemmP& p, int m0, int n0, int 
 //           READ(p + 2) - see the comment in the loop.  Weight-gradient groups of the step 10-20 % faster (encoder block 213 -> 186 us, ViT-Large block 423 -> 353 us,
 //           8192^3 1015 -> 1157 TF), forward / data-gradient layouts 1-3 %, bit-identical results (profiles/r04_aa_p256_loop_ab.txt).
 #define P256_BAR() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#ifdef CINEMA_P256_PROBE  // dev build only (tools/p256_phase_probe.py): shader-clock sums per wave of READ segment / first barrier / MFMA segment / second barrier
-__device__ unsigned long long* g_p256_probe = nullptr;
-#define P256_CLK(v) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#endif
 constexpr int P_HS = 32768;   // half-stage: A sub-tiles 0, 1 then B sub-tiles 0, 1, 8 KiB each
 template <bool A_KMAJ, bool B_KMAJ, int FORM>
 __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int ph_begin, int ph_end, float16v (&acc)[4][2], float (&rs)[4], bool do_rowsum,
@@ -232,10 +228,6 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
   P256_BAR();
   if (wr == 1) P256_BAR();   // waves 4-7 run one barrier behind
   const int bcol = (wc & 1) * 64;
-#ifdef CINEMA_P256_PROBE
-  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tA, tB, tC, tD, tV;
-  P256_CLK(tA);
-#endif
   for (int q = 0; q < nph; q++) {
     const int ph = ph_begin + q;
     const char* hs = smem + (ph & 3) * P_HS;
@@ -259,9 +251,6 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
       __builtin_amdgcn_sched_barrier(0);
       if (q + 3 < nph) {
         issue(ph + 3);
-#ifdef CINEMA_P256_PROBE
-        P256_CLK(tV); pt[5] += tV - tA;   // (drains the fragment reads: issue-to-here = reads + DMA issue)
-#endif
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -271,15 +260,9 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
       if (q + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#ifdef CINEMA_P256_PROBE
-    P256_CLK(tB);
-#endif
     P256_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-#ifdef CINEMA_P256_PROBE
-    P256_CLK(tC);
-#endif
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -294,26 +277,9 @@ __device__ __forceinline__ void p256_loop32(const GemmP& p, int m0, int n0, int 
       }
     }
     __builtin_amdgcn_s_setprio(0);
-#ifdef CINEMA_P256_PROBE
-    __builtin_amdgcn_sched_barrier(0);
-    P256_CLK(tD);
-#endif
     P256_BAR();
-#ifdef CINEMA_P256_PROBE
-    pt[0] += tB - tA; pt[1] += tC - tB; pt[2] += tD - tC;
-    P256_CLK(tA);
-    pt[3] += tA - tD;
-#endif
   }
   if (wr == 0) P256_BAR();
-#ifdef CINEMA_P256_PROBE
-  if (g_p256_probe && lane == 0) {
-    unsigned long long* o = g_p256_probe + ((size_t)blockIdx.x * 8 + wave_u) * 8;
-    for (int i = 0; i < 4; i++) o[i] += pt[i];
-    o[4] += (unsigned long long)nph;
-    o[5] += pt[5];
-  }
-#endif
 }
 
 // ---- main loop, form 3: WEIGHT GRADIENT ON 8-BIT OPERANDS (BASELINE config 5, "fp8 MFMA path"): dW[n][k] = sa * sb * sum_t dY8[t][n] X8[t][k] with both operands
@@ -665,12 +631,6 @@ int cu_count() {
 //   schedule 1 "stream": one problem, equal contiguous (tile, k-tile) ranges per workgroup.
 // workspace: >= cinema_gemm_p256_workspace_bytes(); its first 64 KiB hold the tile counters and must be ZERO before the first use (the kernel
 // leaves them zero); one workspace per stream (concurrent launches must not share one).
-#ifdef CINEMA_P256_PROBE
-extern "C" __attribute__((visibility("default"))) int cinema_debug_p256_probe(void* buf) {
-  unsigned long long* q = (unsigned long long*)buf;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p256_probe), &q, sizeof(q));
-}
-#endif
 CINEMA_API long long cinema_gemm_p256_workspace_bytes(void) { return (long long)P_COUNTER_BYTES + 2LL * cu_count() * P_SLOT_FLOATS * 4; }
 
 static int p256_launch_host(cinema_gemm_args* args, int count, int schedule, void* workspace, long long workspace_bytes, void* stream, bool fp8);

@@ -121,12 +121,6 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, int m, int n0, float v
 // a LOAD half and an APPLY half: the staged tile epilogue issues the loads of all its sub-blocks up front, so the residual / GELU-input
 // reads are in flight while the accumulators go through LDS (as one function the loads sat in the dependency chain of every 32x32
 // sub-block: +20 us for a bias, +130 us for bias + fp32 residual on the 32848x2048 decoder GEMM).
-#ifdef CINEMA_GEMM_TIMING  // dev build only (tools/gemm_phase_timing.py): per-workgroup phase timestamps of the one-shot kernel
-__device__ long long* g_gemm_timing = nullptr;
-#define GEMM_STAMP(i) do { if (g_gemm_timing && threadIdx.x == 0) g_gemm_timing[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define GEMM_STAMP(i) do { } while (0)
-#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4e __attribute__((ext_vector_type(4)));
 // The outputs stream out (67-270 MB per GEMM against 4 MiB of L2 per XCD): non-temporal stores keep them from evicting the operand panels the

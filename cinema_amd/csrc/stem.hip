@@ -302,7 +302,6 @@ struct MlpFwdP {
   const bf16_t* wf1; const float* bf1; const bf16_t* wf2; const float* bf2;
   float* x1; float* x2;
   int rows; float eps;
-  int dbg;   // timing experiments only (tools/bench_stem.py, CINEMA_STEM_DBG): bit 0 no GELU, 1 no fc1 MFMAs, 2 no fc2 MFMAs, 3 no chunk loop, 4 no weight stream, 5 no barriers
 };
 // RES: every chunk of the MLP weights stays in LDS (c = 64: 83 KB) - no weight stream, no barrier in the loop, the waves of a workgroup drift apart so that one
 // wave's row loads / stores hide behind the others' matrix work; otherwise (c = 128: 288 KB of weights) the chunks are double-buffered and the waves walk them in step.
@@ -378,51 +377,36 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdP& p) {
 #pragma unroll
       for (int t = 0; t < HC / 32; t++) {
         f4 z0 = ldsv4(b1, t * 32 + g * 4), z1 = ldsv4(b1, t * 32 + 16 + g * 4);
-        if (!(p.dbg & 2)) {
 #pragma unroll
-          for (int s = 0; s < KS; s++) {
-            z0 = mfma16(wfrag_n(wf1c, P_C, t * 32, s * 32, lane), bx[s], z0);
-            z1 = mfma16(wfrag_n(wf1c, P_C, t * 32 + 16, s * 32, lane), bx[s], z1);
-          }
+        for (int s = 0; s < KS; s++) {
+          z0 = mfma16(wfrag_n(wf1c, P_C, t * 32, s * 32, lane), bx[s], z0);
+          z1 = mfma16(wfrag_n(wf1c, P_C, t * 32 + 16, s * 32, lane), bx[s], z1);
         }
-        if (!(p.dbg & 1)) { gelu_v4(z0); gelu_v4(z1); }
+        gelu_v4(z0); gelu_v4(z1);
         const uint2 lo = pack4(z0), hi = pack4(z1);
         const short8v ba = mk8(lo.x, lo.y, hi.x, hi.y);
-        if (!(p.dbg & 4)) {
 #pragma unroll
-          for (int ob = 0; ob < RB; ob++) y[ob] = mfma16(wfrag_n(wf2c, P_H, ob * 16, t * 32, lane), ba, y[ob]);
-        }
-        if (p.dbg & 64) __builtin_amdgcn_sched_barrier(0);
+        for (int ob = 0; ob < RB; ob++) y[ob] = mfma16(wfrag_n(wf2c, P_H, ob * 16, t * 32, lane), ba, y[ob]);
       }
     };
-    if (p.dbg & 8) {
-    } else if constexpr (RES) {
+    if constexpr (RES) {
       for (int j = 0; j < NCH; j++) chunk(j, smem + L::BUF + j * L::BUF_BYTES);
     } else {
       // the chunk's weights are fetched TWO chunks ahead (registers: sets A / B) and written to the other LDS buffer one chunk ahead: one chunk of matrix work
       // (~1 us) did not cover the fetch (8 x ~2.7 us of waiting per pass at c = 128)
-      const bool stream = !(p.dbg & 16), bar = !(p.dbg & 32);
       for (int j = 0; j < NCH; j += 2) {
-        if (stream) {
-          na1.load(p.wf1 + (size_t)((j + 2) % NCH) * HC * C, C, tid);
-          na2.load(p.wf2 + ((j + 2) % NCH) * HC, H, tid);
-        }
+        na1.load(p.wf1 + (size_t)((j + 2) % NCH) * HC * C, C, tid);
+        na2.load(p.wf2 + ((j + 2) % NCH) * HC, H, tid);
         chunk(j, smem + L::BUF);
-        if (stream) {
-          nb1.store(smem + L::BUF + L::BUF_BYTES, P_C, tid);          // chunk j + 1 (fetched during chunk j - 1)
-          nb2.store(smem + L::BUF + L::BUF_BYTES + L::WF2_OFF, P_H, tid);
-        }
-        if (bar) __syncthreads();
-        if (stream) {
-          nb1.load(p.wf1 + (size_t)((j + 3) % NCH) * HC * C, C, tid);
-          nb2.load(p.wf2 + ((j + 3) % NCH) * HC, H, tid);
-        }
+        nb1.store(smem + L::BUF + L::BUF_BYTES, P_C, tid);          // chunk j + 1 (fetched during chunk j - 1)
+        nb2.store(smem + L::BUF + L::BUF_BYTES + L::WF2_OFF, P_H, tid);
+        __syncthreads();
+        nb1.load(p.wf1 + (size_t)((j + 3) % NCH) * HC * C, C, tid);
+        nb2.load(p.wf2 + ((j + 3) % NCH) * HC, H, tid);
         chunk(j + 1, smem + L::BUF + L::BUF_BYTES);
-        if (stream) {
-          na1.store(smem + L::BUF, P_C, tid);                          // chunk j + 2
-          na2.store(smem + L::BUF + L::WF2_OFF, P_H, tid);
-        }
-        if (bar) __syncthreads();
+        na1.store(smem + L::BUF, P_C, tid);                          // chunk j + 2
+        na2.store(smem + L::BUF + L::WF2_OFF, P_H, tid);
+        __syncthreads();
       }
     }
     if (ok) store_act<C>(y, p.x2, row, g);
@@ -795,8 +779,7 @@ CINEMA_API int cinema_stem_mlp_fwd(const uint16_t* d, const float* x, const uint
                                    const float* bf1, const uint16_t* wf2, const float* bf2, float* x1, float* x2, int rows, int c, void* stream) {
   if (!d || !x || !w2 || !b2 || !gamma || !beta || !wf1 || !bf1 || !wf2 || !bf2 || !x2 || rows <= 0) return CINEMA_ERR_BAD_ARG;
   if (!cinema_stem_supported(c)) return CINEMA_ERR_UNSUPPORTED;
-  static const int dbg = getenv("CINEMA_STEM_DBG") ? atoi(getenv("CINEMA_STEM_DBG")) : 0;
-  const MlpFwdP p{d, x, w2, b2, gamma, beta, wf1, bf1, wf2, bf2, x1, x2, rows, eps, dbg};
+  const MlpFwdP p{d, x, w2, b2, gamma, beta, wf1, bf1, wf2, bf2, x1, x2, rows, eps};
   if (c == 64) {
     static bool f[16] = {};
     constexpr int lds = MlpFwdLds<64, true>::BYTES;

@@ -78,8 +78,7 @@ class Q8Site:
 _LAYOUTS = {1: "true, true", 2: "true, false", 3: "false, false"}
 GEMM_KERNEL_NAMES = {0: "gemm_generic_kernel"}
 GEMM_KERNEL_NAMES[64] = "gemm_mfma_grouped_kernel<false, false, 4>"
-_K32_STAGES = 3 if int(os.environ.get("CINEMA_K32_STAGES", "3")) == 3 else 2  # csrc/gemm.hip reads the same variable: 3 = ring with counted waits (default), 2 = double buffer
-GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}, {_K32_STAGES}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
+GEMM_KERNEL_NAMES.update({128 + lay + 8 * epi: f"gemm_mfma_k32_kernel<{txt}, {epi}, 3>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})
 # main-loop form of the persistent kernel (csrc/gemm256.hip reads the same variable per call): 2 = LDS-DMA issued by the reading wave (default), 1 = between the MFMAs, 0 = k-tile loop
 _P256_LOOP = int(os.environ.get("CINEMA_P256_LOOP", "2"))
@@ -391,7 +390,7 @@ def _dev(*ts: torch.Tensor | None) -> None:
 
 # ---- lane groups (include/cinema_hip.h: cinema_lanes_*): independent, identically shaped launch sequences merged into wide launches -------------
 LANE: int | None = None      # lane being recorded, None outside a group
-LANES_ENABLED = bool(int(os.environ.get("CINEMA_LANES", "1")))
+LANES_ENABLED = True  # (tests/test_lanes_gpu.py compares against one launch per lane)
 LANE_STATS = [0, 0]          # merged / single launches issued by the lane groups so far (diagnostics)
 _LANE_KEEP: list = []
 # when set, a closing lane group hands the buffers it held over to this list instead of dropping them: its launches went to a stream the caching allocator
@@ -483,8 +482,8 @@ _TAIL_COUNTERS: dict = {}
 # sums and finishes ITS share of the tile (reduce-scatter over the slices, csrc/gemm.hip tail_finish_in_launch) - instead of the fix-up launch.  Bit-identical
 # results.  Round 3's form (ONE workgroup, the last arriver, read up to 15 x 64 KiB) was slower than the fix-up launch; this one is time-neutral per shape and in
 # the step (profiles/r04_b_*: 27.31 / 27.13 ms with the fix-up launch, 27.01 / 27.16 without) and removes 117 launches per step.  0: the fix-up launch.
-TAIL_IN_LAUNCH = bool(int(os.environ.get("CINEMA_TAIL_IN_LAUNCH", "1")))
-TAIL_MIN_K = int(os.environ.get("CINEMA_TAIL_MIN_K", "768"))  # shortest reduction that gets split-tail scratch (the library decides per shape)
+TAIL_IN_LAUNCH = True
+TAIL_MIN_K = 768  # shortest reduction that gets split-tail scratch (the library decides per shape)
 
 
 def _tail_counters(device: torch.device) -> torch.Tensor:
@@ -1754,10 +1753,10 @@ def _sparse_nbr(geom: SparseGeom, kdims: tuple, device: torch.device) -> tuple:
     return hit
 
 
-SPARSE_WGRAD_PIPE = bool(int(os.environ.get("CINEMA_SPARSE_WGRAD_PIPE", "1")))  # 0: the per-token index chase (A/B)
+SPARSE_WGRAD_PIPE = True  # False: the per-token index chase (the form the kernel tests compare against)
 # the depthwise conv of the visible-voxel stem as a walk over neighbour TOKENS (csrc/stem_dw.hip; 64 / 128 channels, 4x4 / 2x2 token blocks); 0: the per-voxel neighbour
 # lists of csrc/sparse_conv.hip, which stay the form for every other geometry
-STEM_DW_PAIR = bool(int(os.environ.get("CINEMA_STEM_DW_PAIR", "1")))
+STEM_DW_PAIR = True  # False: the neighbour-list kernels for every geometry (the form the kernel tests compare against)
 
 
 def sparse_pair_form(geom: SparseGeom, c: int, kdims: tuple) -> bool:
@@ -1962,7 +1961,7 @@ def row_copy(dst: torch.Tensor, src: torch.Tensor | None = None, *, dst_idx: tor
     return dst
 
 
-ROW_COPY_MULTI = bool(int(os.environ.get("CINEMA_ROW_MULTI", "1")))  # 0: one launch per copy (A/B)
+ROW_COPY_MULTI = True
 
 
 def row_copy_multi(copies: list) -> None:

@@ -18,7 +18,6 @@ No device->host synchronisation happens inside ``forward`` (the reference has ~1
 from __future__ import annotations
 
 import math
-import os
 from pathlib import Path
 
 import torch
@@ -222,7 +221,7 @@ class CineMA(nn.Module):
 
         geom = lambda v: stem_geometry(self, v, images, sels)  # noqa: E731
         # per-view weights, nothing shared: the long-axis views go out as one lane group, on the long-axis stream beside the short-axis view's fusion
-        T.run_in_lanes(tp, views, geom, fuse, enabled=dev.type == "cuda", beside=os.environ.get("CINEMA_LAX_FUSE", "1") == "1")
+        T.run_in_lanes(tp, views, geom, fuse, enabled=dev.type == "cuda", beside=True)
         for v in views:  # dec_linear is SHARED by the views (one weight-gradient buffer): not a lane group
             z_views[v] = T.op_linear(tp, fused[v], self.dec_linear.weight, self.dec_linear.bias, out_f32=True)
 
@@ -275,7 +274,7 @@ class CineMA(nn.Module):
             patch = self.dec_patch_size_dict[v]
             stats = T.zeros(2, torch.float32, dev)
             pgeom = K.patch_geom(batch, chans, grids[v], patch, tuple(img.stride()))
-            if T.GLUE_TRIMS and img.is_cuda and K.LANE is None:  # metrics only: beside the head GEMM, on the (idle) weight-gradient stream; joined below
+            if img.is_cuda and K.LANE is None:  # metrics only: beside the head GEMM, on the (idle) weight-gradient stream; joined below
                 T._wgrad_launch(lambda: K.patch_stats(img, pgeom, stats), img, stats)  # noqa: SLF001
             else:
                 K.patch_stats(img, pgeom, stats)
@@ -296,12 +295,12 @@ class CineMA(nn.Module):
             if maxes is not None:
                 metrics[f"{v}_normed_target_max"], metrics[f"{v}_pred_max"] = maxes[0], maxes[1]
 
-        T.run_in_lanes(tp, views, geom, head, enabled=dev.type == "cuda", beside=os.environ.get("CINEMA_LAX_HEAD", "1") == "1")  # prediction heads + losses: per-view weights and accumulators
+        T.run_in_lanes(tp, views, geom, head, enabled=dev.type == "cuda", beside=True)  # prediction heads + losses: per-view weights and accumulators
         preds = {v: preds[v] for v in views}
         metrics = {k: metrics[k] for v in views for k in metrics if k.startswith(f"{v}_")}
         losses = [loss_of[v] for v in views]
         loss = T.op_mean_finite(tp, losses)
-        if T.GLUE_TRIMS and dev.type == "cuda":
+        if dev.type == "cuda":
             T.join_side_stream()  # (the target statistics above: a reader of the metrics after the forward pass sees them complete)
         return loss, preds, metrics
 

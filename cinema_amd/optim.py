@@ -21,12 +21,6 @@ import os
 from cinema_amd import hip as K
 from cinema_amd import tape as T
 
-# TrainStep(overlap_update=...): AdamW of the encoder / decoder parameters + zero_grad on a stream of their own beside the next step's stems.  Built, parity-green
-# (tests/test_model_gpu.py::test_overlapped_update_walks_the_same_trajectory) and SLOWER in every variant measured (profiles/r05_q_overlap_update_*.txt: 25.72-25.85 ms
-# without, 25.85-26.5 with - grid caps 128..2^20 workgroups, low-priority stream): the stems are not idle time, they and AdamW want the same HBM bandwidth.  Off.
-OVERLAP_UPDATE = bool(int(os.environ.get("CINEMA_OVERLAP_UPDATE", "0")))
-OVERLAP_UPDATE_BLOCKS = int(os.environ.get("CINEMA_OVERLAP_UPDATE_BLOCKS", "0"))  # workgroups of the overlapped AdamW launch (0: the library default, 4096)
-ASYNC_ZERO_GRAD = bool(int(os.environ.get("CINEMA_ASYNC_ZERO_GRAD", "0")))  # measured neutral (25.98 / 26.11 / 26.15 vs 26.00 / 26.01 / 26.11 ms): off;  # TrainStep: the gradient fill behind an update runs on the weight-gradient stream
 
 
 def adjust_learning_rate(optimizer, step: float, warmup_steps: float, max_n_steps: float, lr: float, min_lr: float) -> float:  # noqa: ANN001
@@ -258,34 +252,6 @@ class FusedAdamW:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         # [updates applied, updates skipped]: lives on the device because the non-finite-gradient decision does (no host sync in a step)
         self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
-        self._cuts: list | None = None  # overlap_update(): per group, the end of the parameters that are updated on the main stream
-
-    def overlap_update(self, early_params) -> bool:  # noqa: ANN001
-        """Split every update into an EARLY part (``early_params``: what the next forward pass reads first - the stems) on the current stream and a LATE part
-        (everything else) + zero_grad on ``tape.update_stream()``, which the forward pass joins behind the stems (``tape.update_join``).  The early parameters
-        must be a prefix of every group's range of the flat buffers (module registration order: ``enc_down_dict`` comes first); returns False - and changes
-        nothing - when they are not, or on the CPU.  Readers of the parameters other than the model's forward pass (checkpoints, ``.cpu()``) must call
-        ``tape.update_join()`` or synchronise the device first."""
-        f = self.flat
-        early = {id(p) for p in early_params}
-        if not f.flat_param.is_cuda or not early:
-            return False
-        cuts = []
-        for g, (a, _) in zip(f.groups, f.ranges):
-            cut, late_seen = a, False
-            for p in g["params"]:
-                if id(p) in early:
-                    if late_seen:
-                        return False
-                    cut = f.offsets[id(p)][1]
-                else:
-                    late_seen = True
-            cuts.append(cut)
-        if all(c == a for c, (a, _) in zip(cuts, f.ranges)) or 2 * len(cuts) > K.ADAMW_MAX_GROUPS:
-            return False
-        T.update_stream(create=True)
-        self._cuts = cuts
-        return True
 
     @property
     def step_count(self) -> int:
@@ -313,27 +279,6 @@ class FusedAdamW:
         K.sqnorm(f.flat_grad, self.sq)
         K.clip_coef(self.sq, float(clip_grad) if clip_grad else 0.0, self.coef, self.grad_norm, self.step_state)
         live = [(a, b, group["lr"], group["weight_decay"]) for group, (a, b) in zip(self.param_groups, f.ranges) if b > a]
-        if self._cuts is not None and not torch._C._cuda_isCurrentStreamCapturing():
-            # late part first, on the update stream (behind clip_coef and every reader of the old parameters = everything queued on this stream); the
-            # early part here; zero_grad follows both on the update stream (TrainStep._zero_grad)
-            early, late = [], []
-            for group, (a, b), c in zip(self.param_groups, f.ranges, self._cuts):
-                if c > a:
-                    early.append((a, c, group["lr"], group["weight_decay"]))
-                if b > c:
-                    late.append((c, b, group["lr"], group["weight_decay"]))
-            main, upd = K._stream(), T.update_stream().cuda_stream  # noqa: SLF001
-            K.stream_fork(main, upd)
-            with K.on_stream(upd):
-                if late:
-                    K.adamw_groups(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, late, self.betas[0], self.betas[1], self.eps, self.coef,
-                                   f.flat_shadow, self.step_state, max_blocks=OVERLAP_UPDATE_BLOCKS)
-            if early:
-                K.adamw_groups(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, early, self.betas[0], self.betas[1], self.eps, self.coef,
-                               f.flat_shadow, self.step_state)
-            K.stream_fork(main, upd)
-            T.WEIGHTS.invalidate()
-            return self.grad_norm
         if 1 < len(live) <= K.ADAMW_MAX_GROUPS and f.flat_param.is_cuda:
             # the layer-decay groups of a fine-tuning step (28 for ViT-Base) as ONE launch: the ranges are ascending slices of the flat buffers
             K.adamw_groups(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, live, self.betas[0], self.betas[1], self.eps, self.coef,
@@ -348,7 +293,6 @@ class FusedAdamW:
         return self.grad_norm
 
     def state_dict(self) -> dict:
-        T.update_join()
         return {"step": self.step_count, "skipped": self.n_skipped, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lrs": [g["lr"] for g in self.param_groups]}
 
     def load_state_dict(self, state: dict) -> None:
@@ -366,7 +310,7 @@ class TrainStep:
 
     def __init__(self, model: nn.Module, lr: float = 1e-3, betas: tuple = (0.9, 0.95), weight_decay: float = 0.05, clip_grad: float | None = 5.0,
                  synchronizer=None, hip_graph: bool = False, replay: bool = False, audit: bool = False, param_groups: list | None = None,  # noqa: ANN001
-                 check_every: int = 100, overlap_update: bool | None = None) -> None:
+                 check_every: int = 100) -> None:
         self.model = model
         # every ``check_every`` optimiser updates (and whenever a checkpoint is saved) the error words of the in-launch split reductions are read back
         # (hip.check_reduction_workspaces: one 4-byte read per workspace, the only host synchronisation of the step loop); 0 disables
@@ -387,52 +331,18 @@ class TrainStep:
         self._graphs: dict = {}
         if hip_graph and self.sync is not None:
             raise ValueError("hip_graph=True captures the single-process step; the data-parallel step runs eagerly")
-        # overlap_update (None: CINEMA_OVERLAP_UPDATE): AdamW of everything but the stems + zero_grad run on a stream of their own beside the NEXT step's stems
-        # (FusedAdamW.overlap_update; the forward pass joins that stream behind the stems).  Results are identical; anyone who reads the parameters between two
-        # steps without going through the model's forward pass calls join_update() (or synchronises the device) first.
-        want = OVERLAP_UPDATE if overlap_update is None else bool(overlap_update)
-        stems = getattr(model, "enc_down_dict", None)
-        self.overlap_update = bool(want and not hip_graph and stems is not None and hasattr(model, "encoder")
-                                   and self._optimizer.overlap_update(list(stems.parameters())))
-
     @property
     def flat(self) -> FlatModel:
-        """The flat buffers, for readers OUTSIDE the step: the current stream first waits for the overlapped part of the last update."""
-        T.update_join()
         return self._flat
 
     @property
     def optimizer(self) -> FusedAdamW:
-        T.update_join()
         return self._optimizer
 
     @property
     def param_groups(self) -> list:
         """The optimiser's groups (``adjust_learning_rate(optimizer=step, ...)`` in a step loop: host-side values only, no stream is made to wait)."""
         return self._optimizer.param_groups
-
-    def join_update(self) -> None:
-        """The current stream waits for the overlapped part of the last update (no-op without ``overlap_update``)."""
-        T.update_join()
-
-    def _zero_grad(self) -> None:
-        """zero_grad behind the update.  With the weight-gradient stream in use the fill runs THERE (ordered behind AdamW by an event): the first writers of the
-        next step's gradients are that stream's own launches, and ``Tape.backward`` makes the main stream wait for it once before its first direct accumulation -
-        so the 364 MB fill (63 us at config 2) overlaps the next step's forward pass instead of standing between two steps."""
-        g = self._flat.flat_grad
-        if self.overlap_update and g.is_cuda:  # behind both halves of the update, on the update stream
-            with torch.cuda.stream(T.update_stream()):
-                g.zero_()
-            return
-        if not (T.SIDE_WGRAD and ASYNC_ZERO_GRAD and g.is_cuda):
-            self._optimizer.zero_grad()
-            return
-        main, side = torch.cuda.current_stream(), T.side_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
-            g.zero_()
 
     def _updated(self) -> None:
         self._n_updates += 1
@@ -461,7 +371,7 @@ class TrainStep:
             if self.sync is not None:
                 self.sync.all_reduce()
             grad_norm = self._optimizer.step(self.clip_grad)
-            self._zero_grad()
+            self._optimizer.zero_grad()
             self._updated()
         return loss.detach(), grad_norm, metrics
 
@@ -491,7 +401,7 @@ class TrainStep:
             if self.sync is not None:
                 self.sync.all_reduce()
             grad_norm = self._optimizer.step(self.clip_grad)
-            self._zero_grad()
+            self._optimizer.zero_grad()
             self._updated()
         return loss, grad_norm, metrics  # static tensors: overwritten by the next step
 
@@ -649,7 +559,6 @@ def save_checkpoint(ckpt_dir, epoch: int, model_wo_ddp: nn.Module, optimizer, lo
     """``ckpt_dir / f"ckpt_{epoch}.pt"`` with the reference's keys (``cinema/optim.py:229-261``): model, optimizer, epoch, scaler, n_samples."""
     from pathlib import Path
 
-    T.update_join()  # (an overlapped optimiser update, TrainStep(overlap_update=True), may still be writing the parameters)
     if torch.cuda.is_available():
         # never write a checkpoint behind a split reduction that gave up (raises HipLibraryError - on every rank when the optimiser carries a synchronizer)
         _check_reductions_on_every_rank(getattr(optimizer, "synchronizer", None))

@@ -37,22 +37,6 @@ _VIEW_OPS = ("view", "reshape", "_unsafe_view", "slice", "select", "detach", "as
 
 _tls = threading.local()
 
-# The random masks of step i + 1 depend on nothing but shapes and the RNG: they are drawn on a separate stream right behind step i's launch list, i.e. beside
-# clip + AdamW, instead of at the head of step i + 1 (four rand + rank + copy chains of ~45 us each with nothing else to run: 0.15 ms of a 26 ms step).
-# The draw order - one set per step - is unchanged; the masks of a step after a re-seed are the ones drawn before it (reset_recordings() drops them).
-import os  # noqa: E402
-
-MASK_PREFETCH = bool(int(os.environ.get("CINEMA_MASK_PREFETCH", "0")))  # measured neutral (profiles/r05_n_prefetch_ab2.txt: 26.00 / 26.01 / 26.11 ms without, 26.02 / 26.93 / 26.15 with): off
-_PREFETCH_STREAMS: dict = {}
-
-
-def _prefetch_stream() -> "torch.cuda.Stream":
-    dev = torch.cuda.current_device()
-    st = _PREFETCH_STREAMS.get(dev)
-    if st is None:
-        st = _PREFETCH_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    return st
-
 
 class _Audit(TorchDispatchMode):
     """Collects ATen ops with device tensors that run inside a recorded step outside tape.host / tape.const."""
@@ -112,24 +96,11 @@ class RecordedStep:
             K.RECORD, T.REC_CALL = None, None
         self.calls = calls
         self.n_launches = sum(1 for fn, _ in calls if fn is not None)
-        self._masks_ready = None  # event: the masks of the NEXT run are in self.masks (drawn by _prefetch_masks behind the previous run)
 
     def _draw_into_static(self) -> None:
         masks, _ = self.model.draw_masks(self.images, self.ratio)
         for k, m in masks.items():
             self.masks[k].copy_(m)
-
-    def _prefetch_masks(self) -> None:
-        """Draw the next step's masks on the prefetch stream, ordered behind everything this step has queued (its launches read the mask tensors until the end of
-        the backward pass) and therefore beside whatever the caller issues next (clip, AdamW)."""
-        main, pre = torch.cuda.current_stream(), _prefetch_stream()
-        done = torch.cuda.Event()
-        done.record(main)
-        with torch.cuda.stream(pre):
-            pre.wait_event(done)
-            self._draw_into_static()
-            self._masks_ready = torch.cuda.Event()
-            self._masks_ready.record(pre)
 
     def _eager_step(self) -> None:
         loss, _, _, metrics = self.model(self.images, self.ratio, enc_mask_dict=self.masks, n_masked=self.n_masked)
@@ -141,11 +112,7 @@ class RecordedStep:
         for k, v in image_dict.items():
             if v.data_ptr() != self.images[k].data_ptr():
                 self.images[k].copy_(v, non_blocking=True)
-        if self._masks_ready is not None:
-            torch.cuda.current_stream().wait_event(self._masks_ready)
-            self._masks_ready = None
-        else:
-            self._draw_into_static()
+        self._draw_into_static()
         for fn, args in self.calls:
             if fn is None:
                 args()  # host entry: mask-dependent index tensors, gradient-exchange hooks
@@ -153,8 +120,6 @@ class RecordedStep:
                 rc = fn(*args)
                 if rc != 0:
                     raise K.HipLibraryError(f"replayed launch {fn.__name__} failed: {rc}")
-        if MASK_PREFETCH and K.LANE is None:
-            self._prefetch_masks()
         return self.loss, self.metrics
 
 

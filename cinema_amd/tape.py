@@ -265,33 +265,6 @@ _SIDE_ALT = [0]   # stream index of the last single weight-gradient launch (what
 _DST_STREAM: dict = {}
 
 
-# The optimiser update of everything BUT the stems on a stream of its own (optim.TrainStep(overlap_update=True)): the next step's stems - a chain of small launches
-# that leaves most of the chip idle - run beside the HBM-bound AdamW pass over the encoder / decoder parameters; the main stream waits for that stream once,
-# between the stems and the token assembly (update_join, called by convvit.encode_views; part of a recorded step's launch list).
-_UPDATE_STREAMS: dict = {}
-
-
-def update_stream(create: bool = False) -> "torch.cuda.Stream | None":
-    dev = torch._C._cuda_getDevice()
-    st = _UPDATE_STREAMS.get(dev)
-    if st is None and create:
-        prio = os.environ.get("CINEMA_UPDATE_STREAM_PRIO")  # "low": the least priority the device offers (its workgroups are dispatched behind the main stream's)
-        if prio == "low":
-            st = torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[0])
-        else:
-            st = torch.cuda.Stream(device=dev)
-        _UPDATE_STREAMS[dev] = st
-    return st
-
-
-def update_join() -> None:
-    """The current stream waits for the update stream (the late part of the previous step's AdamW + zero_grad).  No-op when no TrainStep overlaps its update."""
-    if _UPDATE_STREAMS and torch.cuda.is_available() and not torch._C._cuda_isCurrentStreamCapturing():
-        st = update_stream()
-        if st is not None:
-            K.stream_fork(st.cuda_stream, K._stream())
-
-
 _SIDE_KEEP: deque = deque()  # (completion event, operands) of weight-gradient launches still (possibly) running on the side stream
 
 # The lane group of the long-axis stems on a THIRD stream (default; CINEMA_LAX_STREAM=0: on the main stream, after the short-axis stem): the stems are chains of
@@ -573,7 +546,7 @@ FP8_DGRAD = bool(int(os.environ.get("CINEMA_FP8_DGRAD", "1")))
 # reads the row-major copies directly (ds_read_b64_tr_b8), see csrc/gemm256.hip form 3.  A site has no scale in its first step: that step runs the per-row /
 # bf16 forms and records maxima (``Fp8Sites.update`` at the end of every optimisation step turns them into scales).
 FP8_WGRAD = bool(int(os.environ.get("CINEMA_FP8_WGRAD", "1")))
-FP8_8BIT_ONLY = bool(int(os.environ.get("CINEMA_FP8_8BIT_ONLY", "1")))  # skip the bf16 tensors whose only readers are e4m3 GEMMs (GELU output, its gradient, the bf16 copy of a residual-stream gradient)
+# In the steady state the fp8 path skips the bf16 tensors whose only readers are e4m3 GEMMs (GELU output, its gradient, the bf16 copy of a residual-stream gradient).
 FP8_MARGIN = float(os.environ.get("CINEMA_FP8_MARGIN", "1.25"))  # scale = margin * amax / 448: headroom for a maximum that grows from one step to the next
 
 
@@ -832,8 +805,8 @@ def trainable_params(module: torch.nn.Module) -> list:
     return [p for p in pl if p.requires_grad]
 
 
-SPLITK_SLOTS = int(os.environ.get("CINEMA_SPLITK_SLOTS", "256"))
-SPLITK_MIN_ROWS = int(os.environ.get("CINEMA_SPLITK_MIN_ROWS", "512"))
+SPLITK_SLOTS = 256
+SPLITK_MIN_ROWS = 512
 
 
 def _split_k(m_red: int, n_out: int, k_out: int) -> int:
@@ -845,7 +818,7 @@ def _split_k(m_red: int, n_out: int, k_out: int) -> int:
     return max(1, min(want, (m_red + SPLITK_MIN_ROWS - 1) // SPLITK_MIN_ROWS))
 
 
-CONV_SPLITK_SLOTS = int(os.environ.get("CINEMA_CONV_SPLITK_SLOTS", "256"))
+CONV_SPLITK_SLOTS = 256
 
 
 def _split_k_conv(m_red: int, n_out: int, k_out: int) -> int:
@@ -903,22 +876,15 @@ def _wgrad_launch(fn: Callable, *operands: torch.Tensor, alt: int = 0, keys: tup
 # 32.39 ms): the group can only be issued at the end of the block's backward and its 432 workgroups each run for 160 us, so the side
 # stream no longer fills the main stream's idle slots early and the main stream's kernels wait for slots behind long tiles.  Opt-in.
 # Groups that would leave the slots mostly empty (decoder blocks: 192 tiles) keep the per-GEMM split-K path either way.
-# Round-5 glue trims around the loss and the token assembly (A/B switch): token-parameter gradients (mask_token column sums) on the weight-gradient stream, the
-# target statistics of the metrics on that stream beside the prediction heads, the MSE gradient handed over in bf16 (it was cast to fp32 and back), one
-# launch for the per-view loss weights, assembled-row gradients gathered straight into bf16 where their only reader is a GEMM.
-GLUE_TRIMS = bool(int(os.environ.get("CINEMA_GLUE_TRIMS", "1")))
-EARLY_RELAYOUT = bool(int(os.environ.get("CINEMA_EARLY_RELAYOUT", "1")))  # kernel-layout weight gradients folded into the flat buffer right behind their GEMM (0: at the end of the backward pass)
-GROUP_WGRAD = int(os.environ.get("CINEMA_GROUP_WGRAD", "2"))  # 1: whole-K 128x128 tiles (cinema_gemm_bf16_grouped), 2: persistent 256x256 kernel, k-slices finished in the launch
-# LayerNorm parameter gradients: per-block partial sums reduced for all LayerNorms at once at the end of the backward pass (CINEMA_LN_DEFER=0: per launch)
-DEFER_LN_REDUCE = bool(int(os.environ.get("CINEMA_LN_DEFER", "1")))
+GROUP_WGRAD = 2  # 1: whole-K 128x128 tiles (cinema_gemm_bf16_grouped), 2: persistent 256x256 kernel, k-slices finished in the launch (tests compare the two)
 _GROUP_MIN_TILES = 384
 # A persistent launch is held back until GROUP_FLUSH_MIN problems OR GROUP_FLUSH_GFLOP of work are pending.  Round 3 (main-loop form 1): per block 28.67,
 # two encoder blocks 28.81 ms/step.  Under form 2 (round 4) two ViT-Base blocks per launch (8 problems, 310-344 GFLOP) are 0.15 ms FASTER in every round of two A/Bs (26.17 -> 26.04, 26.91 -> 26.75 ms,
 # profiles/r04_ba_knobs.txt, r04_bb_flush_min.txt), three or more slower (27.4-27.9); a ViT-Large block (319 GFLOP) must go out alone (config 5: 58.9 -> 60.1 ms with two per launch,
 # profiles/r04_bc_flush_min_cfg45.txt) - hence the work threshold.  The same schedule runs under a gradient exchange: the collective of a block whose group is held
-# back starts behind the shared launch (mark_params / flush_wgrads).  CINEMA_GROUP_FLUSH_MIN=1 restores one launch per block.
-GROUP_FLUSH_MIN = int(os.environ.get("CINEMA_GROUP_FLUSH_MIN", "8"))
-GROUP_FLUSH_GFLOP = float(os.environ.get("CINEMA_GROUP_FLUSH_GFLOP", "300"))
+# back starts behind the shared launch (mark_params / flush_wgrads).  GROUP_FLUSH_MIN = 1 is one launch per block.
+GROUP_FLUSH_MIN = 8
+GROUP_FLUSH_GFLOP = 300.0
 P256_MAX_PROBLEMS = 12
 
 
@@ -1006,7 +972,7 @@ def wgrad(tape: Tape, dy16: torch.Tensor, x16: torch.Tensor, wv: PVar, bv: PVar 
     tagged = getattr(wv.to_param_layout, "hip_relayout", None)
     p = wv.param
     flat = getattr(p, "_cinema_flat_grad", None)
-    if (EARLY_RELAYOUT and tagged is not None and total_rows is None and row_offset == 0 and not wv.direct and flat is not None and dst.is_cuda
+    if (tagged is not None and total_rows is None and row_offset == 0 and not wv.direct and flat is not None and dst.is_cuda
             and not getattr(tape, "grouping", False) and flat.data_ptr() == getattr(p.grad, "data_ptr", lambda: 0)()):
         rows = wv.grad
         if tagged[0] == "convt":
@@ -1039,13 +1005,13 @@ def op_layernorm(tape: Tape, x: Var, gamma: torch.nn.Parameter, beta: torch.nn.P
         want16 = x.data.dtype == F32  # fp32 residual-stream input: also emit the bf16 copy for the upstream GEMMs
         res = x.grad if (x.grad is not None and x.grad.dtype == F32) else None
         site8 = x.grad8_site if (x.data.dtype == F32 and FP8_WGRAD and FP8_FORWARD) else None  # the producer of x wants an 8-bit copy of the complete gradient
-        if site8 is not None and site8.ready and FP8_8BIT_ONLY and FP8_DGRAD:
+        if site8 is not None and site8.ready and FP8_DGRAD:
             want16 = False  # the e4m3 copy is what the upstream data- / weight-gradient GEMMs read; a bf16 reader (fallback) casts the fp32 rows lazily
         bias_p = x.grad8_bias if site8 is not None else None
-        colsum = tape.pvar(bias_p).grad_buffer((c,)) if (bias_p is not None and bias_p.requires_grad and DEFER_LN_REDUCE) else None
+        colsum = tape.pvar(bias_p).grad_buffer((c,)) if (bias_p is not None and bias_p.requires_grad) else None
         out = K.layernorm_bwd(y.grad, x.data, gamma.detach(), beta.detach(), mean, rstd, act=act, dx_residual=res,
                               want_f32=x.data.dtype == F32, want_bf16=want16 or x.data.dtype == BF16,
-                              dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln if DEFER_LN_REDUCE else None, q8=site8,
+                              dgamma=gv.grad_buffer((c,)), dbeta=bv.grad_buffer((c,)), deferred=tape.pending_ln, q8=site8,
                               **({"q8_colsum": colsum} if site8 is not None else {}))
         dx32, dx16 = out[0], out[1]
         if x.data.dtype == F32:
@@ -1140,15 +1106,7 @@ def _op_thin_linear(tape: Tape, x: Var, weight: torch.nn.Parameter, bias: torch.
 
 # fc1's epilogue evaluates the erf terms of the GELU anyway: with this flag it stores GELU'(pre-activation) (bf16) instead of the pre-activation, and the
 # data gradient through the activation (fc2's dgrad epilogue) is one multiply per element instead of a second erf evaluation (that epilogue was VALU-bound:
-# 10960x3072x768 data gradient 93.7 us with the erf against 61.5 us plain).  CINEMA_GELU_DERIV=0: the pre-activation form.
-GELU_DERIV = bool(int(os.environ.get("CINEMA_GELU_DERIV", "1")))
-# ... and stores it as an 8-bit code (affine map of GELU''s range [-0.13, 1.13] onto 0..255, csrc/common.cuh gelu8_*): half the bytes fc1 writes beside its
-# activation and fc2's data gradient reads back - those K = 512 / 768 GEMMs move 3-3.9 TB/s, i.e. they sit on the HBM side of the ridge.  Quantisation error
-# <= 0.0025 = a bf16 rounding error at |GELU'| >= 0.5.  MEASURED NEUTRAL (three interleaved same-box rounds, 40 timed steps: 26.09 / 26.09 / 26.10 ms with the
-# bf16 tensor, 26.11 / 26.10 / 26.10 with the code, identical final loss, profiles/r05_g_gelu8_ab.txt): halving these bytes does not move the step - the
-# epilogue stores of these GEMMs are already hidden - so the default stays the bf16 tensor.  CINEMA_GELU8=1: the 8-bit code (saves 1.9 GB of traffic and
-# 0.9 GB of activation memory per step at config 2).
-GELU8 = bool(int(os.environ.get("CINEMA_GELU8", "0")))
+# 10960x3072x768 data gradient 93.7 us with the erf against 61.5 us plain).
 
 
 def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parameter, fc2_w: torch.nn.Parameter, fc2_b: torch.nn.Parameter,
@@ -1157,9 +1115,10 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
     ``residual=None``: the caller adds it (behind a DropPath, :func:`op_droppath_add`)."""
     w1, w2 = w_plain(fc1_w), w_plain(fc2_w)
     m, hidden = x.data.shape[0], w1.shape[0]
-    deriv = GELU_DERIV
-    # GELU'(fc1 output) (GELU_DERIV; as an 8-bit code under GELU8) or the fc1 output itself
-    h = K.empty((m, hidden), dtype=torch.uint8 if (deriv and GELU8 and x.data.is_cuda and hidden % 8 == 0) else BF16, device=x.data.device)
+    deriv = True
+    # h holds GELU'(fc1 output), not the fc1 output.  (The library can also hold GELU' as an 8-bit code - csrc/common.cuh gelu8_*, a uint8 auxiliary tensor in
+    # hip.gemm - which halves these bytes; measured neutral on the step in round 5, profiles/r05_g_gelu8_ab.txt, so the step does not use it.)
+    h = K.empty((m, hidden), dtype=BF16, device=x.data.device)
     x8t = a8t = None  # per-tensor e4m3 copies of x (LayerNorm output) and of the GELU output: operands of the forward AND weight-gradient GEMMs
     site_dy = site_dh = None
     if fp8 and _fp8_ok(x.data, fc1_w, fc2_w) and (residual is None or residual.data.dtype == F32):
@@ -1171,7 +1130,7 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
         x8, sx = a_fp8(x)
         # with its e4m3 copy in hand the bf16 GELU output has no reader in the steady state (fc2's forward and weight gradient take the copy): it is not
         # written at all (113 MB per ViT-Large block); a consumer outside the e4m3 GEMMs (fallback paths below) gets it by one dequantisation pass
-        a8_only = site_a is not None and a8 is not None and FP8_8BIT_ONLY
+        a8_only = site_a is not None and a8 is not None
         a = K.gemm_fp8(x8, sx, *w_fp8(fc1_w), bias=fc1_b.detach(), act=1, aux_out=h, gelu_deriv=deriv, out8=None if site_a is None else (site_a, a8), skip_d=a8_only)
         if site_a is not None and a8 is not None:
             a8t = (a8, site_a.scale)
@@ -1206,7 +1165,7 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
         # fc1's bias gradient = column sums of dh: the data-gradient epilogue that produces dh leaves its sums per strip of 32 rows (3.5 MB), one small launch adds them up
         strips = K.empty(((m + 31) // 32, hidden), dtype=F32, device=x.data.device) if (site_dh is not None and ok8 and not K.FORCE_GENERIC and w_fp8_t(fc2_w) is not None) else None
         # dh in bf16 has no reader either when fc1's weight AND data gradient take the e4m3 copy and the strips give the bias gradient
-        dh8_only = (FP8_8BIT_ONLY and fp8_dg2 and dh8 is not None and x8t is not None and ok8 and strips is not None and w_fp8_t(fc1_w) is not None
+        dh8_only = (fp8_dg2 and dh8 is not None and x8t is not None and ok8 and strips is not None and w_fp8_t(fc1_w) is not None
                     and fc1_w.shape[0] % 16 == 0 and fc1_w.shape[1] % 8 == 0)
         if dh8_only:
             wt2 = w_fp8_t(fc2_w)
@@ -1232,7 +1191,7 @@ def op_mlp(tape: Tape, x: Var, fc1_w: torch.nn.Parameter, fc1_b: torch.nn.Parame
 ATTN_CAPTURE: list | None = None  # set to a list: every self-attention backward appends its operands (dev tooling only)
 # training keeps the second bf16 half of every attention output, O = o + o_lo, for delta = rowsum(dO O) of the backward pass (csrc/attention.hip attn_bwd_dq_mfma:
 # delta from the bf16 output alone put 13 % of error into dQ of the late ViT-Large blocks); 0: one half (A/B, tools/attn_dq_error.py)
-ATTN_O_LO = bool(int(os.environ.get("CINEMA_ATTN_O_LO", "1")))
+ATTN_O_LO = True  # False: delta from the bf16 output alone (tools/attn_dq_error.py and the depth-parity test compare the two)
 
 
 def op_self_attention(tape: Tape, x: Var, batch: int, heads: int, q_w, q_b, kv_w, kv_b, rope: tuple | None = None, fp8: bool = False) -> Var:  # noqa: ANN001
@@ -1335,13 +1294,12 @@ class SharedKV:
 # one GEMM with the concatenated weights (N = n_blocks * 2c: 10.75 rounds of tiles instead of 8 x 1.34), one data-gradient GEMM with K = n_blocks * 2c
 # and one grouped weight-gradient launch instead of 8 of each: 423 vs 610 us per step measured in isolation (tools/bench_gemm.py "X dec").  Off with fp8
 # forward.  Under a gradient exchange the k|v parameters form a marked range of their own (their gradients are complete after the shared backward).
-SHARE_DECODER_KV = bool(int(os.environ.get("CINEMA_SHARE_KV", "1")))
 
 
 def share_kv_ok(xk: Var, attns: list) -> bool:
     # (legal under a gradient exchange since round 4: the k|v parameters are taken out of their blocks' marked ranges and marked as a range of their own,
     # which fires after the shared backward below - see op_shared_kv / Block.tape_forward)
-    return (SHARE_DECODER_KV and len(attns) > 1 and not FP8_FORWARD and xk.data.is_cuda and not K.FORCE_GENERIC
+    return (len(attns) > 1 and not FP8_FORWARD and xk.data.is_cuda and not K.FORCE_GENERIC
             and all(a.kv.weight.shape == attns[0].kv.weight.shape and (a.kv.bias is None) == (attns[0].kv.bias is None) for a in attns)
             and attns[0].kv.weight.shape[0] % 16 == 0 and xk.data.shape[1] % 8 == 0)
 
@@ -1502,7 +1460,7 @@ def op_cast_bf16(tape: Tape, x: Var) -> Var:
 
     def bwd() -> None:
         if y.grad is not None and x.needs_grad:
-            if GLUE_TRIMS and x.grad_any and x.grad is None:
+            if x.grad_any and x.grad is None:
                 x.add_grad(y.grad)  # (the decoder's assembled keys: 5.6 M elements that were cast to fp32 only to be gathered and cast back)
             else:
                 x.add_grad(K.cast(y.grad, F32))
@@ -1645,7 +1603,7 @@ def op_conv_same(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.n
     dev = x.data.device
     # implicit GEMM (cinema_conv_gemm_bf16): the MFMA kernel gathers its A tiles from the volume, the 27x im2col matrix is never written; the
     # 1-channel raw-image block (c = 1) and exotic kernel extents keep the im2col path
-    implicit = IMPLICIT_CONV and x.data.is_cuda and c % 8 == 0 and c_out % 8 == 0 and all(k in (1, 3) for k in ks) and (residual is None or residual.data.dtype == F32)
+    implicit = x.data.is_cuda and c % 8 == 0 and c_out % 8 == 0 and all(k in (1, 3) for k in ks) and (residual is None or residual.data.dtype == F32)
     # narrow layers (c_out <= 64): z-blocked form - a GEMM row is a group of 2 / 4 consecutive z voxels and n = zb * c_out fills the 128-wide tile
     # (c_out = 32: 50 % useful MACs instead of 25 %, half the gathered bytes per output); see cinema_conv_gemm_bf16
     zb_f = conv_zblock(c_out, ks, spatial) if implicit else 1
@@ -1744,14 +1702,12 @@ def _op_conv1ch(tape: Tape, x: Var, batch: int, spatial: tuple, weight: torch.nn
     return y
 
 
-IMPLICIT_CONV = bool(int(os.environ.get("CINEMA_IMPLICIT_CONV", "1")))  # 0: im2col + GEMM everywhere (A/B)
-ZBLOCK_CONV = bool(int(os.environ.get("CINEMA_ZBLOCK_CONV", "1")))  # 0: one GEMM row per voxel for every layer (A/B)
 
 
 def conv_zblock(n_out: int, ks: tuple, spatial: tuple) -> int:
     """z-blocking factor of the implicit convolution for a layer with ``n_out`` output channels: the largest of 4 / 2 that keeps zb * n_out within the
     128-wide tile and divides Z (3x3x3 kernels on 3-D volumes only); 1 = plain."""
-    if not ZBLOCK_CONV or len(spatial) != 3 or tuple(ks) != (3, 3, 3):
+    if len(spatial) != 3 or tuple(ks) != (3, 3, 3):
         return 1
     for zb in (4, 2):
         if zb * n_out <= 128 and spatial[2] % zb == 0:
@@ -1924,12 +1880,12 @@ def op_assemble(tape: Tape, n_rows: int, c: int, segments: list, device: torch.d
         for s in segments:
             if isinstance(s.src, Var):
                 if s.src.needs_grad:
-                    g = K.empty((s.dst_idx.numel(), c), dtype=BF16 if (s.grad_bf16 and GLUE_TRIMS and s.src.grad is None) else F32, device=device)
+                    g = K.empty((s.dst_idx.numel(), c), dtype=BF16 if (s.grad_bf16 and s.src.grad is None) else F32, device=device)
                     gathers.append(dict(dst=g, src=y.grad, src_idx=s.dst_idx))
                     targets.append((s.src, g))
             elif s.src is not None and s.src.requires_grad:
                 buf, yg, idx = tape.pvar(s.src).grad_buffer((c,)), y.grad, s.dst_idx
-                if GLUE_TRIMS and yg.is_cuda:  # a leaf gradient: nothing in the backward chain waits for it
+                if yg.is_cuda:  # a leaf gradient: nothing in the backward chain waits for it
                     _wgrad_launch(lambda buf=buf, yg=yg, idx=idx: K.colsum(yg, buf, row_idx=idx), yg, keys=(buf.data_ptr(),))
                 else:
                     K.colsum(yg, buf, row_idx=idx)
@@ -1953,7 +1909,7 @@ def op_mse(tape: Tape, pred: Var, image: torch.Tensor, geom_masked, norm_target:
             return
         d = K.mse_bwd(image, geom_masked, pred.data, norm_target, eps, y.grad, 1.0 / pred.data.numel())
         # (the prediction head's backward reads the gradient as a bf16 GEMM operand only: no fp32 copy)
-        pred.add_grad(d if (pred.data.dtype == BF16 or (GLUE_TRIMS and pred.grad is None)) else K.cast(d, F32))
+        pred.add_grad(d if (pred.data.dtype == BF16 or pred.grad is None) else K.cast(d, F32))
 
     tape.record(bwd)
     return y, maxes  # maxes: (normed_target_max, pred_max) metrics of the norm_target mode (mae.py:146-150), else None
@@ -1971,13 +1927,9 @@ def op_mean_finite(tape: Tape, losses: list) -> Var:
     def bwd() -> None:
         if y.grad is None:
             return
-        if GLUE_TRIMS:
-            gs = K.mul_scalar(coef, y.grad.reshape(1))  # d loss / d loss_i = coef[i] * upstream, all views in one launch
-            for i, lv in enumerate(losses):
-                lv.add_grad(gs[i:i + 1])
-            return
+        gs = K.mul_scalar(coef, y.grad.reshape(1))  # d loss / d loss_i = coef[i] * upstream, all views in one launch
         for i, lv in enumerate(losses):
-            lv.add_grad(K.mul_scalar(coef[i:i + 1], y.grad.reshape(1)))  # d loss / d loss_i = coef[i] * upstream
+            lv.add_grad(gs[i:i + 1])
 
     tape.record(bwd)
     return y

@@ -982,41 +982,6 @@ def test_convunetr_logits_and_gradients_vs_reference_golden() -> None:
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
-@pytest.mark.parametrize("replay", [False, True])
-def test_overlapped_update_walks_the_same_trajectory(replay: bool) -> None:
-    """TrainStep(overlap_update=True): AdamW of everything but the stems + zero_grad run on a stream of their own beside the next step's stems, and the forward pass
-    joins that stream behind the stems (tape.update_join in convvit.encode_views).  Same seeds -> the same losses, gradient norms and - after join_update() and a
-    wait on the CURRENT stream only - bit-identical parameters, moments and bf16 shadows as the one-stream update."""
-    from cinema_amd import tape as T  # noqa: N812
-    from cinema_amd.optim import TrainStep
-
-    out = {}
-    for overlap in (False, True):
-        torch.manual_seed(7)
-        model = CineMA(**mini_kwargs()).to(DEV)
-        step = TrainStep(model, lr=1e-3, replay=replay, overlap_update=overlap)
-        assert step.overlap_update is overlap
-        if overlap:  # the early part = the stems, a prefix of both weight-decay groups
-            cuts = step._optimizer._cuts  # noqa: SLF001
-            assert all(a < c < b for c, (a, b) in zip(cuts, step._flat.ranges))  # noqa: SLF001
-        torch.manual_seed(11)
-        batches = [{v: torch.rand(2, 1, *s, device=DEV) for v, s in model_sizes(model).items()} for _ in range(2)]
-        traj = []
-        for i in range(5):
-            loss, gn, _ = step(batches[i % 2], 0.75)
-            traj.append((float(loss), float(gn)))
-        step.join_update()
-        torch.cuda.current_stream().synchronize()
-        out[overlap] = (traj, step._flat.flat_param.clone(), step._optimizer.exp_avg.clone(), step._flat.flat_shadow.clone(),  # noqa: SLF001
-                        float(step._flat.flat_grad.abs().max()))  # noqa: SLF001
-    for (l0, g0), (l1, g1) in zip(out[False][0], out[True][0]):
-        assert abs(l0 - l1) <= 2e-4 * abs(l0) + 1e-6 and abs(g0 - g1) <= 2e-4 * abs(g0) + 1e-6, (out[False][0], out[True][0])
-    for a, b in zip(out[False][1:4], out[True][1:4]):
-        assert float((a.float() - b.float()).abs().max()) <= 2e-5  # (fp32 atomics in the bias-gradient row sums reorder between runs)
-    assert out[True][4] == 0.0  # zero_grad ran behind both halves
-    assert T.update_stream() is not None
-
-
 def test_replayed_step_is_reproducible_at_the_real_shape() -> None:
     """tools/replay_race_full.py: the recorded config-2 step (ViT-Base, 4 views, batch 16) replayed 12 times on identical inputs and masks - every parameter's gradient
     agrees with the first replay's to atomics noise.  With kernels of the real durations on the main, long-axis and two weight-gradient streams, two accumulating

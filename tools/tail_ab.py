@@ -1,5 +1,5 @@
 """Split-tail A/B on the step's GEMM shapes (dev tooling): fix-up launch vs the tail finished inside the launch (reduce-scatter over the k-slices).
-   python tools/tail_ab.py      (CINEMA_TAIL_MIN_NKT / CINEMA_TAIL_MIN_KT / CINEMA_TAIL_MIN_K select the thresholds for the whole process)"""
+   python tools/tail_ab.py"""
 from __future__ import annotations
 
 import sys
