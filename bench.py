@@ -45,6 +45,64 @@ def gemm_roof(flops: float, alg_bytes: float, secs: float, peak_tflops: float = 
             "frac": round(gbs / HBM_PEAK_GBS if hbm else tf / peak_tflops, 4), "frac_of_mfma_peak": round(tf / peak_tflops, 4)}
 
 
+def hipblaslt_reference(prof: list, steps: int, names: dict) -> dict:
+    """MEASUREMENT ONLY (the library never calls a BLAS): for every GEMM instance of the profiled steps, the time hipBLASLt (through ``torch.mm``) takes for the same
+    problems - same m, n, k, same operand layouts in memory, bf16 operands and a bf16 result, NO epilogue, one call per problem back to back on an otherwise idle
+    chip - next to the time this library's launches took inside the step (which includes their fused epilogues: bias, GELU, residual, fp32 accumulation, bias-gradient
+    row sums).  ``vs_hipblaslt`` = hipBLASLt time / this library's time (> 1: faster than the vendor GEMM on these shapes).  e4m3 instances are skipped."""
+    import torch
+    from collections import Counter
+
+    per_kind: dict = {}
+    for kind, _f, _e0, _e1, _shape, *rest in prof:
+        if kind >= 4096 or not rest:  # e4m3 weight gradients: no bf16 BLAS equivalent of the same bytes
+            continue
+        per_kind.setdefault(kind, Counter()).update(rest[0])
+    shapes = sorted({s for c in per_kind.values() for s in c})
+    t_us: dict = {}
+    for m, n, k, akm, bkm in shapes:
+        try:
+            a = torch.randn((m, k) if akm else (k, m), device="cuda").mul_(0.5).to(torch.bfloat16)
+            b = torch.randn((n, k) if bkm else (k, n), device="cuda").mul_(0.05).to(torch.bfloat16)
+            av, bv = (a if akm else a.t()), (b.t() if bkm else b)
+            y = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+            for _ in range(3):
+                torch.mm(av, bv, out=y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                torch.mm(av, bv, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            t_us[(m, n, k, akm, bkm)] = e0.elapsed_time(e1) / 8 * 1e3
+            del a, b, y
+        except RuntimeError:
+            t_us[(m, n, k, akm, bkm)] = None
+    ours: dict = {}  # (kind, problem) -> [seconds, launches] of the single-problem launches (a grouped launch has one time for all its problems)
+    ours_kind: dict = {}
+    for kind, _f, e0, e1, _shape, *rest in prof:
+        if kind in per_kind:
+            dt = e0.elapsed_time(e1) * 1e-3
+            ours_kind[kind] = ours_kind.get(kind, 0.0) + dt
+            if len(rest[0]) == 1:
+                o = ours.setdefault((kind, rest[0][0]), [0.0, 0])
+                o[0] += dt
+                o[1] += 1
+    out = {}
+    for kind, cnt in per_kind.items():
+        if any(t_us[s] is None for s in cnt):
+            continue
+        blas_ms = sum(t_us[s] * c for s, c in cnt.items()) / steps * 1e-3
+        rows = []
+        for (kd, sh), (secs, n) in ours.items():
+            if kd == kind:
+                rows.append({"m_n_k": list(sh[:3]), "a_kmajor": sh[3], "b_kmajor": sh[4], "launches_per_step": n // steps, "us": round(secs / n * 1e6, 1),
+                             "hipblaslt_us": round(t_us[sh], 1), "vs_hipblaslt": round(t_us[sh] / (secs / n * 1e6), 3)})
+        rows.sort(key=lambda r: -r["us"] * r["launches_per_step"])
+        out[names[kind]] = {"hipblaslt_ms_per_step": round(blas_ms, 3), "vs_hipblaslt": round(blas_ms / (ours_kind[kind] / steps * 1e3), 3), "shapes": rows[:8]}
+    return out
+
+
 HBM_KERNEL_FAMILIES = ("ln_fwd_kernel", "ln_bwd_kernel", "adamw_kernel", "sqnorm_kernel", "attn_fwd_mfma", "attn_bwd_", "row_copy_multi_kernel", "cast_kernel",
                        "splitk_reduce_kernel", "sparse_dwconv", "mse_", "patch_")
 
@@ -285,7 +343,7 @@ def seg_main(args, rank: int, world: int, device: str, sync) -> None:  # noqa: A
         T_.SIDE_WGRAD = side
         if rank == 0:
             agg: dict = {}
-            for kind, flops, e0, e1, _shape in prof:
+            for kind, flops, e0, e1, _shape, *_ in prof:
                 a = agg.setdefault(kind, [0.0, 0.0, 0])
                 a[0] += flops
                 a[1] += e0.elapsed_time(e1) * 1e-3
@@ -530,6 +588,7 @@ def main() -> None:
                     help="gradient exchange algorithm (N > 1): all_reduce = torch.distributed.all_reduce per range (RCCL chooses ring / tree / direct); rs_ag = explicit "
                          "reduce_scatter_tensor + all_gather_into_tensor on the flat ranges (one-hop phases on the fully connected xGMI mesh)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short config-4 / config-5 measurements appended to the default one-GPU line")
+    ap.add_argument("--no-blas-reference", action="store_true", help="skip the hipBLASLt timing of the step's GEMM shapes (roofline.all_gemm_kernels[*].vs_hipblaslt)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -692,12 +751,13 @@ def main() -> None:
         T_.SIDE_WGRAD = side
     if rank == 0 and args.profile_steps > 0:
         agg: dict = {}
-        for kind, flops, e0, e1, shape in prof:
+        for kind, flops, e0, e1, shape, *_ in prof:
             a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
             a[3] += shape[-1]
+        blas = hipblaslt_reference(prof, args.profile_steps, K.GEMM_KERNEL_NAMES) if not args.no_blas_reference else {}
         kind = max(agg, key=lambda k: agg[k][1])
         flops, secs, n, alg_bytes = agg[kind]
         traffic = pmc_traffic(K.GEMM_KERNEL_NAMES[kind])
@@ -720,7 +780,9 @@ def main() -> None:
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(secs / n * 1e6, 2),
                     "gflop_per_launch": round(flops / n / 1e9, 3),
                     "all_gemm_kernels": {K.GEMM_KERNEL_NAMES[k]: {**gemm_roof(v[0], v[3], v[1]), "ms_per_step": round(v[1] / args.profile_steps * 1e3, 3),
-                                                                  "launches_per_step": v[2] // args.profile_steps} for k, v in agg.items()},
+                                                                  "launches_per_step": v[2] // args.profile_steps, **blas.get(K.GEMM_KERNEL_NAMES[k], {})} for k, v in agg.items()},
+                    "vs_hipblaslt_note": "measurement only - the library never calls a BLAS: hipBLASLt (torch.mm) on the same problems (same m, n, k and operand layouts, bf16 result, NO "
+                                         "epilogue, one call per problem back to back, idle chip) / this library's launch times inside the step (fused epilogues included); > 1 = faster than hipBLASLt",
                     "all_gemm_kernels_note": "bound / frac per instance from its algorithmic intensity (FLOP per algorithmic byte vs the 312.5 FLOP/B ridge of 2.5 PF / 8 TB/s): "
                                              "hbm-bound instances are priced against 8 TB/s, mfma-bound ones against 2.5 PF; frac_of_mfma_peak is kept for comparison with earlier rounds",
                     "hbm_kernels": hbm_kernel_rows(PMC_TRAFFIC_FILE)}

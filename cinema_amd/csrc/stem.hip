@@ -208,7 +208,7 @@ __device__ __forceinline__ void ln_linear_body(const LnLinP& p) {
   for (int i = tid; i < C; i += NT) { vec[i] = p.gamma[i]; vec[C + i] = p.beta[i]; vec[2 * C + i] = p.bias ? p.bias[i] : 0.f; }
   __syncthreads();
   const int n_tiles = (p.rows + 15) >> 4;
-  for (int tile = blockIdx.x * NW + wave; tile < n_tiles; tile += gridDim.x * NW) {
+  for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * NW) {  // consecutive tiles on different workgroups: a ragged last round is spread over the chip
     const int row = tile * 16 + v;
     const bool ok = row < p.rows;
     const int rowc = ok ? row : p.rows - 1;
@@ -255,7 +255,7 @@ __device__ __forceinline__ void ln_linear_bwd_body(const LnLinBwdP& p) {
 #pragma unroll
   for (int rb = 0; rb < RB; rb++) { dgam[rb] = f4{0.f, 0.f, 0.f, 0.f}; dbet[rb] = f4{0.f, 0.f, 0.f, 0.f}; }
   const int n_tiles = (p.rows + 15) >> 4;
-  for (int tile = blockIdx.x * NW + wave; tile < n_tiles; tile += gridDim.x * NW) {
+  for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * NW) {  // consecutive tiles on different workgroups: a ragged last round is spread over the chip
     const int row = tile * 16 + v;
     const bool ok = row < p.rows;
     const int rowc = ok ? row : p.rows - 1;
@@ -340,8 +340,11 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdP& p) {
     nb2.load(p.wf2 + HC, H, tid);
   }
   for (int pass = 0; pass < passes; pass++) {
-    const int tile = (pass * gridDim.x + blockIdx.x) * NWV + wave;
-    if (RES && tile >= n_tiles) break;  // (no barrier below: a wave without rows just leaves)
+    // consecutive tiles go to different workgroups, so a ragged last pass (config 2, c = 128: 2304 tiles on 256 x 8 waves) puts ONE more tile on every compute unit
+    // instead of a full pass on 32 of them - the pass time follows the LDS traffic of the busiest unit
+    const int tile = (pass * NWV + wave) * gridDim.x + blockIdx.x;
+    const bool has = tile < n_tiles;
+    if (RES && !has) break;  // (no barrier below: a wave without rows just leaves)
     const int row = tile * 16 + v;
     const bool ok = row < p.rows;
     const int rowc = ok ? row : p.rows - 1;
@@ -397,13 +400,13 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdP& p) {
       for (int j = 0; j < NCH; j += 2) {
         na1.load(p.wf1 + (size_t)((j + 2) % NCH) * HC * C, C, tid);
         na2.load(p.wf2 + ((j + 2) % NCH) * HC, H, tid);
-        chunk(j, smem + L::BUF);
+        if (has) chunk(j, smem + L::BUF);   // (a wave without a tile still moves the weights and meets the barriers)
         nb1.store(smem + L::BUF + L::BUF_BYTES, P_C, tid);          // chunk j + 1 (fetched during chunk j - 1)
         nb2.store(smem + L::BUF + L::BUF_BYTES + L::WF2_OFF, P_H, tid);
         __syncthreads();
         nb1.load(p.wf1 + (size_t)((j + 3) % NCH) * HC * C, C, tid);
         nb2.load(p.wf2 + ((j + 3) % NCH) * HC, H, tid);
-        chunk(j + 1, smem + L::BUF + L::BUF_BYTES);
+        if (has) chunk(j + 1, smem + L::BUF + L::BUF_BYTES);
         na1.store(smem + L::BUF, P_C, tid);                          // chunk j + 2
         na2.store(smem + L::BUF + L::WF2_OFF, P_H, tid);
         __syncthreads();
@@ -453,7 +456,8 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdP& p) {
   const int n_tiles = (p.rows + 15) >> 4;
   const int passes = (n_tiles + gridDim.x * NW - 1) / (gridDim.x * NW);
   for (int pass = 0; pass < passes; pass++) {
-    const int tile = (pass * gridDim.x + blockIdx.x) * NW + wave;
+    const int tile = (pass * NW + wave) * gridDim.x + blockIdx.x;   // (as in the forward kernel: a ragged last pass is spread over all workgroups)
+    const bool has = tile < n_tiles;
     const int row = tile * 16 + v;
     const bool ok = row < p.rows;
     const int rowc = ok ? row : p.rows - 1;
@@ -480,6 +484,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdP& p) {
       const char* wf1c = smem + L::BUF + (j & 1) * L::BUF_BYTES;
       const char* wf2c = wf1c + L::WF2_OFF;
       const float* b1 = vec + 2 * C + j * HC;
+      if (has) {
 #pragma unroll
       for (int t = 0; t < HC / 32; t++) {
         f4 z0 = ldsv4(b1, t * 32 + g * 4), z1 = ldsv4(b1, t * 32 + 16 + g * 4);
@@ -506,11 +511,13 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdP& p) {
         for (int ob = 0; ob < RB; ob++) dxn[ob] = mfma16(wfrag_t(wf1c, P_C, t * 32, ob * 16, lane), bz, dxn[ob]);
         __builtin_amdgcn_sched_barrier(0);
       }
+      }
       char* nb = smem + L::BUF + ((j + 1) & 1) * L::BUF_BYTES;
       n1.store(nb, P_C, tid);
       n2.store(nb + L::WF2_OFF, PT_H, tid);
       __syncthreads();
     }
+    if (!has) continue;  // (the barriers of the chunk loop are behind it)
     // LN2 backward + the residual gradient (the normalised rows are formed again from x1 - an L2 hit - instead of living in 32 registers through the chunk loop)
     f4 xh[RB];
     load_act<C>(xh, p.x1, rowc, g);
@@ -606,8 +613,10 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
   const int sp = __ffs(np >> 3) - 1, sq = __ffs(nq >> 3) - 1;   // log2 of the 16-byte chunks per row
   const int n_p = RT << sp, n_chunks = n_p + (RT << sq);
   constexpr int NLD = (RT * WG_MAX_PQ / 8 + NT - 1) / NT;
-  u4 stg[NLD];
-  auto fetch = [&](int rb) {
+  // two staging sets: the rows of step i + 2 are requested as soon as set (i & 1) has been written to LDS, so two steps' bytes are in flight per workgroup (with one
+  // set the loop ran at one HBM latency per step: 3.1 us per 45 KB step, 2.3 TB/s over the chip)
+  u4 stg_a[NLD], stg_b[NLD];
+  auto fetch = [&](u4 (&stg)[NLD], int rb) {
 #pragma unroll
     for (int u = 0; u < NLD; u++) {
       const int i = tid + u * NT;
@@ -620,8 +629,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
       }
     }
   };
-  if (r0 < r1) fetch(r0);
-  for (int rb = r0; rb < r1; rb += RT) {
+  auto step = [&](u4 (&stg)[NLD], int rb) {
     __syncthreads();   // the previous step's fragments have been read
 #pragma unroll
     for (int u = 0; u < NLD; u++) {
@@ -634,7 +642,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
       }
     }
     __syncthreads();
-    if (rb + RT < r1) fetch(rb + RT);   // in flight while this step is multiplied
+    if (rb + 2 * RT < r1) fetch(stg, rb + 2 * RT);   // in flight while this step and the next are multiplied
     if (pr.db && tid < pr.n) {
 #pragma unroll 8
       for (int r = 0; r < RT; r++) bsum += bf2f(*reinterpret_cast<const bf16_t*>(ldy + r * pdy + tid * 2));
@@ -654,6 +662,12 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
           if (b < per_q && wqi * per_q + b < tq) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp, fq[b], acc[a][b], 0, 0, 0);
       }
     }
+  };
+  if (r0 < r1) fetch(stg_a, r0);
+  if (r0 + RT < r1) fetch(stg_b, r0 + RT);
+  for (int rb = r0; rb < r1; rb += 2 * RT) {
+    step(stg_a, rb);
+    if (rb + RT < r1) step(stg_b, rb + RT);
   }
   // partial slab of this workgroup: [n][k] in the destination's orientation, then [n] column sums
   float* slab = q.slabs + (size_t)blockIdx.x * q.slab_floats + pr.slab_off;

@@ -84,8 +84,8 @@ GEMM_KERNEL_NAMES.update({lay + 8 * epi: f"gemm_mfma_kernel<{txt}, {epi}>" for l
 _P256_LOOP = int(os.environ.get("CINEMA_P256_LOOP", "2"))
 GEMM_KERNEL_NAMES.update({2048 + lay + 8 * epi: f"gemm_p256_kernel<{txt}, {epi}, {min(_P256_LOOP, 2)}>" for lay, txt in _LAYOUTS.items() for epi in range(5)})  # csrc/gemm256.hip
 GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4] = f"gemm_p256_kernel<false, false, 4, {10 if _P256_LOOP >= 2 else 3}>"  # weight gradients on e4m3 operands (cinema_gemm_fp8_wgrad_p256)
-# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
-# entries are (kernel_used, algorithmic_flops, start_event, end_event)
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream: entries are (kernel_used, algorithmic_flops, start_event,
+# end_event, (m, n, k, a_kmajor, b_kmajor, split_k | problems, algorithmic_bytes), the launch's problems as (m, n, k, a_kmajor, b_kmajor) each)
 GEMM_PROFILE: list | None = None
 
 
@@ -633,7 +633,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
         ev1.record()
         extra = sum(t.numel() * t.element_size() for t in (residual, gelu_in, aux_out) if t is not None)
         alg_bytes = 2.0 * (m * k + k * n) + out.element_size() * m * n * (2 if accumulate else 1) + extra
-        GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), 0, alg_bytes)))
+        GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), 0, alg_bytes), ((m, n, k, int(a_kmajor), int(b_kmajor)),)))
         return out
     ws = None
     if split_k > 1 and out.dtype == torch.float32:  # deterministic two-pass split-K: per-split fp32 slabs + one reduce kernel
@@ -656,7 +656,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ob = out.element_size()
     extra = sum(t.numel() * t.element_size() for t in (residual, gelu_in, aux_out) if t is not None)
     alg_bytes = 2.0 * (m * k + k * n) + ob * m * n * (2 if accumulate else 1) + extra  # every operand read once, the result written once
-    GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k, alg_bytes)))
+    GEMM_PROFILE.append((g.kernel_used, 2.0 * m * n * k, ev0, ev1, (m, n, k, int(a_kmajor), int(b_kmajor), split_k, alg_bytes), ((m, n, k, int(a_kmajor), int(b_kmajor)),)))
     return out
 
 
@@ -833,7 +833,7 @@ def gemm_wgrad_grouped(problems: list, p256: bool = False, split_k: int = 0) -> 
         ev1.record()
         flops = sum(2.0 * g.m * g.n * g.k for g in arr)
         alg = sum(2.0 * (g.m * g.k + g.k * g.n) + 8.0 * g.m * g.n for g in arr)  # every operand once, the fp32 gradient read + written once
-        GEMM_PROFILE.append((arr[0].kernel_used, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg)))
+        GEMM_PROFILE.append((arr[0].kernel_used, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg), tuple((g.m, g.n, g.k, 0, 0) for g in arr)))
         return
     if GEMM_PROFILE is None:
         _check(load().cinema_gemm_bf16_grouped(arr, len(problems), _stream()), "gemm_grouped")
@@ -844,7 +844,7 @@ def gemm_wgrad_grouped(problems: list, p256: bool = False, split_k: int = 0) -> 
     ev1.record()
     flops = sum(2.0 * g.m * g.n * g.k for g in arr)
     alg = sum(2.0 * (g.m * g.k + g.k * g.n) + 8.0 * g.m * g.n for g in arr)
-    GEMM_PROFILE.append((64, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg)))
+    GEMM_PROFILE.append((64, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg), tuple((g.m, g.n, g.k, 0, 0) for g in arr)))
 
 
 def gemm_fp8_wgrad_grouped(problems: list) -> None:
@@ -872,7 +872,7 @@ def gemm_fp8_wgrad_grouped(problems: list) -> None:
     ev1.record()
     flops = sum(2.0 * g.m * g.n * g.k for g in arr)
     alg = sum(1.0 * (g.m * g.k + g.k * g.n) + 8.0 * g.m * g.n for g in arr)  # every 8-bit operand once, the fp32 gradient read + written once
-    GEMM_PROFILE.append((arr[0].kernel_used, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg)))
+    GEMM_PROFILE.append((arr[0].kernel_used, flops, ev0, ev1, (sum(g.m for g in arr), arr[0].n, arr[0].k, 0, 0, len(problems), alg), tuple((g.m, g.n, g.k, 0, 0) for g in arr)))
 
 
 def _warn_generic(m: int, n: int, k: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:

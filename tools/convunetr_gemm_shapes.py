@@ -42,7 +42,7 @@ step()
 torch.cuda.synchronize()
 prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
 agg = {}
-for kind, flops, e0, e1, shape in prof:
+for kind, flops, e0, e1, shape, *_ in prof:
     a = agg.setdefault((kind, shape), [0.0, 0.0, 0])
     a[0] += flops
     a[1] += e0.elapsed_time(e1) * 1e-3

@@ -26,7 +26,7 @@ for _ in range(N):
 torch.cuda.synchronize()
 prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
 agg: dict = {}
-for kind, flops, e0, e1, shape in prof:
+for kind, flops, e0, e1, shape, *_ in prof:
     a = agg.setdefault((kind, shape), [0.0, 0.0, 0])
     a[0] += flops
     a[1] += e0.elapsed_time(e1) * 1e-3
