@@ -836,7 +836,9 @@ CINEMA_API int cinema_stem_mlp_bwd(const float* g2, const float* x1, const uint1
 
 CINEMA_API int cinema_stem_wgrad_slices(int rows) {
   int s = (rows + 255) / 256;
-  const int cap = n_cus();
+  // a block hands over four problems (fc2, fc1, conv2, conv1) that run side by side, one workgroup per CU: a quarter of the CUs per problem is one round of the chip,
+  // and the partial slabs (and the reduce pass over them) shrink fourfold against one slice per CU (42 MB -> 10 MB at config 2's stage 1)
+  const int cap = n_cus() / 4 > 32 ? n_cus() / 4 : 32;
   return s < 1 ? 1 : (s > cap ? cap : s);
 }
 CINEMA_API long long cinema_stem_wgrad_workspace_bytes(const cinema_stem_wgrad_problem* probs, int count) {
