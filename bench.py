@@ -601,7 +601,7 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus {args.gpus}`)")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        raise SystemExit(f"bench.py needs an MI355X: the HIP path has no CPU fallback (rank {os.environ.get('RANK', '0')} of {world})")
     # path check of the multi-rank branch on a ONE-GPU box (dev only, never a metric): CINEMA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # CINEMA_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
     backend = os.environ.get("CINEMA_BENCH_BACKEND", "nccl")
