@@ -475,7 +475,7 @@ def secondary_configs(device: str, with_parity: bool) -> dict:
                                 "launches_per_step": len(recs) // 2, "avg_launch_us": round(secs / len(recs) * 1e6, 2),
                                 "gflop_per_launch": round(flops / len(recs) / 1e9, 3), "algorithmic_bytes_per_launch": int(alg / len(recs)),
                                 "traffic": (_committed(PMC_TRAFFIC_FP8_FILE, K_.GEMM_KERNEL_NAMES[4096 + 3 + 8 * 4]) or {}).get("hbm_bytes_per_launch"),
-                                "traffic_source": f"committed {PMC_TRAFFIC_FP8_FILE} (FETCH_SIZE / WRITE_SIZE passes over this config's fp8 step, tools/gpu_r05_final.sh)",
+                                "traffic_source": f"committed {PMC_TRAFFIC_FP8_FILE} (FETCH_SIZE / WRITE_SIZE passes over this config's fp8 step, tools/gpu_r06_final.sh)",
                                 "traffic_stale": pmc_binding(PMC_TRAFFIC_FP8_FILE)["stale"],
                                 "timing": "HIP events on the launch stream around every launch (two eager steps, one stream)",
                                 "what": "weight gradients of a transformer block (qkv, proj, fc1, fc2) on row-major e4m3 operands in one persistent launch, k-slices reduced in the launch"}

@@ -31,9 +31,11 @@ from conftest import load_golden  # noqa: E402
 
 DEV = "cuda"
 LOSS_RTOL, PRED_ATOL, GRAD_L2, GRAD_MAX = 2e-3, 5e-2, 6e-2, 12e-2   # default gates (the mini goldens carry their own, below)
-# mini goldens (16 / 32-channel stems, 8- and 16-wide heads: everything below the MFMA tile sizes), 1.6 x the round-5 measurement of the worst tensor - always a
-# LayerNorm / bias vector of a long-axis stem: plain + self-attention 2.8 % rel-L2 / 3.4 % max-abs, norm_target (gradients scaled by 1 / patch std) 4.9 % / 6.9 %
-MINI_GATES = {"mini_4view": (4.6e-2, 5.5e-2), "mini_4view_selfattn": (4.6e-2, 5.5e-2), "mini_4view_normtarget": (7.8e-2, 11e-2)}
+# mini goldens (16 / 32-channel stems, 8- and 16-wide heads: everything below the MFMA tile sizes).  FIXED bounds since round 6, per class: every weight MATRIX
+# within 3 % rel-L2 of the reference's gradient, every VECTOR (LayerNorm / bias: sums over all rows of bf16-rounded gradients) within 5 %; largest element error 6 % of
+# the tensor's largest element.  Measured (MI355X, round 6): plain 2.2 % / 2.8 % / 3.9 %, self-attention 2.0 % / 2.5 % / 3.2 %, norm_target (gradients scaled by
+# 1 / patch std) 2.8 % / 4.0 % / 4.9 % - the worst tensors are LayerNorm vectors and the 1x1 convolutions of a long-axis stem.
+MINI_GATES = {"mini_4view": ((3e-2, 5e-2), 6e-2), "mini_4view_selfattn": ((3e-2, 5e-2), 6e-2), "mini_4view_normtarget": ((3e-2, 5e-2), 6e-2)}
 TINY_GRAD_L2, TINY_GRAD_MAX = 2.5e-2, 2.5e-2                          # cfg 1: measured 0.75 % / 0.73 %
 MID_GRAD_L2, MID_GRAD_MAX = 5.5e-2, 10e-2                             # MFMA-sized models: measured 1.7 % / 3.3 %
 # config-2 real-shape first-step parity (test_base_4view_192_first_step_vs_oracle) = 3 x measured (6.9e-4, 1.2e-3, 5.7e-4, 0.79 %); the worst tensor: a REQUIRED
@@ -87,10 +89,12 @@ def check_against(model: CineMA, images: dict, masks: dict, ref_loss: torch.Tens
         l2 = float(diff.norm() / t.norm().clamp_min(1e-12))
         worst[k] = l2
         worst_max[k] = err / max(scale, 1e-30)
-        assert l2 <= grad_l2, (k, l2)
+        gate = grad_l2 if not isinstance(grad_l2, tuple) else grad_l2[0 if named[k].ndim > 1 else 1]   # (matrices, vectors)
+        assert l2 <= gate, (k, l2)
         assert err <= grad_max * scale + 1e-7, (k, err, scale)
     mats = {k: v for k, v in worst.items() if named[k].ndim > 1}
-    print("measured: loss rel", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "worst grad rel-L2:", max(worst.items(), key=lambda kv: kv[1]),
+    vecs = {k: v for k, v in worst.items() if named[k].ndim <= 1}
+    print("measured: loss rel", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "worst vector rel-L2:", max(vecs.items(), key=lambda kv: kv[1]) if vecs else None,
           "worst max-abs/max:", max(worst_max.items(), key=lambda kv: kv[1]), "worst matrix rel-L2:", max(mats.items(), key=lambda kv: kv[1]) if mats else None,
           "pred max-abs:", max(float((pred[v].float().cpu() - t).abs().max()) for v, t in ref_pred.items()) if ref_pred else None)
 
