@@ -164,6 +164,20 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* dy, 
     if (accumulate) dst[(size_t)r * lddx] += g; else dst[(size_t)r * lddx] = g;
   }
 }
+// y[r][j] = a[r][j] * (b_rows ? b[r][j] : b[j]): timm LayerScale (x * gamma, cinema/vit.py:561,576 - forward, and dx = dy * gamma), and with a full second operand the
+// element products behind d gamma = column sums of dy * x and the GELU derivative of an unfused Mlp.  Contiguous rows of c elements; fp32 / bf16 operands and result.
+struct MulRowsP { const void* a; const void* b; void* y; long long n; int c; int a_bf16, b_bf16, b_rows, y_bf16; };
+__device__ __forceinline__ float ld_any(const void* p, long long i, int is_bf16) {
+  return is_bf16 ? bf2f(reinterpret_cast<const bf16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+__global__ __launch_bounds__(256) void mul_rows_kernel(MulRowsP p) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (long long)gridDim.x * 256) {
+    const float v = ld_any(p.a, i, p.a_bf16) * ld_any(p.b, p.b_rows ? i : i % p.c, p.b_bf16);
+    if (p.y_bf16) reinterpret_cast<bf16_t*>(p.y)[i] = f2bf(v);
+    else reinterpret_cast<float*>(p.y)[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_f32_kernel(const float* x, float alpha, float* y, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * alpha;
 }
@@ -286,6 +300,13 @@ CINEMA_API int cinema_segment_mean_fwd(const float* x, int ldx, int n_seg, int s
 CINEMA_API int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, float scale, float* dx, int lddx, int accumulate, void* stream) {
   if (!dy || !dx || n_seg <= 0 || seg_rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
   CINEMA_LAUNCH(segment_mean_bwd_kernel, dim3((c + 255) / 256, n_seg), dim3(256), 0, (hipStream_t)stream, dy, seg_rows, c, scale, dx, lddx, accumulate);
+  return launch_status();
+}
+
+CINEMA_API int cinema_mul_rows(const void* a, int a_bf16, const void* b, int b_bf16, int b_rows, void* y, int y_bf16, long long rows, int c, void* stream) {
+  if (!a || !b || !y || rows <= 0 || c <= 0) return CINEMA_ERR_BAD_ARG;
+  const long long n = rows * c;
+  CINEMA_LAUNCH(mul_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, MulRowsP{a, b, y, n, c, a_bf16, b_bf16, b_rows, y_bf16});
   return launch_status();
 }
 

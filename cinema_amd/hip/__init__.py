@@ -219,6 +219,7 @@ _PROTOS = {
     "cinema_scale_rows_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "cinema_rope_heads": [_vp, _i, _ll, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "cinema_mul_scalar_f32": [_vp, _vp, _vp, _ll, _vp],
+    "cinema_mul_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _ll, _i, _vp],
     "cinema_mask_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cinema_visible_index": [_vp, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp, _vp, _vp],
     "cinema_stream_fork": [_vp, _vp],

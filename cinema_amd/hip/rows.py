@@ -15,7 +15,7 @@ from cinema_amd.hip import (  # noqa: F401
     HipLibraryError, PatchGeom, RowCopyArgs, _DT, _check, _dev, _empty, _empty_like, _p, _rowmajor, _stream, _workspace, load, persistent,
 )
 
-__all__ = ['_RNG_STATE', 'cast', 'colsum', 'convt_weight_grad_accumulate', 'convt_weight_rows', 'dropout', 'droppath_scale', 'full', 'gelu_bwd', 'gelu_fwd', 'mask_select', 'mul_scalar', 'patch_gather', 'patch_geom', 'patch_scatter', 'patch_weight_grad_accumulate', 'patch_weight_rows', 'random_mask', 'rng_advance', 'rng_seed', 'rng_state', 'rope_heads', 'row_copy', 'row_copy_multi', 'scale', 'scale_rows_add', 'scale_rows_bf16', 'segment_mean', 'segment_mean_bwd', 'transpose_cast', 'visible_index', 'zeros', 'zoom_scale_pad']
+__all__ = ['mul_rows', '_RNG_STATE', 'cast', 'colsum', 'convt_weight_grad_accumulate', 'convt_weight_rows', 'dropout', 'droppath_scale', 'full', 'gelu_bwd', 'gelu_fwd', 'mask_select', 'mul_scalar', 'patch_gather', 'patch_geom', 'patch_scatter', 'patch_weight_grad_accumulate', 'patch_weight_rows', 'random_mask', 'rng_advance', 'rng_seed', 'rng_state', 'rope_heads', 'row_copy', 'row_copy_multi', 'scale', 'scale_rows_add', 'scale_rows_bf16', 'segment_mean', 'segment_mean_bwd', 'transpose_cast', 'visible_index', 'zeros', 'zoom_scale_pad']
 
 
 def segment_mean(x: torch.Tensor, n_seg: int, scale: float | None = None) -> torch.Tensor:
@@ -56,6 +56,21 @@ def mul_scalar(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
         raise HipLibraryError("mul_scalar: contiguous fp32 x, one-element fp32 s")
     y = _empty_like(x)
     _check(load().cinema_mul_scalar_f32(x.data_ptr(), s.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mul_scalar")
+    return y
+
+
+def mul_rows(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """a [rows, c] * b, with b either [c] (one factor per channel: timm ``LayerScale``, ``cinema/vit.py:561,576``) or [rows, c]; fp32 / bf16 operands, contiguous."""
+    _dev(a, b)
+    rows, c = a.shape
+    full = b.dim() == 2
+    if not a.is_contiguous() or not b.is_contiguous() or (tuple(b.shape) != (rows, c) if full else tuple(b.shape) != (c,)):
+        raise HipLibraryError(f"mul_rows: contiguous [rows, c] times [c] or [rows, c], got {tuple(a.shape)} and {tuple(b.shape)}")
+    if any(t.dtype not in (torch.float32, torch.bfloat16) for t in (a, b)) or out_dtype not in (torch.float32, torch.bfloat16):
+        raise HipLibraryError("mul_rows: fp32 / bf16 only")
+    y = _empty((rows, c), dtype=out_dtype, device=a.device)
+    _check(load().cinema_mul_rows(a.data_ptr(), int(a.dtype == torch.bfloat16), b.data_ptr(), int(b.dtype == torch.bfloat16), int(full), y.data_ptr(),
+                                  int(out_dtype == torch.bfloat16), rows, c, _stream()), "mul_rows")
     return y
 
 

@@ -1078,3 +1078,4 @@ def taped_call(runner: Callable, inputs: list, params: list) -> tuple:
 from cinema_amd.tape.ops_block import *  # noqa: E402, F401, F403
 from cinema_amd.tape.ops_conv import *  # noqa: E402, F401, F403
 from cinema_amd.tape.ops_rows import *  # noqa: E402, F401, F403
+from cinema_amd.tape.ops_options import *  # noqa: E402, F401, F403

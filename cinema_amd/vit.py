@@ -153,8 +153,6 @@ class PatchEmbed(nn.Module, _CkptFlag):
     def __init__(self, image_size: tuple, patch_size: tuple, in_chans: int, embed_dim: int, norm_layer: type | None = None, bias: bool = True,
                  strict_image_size: bool = False, dynamic_img_pad: bool = False) -> None:
         super().__init__()
-        if dynamic_img_pad:
-            raise NotImplementedError("dynamic_img_pad is not used by any CineMA model and has no HIP path.")
         self.n_dims = len(image_size)
         self.patch_size = tuple(patch_size)
         self.image_size = tuple(image_size)
@@ -178,13 +176,19 @@ class PatchEmbed(nn.Module, _CkptFlag):
             for i in range(self.n_dims):
                 if self.image_size[i] != image_size[i]:
                     raise ValueError(f"Input size ({image_size}) doesn't match config (batch, channel) + {self.image_size}.")
-        else:
+        elif not self.dynamic_img_pad:
             for i in range(self.n_dims):
                 if image_size[i] % self.patch_size[i] != 0:
                     raise ValueError(f"Input size ({image_size}) should be divisible by patch size ({self.patch_size}).")
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
-        self.check_size(tuple(image.shape[2:]))
+        size = tuple(image.shape[2:])
+        self.check_size(size)
+        if self.dynamic_img_pad:
+            # ``vit.py:332-337``: the (0, missing) pairs are listed in AXIS order and handed to ``F.pad``, which applies its first pair to the LAST axis - kept as
+            # it is (the amounts land on the right axes only when they agree, e.g. an isotropic patch on a cubic image)
+            pad = sum([(0, (p - size[i] % p) % p) for i, p in enumerate(self.patch_size)], ())
+            image = torch.nn.functional.pad(image, pad)
         return self.proj(patchify(image, self.patch_size))
 
 
@@ -192,18 +196,23 @@ class Attention(nn.Module):
     """Multi-head attention with separate ``q`` and fused ``kv`` projections (reference ``cinema/vit.py:446-522``)."""
 
     def __init__(self, dim: int, n_heads: int = 8, qkv_bias: bool = False, qk_norm: bool = False, attn_drop: float = 0.0, proj_drop: float = 0.0,
-                 norm_layer: type = nn.LayerNorm, norm_eps: float = 1e-5, rotary: bool = False) -> None:  # noqa: ARG002
+                 norm_layer: type = nn.LayerNorm, norm_eps: float = 1e-5, rotary: bool = False) -> None:
         super().__init__()
         if dim % n_heads != 0:
             raise ValueError(f"dim {dim} should be divisible by n_heads {n_heads}")
-        if qk_norm or attn_drop > 0.0 or proj_drop > 0.0:
-            raise NotImplementedError("qk_norm / attention dropout are not used by the CineMA models and have no HIP path.")
+        if attn_drop > 0.0:
+            raise NotImplementedError("attention-probability dropout (attn_drop) is not used by the CineMA models and has no HIP path.")
+        if qk_norm and rotary:
+            raise NotImplementedError("qk_norm together with rotary embedding has no HIP path (no CineMA model uses either with the other).")
         self.n_heads = n_heads
         self.head_dim = dim // n_heads
         self.scale = self.head_dim**-0.5
         self.q = nn.Linear(dim, dim, bias=qkv_bias)
         self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
-        self.q_norm, self.k_norm = nn.Identity(), nn.Identity()
+        # qk_norm (``vit.py:476-477``): LayerNorm over the head dimension of q and k; runs unfused (tape.op_attention on given projections)
+        self.q_norm = norm_layer(self.head_dim, eps=norm_eps) if qk_norm else nn.Identity()
+        self.k_norm = norm_layer(self.head_dim, eps=norm_eps) if qk_norm else nn.Identity()
+        self.qk_norm = bool(qk_norm)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
@@ -217,6 +226,15 @@ class Attention(nn.Module):
         ``shared_kv`` = (tape.SharedKV, index): k|v of this block were projected together with the other decoder blocks'."""
         if xk is not None and self.rotary:
             raise ValueError("Rotary positional embedding is not supported with different query and key.")
+        if self.qk_norm:
+            if shared_kv is not None:
+                raise NotImplementedError("qk_norm with the shared decoder k|v projection")
+            c, hd = self.n_heads * self.head_dim, self.head_dim
+            q = T.op_linear(tp, xq, self.q.weight, self.q.bias)
+            k, v = T.op_split_cols(tp, T.op_linear(tp, xq if xk is None else xk, self.kv.weight, self.kv.bias), [c, c])
+            qn = T.op_layernorm(tp, T.op_view(tp, q, (q.data.shape[0] * self.n_heads, hd)), self.q_norm.weight, self.q_norm.bias, self.q_norm.eps)
+            kn = T.op_layernorm(tp, T.op_view(tp, k, (k.data.shape[0] * self.n_heads, hd)), self.k_norm.weight, self.k_norm.bias, self.k_norm.eps)
+            return T.op_attention(tp, T.op_view(tp, qn, tuple(q.data.shape)), T.op_view(tp, kn, tuple(k.data.shape)), v, batch, self.n_heads)
         if xk is None:
             rope = None
             if self.rotary is not None:
@@ -234,6 +252,10 @@ class Attention(nn.Module):
             q16 = T.op_cast_bf16(tp, qv)
             k16 = None if kv is None else T.op_cast_bf16(tp, kv)
             o = self.tape_forward(tp, q16, k16, b)
+            p = self.proj_drop.p if self.training else 0.0
+            if p > 0.0:
+                T.begin_stochastic(self, q.device)
+                return [T.op_cast_f32(tp, T.op_dropout(tp, T.op_linear(tp, o, self.proj.weight, self.proj.bias), p))], []
             return [T.op_linear(tp, o, self.proj.weight, self.proj.bias, out_f32=True)], []
 
         inputs = [q.float().reshape(-1, c).contiguous()] + ([] if k is None else [k.float().reshape(-1, c).contiguous()])
@@ -247,8 +269,8 @@ class Mlp(nn.Module):
     def __init__(self, in_features: int, hidden_features: int | None = None, out_features: int | None = None, act_layer: type = nn.GELU,
                  norm_layer: type | None = None, bias: bool = True, drop: float = 0.0, use_conv: bool = False) -> None:
         super().__init__()
-        if act_layer is not nn.GELU or norm_layer is not None or drop > 0.0 or use_conv:
-            raise NotImplementedError("cinema_amd Mlp: GELU, no inner norm, no dropout.")
+        if act_layer is not nn.GELU or norm_layer is not None or use_conv:
+            raise NotImplementedError("cinema_amd Mlp: GELU, no inner norm, Linear layers.")
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
         self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
@@ -288,6 +310,20 @@ class DropPath(nn.Module):
         return f"drop_prob={round(self.drop_prob, 3):0.3f}"
 
 
+class LayerScale(nn.Module):
+    """timm 1.0.15 ``LayerScale`` (``timm/models/vision_transformer.py``; used at ``cinema/vit.py:561,576``): x * gamma with gamma = init_values * ones(dim)."""
+
+    def __init__(self, dim: int, init_values: float = 1e-5, inplace: bool = False) -> None:
+        super().__init__()
+        self.inplace = inplace
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        c = x.shape[-1]
+        (y,) = T.taped_call(lambda tp, xv: ([T.op_layerscale(tp, xv, self.gamma)], []), [x.float().reshape(-1, c).contiguous()], [self.gamma])
+        return y.reshape(x.shape).to(x.dtype)
+
+
 class Block(nn.Module, _CkptFlag):
     """Pre-LN transformer block with optional cross-attention keys (reference ``cinema/vit.py:525-609``)."""
 
@@ -295,8 +331,6 @@ class Block(nn.Module, _CkptFlag):
                  act_layer: type, mlp_layer: type, qk_norm: bool = False, proj_drop: float = 0.0, attn_drop: float = 0.0,
                  init_values: float | None = None) -> None:
         super().__init__()
-        if init_values:
-            raise NotImplementedError("LayerScale is a fine-tuning option outside the HIP path.")
         # stochastic depth (the fine-tuning configs use 0.1, cinema/segmentation/acdc/config.yaml:65): identity in eval mode like timm's DropPath;
         # in training mode the residual adds go through tape.op_droppath_add (per-sample Philox draws, cinema_droppath_scale)
         self.drop_path_rate = float(drop_path)
@@ -305,11 +339,14 @@ class Block(nn.Module, _CkptFlag):
         self.norm1 = norm_layer(dim, eps=norm_eps)
         self.attn = Attention(dim, n_heads=n_heads, qkv_bias=qkv_bias, qk_norm=qk_norm, attn_drop=attn_drop, proj_drop=proj_drop,
                               norm_layer=norm_layer, norm_eps=norm_eps, rotary=rotary)
-        self.ls1 = nn.Identity()
+        # LayerScale (init_values) and proj_drop (nn.Dropout behind the attention projection and inside the Mlp) take the block off the fused epilogues: the
+        # residual adds, the scale and the dropout are launches of their own (tape/ops_options.py); no shipped configuration sets either
+        self.ls1 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.proj_drop = float(proj_drop)
         self.drop_path1 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = norm_layer(dim, eps=norm_eps)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=proj_drop)
-        self.ls2 = nn.Identity()
+        self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
         self.drop_path2 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def _param_list(self) -> list:
@@ -330,7 +367,10 @@ class Block(nn.Module, _CkptFlag):
         T.wgrad_group(tp)                      # ... which includes the grouped weight-gradient launch: its flush runs before that marker fires
         qn = T.op_layernorm(tp, xq, self.norm1.weight, self.norm1.bias, self.norm1.eps, fp8=True)
         att = self.attn.tape_forward(tp, qn, xk, batch, shared_kv=shared_kv)
-        if drop > 0.0:  # q + drop_path1(path1(q)), q + drop_path2(path2(q)) (vit.py:606-609): the residual adds leave the GEMM epilogues
+        p_drop = self.proj_drop if self.training else 0.0
+        if isinstance(self.ls1, LayerScale) or p_drop > 0.0:
+            y = self._tape_forward_options(tp, xq, att, batch, drop, p_drop)
+        elif drop > 0.0:  # q + drop_path1(path1(q)), q + drop_path2(path2(q)) (vit.py:606-609): the residual adds leave the GEMM epilogues
             h1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, out_f32=True, fp8=T.FP8_FORWARD)
             x1 = T.op_droppath_add(tp, h1, xq, batch, drop)
             xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps, fp8=True)
@@ -343,10 +383,38 @@ class Block(nn.Module, _CkptFlag):
         T.wgrad_group_end(tp)
         return y
 
+    def _tape_forward_options(self, tp: T.Tape, xq: T.Var, att: T.Var, batch: int, drop: float, p_drop: float) -> T.Var:
+        """``q + drop_path1(ls1(proj_drop(proj(att))))`` then ``x1 + drop_path2(ls2(mlp(norm2(x1))))`` with timm's Mlp = fc1 -> GELU -> drop -> fc2 -> drop
+        (``vit.py:593-609``), every piece a launch of its own."""
+        ls = isinstance(self.ls1, LayerScale)
+
+        def branch_out(h: T.Var, scale: nn.Module) -> T.Var:  # h: bf16 behind a dropout, fp32 otherwise -> fp32 branch output
+            if ls:
+                return T.op_layerscale(tp, h, scale.gamma)
+            return h if h.data.dtype == torch.float32 else T.op_cast_f32(tp, h)
+
+        def add(h: T.Var, res: T.Var) -> T.Var:
+            return T.op_droppath_add(tp, h, res, batch, drop) if drop > 0.0 else T.op_add(tp, h, res, batch)
+
+        if p_drop > 0.0:
+            h1 = T.op_dropout(tp, T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias), p_drop)
+        else:
+            h1 = T.op_linear(tp, att, self.attn.proj.weight, self.attn.proj.bias, out_f32=True)
+        x1 = add(branch_out(h1, self.ls1), xq)
+        xn2 = T.op_layernorm(tp, x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        if p_drop > 0.0:
+            a = T.op_dropout(tp, T.op_linear_gelu(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias), p_drop)
+            h2 = T.op_dropout(tp, T.op_linear(tp, a, self.mlp.fc2.weight, self.mlp.fc2.bias), p_drop)
+        else:
+            h2 = T.op_mlp(tp, xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=None)
+        return add(branch_out(h2, self.ls2), x1)
+
     def forward(self, q: torch.Tensor, k: torch.Tensor | None = None) -> torch.Tensor:
         b, tq, c = q.shape
 
         def run(tp: T.Tape, qv: T.Var, kv: T.Var | None = None):  # noqa: ANN202
+            if self.training and (self.proj_drop > 0.0 or self.drop_path_rate > 0.0):
+                T.begin_stochastic(self, q.device)
             return [self.tape_forward(tp, qv, None if kv is None else T.op_cast_bf16(tp, kv), b)], []
 
         inputs = [q.float().reshape(-1, c).contiguous()] + ([] if k is None else [k.float().reshape(-1, c).contiguous()])

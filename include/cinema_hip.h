@@ -427,6 +427,11 @@ int cinema_segment_mean_bwd(const float* dy, int n_seg, int seg_rows, int c, flo
 int cinema_scale_f32(const float* x, float alpha, float* y, long long n, void* stream);
 /* y[i] = x[i] * s[0], the scalar s read from device memory (chain rule through the scalar loss mean, cinema/mae/mae.py:604-608). */
 int cinema_mul_scalar_f32(const float* x, const float* s, float* y, long long n, void* stream);
+/* y[r][j] = a[r][j] * (b_rows ? b[r][j] : b[j]) on contiguous [rows][c] tensors (fp32 or bf16 each).  timm LayerScale as used at cinema/vit.py:561,576
+ * (forward x * gamma, backward dy * gamma), and - with a full second operand - the element products behind d gamma = column sums of dy * x (cinema_colsum)
+ * and the GELU derivative of an Mlp whose activation is followed by nn.Dropout (timm Mlp, cinema/vit.py:570-575 with proj_drop > 0). */
+int cinema_mul_rows(const void* a, int a_bf16, const void* b, int b_bf16, int b_rows, void* y, int y_bf16, long long rows, int c, void* stream);
+
 /* Rotary embedding of q / k as the reference calls it (cinema/vit.py:496-499 -> cinema/rotary.py:30-60, 109-128): the table row is the HEAD index
  * (q, k are (batch, heads, tokens, head_dim) and the module indexes dim 1), the rotation acts on the two halves of the first rotary_dim columns of
  * every head (rotate_half, cinema/rotary.py:12-24).  In place on bf16 rows [rows][ld]: n_slots consecutive head slots of head_dim columns from

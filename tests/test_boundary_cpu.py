@@ -280,3 +280,23 @@ def test_module_level_helper_symbols_of_the_reference_resolve() -> None:
                            {"params": [lin.bias], "lr_scale": 1.0, "weight_decay_scale": 0.0, "is_last_layer": True}], lr=1.0)
     apply_optim_scheduler(opt, lr=0.2, last_layer_lr=0.05, weight_decay=0.1)
     assert [g["lr"] for g in opt.param_groups] == [0.1, 0.05] and [g["weight_decay"] for g in opt.param_groups] == [0.1, 0.0]
+
+
+def test_block_options_are_accepted_with_the_reference_parameter_names() -> None:
+    """``init_values`` (timm LayerScale), ``qk_norm`` and ``proj_drop`` of ``cinema/vit.py:446-609`` and ``PatchEmbed(dynamic_img_pad=True)`` construct (rounds 1-5
+    raised NotImplementedError) and their parameters carry the reference's names; ``attn_drop`` still has no HIP path and says so."""
+    import pytest
+    from torch import nn
+
+    from cinema.vit import Attention, Block, PatchEmbed
+    from cinema_amd.vit import Mlp
+
+    blk = Block(dim=32, n_heads=4, mlp_ratio=2, norm_layer=nn.LayerNorm, norm_eps=1e-6, drop_path=0.0, qkv_bias=True, rotary=False, act_layer=nn.GELU, mlp_layer=Mlp,
+                qk_norm=True, proj_drop=0.1, init_values=1e-5)
+    keys = set(blk.state_dict())
+    assert {"ls1.gamma", "ls2.gamma", "attn.q_norm.weight", "attn.q_norm.bias", "attn.k_norm.weight", "attn.k_norm.bias"} <= keys
+    assert float(blk.ls1.gamma[0]) == pytest.approx(1e-5) and blk.attn.q_norm.normalized_shape == (8,)
+    assert blk.attn.proj_drop.p == 0.1 and blk.mlp.drop1.p == 0.1 and blk.mlp.drop2.p == 0.1
+    assert PatchEmbed(image_size=(30, 30), patch_size=(4, 4), in_chans=1, embed_dim=8, dynamic_img_pad=True).dynamic_img_pad
+    with pytest.raises(NotImplementedError):
+        Attention(32, n_heads=4, attn_drop=0.1)
