@@ -72,6 +72,7 @@ def main() -> None:
             ("dw_wgrad", lambda: K.sparse_dwconv_bwd_weight(d, dh, tuple(wdw.shape), dwg, dbg, geom), mb * (2 + 2)),
             ("ln_linear_bwd", lambda: K.stem_ln_linear_bwd(dh, x, g2, gam, 1e-6, w1), mb * (2 + 4 + 4 + 4)),
             ("wgrad", lambda: K.stem_wgrad(probs), mb * 2 * (1 + 4 + 4 + 1 + 1 + 1 + 1 + 1)),
+            ("wgrad_p256", lambda: K.gemm_wgrad_grouped(probs, p256=True), mb * 2 * (1 + 4 + 4 + 1 + 1 + 1 + 1 + 1)),
         ]
         for nm, fn, mbytes in cases:
             if flt and flt not in nm:
