@@ -42,7 +42,7 @@ for name in names:
     orig = getattr(K, name)
 
     def wrap(*a, _orig=orig, _name=name, **k):
-        st = [f for f in traceback.extract_stack()[:-1] if "cinema_amd" in f.filename and "hip.py" not in f.filename][-2:]
+        st = [f for f in traceback.extract_stack()[:-1] if "cinema_amd" in f.filename and "/hip/" not in f.filename][-2:]
         key = _name + " <- " + " <- ".join(f"{Path(f.filename).name}:{f.lineno} {f.name}" for f in reversed(st))
         t = next((x for x in a if isinstance(x, torch.Tensor)), None)
         sites[key][0] += 1

@@ -27,7 +27,7 @@ for n in names:
     orig = entry.fn
 
     def wrapped(*a, _orig=orig, _n=n):
-        fr = [f for f in traceback.extract_stack() if "/cinema_amd/" in f.filename and not f.filename.endswith("hip.py")]
+        fr = [f for f in traceback.extract_stack() if "/cinema_amd/" in f.filename and "/cinema_amd/hip/" not in f.filename]
         key = " <- ".join(f"{f.filename.split('/cinema_amd/')[-1]}:{f.lineno}" for f in fr[-3:][::-1])
         counts[_n][key] += 1
         return _orig(*a)
