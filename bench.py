@@ -757,7 +757,10 @@ def main() -> None:
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
             a[3] += shape[-1]
-        blas = hipblaslt_reference(prof, args.profile_steps, K.GEMM_KERNEL_NAMES) if not args.no_blas_reference else {}
+        try:  # (information only: the headline line must not depend on it)
+            blas = hipblaslt_reference(prof, args.profile_steps, K.GEMM_KERNEL_NAMES) if not args.no_blas_reference else {}
+        except Exception:  # noqa: BLE001
+            blas = {}
         kind = max(agg, key=lambda k: agg[k][1])
         flops, secs, n, alg_bytes = agg[kind]
         traffic = pmc_traffic(K.GEMM_KERNEL_NAMES[kind])
