@@ -691,6 +691,136 @@ __device__ __forceinline__ void wgrad_body(const WgP& q) {
 template <int MP, int MQ, int RT> __global__ __launch_bounds__(NT) void stem_wgrad_kernel(WgP q) { wgrad_body<MP, MQ, RT>(q); }
 template <int MP, int MQ, int RT> __global__ __launch_bounds__(NT) void stem_wgrad_lanes_kernel(Lanes<WgP> L) { wgrad_body<MP, MQ, RT>(L.p[blockIdx.z]); }
 
+// The same row-slice weight gradient with EVERYTHING about the shapes known at compile time (the four problems of a MaskedConvBlock are [c x 4c], [4c x c] and twice
+// [c x c]): the general body above guards every staging chunk and every fragment with run-time conditions, which the compiler turns into ~40 basic blocks per step with
+// a full s_waitcnt at each boundary - the second staging set was waited for before the first was refilled, and every transpose read was waited for before the next was
+// issued.  Here a step is straight-line code: NP x RT / 8 = 512 chunks of the narrow operand (one per thread) + NQ / NP chunks of the wide one per thread, no guards in
+// the full steps; the bias gradient is summed from the staged registers (8 columns per thread) and reduced across the threads once, at the end.
+template <int NP, int NQ, int RT>
+__device__ __forceinline__ void wgrad_fixed_body(const WgP& q, const WgProb& pr, char* smem) {
+  constexpr int PP = 2 * NP + 32, PQ = 2 * NQ + 32;          // LDS pitches (bytes)
+  constexpr int TP = NP / 32, TQ = NQ / 32, WP = 2, WQ = NW / WP;
+  constexpr int MP = TP / WP, MQ = TQ >= WQ ? TQ / WQ : 1, QW = TQ >= WQ ? WQ : TQ;
+  constexpr int CP = NP / 8, CQ = NQ / 8;                     // 16-byte chunks per row
+  static_assert(RT * CP == NT && (RT * CQ) % NT == 0 && TP % WP == 0, "one narrow chunk per thread and step");
+  constexpr int NQL = RT * CQ / NT, QSTEP = NT / CQ;          // wide chunks per thread and step, rows between them
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool swap = pr.n > pr.k;                              // P = the narrower operand
+  const bf16_t* P = swap ? pr.x : pr.dy;
+  const bf16_t* Q = swap ? pr.dy : pr.x;
+  char* lp = smem;
+  char* lq = smem + RT * PP;
+  const int wpi = wave % WP, wqi = wave / WP;
+  float16v acc[MP][MQ];
+#pragma unroll
+  for (int a = 0; a < MP; a++)
+#pragma unroll
+    for (int b = 0; b < MQ; b++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
+  const int per = (pr.rows + q.n_slices - 1) / q.n_slices;
+  const int rows_per = ((per + RT - 1) / RT) * RT;
+  const int r0 = blockIdx.x * rows_per, r1 = min(pr.rows, r0 + rows_per);
+  const int prow = tid / CP, pc = tid % CP, qrow = tid / CQ, qc = tid % CQ;
+  float bacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) bacc[i] = 0.f;
+  struct Stage { u4 p; u4 qv[NQL]; };
+  Stage sa, sb;
+  auto fetch = [&](Stage& st, int rb) {
+    if (rb + RT <= r1) {   // a whole step: no guards
+      st.p = *reinterpret_cast<const u4*>(P + (size_t)(rb + prow) * NP + pc * 8);
+#pragma unroll
+      for (int u = 0; u < NQL; u++) st.qv[u] = *reinterpret_cast<const u4*>(Q + (size_t)(rb + qrow + u * QSTEP) * NQ + qc * 8);
+    } else {               // the ragged last step of the tensor: missing rows are zeros
+      st.p = u4{0u, 0u, 0u, 0u};
+      if (rb + prow < r1) st.p = *reinterpret_cast<const u4*>(P + (size_t)(rb + prow) * NP + pc * 8);
+#pragma unroll
+      for (int u = 0; u < NQL; u++) {
+        st.qv[u] = u4{0u, 0u, 0u, 0u};
+        if (rb + qrow + u * QSTEP < r1) st.qv[u] = *reinterpret_cast<const u4*>(Q + (size_t)(rb + qrow + u * QSTEP) * NQ + qc * 8);
+      }
+    }
+  };
+  auto bias_add = [&](const u4& v) {
+#pragma unroll
+    for (int w = 0; w < 4; w++) { bacc[2 * w] += __uint_as_float(v[w] << 16); bacc[2 * w + 1] += __uint_as_float(v[w] & 0xffff0000u); }
+  };
+  auto step = [&](Stage& st, int rb) {
+    __syncthreads();   // the previous step's fragments have been read
+    *reinterpret_cast<u4*>(lp + prow * PP + pc * 16) = st.p;
+#pragma unroll
+    for (int u = 0; u < NQL; u++) *reinterpret_cast<u4*>(lq + (qrow + u * QSTEP) * PQ + qc * 16) = st.qv[u];
+    if (pr.db) {
+      if (!swap) bias_add(st.p);
+      else {
+#pragma unroll
+        for (int u = 0; u < NQL; u++) bias_add(st.qv[u]);
+      }
+    }
+    __syncthreads();
+    if (rb + 2 * RT < r1) fetch(st, rb + 2 * RT);   // in flight while this step and the next are multiplied
+    if (wqi < QW) {
+#pragma unroll
+      for (int ks = 0; ks < RT / 16; ks++) {
+        short8v fq[MQ], fp[MP];
+#pragma unroll
+        for (int b = 0; b < MQ; b++) fq[b] = frag32_t(lq, PQ, ks * 16, (wqi * MQ + b) * 32, lane);
+#pragma unroll
+        for (int a = 0; a < MP; a++) fp[a] = frag32_t(lp, PP, ks * 16, (wpi * MP + a) * 32, lane);
+#pragma unroll
+        for (int a = 0; a < MP; a++)
+#pragma unroll
+          for (int b = 0; b < MQ; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[a], fq[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  };
+  if (r0 < r1) fetch(sa, r0);
+  if (r0 + RT < r1) fetch(sb, r0 + RT);
+  for (int rb = r0; rb < r1; rb += 2 * RT) {
+    step(sa, rb);
+    if (rb + RT < r1) step(sb, rb + RT);
+  }
+  float* slab = q.slabs + (size_t)blockIdx.x * q.slab_floats + pr.slab_off;
+  if (wqi < QW) {
+#pragma unroll
+    for (int a = 0; a < MP; a++)
+#pragma unroll
+      for (int b = 0; b < MQ; b++) {
+        const int p0 = (wpi * MP + a) * 32, q0 = (wqi * MQ + b) * 32;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int ip = p0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), iq = q0 + (lane & 31);   // D[row = P index][col = Q index]
+          if (swap) slab[(size_t)iq * pr.k + ip] = acc[a][b][i];
+          else slab[(size_t)ip * pr.k + iq] = acc[a][b][i];
+        }
+      }
+  }
+  if (pr.db) {   // column sums of dy: the threads that staged the same 8 columns hold partial sums over different rows
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [8 columns of a chunk][NT threads] - 16 KB, the staging tiles are free now
+#pragma unroll
+    for (int i = 0; i < 8; i++) red[i * NT + tid] = bacc[i];
+    __syncthreads();
+    const int cd = swap ? CQ : CP;                  // chunks per dy row; thread t staged chunk t % cd
+    if (tid < pr.n) {
+      const int c = tid >> 3, i = tid & 7;
+      float sum = 0.f;
+      for (int t = c; t < NT; t += cd) sum += red[i * NT + t];
+      slab[(size_t)pr.n * pr.k + tid] = sum;
+    }
+  }
+}
+template <int C, int RT>
+__device__ __forceinline__ void wgrad_block_body(const WgP& q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WgProb& pr = q.pr[blockIdx.y];
+  if (pr.n == pr.k) wgrad_fixed_body<C, C, RT>(q, pr, smem);
+  else wgrad_fixed_body<C, 4 * C, RT>(q, pr, smem);
+}
+template <int C, int RT> __global__ __launch_bounds__(NT) void stem_wgrad_block_kernel(WgP q) { wgrad_block_body<C, RT>(q); }
+template <int C, int RT> __global__ __launch_bounds__(NT) void stem_wgrad_block_lanes_kernel(Lanes<WgP> L) { wgrad_block_body<C, RT>(L.p[blockIdx.z]); }
+
 __device__ __forceinline__ void wgrad_reduce_body(const WgP& q) {  // block = 32 elements x 8 slice groups
   __shared__ float red[8][32];
   const WgProb& pr = q.pr[blockIdx.y];
@@ -876,11 +1006,29 @@ CINEMA_API int cinema_stem_wgrad(const cinema_stem_wgrad_problem* probs, int cou
   q.slab_floats = off;
   q.n_slices = cinema_stem_wgrad_slices(probs[0].rows);
   if (workspace_bytes < (long long)off * 4 * q.n_slices) return CINEMA_ERR_BAD_ARG;
+  // the four problems of a MaskedConvBlock ([c x 4c], [4c x c], [c x c] twice; c = 64 / 128): the compile-time form
+  int block_c = 0;
+  for (int c : {64, 128}) {
+    bool all = true;
+    for (int i = 0; i < count; i++) {
+      const int np = q.pr[i].n < q.pr[i].k ? q.pr[i].n : q.pr[i].k, nq = q.pr[i].n < q.pr[i].k ? q.pr[i].k : q.pr[i].n;
+      all = all && np == c && (nq == c || nq == 4 * c);
+    }
+    if (all) block_c = c;
+  }
   const bool big = !(mp <= 1 && mq <= 2);
   const int lds = (big ? 32 : WG_RT) * ((2 * max_np + 32) + (2 * max_nq + 32));
   const dim3 grid(q.n_slices, count);
   hipStream_t st = (hipStream_t)stream;
-  if (!big) {
+  if (block_c == 64) {
+    static bool f[16] = {};
+    if (set_lds(f, stem_wgrad_block_kernel<64, 64>, stem_wgrad_block_lanes_kernel<64, 64>, 96 * 1024)) return CINEMA_ERR_UNSUPPORTED;
+    launch_lanes(stem_wgrad_block_kernel<64, 64>, stem_wgrad_block_lanes_kernel<64, 64>, 2, grid, dim3(NT), 64 * ((2 * 64 + 32) + (2 * 256 + 32)), st, q);
+  } else if (block_c == 128) {
+    static bool f[16] = {};
+    if (set_lds(f, stem_wgrad_block_kernel<128, 32>, stem_wgrad_block_lanes_kernel<128, 32>, 96 * 1024)) return CINEMA_ERR_UNSUPPORTED;
+    launch_lanes(stem_wgrad_block_kernel<128, 32>, stem_wgrad_block_lanes_kernel<128, 32>, 2, grid, dim3(NT), 32 * ((2 * 128 + 32) + (2 * 512 + 32)), st, q);
+  } else if (!big) {
     static bool f[16] = {};
     if (set_lds(f, stem_wgrad_kernel<1, 2, WG_RT>, stem_wgrad_lanes_kernel<1, 2, WG_RT>, 96 * 1024)) return CINEMA_ERR_UNSUPPORTED;
     launch_lanes(stem_wgrad_kernel<1, 2, WG_RT>, stem_wgrad_lanes_kernel<1, 2, WG_RT>, 2, grid, dim3(NT), lds, st, q);
